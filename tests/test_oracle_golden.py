@@ -1,0 +1,202 @@
+"""Pins the CPU oracle (oracle/lr_oracle.c) against the reference's own golden vectors, at the
+reference's own epsilons, in both modes of tests/jigs.lua (whole vector / one sample per call)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import golden_util as G
+
+RATE = 2.0   # tests/jigs.lua:69 monkey-patches get_rate() to 2.0
+
+
+def _check(make, vec, eps):
+    x, want = vec["inputs"][0], vec["outputs"][0]
+    whole, samplewise = G.run_whole_and_samplewise(make, x)
+    assert G.max_abs_err(whole[:len(want)], want) < eps, vec["desc"]
+    assert len(whole) == len(want)
+    assert G.max_abs_err(samplewise, want) < eps, vec["desc"]
+
+
+@pytest.mark.parametrize("mode", [O.MODE_LUA, O.MODE_FMA, O.MODE_F64])
+def test_firfilter_dotprod(mode):
+    doc = G.load("firfilter_spec")
+    n = 0
+    for vec in doc["vectors"]:
+        taps, use_fft = vec["args"]
+        if use_fft:
+            continue
+        cplx = np.iscomplexobj(vec["inputs"][0])
+        _check(lambda: O.FIR(taps, cplx, mode), vec, doc["epsilon"])
+        n += 1
+    assert n == 12
+
+
+def test_firfilter_fft_overlap_save():
+    doc = G.load("firfilter_spec")
+    n = 0
+    for vec in doc["vectors"]:
+        taps, use_fft = vec["args"]
+        if not use_fft:
+            continue
+        cplx = np.iscomplexobj(vec["inputs"][0])
+        _check(lambda: O.FIRFFT(taps, cplx), vec, doc["epsilon"])
+        n += 1
+    assert n == 12
+
+
+@pytest.mark.parametrize("mode", [O.MODE_LUA, O.MODE_FMA, O.MODE_F64])
+def test_lowpassfilter(mode):
+    doc = G.load("lowpassfilter_spec")
+    for vec in doc["vectors"]:
+        a = vec["args"]
+        num_taps, cutoff = a[0], a[1]
+        nyq = a[2] if len(a) > 2 else None
+        win = a[3] if len(a) > 3 else "hamming"
+        cplx = np.iscomplexobj(vec["inputs"][0])
+        _check(lambda: O.lowpass(num_taps, cutoff, RATE, cplx, nyq, win, mode), vec, doc["epsilon"])
+
+
+def _firwin_block(design, vec, cplx, mode=O.MODE_LUA):
+    a = vec["args"]
+    nyq = a[2] if len(a) > 2 and a[2] is not None else RATE / 2
+    win = a[3] if len(a) > 3 else "hamming"
+    c = a[1]
+    c = [v / nyq for v in c] if isinstance(c, list) else c / nyq
+    return O.FIR(design(a[0], c, win).astype(np.float32), cplx, mode)
+
+
+@pytest.mark.parametrize("name,design", [("highpassfilter_spec", O.firwin_highpass),
+                                         ("bandpassfilter_spec", O.firwin_bandpass),
+                                         ("bandstopfilter_spec", O.firwin_bandstop)])
+def test_other_firwin_blocks(name, design):
+    doc = G.load(name)
+    for vec in doc["vectors"]:
+        cplx = np.iscomplexobj(vec["inputs"][0])
+        _check(lambda: _firwin_block(design, vec, cplx), vec, doc["epsilon"])
+
+
+@pytest.mark.parametrize("mode", [O.MODE_LUA, O.MODE_F64])
+def test_frequencytranslator(mode):
+    doc = G.load("frequencytranslator_spec")
+    assert doc["epsilon"] == 1e-5
+    for vec in doc["vectors"]:
+        omega = 2 * np.pi * (vec["args"][0] / RATE)
+        _check(lambda: O.Rotator(omega, mode), vec, doc["epsilon"])
+
+
+def test_frequencydiscriminator():
+    doc = G.load("frequencydiscriminator_spec")
+    for vec in doc["vectors"]:
+        _check(lambda: O.FMDiscriminator(vec["args"][0]), vec, doc["epsilon"])
+
+
+def test_downsampler_bit_exact():
+    doc = G.load("downsampler_spec")
+    assert len(doc["vectors"]) == 20
+    for vec in doc["vectors"]:
+        x, want = vec["inputs"][0], vec["outputs"][0]
+        cplx = np.iscomplexobj(x)
+        whole, samplewise = G.run_whole_and_samplewise(lambda: O.Downsampler(vec["args"][0], cplx), x)
+        assert np.array_equal(whole, want) and np.array_equal(samplewise, want), vec["desc"]
+
+
+@pytest.mark.parametrize("mode", [O.MODE_LUA, O.MODE_F64])
+def test_iirfilter(mode):
+    doc = G.load("iirfilter_spec")
+    for vec in doc["vectors"]:
+        b, a = vec["args"]
+        cplx = np.iscomplexobj(vec["inputs"][0])
+        _check(lambda: O.IIR(b, a, cplx, mode), vec, doc["epsilon"])
+
+
+@pytest.mark.parametrize("mode", [O.MODE_LUA, O.MODE_F64])
+def test_singlepole_and_deemphasis(mode):
+    doc = G.load("singlepolelowpassfilter_spec")
+    for vec in doc["vectors"]:
+        b, a = O.singlepole_lowpass_taps(vec["args"][0], RATE)
+        cplx = np.iscomplexobj(vec["inputs"][0])
+        _check(lambda: O.IIR(b, a, cplx, mode), vec, doc["epsilon"])
+    doc = G.load("fmdeemphasisfilter_spec")
+    for vec in doc["vectors"]:
+        b, a = O.fm_deemphasis_taps(vec["args"][0], RATE)
+        cplx = np.iscomplexobj(vec["inputs"][0])
+        _check(lambda: O.IIR(b, a, cplx, mode), vec, doc["epsilon"])
+
+
+def test_decimator():
+    doc = G.load("decimator_spec")
+    for vec in doc["vectors"]:
+        cplx = np.iscomplexobj(vec["inputs"][0])
+        # composite jig runs the graph once over the whole file (tests/jigs.lua:89-147); also check sample-wise
+        _check(lambda: O.decimator(vec["args"][0], RATE, cplx), vec, doc["epsilon"])
+
+
+@pytest.mark.parametrize("rot_mode", [O.MODE_LUA, O.MODE_F64])
+def test_tuner(rot_mode):
+    doc = G.load("tuner_spec")
+    assert doc["epsilon"] == 1e-5
+    for vec in doc["vectors"]:
+        off, bw, dec = vec["args"]
+        _check(lambda: O.tuner(off, bw, dec, RATE, rot_mode=rot_mode), vec, doc["epsilon"])
+
+
+def test_window_utils():
+    vals = G.load("window_utils_vectors")["values"]
+    for name, want in vals.items():
+        kind = name[len("window_"):]
+        periodic = kind.endswith("_periodic")
+        kind = kind[:-len("_periodic")] if periodic else kind
+        got = O.window(128, kind, periodic).astype(np.float32)
+        assert G.max_abs_err(got, want) < 1e-6, name
+
+
+def test_filter_utils():
+    vals = G.load("filter_utils_vectors")["values"]   # args from tests/utilities/filter_utils_spec.lua:8-27
+    assert G.max_abs_err(O.firwin_lowpass(128, 0.5).astype(np.float32), vals["firwin_lowpass"]) < 1e-6
+    assert G.max_abs_err(O.firwin_highpass(129, 0.5).astype(np.float32), vals["firwin_highpass"]) < 1e-6
+    assert G.max_abs_err(O.firwin_bandpass(129, [0.4, 0.6]).astype(np.float32), vals["firwin_bandpass"]) < 1e-6
+    assert G.max_abs_err(O.firwin_bandstop(129, [0.4, 0.6]).astype(np.float32), vals["firwin_bandstop"]) < 1e-6
+
+
+def test_spectrum_utils():
+    v = G.load("spectrum_utils_vectors")["values"]    # tests/utilities/spectrum_utils_spec.lua:58-91
+    cx, rx = v["complex_test_vector"], v["real_test_vector"]
+    assert G.max_abs_err(O.dft(cx), v["complex_test_vector_dft"]) < 1e-5
+    assert G.max_abs_err(O.dft(rx), v["real_test_vector_dft"]) < 1e-5
+    assert G.max_abs_err(O.idft(v["complex_test_vector_dft"], True), cx) < 1e-5
+    assert G.max_abs_err(O.idft(v["real_test_vector_dft"], False), rx) < 1e-5
+    for x, nm in ((cx, "complex"), (rx, "real")):
+        for win in ("rectangular", "hamming"):
+            assert G.max_abs_err(O.psd(x, win, 44100, False), v["%s_test_vector_%s_psd" % (nm, win)]) < 1e-5
+            assert G.max_abs_err(O.psd(x, win, 44100, True), v["%s_test_vector_%s_psd_log" % (nm, win)]) < 3
+    assert np.array_equal(O.fftshift(cx), v["complex_test_vector_fftshift"])
+    assert np.array_equal(O.fftshift(rx), v["real_test_vector_fftshift"])
+
+
+def test_top_chain():
+    """tests/top_spec.lua:13-54: IQ x2 -> MultiplyConjugate -> Lowpass(16,100e3) -> Discriminator(5) ->
+    Decimator(25,{num_taps=16}) at 1 MHz, against tests/top_vectors.gen.lua (epsilon 1e-6)."""
+    v = G.load("top_vectors")["values"]
+    s1 = np.frombuffer(v["SRC1_TEST_VECTOR"], np.complex64)
+    s2 = np.frombuffer(v["SRC2_TEST_VECTOR"], np.complex64)
+    want = np.frombuffer(v["SNK_TEST_VECTOR"], np.float32)
+    x = O.multiply_conjugate(s1, s2)
+    x = O.lowpass(16, 100e3, 1e6, True).process(x)
+    x = O.FMDiscriminator(5.0).process(x)
+    x = O.decimator(25, 1e6, False, num_taps=16).process(x)
+    assert len(x) == len(want)
+    assert G.max_abs_err(x, want) < 1e-6
+
+
+def test_fir_modes_agree_long():
+    rng = np.random.default_rng(7)
+    x = (rng.uniform(-1, 1, 5000) + 1j * rng.uniform(-1, 1, 5000)).astype(np.complex64)
+    taps = O.firwin_lowpass(128, 0.136).astype(np.float32)
+    ref = O.FIR(taps, True, O.MODE_F64).process(x)
+    for mode in (O.MODE_LUA, O.MODE_FMA):
+        assert G.max_abs_err(O.FIR(taps, True, mode).process(x), ref) < 1e-6
+    # chunking must not change a single bit (history carry)
+    f = O.FIR(taps, True, O.MODE_FMA)
+    whole = O.FIR(taps, True, O.MODE_FMA).process(x)
+    parts = np.concatenate([f.process(x[a:b]) for a, b in ((0, 1), (1, 130), (130, 131), (131, 4000), (4000, 5000))])
+    assert np.array_equal(whole, parts)
