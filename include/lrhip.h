@@ -1,0 +1,137 @@
+/*
+ * lrhip.h - C ABI of liblrhip.so, the MI355X (gfx950) DSP block engine behind LuaRadio's block API.
+ *
+ * This is the drop-in boundary: what a LuaJIT `ffi.cdef` (see INTEGRATION.md and lua/radio/) binds in
+ * place of the VOLK / liquid-dsp / FFTW3f entry points the reference's blocks call from process().
+ * Plain pointers and sizes only; no C++ or torch types.  All paths below are relative to /root/reference.
+ *
+ * Conventions (liquid-dsp style, as used by the reference at radio/blocks/signal/firfilter.lua:167-226):
+ *   - `T *q = lrhip_X_create(params)` returns NULL on error (the reference's blocks then raise
+ *     `error("Creating ... object")`, firfilter.lua:199-201); `lrhip_strerror()` gives the text.
+ *   - `lrhip_stage_execute(q, in, n, out, cap)` is one block's process(): host pointers in, host pointers
+ *     out, returns the number of output samples written (>= 0) or < 0 on error.  All cross-call state
+ *     (FIR history, rotator phase, downsampler index, discriminator previous sample, IIR state) lives in
+ *     the stage object on the device, so arbitrary chunking gives identical sample values
+ *     (the property tests/jigs.lua:213-250 pins with one-sample chunks).
+ *   - `lrhip_stage_destroy(q)` is bound with ffi.gc.
+ *   - Sample layouts are the reference's: ComplexFloat32 = struct{float real, imag} (8 B, interleaved,
+ *     radio/types/complexfloat32.lua:19-24), Float32 = struct{float value} (4 B, radio/types/float32.lua:17-21).
+ *   - Nothing here throws, aborts or prints.  Single-threaded use per process, like a LuaRadio block
+ *     (one process per block after fork(): radio/core/composite.lua:569); lrhip_init() must first be
+ *     called AFTER fork (it creates the HIP context lazily on first use).
+ */
+#ifndef LRHIP_H
+#define LRHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lrhip_stage lrhip_stage_t;   /* one block's device state + kernels */
+typedef struct lrhip_chain lrhip_chain_t;   /* a linear run of stages with device-resident edges */
+
+/* ---- runtime -------------------------------------------------------------------------------------- */
+/* Select the device and create the stream.  Replaces platform.load()/feature detection for a native
+ * library (radio/core/platform.lua:277-299).  device < 0 => current device.  Idempotent. */
+int lrhip_init(int device);
+/* Text of the last error on this thread ("" if none). */
+const char *lrhip_strerror(void);
+/* Number of visible HIP devices (for the fan-out scheduler), or < 0 on error. */
+int lrhip_device_count(void);
+/* Launch all subsequent work on an externally owned hipStream_t (NULL => the library's own stream). */
+int lrhip_set_stream(void *hip_stream);
+/* Block until everything queued by this library has finished. */
+int lrhip_synchronize(void);
+/* Library version string. */
+const char *lrhip_version(void);
+
+/* ---- stage constructors ---------------------------------------------------------------------------- */
+/* FIRFilterBlock (firfilter.lua:43-74 instantiate, :90-163 / :230-305 dot-product form, :320-398 overlap-save
+ * framing).  taps: ntaps floats (taps_complex = 0) or ntaps {re,im} pairs (taps_complex = 1), in the
+ * reference's natural order h[0..M-1] (the library reverses them, :234-238).  input_complex selects
+ * ComplexFloat32 or Float32 samples; complex taps require complex input (:69-74).
+ * decim >= 1 fuses a following DownsamplerBlock(decim) (radio/composites/decimator.lua:37-39): only every
+ * decim-th filter output is computed and emitted, with the downsampler's carried phase index.
+ * use_fft != 0 reproduces the overlap-save emission framing (:451: only whole L = N-M+1 blocks are
+ * emitted, N = 2^floor(log2(8M)); the tail is retained) - sample values are the same. */
+lrhip_stage_t *lrhip_fir_create(const float *taps, unsigned ntaps, int taps_complex, int input_complex,
+                                unsigned decim, int use_fft);
+/* FrequencyTranslatorBlock (radio/blocks/signal/frequencytranslator.lua:26-53, :93-110):
+ * y[n] = x[n] * exp(j*omega*n), omega = 2*pi*offset/rate computed by the caller as at :95. */
+lrhip_stage_t *lrhip_rotator_create(double omega);
+/* DownsamplerBlock (radio/blocks/signal/downsampler.lua:29-56). elem_size = 8 (ComplexFloat32) or 4 (Float32). */
+lrhip_stage_t *lrhip_downsampler_create(unsigned factor, int elem_size);
+/* FrequencyDiscriminatorBlock (radio/blocks/signal/frequencydiscriminator.lua:25-38, :48-88).
+ * gain = 2*pi*modulation_index (:28).  ComplexFloat32 in, Float32 out. */
+lrhip_stage_t *lrhip_fmdiscrim_create(double gain);
+/* IIRFilterBlock (radio/blocks/signal/iirfilter.lua:39-61, :113-181): b[nb] feed-forward, a[na] feedback
+ * (a[0] divides).  SinglepoleLowpassFilterBlock / FMDeemphasisFilterBlock compute b,a on the host
+ * (singlepolelowpassfilter.lua:55-67) and call this with nb = na = 2. */
+lrhip_stage_t *lrhip_iir_create(const float *b, unsigned nb, const float *a, unsigned na, int input_complex);
+/* spectrum_utils.PSD (radio/utilities/spectrum_utils.lua:522-561, :585-640) over frames of n samples:
+ * window multiply -> n-point DFT -> |X|^2/scale -> optional 10*log10 -> optional fftshift (:654-667).
+ * window: n floats (the caller builds the periodic window as at :547); scale = sample_rate * sum(w^2) (:597).
+ * Input n_in must be a multiple of n; output is n_in Float32 values.  n must be a power of two, 8..4096. */
+lrhip_stage_t *lrhip_psd_create(unsigned n, const float *window, double scale, int logarithmic,
+                                int input_complex, int fftshift);
+/* spectrum_utils.DFT / IDFT (spectrum_utils.lua:25-113, :259-349) over frames of n samples.
+ * inverse != 0 applies the 1/n normalisation (:335-338).  real_side: for forward transforms a Float32 input,
+ * for inverse transforms a Float32 output (real part, :499-503).  Complex side is ComplexFloat32. */
+lrhip_stage_t *lrhip_dft_create(unsigned n, int inverse, int real_side);
+
+void lrhip_stage_destroy(lrhip_stage_t *q);
+/* Back to the just-created state (zero history, phase 0, index 0). */
+int lrhip_stage_reset(lrhip_stage_t *q);
+/* Bytes per input / output sample (8 or 4). */
+int lrhip_stage_input_size(const lrhip_stage_t *q);
+int lrhip_stage_output_size(const lrhip_stage_t *q);
+/* Upper bound on the samples execute() will write for n_in inputs, so the caller can
+ * `self.out:resize()` first (firfilter.lua:130). */
+unsigned long lrhip_stage_max_output(const lrhip_stage_t *q, unsigned long n_in);
+
+/* ---- execution --------------------------------------------------------------------------------------- */
+/* One block's process() with host buffers: H2D through a pinned ring, kernels, D2H, wait.
+ * Returns the number of output samples written, or < 0. */
+long lrhip_stage_execute(lrhip_stage_t *q, const void *in_host, unsigned long n_in,
+                         void *out_host, unsigned long out_capacity);
+/* Same, with device pointers, asynchronous on the library stream (no copies, no wait).  The output count is
+ * known on the host without a device round-trip.  This is what chains and bench.py use. */
+long lrhip_stage_execute_device(lrhip_stage_t *q, const void *in_dev, unsigned long n_in,
+                                void *out_dev, unsigned long out_capacity);
+
+/* ---- chains: several blocks, device-resident edges ------------------------------------------------------ */
+/* A maximal linear run of device-capable blocks collapsed into one object (what CompositeBlock's
+ * _prepare_to_run would build, radio/core/composite.lua:426): one H2D at the head, one D2H at the tail,
+ * intermediate vectors never leave HBM.  The chain borrows the stages (caller keeps ownership) and fuses
+ * adjacent stages where a fused kernel exists (rotator -> FIR -> downsampler, FIR -> downsampler). */
+lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages);
+void lrhip_chain_destroy(lrhip_chain_t *c);
+unsigned long lrhip_chain_max_output(const lrhip_chain_t *c, unsigned long n_in);
+long lrhip_chain_execute(lrhip_chain_t *c, const void *in_host, unsigned long n_in,
+                         void *out_host, unsigned long out_capacity);
+long lrhip_chain_execute_device(lrhip_chain_t *c, const void *in_dev, unsigned long n_in,
+                                void *out_dev, unsigned long out_capacity);
+/* Number of kernels launched by the last chain execute (diagnostic for the fusion tests). */
+int lrhip_chain_last_launches(const lrhip_chain_t *c);
+
+/* ---- device memory helpers for FFI callers that want resident vectors ------------------------------------- */
+void *lrhip_malloc(unsigned long bytes);
+void  lrhip_free(void *dev_ptr);
+int   lrhip_memcpy_h2d(void *dev_dst, const void *host_src, unsigned long bytes);
+int   lrhip_memcpy_d2h(void *host_dst, const void *dev_src, unsigned long bytes);
+/* Pinned host vectors (what radio/core/vector.lua's platform.alloc would return for device-fed blocks). */
+void *lrhip_host_alloc(unsigned long bytes);
+void  lrhip_host_free(void *host_ptr);
+
+/* ---- timing on the library stream (HIP events; used by bench.py for the roofline figure) ------------------- */
+typedef struct lrhip_timer lrhip_timer_t;
+lrhip_timer_t *lrhip_timer_create(void);
+void  lrhip_timer_destroy(lrhip_timer_t *t);
+int   lrhip_timer_start(lrhip_timer_t *t);   /* records an event on the current stream */
+int   lrhip_timer_stop(lrhip_timer_t *t);    /* records the closing event */
+double lrhip_timer_elapsed_ms(lrhip_timer_t *t);   /* waits for the closing event; < 0 on error */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRHIP_H */

@@ -1,0 +1,73 @@
+---
+-- Device variants of FrequencyTranslatorBlock (radio/blocks/signal/frequencytranslator.lua:32-53),
+-- DownsamplerBlock (downsampler.lua:40-56), FrequencyDiscriminatorBlock (frequencydiscriminator.lua:33-64)
+-- and IIRFilterBlock (iirfilter.lua:79-109). Each is the `if platform.features.hip then` branch of the
+-- corresponding file; instantiate() and type signatures are unchanged.  Stages are created lazily on the
+-- first process() because initialize() runs pre-fork (radio/core/composite.lua:443 vs :569).
+
+local ffi = require('ffi')
+
+local lrhip = require('radio.core.lrhip')
+local types = require('radio.types')
+
+local M = {}
+
+local function lazy(self, create)
+    if self.stage == nil then
+        lrhip.ensure()
+        self.stage = ffi.gc(lrhip.check_object(create(), "Creating lrhip " .. self.name .. " object"),
+                            lrhip.lib.lrhip_stage_destroy)
+    end
+    return self.stage
+end
+
+function M.patch_frequencytranslator(FrequencyTranslatorBlock)
+    function FrequencyTranslatorBlock:initialize()
+        self.omega = 2*math.pi*(self.offset/self:get_rate())
+        self.out = types.ComplexFloat32.vector()
+    end
+    function FrequencyTranslatorBlock:process(x)
+        local stage = lazy(self, function () return lrhip.lib.lrhip_rotator_create(self.omega) end)
+        return lrhip.execute(stage, x, self.out)
+    end
+end
+
+function M.patch_downsampler(DownsamplerBlock)
+    function DownsamplerBlock:initialize()
+        self.out = self:get_input_type().vector()
+    end
+    function DownsamplerBlock:process(x)
+        local stage = lazy(self, function ()
+            return lrhip.lib.lrhip_downsampler_create(self.factor, ffi.sizeof(self:get_input_type()))
+        end)
+        return lrhip.execute(stage, x, self.out)
+    end
+end
+
+function M.patch_frequencydiscriminator(FrequencyDiscriminatorBlock)
+    function FrequencyDiscriminatorBlock:initialize()
+        self.out = types.Float32.vector()
+    end
+    function FrequencyDiscriminatorBlock:process(x)
+        local stage = lazy(self, function () return lrhip.lib.lrhip_fmdiscrim_create(self.gain) end)
+        return lrhip.execute(stage, x, self.out)
+    end
+end
+
+function M.patch_iirfilter(IIRFilterBlock)
+    function IIRFilterBlock:initialize()
+        self.out = self:get_input_type().vector()
+    end
+    local function process(self, x)
+        local stage = lazy(self, function ()
+            return lrhip.lib.lrhip_iir_create(ffi.cast("const float *", self.b_taps.data), self.b_taps.length,
+                                              ffi.cast("const float *", self.a_taps.data), self.a_taps.length,
+                                              (self:get_input_type() == types.ComplexFloat32) and 1 or 0)
+        end)
+        return lrhip.execute(stage, x, self.out)
+    end
+    IIRFilterBlock.process_complex = process
+    IIRFilterBlock.process_real = process
+end
+
+return M

@@ -1,0 +1,117 @@
+---
+-- LuaJIT FFI binding of liblrhip.so (include/lrhip.h), the MI355X DSP block engine.
+--
+-- Drop-in for a LuaRadio checkout: copy this file to radio/core/lrhip.lua. It registers the library the
+-- same way radio/core/platform.lua:277-299 registers VOLK / liquid-dsp / FFTW3f: `platform.libs.hip` and
+-- `platform.features.hip`, with the `LUARADIO_DISABLE_HIP` escape hatch mirroring platform.lua:328-330.
+--
+-- NOTE: LuaJIT is not installed in the build image, so this file is exercised only by the structural test
+-- tests/test_host_cpu.py::test_lua_glue_declares_the_same_abi; the identical call sequence is exercised
+-- through Python ctypes (luaradio_amd/_lib.py).
+--
+-- @module radio.core.lrhip
+
+local ffi = require('ffi')
+
+local platform = require('radio.core.platform')
+
+ffi.cdef[[
+typedef struct lrhip_stage lrhip_stage_t;
+typedef struct lrhip_chain lrhip_chain_t;
+typedef struct lrhip_timer lrhip_timer_t;
+
+int lrhip_init(int device);
+const char *lrhip_strerror(void);
+int lrhip_device_count(void);
+int lrhip_set_stream(void *hip_stream);
+int lrhip_synchronize(void);
+const char *lrhip_version(void);
+
+lrhip_stage_t *lrhip_fir_create(const float *taps, unsigned ntaps, int taps_complex, int input_complex, unsigned decim, int use_fft);
+lrhip_stage_t *lrhip_rotator_create(double omega);
+lrhip_stage_t *lrhip_downsampler_create(unsigned factor, int elem_size);
+lrhip_stage_t *lrhip_fmdiscrim_create(double gain);
+lrhip_stage_t *lrhip_iir_create(const float *b, unsigned nb, const float *a, unsigned na, int input_complex);
+lrhip_stage_t *lrhip_psd_create(unsigned n, const float *window, double scale, int logarithmic, int input_complex, int fftshift);
+lrhip_stage_t *lrhip_dft_create(unsigned n, int inverse, int real_side);
+void lrhip_stage_destroy(lrhip_stage_t *q);
+int lrhip_stage_reset(lrhip_stage_t *q);
+int lrhip_stage_input_size(const lrhip_stage_t *q);
+int lrhip_stage_output_size(const lrhip_stage_t *q);
+unsigned long lrhip_stage_max_output(const lrhip_stage_t *q, unsigned long n_in);
+long lrhip_stage_execute(lrhip_stage_t *q, const void *in_host, unsigned long n_in, void *out_host, unsigned long out_capacity);
+long lrhip_stage_execute_device(lrhip_stage_t *q, const void *in_dev, unsigned long n_in, void *out_dev, unsigned long out_capacity);
+
+lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages);
+void lrhip_chain_destroy(lrhip_chain_t *c);
+unsigned long lrhip_chain_max_output(const lrhip_chain_t *c, unsigned long n_in);
+long lrhip_chain_execute(lrhip_chain_t *c, const void *in_host, unsigned long n_in, void *out_host, unsigned long out_capacity);
+long lrhip_chain_execute_device(lrhip_chain_t *c, const void *in_dev, unsigned long n_in, void *out_dev, unsigned long out_capacity);
+int lrhip_chain_last_launches(const lrhip_chain_t *c);
+
+void *lrhip_malloc(unsigned long bytes);
+void lrhip_free(void *dev_ptr);
+int lrhip_memcpy_h2d(void *dev_dst, const void *host_src, unsigned long bytes);
+int lrhip_memcpy_d2h(void *host_dst, const void *dev_src, unsigned long bytes);
+void *lrhip_host_alloc(unsigned long bytes);
+void lrhip_host_free(void *host_ptr);
+
+lrhip_timer_t *lrhip_timer_create(void);
+void lrhip_timer_destroy(lrhip_timer_t *t);
+int lrhip_timer_start(lrhip_timer_t *t);
+int lrhip_timer_stop(lrhip_timer_t *t);
+double lrhip_timer_elapsed_ms(lrhip_timer_t *t);
+]]
+
+local M = {available = false}
+
+if not os.getenv("LUARADIO_DISABLE_HIP") then
+    local ok, lib = pcall(ffi.load, "lrhip")
+    if not ok then ok, lib = pcall(ffi.load, "liblrhip.so") end
+    if ok then
+        M.lib = lib
+        M.available = true
+        platform.libs.hip = lib
+        platform.features.hip = true
+    end
+end
+
+---
+-- Raise a Lua error carrying the library's message, the way the reference raises
+-- `error("Creating liquid firfilt object.")` (radio/blocks/signal/firfilter.lua:199-201).
+function M.check_object(obj, what)
+    if obj == nil then
+        error(what .. ": " .. ffi.string(M.lib.lrhip_strerror()))
+    end
+    return obj
+end
+
+---
+-- The device context must be created in the block's own process: CompositeBlock calls initialize() in the
+-- parent before fork() (radio/core/composite.lua:443 vs :569), so device blocks create their stage lazily on
+-- the first process() call.  ensure() is what they call first.
+local initialized_pid = nil
+function M.ensure()
+    local pid = ffi.C.getpid()
+    if initialized_pid ~= pid then
+        if M.lib.lrhip_init(-1) ~= 0 then
+            error("lrhip_init: " .. ffi.string(M.lib.lrhip_strerror()))
+        end
+        initialized_pid = pid
+    end
+end
+
+---
+-- One process() call: resize the output vector to the bound, execute, trim (firfilter.lua:130 pattern).
+function M.execute(stage, x, out)
+    local lib = M.lib
+    local cap = tonumber(lib.lrhip_stage_max_output(stage, x.length))
+    out:resize(cap)
+    local n = tonumber(lib.lrhip_stage_execute(stage, x.data, x.length, out.data, cap))
+    if n < 0 then
+        error("lrhip_stage_execute: " .. ffi.string(lib.lrhip_strerror()))
+    end
+    return out:resize(n)
+end
+
+return M

@@ -1,0 +1,15 @@
+"""luaradio_amd - MI355X-native DSP block engine behind LuaRadio's block API (hot path only).
+
+Python mirror of the reference's Lua host side (radio.block / radio.types / blocks / composites) over the
+C ABI of liblrhip.so (include/lrhip.h).  The Lua glue a LuaRadio checkout would use is under lua/.
+"""
+from . import _lib, filter_utils, spectrum_utils, types, window_utils  # noqa: F401
+from ._lib import LrhipError, init  # noqa: F401
+from .block import Block, Input, Output  # noqa: F401
+from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock, FIRFilterBlock,  # noqa: F401
+                     FMDeemphasisFilterBlock, FrequencyDiscriminatorBlock, FrequencyTranslatorBlock,
+                     HighpassFilterBlock, IIRFilterBlock, LowpassFilterBlock, SinglepoleLowpassFilterBlock)
+from .composites import (Chain, CompositeBlock, DecimatorBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401
+                         wbfm_mono_receiver)
+
+version = "0.1.0"

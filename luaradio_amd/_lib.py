@@ -1,0 +1,97 @@
+"""ctypes binding of liblrhip.so - exactly the declarations a LuaJIT ffi.cdef of include/lrhip.h makes.
+
+The product path FAILS LOUDLY when the HIP library is missing or no GPU is visible: there is no CPU
+fallback anywhere in this package (the CPU oracle under oracle/ is test infrastructure and is never
+imported from here).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblrhip.so")
+
+
+class LrhipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_vp, _ul, _fp = C.c_void_p, C.c_ulong, C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); mirrors include/lrhip.h one to one
+SIGNATURES = {
+    "lrhip_init": (C.c_int, [C.c_int]),
+    "lrhip_strerror": (C.c_char_p, []),
+    "lrhip_device_count": (C.c_int, []),
+    "lrhip_set_stream": (C.c_int, [_vp]),
+    "lrhip_synchronize": (C.c_int, []),
+    "lrhip_version": (C.c_char_p, []),
+    "lrhip_fir_create": (_vp, [_fp, C.c_uint, C.c_int, C.c_int, C.c_uint, C.c_int]),
+    "lrhip_rotator_create": (_vp, [C.c_double]),
+    "lrhip_downsampler_create": (_vp, [C.c_uint, C.c_int]),
+    "lrhip_fmdiscrim_create": (_vp, [C.c_double]),
+    "lrhip_iir_create": (_vp, [_fp, C.c_uint, _fp, C.c_uint, C.c_int]),
+    "lrhip_psd_create": (_vp, [C.c_uint, _fp, C.c_double, C.c_int, C.c_int, C.c_int]),
+    "lrhip_dft_create": (_vp, [C.c_uint, C.c_int, C.c_int]),
+    "lrhip_stage_destroy": (None, [_vp]),
+    "lrhip_stage_reset": (C.c_int, [_vp]),
+    "lrhip_stage_input_size": (C.c_int, [_vp]),
+    "lrhip_stage_output_size": (C.c_int, [_vp]),
+    "lrhip_stage_max_output": (_ul, [_vp, _ul]),
+    "lrhip_stage_execute": (C.c_long, [_vp, _vp, _ul, _vp, _ul]),
+    "lrhip_stage_execute_device": (C.c_long, [_vp, _vp, _ul, _vp, _ul]),
+    "lrhip_chain_create": (_vp, [C.POINTER(_vp), C.c_uint]),
+    "lrhip_chain_destroy": (None, [_vp]),
+    "lrhip_chain_max_output": (_ul, [_vp, _ul]),
+    "lrhip_chain_execute": (C.c_long, [_vp, _vp, _ul, _vp, _ul]),
+    "lrhip_chain_execute_device": (C.c_long, [_vp, _vp, _ul, _vp, _ul]),
+    "lrhip_chain_last_launches": (C.c_int, [_vp]),
+    "lrhip_malloc": (_vp, [_ul]),
+    "lrhip_free": (None, [_vp]),
+    "lrhip_memcpy_h2d": (C.c_int, [_vp, _vp, _ul]),
+    "lrhip_memcpy_d2h": (C.c_int, [_vp, _vp, _ul]),
+    "lrhip_host_alloc": (_vp, [_ul]),
+    "lrhip_host_free": (None, [_vp]),
+    "lrhip_timer_create": (_vp, []),
+    "lrhip_timer_destroy": (None, [_vp]),
+    "lrhip_timer_start": (C.c_int, [_vp]),
+    "lrhip_timer_stop": (C.c_int, [_vp]),
+    "lrhip_timer_elapsed_ms": (C.c_double, [_vp]),
+}
+
+
+def load():
+    """dlopen liblrhip.so and declare every entry point. Raises LrhipError if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LrhipError("liblrhip.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "or `make -C luaradio_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)      # AttributeError here == missing export
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return load().lrhip_strerror().decode()
+
+
+def check(rc, what):
+    if rc is None or (isinstance(rc, int) and rc < 0):
+        raise LrhipError("%s: %s" % (what, last_error()))
+    return rc
+
+
+def check_ptr(p, what):
+    if not p:
+        raise LrhipError("%s: %s" % (what, last_error()))
+    return p
+
+
+def init(device=-1):
+    check(load().lrhip_init(device), "lrhip_init")

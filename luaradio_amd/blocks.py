@@ -1,0 +1,189 @@
+"""Device variants of the signal blocks on the hot path (same names, arguments and semantics as the
+reference's radio/blocks/signal/*.lua).  All arithmetic runs in liblrhip.so on the GPU; this file is the
+host glue the reference keeps in Lua (tap design, argument checks, rate bookkeeping).
+"""
+import math
+
+import numpy as np
+
+from . import _lib, filter_utils, types
+from .block import Block, Input, Output, _fptr, as_taps
+
+
+class FIRFilterBlock(Block):
+    """radio/blocks/signal/firfilter.lua.  FIRFilterBlock(taps[, use_fft]).
+
+    use_fft=True reproduces the overlap-save emission framing of firfilter.lua:361-398 (only whole
+    L = N-M+1 blocks are emitted); the default here is False - there is no FFTW on the device path and the
+    direct form is what the MFMA kernel computes."""
+    name = "FIRFilterBlock"
+
+    def instantiate(self, taps, use_fft=None):
+        self.taps = as_taps(taps)
+        self.use_fft = bool(use_fft) if use_fft is not None else False
+        self.decimation = 1
+        if self.taps.dtype == np.complex64:      # firfilter.lua:68-74
+            self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+        else:
+            self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+            self.add_type_signature([Input("in", types.Float32)], [Output("out", types.Float32)])
+
+    def initialize(self):
+        L = _lib.load()
+        tc = self.taps.dtype == np.complex64
+        flat = self.taps.view(np.float32) if tc else self.taps
+        self._set_stage(L.lrhip_fir_create(_fptr(flat), len(self.taps), int(tc),
+                                           int(self.get_input_type() is types.ComplexFloat32),
+                                           self.decimation, int(self.use_fft)),
+                        "Creating lrhip fir object")
+
+    def process(self, x):
+        return self._execute(x, self.get_output_type().dtype)
+
+
+class LowpassFilterBlock(FIRFilterBlock):
+    """radio/blocks/signal/lowpassfilter.lua:32-50. LowpassFilterBlock(num_taps, cutoff[, nyquist[, window]])."""
+    name = "LowpassFilterBlock"
+
+    def instantiate(self, num_taps, cutoff, nyquist=None, window=None):
+        assert num_taps, "Missing argument #1 (num_taps)"
+        assert cutoff is not None, "Missing argument #2 (cutoff)"
+        self.cutoff = cutoff
+        self.window = window or "hamming"
+        self.nyquist = nyquist
+        FIRFilterBlock.instantiate(self, types.Float32.vector(num_taps))
+
+    def _design(self, nyquist):
+        return filter_utils.firwin_lowpass(len(self.taps), self.cutoff / nyquist, self.window)
+
+    def initialize(self):
+        nyquist = self.nyquist or (self.get_rate() / 2)       # lowpassfilter.lua:43
+        self.taps = types.Float32.vector_from_array(self._design(nyquist))
+        FIRFilterBlock.initialize(self)
+
+
+class HighpassFilterBlock(LowpassFilterBlock):
+    """radio/blocks/signal/highpassfilter.lua"""
+    name = "HighpassFilterBlock"
+
+    def _design(self, nyquist):
+        return filter_utils.firwin_highpass(len(self.taps), self.cutoff / nyquist, self.window)
+
+
+class BandpassFilterBlock(LowpassFilterBlock):
+    """radio/blocks/signal/bandpassfilter.lua: cutoff = {low, high}"""
+    name = "BandpassFilterBlock"
+
+    def _design(self, nyquist):
+        return filter_utils.firwin_bandpass(len(self.taps), [self.cutoff[0] / nyquist, self.cutoff[1] / nyquist], self.window)
+
+
+class BandstopFilterBlock(LowpassFilterBlock):
+    """radio/blocks/signal/bandstopfilter.lua: cutoff = {low, high}"""
+    name = "BandstopFilterBlock"
+
+    def _design(self, nyquist):
+        return filter_utils.firwin_bandstop(len(self.taps), [self.cutoff[0] / nyquist, self.cutoff[1] / nyquist], self.window)
+
+
+class FrequencyTranslatorBlock(Block):
+    """radio/blocks/signal/frequencytranslator.lua:26-30, :93-110. FrequencyTranslatorBlock(offset)."""
+    name = "FrequencyTranslatorBlock"
+
+    def instantiate(self, offset):
+        assert offset is not None, "Missing argument #1 (offset)"
+        self.offset = offset
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+
+    def initialize(self):
+        self.omega = 2 * math.pi * (self.offset / self.get_rate())     # frequencytranslator.lua:95
+        self._set_stage(_lib.load().lrhip_rotator_create(self.omega), "Creating lrhip rotator object")
+
+    def process(self, x):
+        return self._execute(x, np.complex64)
+
+
+class DownsamplerBlock(Block):
+    """radio/blocks/signal/downsampler.lua:29-56. DownsamplerBlock(factor)."""
+    name = "DownsamplerBlock"
+
+    def instantiate(self, factor):
+        assert factor, "Missing argument #1 (factor)"
+        self.factor = int(factor)
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+        self.add_type_signature([Input("in", types.Float32)], [Output("out", types.Float32)])
+
+    def get_rate(self):
+        return Block.get_rate(self) / self.factor          # downsampler.lua:36-38
+
+    def initialize(self):
+        self._set_stage(_lib.load().lrhip_downsampler_create(self.factor, self.get_input_type().size),
+                        "Creating lrhip downsampler object")
+
+    def process(self, x):
+        return self._execute(x, self.get_output_type().dtype)
+
+
+class FrequencyDiscriminatorBlock(Block):
+    """radio/blocks/signal/frequencydiscriminator.lua:25-38. FrequencyDiscriminatorBlock(modulation_index)."""
+    name = "FrequencyDiscriminatorBlock"
+
+    def instantiate(self, modulation_index):
+        assert modulation_index, "Missing argument #1 (modulation_index)"
+        self.gain = 2 * math.pi * modulation_index          # frequencydiscriminator.lua:28
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.Float32)])
+
+    def initialize(self):
+        self._set_stage(_lib.load().lrhip_fmdiscrim_create(self.gain), "Creating lrhip fmdiscrim object")
+
+    def process(self, x):
+        return self._execute(x, np.float32)
+
+
+class IIRFilterBlock(Block):
+    """radio/blocks/signal/iirfilter.lua:39-61. IIRFilterBlock(b_taps, a_taps)."""
+    name = "IIRFilterBlock"
+
+    def instantiate(self, b_taps, a_taps):
+        assert b_taps is not None, "Missing argument #1 (b_taps)"
+        assert a_taps is not None, "Missing argument #2 (a_taps)"
+        self.b_taps = types.Float32.vector_from_array(b_taps)
+        self.a_taps = types.Float32.vector_from_array(a_taps)
+        assert len(self.a_taps) >= 1, "Feedback taps must be at least length 1"
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+        self.add_type_signature([Input("in", types.Float32)], [Output("out", types.Float32)])
+
+    def initialize(self):
+        self._set_stage(_lib.load().lrhip_iir_create(_fptr(self.b_taps), len(self.b_taps), _fptr(self.a_taps), len(self.a_taps),
+                                                     int(self.get_input_type() is types.ComplexFloat32)),
+                        "Creating lrhip iir object")
+
+    def process(self, x):
+        return self._execute(x, self.get_output_type().dtype)
+
+
+class SinglepoleLowpassFilterBlock(IIRFilterBlock):
+    """radio/blocks/signal/singlepolelowpassfilter.lua:27-67. SinglepoleLowpassFilterBlock(cutoff)."""
+    name = "SinglepoleLowpassFilterBlock"
+
+    def instantiate(self, cutoff):
+        assert cutoff, "Missing argument #1 (cutoff)"
+        self.cutoff = cutoff
+        IIRFilterBlock.instantiate(self, types.Float32.vector(2), types.Float32.vector(2))
+
+    def initialize(self):
+        rate = self.get_rate()
+        tau = 1 / (2 * math.pi * self.cutoff)                       # :57
+        tau = 1 / (2 * rate * math.tan(1 / (2 * rate * tau)))       # :58 pre-warp
+        self.b_taps = types.Float32.vector_from_array([1 / (1 + 2 * tau * rate), 1 / (1 + 2 * tau * rate)])
+        self.a_taps = types.Float32.vector_from_array([1, (1 - 2 * tau * rate) / (1 + 2 * tau * rate)])
+        IIRFilterBlock.initialize(self)
+
+
+class FMDeemphasisFilterBlock(SinglepoleLowpassFilterBlock):
+    """radio/blocks/signal/fmdeemphasisfilter.lua:24-27. FMDeemphasisFilterBlock(tau)."""
+    name = "FMDeemphasisFilterBlock"
+
+    def instantiate(self, tau):
+        assert tau, "Missing argument #1 (tau)"
+        SinglepoleLowpassFilterBlock.instantiate(self, 1 / (2 * math.pi * tau))

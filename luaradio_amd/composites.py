@@ -1,0 +1,169 @@
+"""Composite blocks and the linear-run collapse (host side).
+
+The reference's CompositeBlock (radio/core/composite.lua) forks one process per block and moves every
+vector over a UNIX socket per edge (radio/core/pipe.lua:53-69).  Here a maximal linear run of
+device-capable blocks is collapsed into ONE `lrhip_chain_t` (include/lrhip.h): one H2D at the head, one
+D2H at the tail, device-resident edges in between, and adjacent rotator / FIR / downsampler blocks fused
+into a single decimating kernel.  Mirrors connect() (:111), rate propagation (:394), differentiate (:314)
+and initialize (:416-424) for linear graphs, which is all the hot path's composites need.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, types
+from .block import Block, Input, Output
+from . import blocks as B
+
+
+class Chain:
+    """A linear run of initialized device blocks executed as one lrhip_chain_t."""
+
+    def __init__(self, blocks):
+        self.blocks = list(blocks)
+        L = _lib.load()
+        arr = (C.c_void_p * len(self.blocks))(*[b.stage_handle() for b in self.blocks])
+        self._chain = _lib.check_ptr(L.lrhip_chain_create(arr, len(self.blocks)), "Creating lrhip chain object")
+        self.in_type = self.blocks[0].get_input_type()
+        self.out_type = self.blocks[-1].get_output_type()
+
+    def __del__(self):
+        try:
+            if self._chain:
+                _lib.load().lrhip_chain_destroy(self._chain)
+                self._chain = None
+        except Exception:
+            pass
+
+    def max_output(self, n_in):
+        return _lib.load().lrhip_chain_max_output(self._chain, n_in)
+
+    def process(self, x):
+        L = _lib.load()
+        x = np.ascontiguousarray(x)
+        if x.dtype != self.in_type.dtype:
+            raise TypeError("chain expects %s input, got %s" % (self.in_type, x.dtype))
+        cap = L.lrhip_chain_max_output(self._chain, len(x))
+        out = np.empty(cap, dtype=self.out_type.dtype)
+        n = L.lrhip_chain_execute(self._chain, x.ctypes.data_as(C.c_void_p), len(x), out.ctypes.data_as(C.c_void_p), cap)
+        _lib.check(n, "chain:process")
+        return out[:n]
+
+    def process_device(self, in_ptr, n_in, out_ptr, out_capacity):
+        n = _lib.load().lrhip_chain_execute_device(self._chain, in_ptr, n_in, out_ptr, out_capacity)
+        return _lib.check(n, "chain:process_device")
+
+    @property
+    def last_launches(self):
+        return _lib.load().lrhip_chain_last_launches(self._chain)
+
+
+class CompositeBlock(Block):
+    """Linear composite: connect(b1, b2, ...) then differentiate / initialize / process like a block.
+
+    Rates propagate downstream through get_rate() overrides exactly as in the reference
+    (radio/core/block.lua:383-390; DownsamplerBlock divides, downsampler.lua:36-38)."""
+    name = "CompositeBlock"
+
+    def instantiate(self):
+        self._blocks = []
+        self._chain = None
+
+    def connect(self, *blocks):
+        for b in blocks:
+            if isinstance(b, CompositeBlock) and b is not self:
+                self._blocks.extend(b._blocks)
+            elif b is not self:
+                self._blocks.append(b)
+        return self
+
+    def differentiate(self, input_types):
+        t = list(input_types)
+        for b in self._blocks:
+            b.differentiate(t)
+            t = [b.get_output_type()]
+        self.signature = ([Input("in", input_types[0])], [Output("out", t[0])], None)
+
+    def get_rate(self):
+        return self._blocks[-1].get_rate() if self._blocks else Block.get_rate(self)
+
+    def _propagate_rates(self):
+        rate = Block.get_rate(self)
+        for b in self._blocks:
+            b.rate = rate
+            rate = b.get_rate()
+
+    def initialize(self):
+        self._propagate_rates()
+        for b in self._blocks:
+            b.initialize()
+        self._chain = Chain(self._blocks)
+
+    def process(self, x):
+        return self._chain.process(x)
+
+    def process_device(self, in_ptr, n_in, out_ptr, out_capacity):
+        return self._chain.process_device(in_ptr, n_in, out_ptr, out_capacity)
+
+    def max_output(self, n_in):
+        return self._chain.max_output(n_in)
+
+    @property
+    def chain(self):
+        return self._chain
+
+
+class DecimatorBlock(CompositeBlock):
+    """radio/composites/decimator.lua:28-42. DecimatorBlock(decimation[, {num_taps=, window=}])."""
+    name = "DecimatorBlock"
+
+    def instantiate(self, decimation, options=None):
+        CompositeBlock.instantiate(self)
+        assert decimation, "Missing argument #1 (decimation)"
+        options = options or {}
+        filt = B.LowpassFilterBlock(options.get("num_taps") or 128, 1 / decimation, 1.0, options.get("window"))
+        downsampler = B.DownsamplerBlock(decimation)
+        self.connect(filt, downsampler)
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+        self.add_type_signature([Input("in", types.Float32)], [Output("out", types.Float32)])
+
+
+class TunerBlock(CompositeBlock):
+    """radio/composites/tuner.lua:32-48. TunerBlock(offset, bandwidth, decimation[, options])."""
+    name = "TunerBlock"
+
+    def instantiate(self, offset, bandwidth, decimation, options=None):
+        CompositeBlock.instantiate(self)
+        assert offset is not None, "Missing argument #1 (offset)"
+        assert bandwidth, "Missing argument #2 (bandwidth)"
+        assert decimation, "Missing argument #3 (decimation)"
+        options = options or {}
+        translator = B.FrequencyTranslatorBlock(offset)
+        filt = B.LowpassFilterBlock(options.get("num_taps") or 128, bandwidth / 2, None, options.get("window"))
+        downsampler = B.DownsamplerBlock(decimation)
+        self.connect(translator, filt, downsampler)
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+
+
+class WBFMMonoDemodulator(CompositeBlock):
+    """radio/composites/wbfmmonodemodulator.lua:22-36. WBFMMonoDemodulator([tau])."""
+    name = "WBFMMonoDemodulator"
+
+    def instantiate(self, tau=None):
+        CompositeBlock.instantiate(self)
+        tau = tau or 75e-6
+        bandwidth = 15e3
+        self.connect(B.FrequencyDiscriminatorBlock(1.25), B.LowpassFilterBlock(128, bandwidth), B.FMDeemphasisFilterBlock(tau))
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.Float32)])
+
+
+def wbfm_mono_receiver(rate=1102500.0, tune_offset=-250e3):
+    """The compute blocks of examples/rtlsdr_wbfm_mono.lua:12-17,28 as one composite:
+    Tuner(-250e3, 200e3, 5) -> FrequencyDiscriminator(1.25) -> Lowpass(128, 15e3) -> FMDeemphasis(75e-6) -> Downsampler(5)."""
+    top = CompositeBlock()
+    top.connect(TunerBlock(tune_offset, 200e3, 5), B.FrequencyDiscriminatorBlock(1.25), B.LowpassFilterBlock(128, 15e3),
+                B.FMDeemphasisFilterBlock(75e-6), B.DownsamplerBlock(5))
+    top.rate = rate
+    top.differentiate([types.ComplexFloat32])
+    top.initialize()
+    return top

@@ -1,0 +1,274 @@
+// kernels_fir.h - FIRFilterBlock on CDNA4.
+//
+// Reference semantics (radio/blocks/signal/firfilter.lua:230-305): with s = [last M-1 inputs | chunk] and
+// taps_rev[j] = h[M-1-j], output k is  y[k] = sum_{j<M} taps_rev[j] * s[q_k + j]  (oldest sample first),
+// q_k = first + k*D  (D = 1 for a plain FIRFilterBlock; D > 1 fuses the following DownsamplerBlock,
+// radio/composites/decimator.lua:37-39, `first` being the downsampler's carried index).
+//
+// Two kernels:
+//   fir_mfma_kernel   real taps (rr / cr - the headline): the filter is applied as a banded-Toeplitz
+//                     matrix product on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32, = fmaf
+//                     chain in ascending-k order), data staged once per tile into LDS.
+//   fir_direct_kernel any taps/decimation (complex taps, very long filters, odd decimations): one output
+//                     per thread, taps via scalar loads, inputs through L1/L2.
+//
+// Both produce BIT-IDENTICAL results to the fmaf chain  acc = fmaf(s[q+j], taps_rev[j], acc), j ascending
+// (oracle LRO_MODE_FMA), for finite inputs.
+#pragma once
+#include "common.h"
+#include "kernels_elem.h"
+
+namespace lrhip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// s(p): the "state" vector of firfilter.lua:244-250 without materialising it:
+// p < M-1 -> hist[p] (carried), else x[p-(M-1)]; beyond the chunk reads as 0 (never used by a valid output).
+template <int S>
+__device__ __forceinline__ float stream_at(const float *__restrict__ hist, const float *__restrict__ x,
+                                           long p, int c, int M, long n)
+{
+    if (p < 0) return 0.0f;
+    if (p < M - 1) return hist[p * S + c];
+    long xi = p - (M - 1);
+    return xi < n ? x[xi * S + c] : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// history carry: hist_out[i] = s[n + i], i < M-1   (firfilter.lua:248 memmove of the last M-1 state samples)
+// ping-pong buffers, so it can run concurrently with nothing and after the filter kernel in stream order.
+// ------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void fir_history_kernel(const float *__restrict__ hist_in, const float *__restrict__ x,
+                                                          float *__restrict__ hist_out, int M, long n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (M - 1) * S) return;
+    int r = i / S, c = i % S;
+    hist_out[i] = stream_at<S>(hist_in, x, n + r, c, M, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Direct form, one output per thread.  MODE: 0 = rr, 1 = cr, 2 = cc.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void fir_direct_kernel(const float *__restrict__ hist, const float *__restrict__ x,
+                                                         const float *__restrict__ taps_rev, float *__restrict__ y,
+                                                         int M, long n, long n_out, long first, long D)
+{
+    constexpr int S = MODE == 0 ? 1 : 2;
+    long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_out) return;
+    long q = first + k * D;
+    float re = 0.f, im = 0.f;
+    for (int j = 0; j < M; j++) {
+        float xr = stream_at<S>(hist, x, q + j, 0, M, n);
+        if (MODE == 0) {
+            re = fmaf(xr, taps_rev[j], re);
+        } else if (MODE == 1) {
+            float xi = stream_at<S>(hist, x, q + j, 1, M, n);
+            float h = taps_rev[j];
+            re = fmaf(xr, h, re);
+            im = fmaf(xi, h, im);
+        } else {
+            float xi = stream_at<S>(hist, x, q + j, 1, M, n);
+            float hr = taps_rev[2 * j], hi = taps_rev[2 * j + 1];
+            re = fmaf(xr, hr, re);
+            re = fmaf(xi, -hi, re);
+            im = fmaf(xr, hi, im);
+            im = fmaf(xi, hr, im);
+        }
+    }
+    if (S == 1) y[k] = re;
+    else reinterpret_cast<float2 *>(y)[k] = make_float2(re, im);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Banded-Toeplitz MFMA FIR (real taps).
+//
+// One MFMA accumulator = 16 columns x 16 rows.  A column is (block, component): `block` = 16 consecutive
+// (decimated) outputs, component = re/im for ComplexFloat32 (S = 2) so an accumulator covers 16/S blocks =
+// 256/S output samples.  Row m of block b is output k = 16*b + m.  With the tile's input samples r = 0.. in
+// LDS (r = 0 is stream position first + tile_k0*D - e, `e` = 0..3 samples of slack that makes the global
+// source 16-B aligned), block b's window starts at r0 = 16*D*b and
+//        Y[m][col] = sum_t A[m][t] * X[t][col],   X[t][col] = lds[S*(r0 + t) + c],
+//        A[m][t]   = taps_rev[t - e - m*D]  (0 outside [0, M))          <- banded Toeplitz, built on the host
+// K = e + 15*D + M, issued as K/4 v_mfma_f32_16x16x4_f32 steps (A: lane -> A[m = lane&15][t = 4*step + (lane>>4)],
+// B: lane -> X[t = 4*step + (lane>>4)][col = lane&15]).  t ascends, zero entries add exactly 0, so every output
+// is the fmaf chain over its M taps in the reference's order.
+//
+// LDS layout: logical float address a = S*r + c; rows of ROW = 16*D*S floats are padded by PAD = 2*S floats
+// (physical = a + PAD*(a/ROW)), which makes the 32 lanes of each ds_read_b32 lane group hit 32 distinct banks
+// ((ROW+PAD)*b + S*k + c are all distinct mod 32 for the 16/S blocks x S components x 2 k's of a lane group).
+// B-fragment address = lane_base + immediate: the row-crossing term floor((S*t+c)/ROW) = floor(step/(4*D))
+// is lane-invariant.
+//
+// Work per workgroup (256 threads = 4 waves): 4*NACC accumulators = TILE_OUT = 1024*NACC/S output samples.
+// ------------------------------------------------------------------------------------------------
+template <int S, int D>
+struct FirMfmaGeom {
+    static constexpr int ROW = 16 * D * S;        // floats per LDS row (= one block's input stride)
+    static constexpr int PAD = 2 * S;             // floats of padding per row
+    static constexpr int BPA = 16 / S;            // blocks per accumulator
+    static constexpr int GROUP = 4 * D;           // MFMA steps per LDS row of t
+    __host__ __device__ static constexpr int tile_out(int nacc) { return 4 * nacc * BPA * 16; }
+    // samples staged per tile for `ksteps` MFMA steps (ksteps a multiple of GROUP)
+    __host__ __device__ static constexpr int span(int nacc, int ksteps) { return 16 * D * (4 * nacc * BPA - 1) + 4 * ksteps; }
+    __host__ __device__ static constexpr int phys(int a) { return a + PAD * (a / ROW); }
+};
+
+template <int S, int D, int NACC, bool ROT>
+__global__ __launch_bounds__(256) void fir_mfma_kernel(
+    const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ atab, float *__restrict__ y,
+    int M, long n, long n_out, long first, int e, int ksteps, int out_aligned,
+    uint64_t rot_step_fx, uint64_t rot_count0)
+{
+    using G = FirMfmaGeom<S, D>;
+    constexpr int TILE_OUT = G::tile_out(NACC);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ldsA = lds;                       // ksteps * 64 floats
+    float *ldsX = lds + ksteps * 64;         // staged samples (padded rows)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long tile_k0 = (long)blockIdx.x * TILE_OUT;
+    const long base = first + tile_k0 * D - e;               // stream position of r = 0
+    const int span = G::span(NACC, ksteps);                   // samples to stage
+    const int nflt = span * S;
+
+    // ---- A fragments (Toeplitz table for this launch's e) -> LDS
+    for (int i = tid; i < ksteps * 64; i += 256) ldsA[i] = atab[i];
+
+    // ---- stage the tile: global -> LDS (padded rows)
+    const long xlo = base - (M - 1);                          // x index of r = 0
+    const bool interior = (xlo >= 0) && (xlo + span <= n) && ((nflt & 3) == 0);
+    if (interior) {
+        const float4 *src = reinterpret_cast<const float4 *>(x + xlo * S);   // 16-B aligned by choice of e
+        for (int i4 = tid; i4 < nflt / 4; i4 += 256) {
+            float4 v = src[i4];
+            if (ROT) {   // fused FrequencyTranslatorBlock: rotate on the way in (S == 2)
+                float c0, s0, c1, s1;
+                uint64_t cnt = rot_count0 + (uint64_t)(xlo + 2 * (long)i4);
+                phasor_from_turns(rot_step_fx * cnt, c0, s0);
+                phasor_from_turns(rot_step_fx * (cnt + 1), c1, s1);
+                double xr = v.x, xi = v.y;
+                v.x = (float)(xr * (double)c0 - xi * (double)s0);
+                v.y = (float)(xr * (double)s0 + xi * (double)c0);
+                xr = v.z; xi = v.w;
+                v.z = (float)(xr * (double)c1 - xi * (double)s1);
+                v.w = (float)(xr * (double)s1 + xi * (double)c1);
+            }
+            int p = G::phys(4 * i4);
+            if (S == 2) {
+                *reinterpret_cast<float4 *>(ldsX + p) = v;
+            } else {
+                *reinterpret_cast<float2 *>(ldsX + p) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2 *>(ldsX + p + 2) = make_float2(v.z, v.w);
+            }
+        }
+    } else {
+        for (int r = tid; r < span; r += 256) {
+            long p = base + r;
+            float v0 = stream_at<S>(hist, x, p, 0, M, n);
+            float v1 = S == 2 ? stream_at<S>(hist, x, p, 1, M, n) : 0.f;
+            if (ROT) {
+                float c0, s0;
+                // absolute sample index of stream position p is rot_count0 + p - (M-1); history before the
+                // start of the stream is zero, so its phase is irrelevant
+                phasor_from_turns(rot_step_fx * (rot_count0 + (uint64_t)(p - (M - 1))), c0, s0);
+                double xr = v0, xi = v1;
+                v0 = (float)(xr * (double)c0 - xi * (double)s0);
+                v1 = (float)(xr * (double)s0 + xi * (double)c0);
+            }
+            int pa = G::phys(S * r);
+            ldsX[pa] = v0;
+            if (S == 2) ldsX[pa + 1] = v1;
+        }
+    }
+    __syncthreads();
+
+    // ---- MFMA main loop
+    const int col = lane & 15, kq = lane >> 4;
+    const int blk_in_acc = S == 2 ? (col >> 1) : col;
+    const int comp = S == 2 ? (col & 1) : 0;
+    constexpr int ACC_STRIDE = (G::ROW + G::PAD) * G::BPA;    // floats between consecutive accumulators' blocks
+    const float *bptr = ldsX + (G::ROW + G::PAD) * ((wave * NACC) * G::BPA + blk_in_acc) + S * kq + comp;
+    const float *aptr = ldsA + lane;
+
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ngroups = ksteps / G::GROUP;
+    for (int g = 0; g < ngroups; g++) {
+#pragma unroll
+        for (int j = 0; j < G::GROUP; j++) {
+            float av = aptr[j * 64];
+#pragma unroll
+            for (int a = 0; a < NACC; a++) {
+                float bv = bptr[a * ACC_STRIDE + j * 4 * S];
+                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[a], 0, 0, 0);
+            }
+        }
+        aptr += G::GROUP * 64;
+        bptr += G::ROW + G::PAD;
+    }
+
+    // ---- epilogue: accumulator lane (col, kq) holds rows 4*kq .. 4*kq+3 of column col
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+        const long kblk = tile_k0 + 16 * (long)((wave * NACC + a) * G::BPA + blk_in_acc);
+        if (S == 1) {
+            long k = kblk + 4 * kq;
+            if (out_aligned && k + 3 < n_out) {
+                *reinterpret_cast<float4 *>(y + k) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (k + r < n_out) y[k + r] = acc[a][r];
+            }
+        } else {
+            // even lane = re column, odd lane = im column of the same block: trade halves so each lane owns
+            // two whole ComplexFloat32 outputs (rows 4kq+{0,1} on the even lane, 4kq+{2,3} on the odd lane)
+            const bool odd = col & 1;
+            float send0 = odd ? acc[a][0] : acc[a][2];
+            float send1 = odd ? acc[a][1] : acc[a][3];
+            float recv0 = __shfl_xor(send0, 1);
+            float recv1 = __shfl_xor(send1, 1);
+            float4 o = odd ? make_float4(recv0, acc[a][2], recv1, acc[a][3])
+                           : make_float4(acc[a][0], recv0, acc[a][1], recv1);
+            long k = kblk + 4 * kq + (odd ? 2 : 0);
+            if (out_aligned && k + 1 < n_out) {
+                *reinterpret_cast<float4 *>(y + 2 * k) = o;
+            } else {
+                if (k < n_out) *reinterpret_cast<float2 *>(y + 2 * k) = make_float2(o.x, o.y);
+                if (k + 1 < n_out) *reinterpret_cast<float2 *>(y + 2 * k + 2) = make_float2(o.z, o.w);
+            }
+        }
+    }
+}
+
+// Host: build the Toeplitz A-fragment tables, one per alignment slack e in [0, 4/S):
+//   tab[e][step][lane] = A[m = lane&15][t = 4*step + (lane>>4)] = taps_rev[t - e - m*D]  (0 outside [0, M))
+// ksteps = (emax + 15*D + M) rounded up to a multiple of 4*D steps (zero rows; fma(0,b,acc) == acc).
+inline int fir_mfma_ksteps(int M, int D, int S)
+{
+    int emax = 4 / S - 1;
+    int K = emax + 15 * D + M;
+    int ks = (K + 3) / 4;
+    int group = 4 * D;
+    return (ks + group - 1) / group * group;
+}
+inline void fir_mfma_build_tables(const float *taps_rev, int M, int D, int S, int ksteps, std::vector<float> &out)
+{
+    int ne = 4 / S;
+    out.assign((size_t)ne * ksteps * 64, 0.f);
+    for (int e = 0; e < ne; e++)
+        for (int st = 0; st < ksteps; st++)
+            for (int lane = 0; lane < 64; lane++) {
+                int m = lane & 15, t = 4 * st + (lane >> 4);
+                int j = t - e - m * D;
+                if (j >= 0 && j < M) out[((size_t)e * ksteps + st) * 64 + lane] = taps_rev[j];
+            }
+}
+
+}  // namespace lrhip

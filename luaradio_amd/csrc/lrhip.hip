@@ -1,0 +1,866 @@
+// lrhip.hip - liblrhip.so: the C ABI of include/lrhip.h over the CDNA4 kernels in kernels_*.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o luaradio_amd/liblrhip.so lrhip.hip
+#include "../../include/lrhip.h"
+
+#include <cmath>
+#include <memory>
+
+#include "common.h"
+#include "kernels_elem.h"
+#include "kernels_fft.h"
+#include "kernels_fir.h"
+#include "kernels_iir.h"
+
+using namespace lrhip;
+
+static int g_launches = 0;   // kernels enqueued since the counter was last cleared (chain diagnostics)
+#define LR_LAUNCH_CHECK()                                                                              \
+    do {                                                                                               \
+        g_launches++;                                                                                  \
+        hipError_t e__ = hipGetLastError();                                                            \
+        if (e__ != hipSuccess) return set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+// =====================================================================================================
+// stage base
+// =====================================================================================================
+struct lrhip_stage {
+    int in_size = 8, out_size = 8;     // bytes per sample
+    PinnedBuf h_in, h_out;             // pinned staging for the host-pointer execute
+    DeviceBuf d_in, d_out;
+    virtual ~lrhip_stage() {}
+    virtual unsigned long max_output(unsigned long n_in) const { return n_in; }
+    virtual long run(const void *in_dev, unsigned long n_in, void *out_dev, unsigned long cap) = 0;
+    virtual int reset() = 0;
+    virtual const char *kind() const = 0;
+};
+
+static int upload(DeviceBuf &b, const void *src, size_t bytes)
+{
+    if (b.reserve(bytes ? bytes : 4)) return -1;
+    if (bytes) LR_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+static int zero_fill(DeviceBuf &b, size_t bytes)
+{
+    if (b.reserve(bytes ? bytes : 4)) return -1;
+    LR_HIP(hipMemsetAsync(b.p, 0, bytes ? bytes : 4, ctx().stream));
+    return 0;
+}
+
+// =====================================================================================================
+// FIRFilterBlock (+ fused FrequencyTranslatorBlock in front, + fused DownsamplerBlock behind)
+// =====================================================================================================
+struct FirStage : lrhip_stage {
+    int M = 0, S = 2, taps_complex = 0;
+    unsigned D = 1;
+    bool use_fft = false;
+    std::vector<float> taps_rev;          // host copy, reversed (firfilter.lua:234-238)
+    DeviceBuf d_taps, d_atab;
+    int ksteps = 0;                       // 0 => MFMA path unavailable for this (M, D)
+    DeviceBuf hist[2];
+    int cur = 0;
+    unsigned long index = 0;              // carried downsampler index (downsampler.lua:53)
+    bool rot = false;                     // fused rotator in front
+    uint64_t rot_step = 0, count = 0;     // absolute index of the next input sample
+    // overlap-save emission framing (firfilter.lua:451-485)
+    long L = 0, fill = 0;
+    DeviceBuf pending, work;
+
+    const char *kind() const override { return "fir"; }
+    unsigned long max_output(unsigned long n) const override
+    {
+        if (use_fft) return (unsigned long)(((fill + (long)n) / L) * L);
+        return D == 1 ? n : n / D + 1;
+    }
+    int reset() override
+    {
+        cur = 0; index = 0; count = 0; fill = 0;
+        size_t hb = (size_t)(M > 1 ? M - 1 : 1) * S * sizeof(float);
+        if (zero_fill(hist[0], hb) || zero_fill(hist[1], hb)) return -1;
+        return 0;
+    }
+
+    template <int SS, int DD, int NACC>
+    int launch_mfma(const float *x, long n, float *y, long n_out)
+    {
+        using G = FirMfmaGeom<SS, DD>;
+        constexpr int TILE_OUT = G::tile_out(NACC);
+        // alignment slack so that the tile's first staged sample is 16-B aligned in global memory
+        long sample_addr = (long)((uintptr_t)x / (4 * SS));
+        int q = 4 / SS;
+        long v = sample_addr + (long)index - (M - 1);
+        int e = (int)(((v % q) + q) % q);
+        bool sample_aligned = ((uintptr_t)x % (4 * SS)) == 0;
+        if (!sample_aligned) return launch_direct(x, n, y, n_out);
+        int span = G::span(NACC, ksteps);
+        size_t lds_floats = (size_t)ksteps * 64 + (size_t)G::phys(SS * span) + G::PAD + 8;
+        size_t lds_bytes = lds_floats * sizeof(float);
+        unsigned grid = (unsigned)((n_out + TILE_OUT - 1) / TILE_OUT);
+        const float *atab = (const float *)d_atab.p + (size_t)e * ksteps * 64;
+        int out_aligned = ((uintptr_t)y % 16) == 0;
+        if (rot) {
+            if constexpr (SS == 2) {
+                auto kern = fir_mfma_kernel<2, DD, NACC, true>;
+                if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p, x, atab, y,
+                                   M, n, n_out, (long)index, e, ksteps, out_aligned, rot_step, count);
+            } else {
+                return set_error("rotator fusion needs complex input");
+            }
+        } else {
+            auto kern = fir_mfma_kernel<SS, DD, NACC, false>;
+            if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p, x, atab, y,
+                               M, n, n_out, (long)index, e, ksteps, out_aligned, (uint64_t)0, (uint64_t)0);
+        }
+        LR_LAUNCH_CHECK();
+        return 0;
+    }
+
+    int launch_direct(const float *x, long n, float *y, long n_out)
+    {
+        if (rot) return set_error("internal: direct FIR kernel has no fused rotator");
+        unsigned grid = grid_for((unsigned long)n_out, 256);
+        const float *h = (const float *)hist[cur].p, *t = (const float *)d_taps.p;
+        if (S == 1)
+            hipLaunchKernelGGL(fir_direct_kernel<0>, dim3(grid), dim3(256), 0, ctx().stream, h, x, t, y, M, n, n_out, (long)index, (long)D);
+        else if (!taps_complex)
+            hipLaunchKernelGGL(fir_direct_kernel<1>, dim3(grid), dim3(256), 0, ctx().stream, h, x, t, y, M, n, n_out, (long)index, (long)D);
+        else
+            hipLaunchKernelGGL(fir_direct_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, h, x, t, y, M, n, n_out, (long)index, (long)D);
+        LR_LAUNCH_CHECK();
+        return 0;
+    }
+
+    template <int SS>
+    int dispatch_mfma(const float *x, long n, float *y, long n_out)
+    {
+        switch (D) {
+            case 1: return launch_mfma<SS, 1, 8>(x, n, y, n_out);
+            case 2: return launch_mfma<SS, 2, 4>(x, n, y, n_out);
+            case 3: return launch_mfma<SS, 3, 2>(x, n, y, n_out);
+            case 4: return launch_mfma<SS, 4, 2>(x, n, y, n_out);
+            case 5: return launch_mfma<SS, 5, 2>(x, n, y, n_out);
+            case 6: return launch_mfma<SS, 6, 1>(x, n, y, n_out);
+            case 7: return launch_mfma<SS, 7, 1>(x, n, y, n_out);
+            case 8: return launch_mfma<SS, 8, 1>(x, n, y, n_out);
+            case 10: return launch_mfma<SS, 10, 1>(x, n, y, n_out);
+            default: return launch_direct(x, n, y, n_out);
+        }
+    }
+
+    static bool mfma_supported_decim(unsigned d) { return (d >= 1 && d <= 8) || d == 10; }
+
+    // filter n inputs (device), emit the retained outputs; advances history / index / count
+    long core(const float *x, long n, float *y, unsigned long cap)
+    {
+        if (n <= 0) return 0;
+        long n_out = (unsigned long)n > index ? (long)((n - index + D - 1) / D) : 0;
+        if ((unsigned long)n_out > cap) return set_error("fir: output capacity %lu < %ld", cap, n_out);
+        if (n_out > 0) {
+            int rc = ksteps ? (S == 1 ? dispatch_mfma<1>(x, n, y, n_out) : dispatch_mfma<2>(x, n, y, n_out))
+                            : launch_direct(x, n, y, n_out);
+            if (rc) return rc;
+        }
+        if (M > 1) {
+            unsigned grid = grid_for((unsigned long)(M - 1) * S, 256);
+            if (S == 1)
+                hipLaunchKernelGGL(fir_history_kernel<1>, dim3(grid), dim3(256), 0, ctx().stream, (const float *)hist[cur].p, x, (float *)hist[cur ^ 1].p, M, n);
+            else
+                hipLaunchKernelGGL(fir_history_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, (const float *)hist[cur].p, x, (float *)hist[cur ^ 1].p, M, n);
+            LR_LAUNCH_CHECK();
+            cur ^= 1;
+        }
+        index = index + (unsigned long)n_out * D - (unsigned long)n;
+        count += (uint64_t)n;
+        return n_out;
+    }
+
+    long run(const void *in_dev, unsigned long n_in, void *out_dev, unsigned long cap) override
+    {
+        const float *x = (const float *)in_dev;
+        float *y = (float *)out_dev;
+        if (!use_fft) return core(x, (long)n_in, y, cap);
+        // overlap-save framing: emit only whole L-blocks, keep the tail pending (firfilter.lua:451-485)
+        long total = fill + (long)n_in, emit = (total / L) * L;
+        size_t ss = (size_t)S * sizeof(float);
+        if (emit == 0) {
+            if (n_in) LR_HIP(hipMemcpyAsync((char *)pending.p + fill * ss, x, n_in * ss, hipMemcpyDeviceToDevice, ctx().stream));
+            fill = total;
+            return 0;
+        }
+        if ((unsigned long)emit > cap) return set_error("fir(fft framing): output capacity %lu < %ld", cap, emit);
+        if (work.reserve((size_t)total * ss)) return -1;
+        if (fill) LR_HIP(hipMemcpyAsync(work.p, pending.p, fill * ss, hipMemcpyDeviceToDevice, ctx().stream));
+        LR_HIP(hipMemcpyAsync((char *)work.p + fill * ss, x, n_in * ss, hipMemcpyDeviceToDevice, ctx().stream));
+        long rc = core((const float *)work.p, emit, y, cap);
+        if (rc < 0) return rc;
+        fill = total - emit;
+        if (fill) LR_HIP(hipMemcpyAsync(pending.p, (char *)work.p + emit * ss, fill * ss, hipMemcpyDeviceToDevice, ctx().stream));
+        return emit;
+    }
+};
+
+static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, int input_complex, unsigned decim,
+                           int use_fft, bool rot, double omega)
+{
+    if (!taps || ntaps < 1) { set_error("fir: need at least one tap"); return nullptr; }
+    if (taps_complex && !input_complex) { set_error("fir: complex taps require ComplexFloat32 input (firfilter.lua:69-74)"); return nullptr; }
+    if (decim < 1) { set_error("fir: decimation must be >= 1"); return nullptr; }
+    if (use_fft && decim != 1) { set_error("fir: overlap-save framing cannot be combined with decimation"); return nullptr; }
+    if (ntaps > (1u << 20)) { set_error("fir: too many taps"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    std::unique_ptr<FirStage> q(new (std::nothrow) FirStage());
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->M = (int)ntaps; q->S = input_complex ? 2 : 1; q->taps_complex = taps_complex; q->D = decim;
+    q->use_fft = use_fft != 0; q->rot = rot;
+    q->in_size = q->out_size = 4 * q->S;
+    int ts = taps_complex ? 2 : 1;
+    q->taps_rev.resize((size_t)ntaps * ts);
+    for (unsigned i = 0; i < ntaps; i++)
+        for (int c = 0; c < ts; c++) q->taps_rev[(size_t)i * ts + c] = taps[(size_t)(ntaps - 1 - i) * ts + c];
+    if (upload(q->d_taps, q->taps_rev.data(), q->taps_rev.size() * sizeof(float))) return nullptr;
+    if (!taps_complex && FirStage::mfma_supported_decim(decim)) {
+        int ks = fir_mfma_ksteps(q->M, (int)decim, q->S);
+        if ((size_t)ks * 64 * sizeof(float) <= 40 * 1024) {   // A-table must leave LDS room for the tile
+            std::vector<float> tab;
+            fir_mfma_build_tables(q->taps_rev.data(), q->M, (int)decim, q->S, ks, tab);
+            if (upload(q->d_atab, tab.data(), tab.size() * sizeof(float))) return nullptr;
+            q->ksteps = ks;
+        }
+    }
+    if (rot) {
+        if (!q->ksteps) { set_error("fir: rotator fusion unavailable for this tap count / decimation"); return nullptr; }
+        long double turns = (long double)omega / (2.0L * 3.14159265358979323846264338327950288L);
+        turns -= floorl(turns);
+        q->rot_step = (uint64_t)(turns * 18446744073709551616.0L);
+    }
+    if (q->use_fft) {
+        long N = 1L << (long)std::floor(std::log(8.0 * ntaps) / std::log(2.0));   // firfilter.lua:329
+        q->L = N - (long)ntaps + 1;
+        if (q->pending.reserve((size_t)q->L * q->S * sizeof(float))) return nullptr;
+    }
+    if (q->reset()) return nullptr;
+    return q.release();
+}
+
+// =====================================================================================================
+// FrequencyTranslatorBlock
+// =====================================================================================================
+static uint64_t turns_fixed(double omega)
+{
+    long double turns = (long double)omega / (2.0L * 3.14159265358979323846264338327950288L);
+    turns -= floorl(turns);
+    return (uint64_t)(turns * 18446744073709551616.0L);
+}
+
+struct RotatorStage : lrhip_stage {
+    double omega = 0;
+    uint64_t step = 0, count = 0;
+    const char *kind() const override { return "rotator"; }
+    int reset() override { count = 0; return 0; }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n > cap) return set_error("rotator: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+        hipLaunchKernelGGL(rotator_kernel, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n, step, count);
+        LR_LAUNCH_CHECK();
+        count += n;
+        return (long)n;
+    }
+};
+
+// =====================================================================================================
+// DownsamplerBlock
+// =====================================================================================================
+struct DownsamplerStage : lrhip_stage {
+    unsigned long factor = 1, index = 0;
+    const char *kind() const override { return "downsampler"; }
+    int reset() override { index = 0; return 0; }
+    unsigned long max_output(unsigned long n) const override { return n / factor + 1; }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        unsigned long n_out = n > index ? (n - index + factor - 1) / factor : 0;   // downsampler.lua:46
+        if (n_out > cap) return set_error("downsampler: output capacity %lu < %lu", cap, n_out);
+        if (n_out) {
+            unsigned grid = grid_for(n_out, 256, ctx().num_cus * 16);
+            if (in_size == 8)
+                hipLaunchKernelGGL(downsample_kernel<float2>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n_out, index, factor);
+            else
+                hipLaunchKernelGGL(downsample_kernel<float>, dim3(grid), dim3(256), 0, ctx().stream, (const float *)in_dev, (float *)out_dev, n_out, index, factor);
+            LR_LAUNCH_CHECK();
+        }
+        index = index + n_out * factor - n;                                          // downsampler.lua:53
+        return (long)n_out;
+    }
+};
+
+// =====================================================================================================
+// FrequencyDiscriminatorBlock
+// =====================================================================================================
+struct FmDiscrimStage : lrhip_stage {
+    double gain = 1;
+    DeviceBuf prev;     // two float2 slots, ping-pong
+    int cur = 0;
+    const char *kind() const override { return "fmdiscrim"; }
+    int reset() override { cur = 0; return zero_fill(prev, 4 * sizeof(float)); }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n > cap) return set_error("fmdiscrim: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+        float2 *p = (float2 *)prev.p;
+        hipLaunchKernelGGL(fmdiscrim_kernel, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float *)out_dev, n, 1.0 / gain,
+                           (const float2 *)(p + cur), p + (cur ^ 1));
+        LR_LAUNCH_CHECK();
+        cur ^= 1;
+        return (long)n;
+    }
+};
+
+// =====================================================================================================
+// IIRFilterBlock
+// =====================================================================================================
+struct IirStage : lrhip_stage {
+    int S = 1, nb = 0, na = 0, P = 0;
+    bool scan = false;
+    IirCoeffs co;
+    IirSeqCoeffs seq;
+    DeviceBuf xhist[2], state[2], tile_end, tile_start, seq_xs, seq_ys;
+    int cur = 0;
+    const char *kind() const override { return "iir"; }
+    int reset() override
+    {
+        cur = 0;
+        for (int i = 0; i < 2; i++) {
+            if (zero_fill(xhist[i], sizeof(float) * S * IIR_MAX_NB)) return -1;
+            if (zero_fill(state[i], sizeof(float) * S * (IIR_MAX_P + 1))) return -1;
+        }
+        if (zero_fill(seq_xs, sizeof(float) * S * IIR_SEQ_MAX) || zero_fill(seq_ys, sizeof(float) * S * IIR_SEQ_MAX)) return -1;
+        return 0;
+    }
+    template <int SS, int PP>
+    int run_scan(const float *x, float *y, long n)
+    {
+        long ntiles = (n + IIR_TILE - 1) / IIR_TILE;
+        if (tile_end.reserve(sizeof(float) * ntiles * SS * PP) || tile_start.reserve(sizeof(float) * ntiles * SS * PP)) return -1;
+        const float *xh = (const float *)xhist[cur].p, *st = (const float *)state[cur].p;
+        if (ntiles > 1) {
+            hipLaunchKernelGGL((iir_scan_kernel<SS, PP, false>), dim3((unsigned)ntiles), dim3(256), 0, ctx().stream, x, (float *)nullptr, n, xh,
+                               (const float *)nullptr, (float *)tile_end.p, co);
+            LR_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL((iir_carry_kernel<SS, PP>), dim3(1), dim3(64), 0, ctx().stream, (const float *)tile_end.p, (float *)tile_start.p,
+                           ntiles > 1 ? ntiles : 1, st, co);
+        LR_LAUNCH_CHECK();
+        hipLaunchKernelGGL((iir_scan_kernel<SS, PP, true>), dim3((unsigned)ntiles), dim3(256), 0, ctx().stream, x, y, n, xh,
+                           (const float *)tile_start.p, (float *)nullptr, co);
+        LR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(iir_state_kernel<SS>, dim3(1), dim3(64), 0, ctx().stream, x, (const float *)y, n, nb, PP, xh, (float *)xhist[cur ^ 1].p,
+                           st, (float *)state[cur ^ 1].p);
+        LR_LAUNCH_CHECK();
+        cur ^= 1;
+        return 0;
+    }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n > cap) return set_error("iir: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        const float *x = (const float *)in_dev;
+        float *y = (float *)out_dev;
+        int rc = 0;
+        if (scan) {
+            // with a single tile the carry kernel just seeds tile_start[0] from the carried state
+            if (S == 1) rc = P == 1 ? run_scan<1, 1>(x, y, (long)n) : P == 2 ? run_scan<1, 2>(x, y, (long)n) : P == 3 ? run_scan<1, 3>(x, y, (long)n) : run_scan<1, 4>(x, y, (long)n);
+            else rc = P == 1 ? run_scan<2, 1>(x, y, (long)n) : P == 2 ? run_scan<2, 2>(x, y, (long)n) : P == 3 ? run_scan<2, 3>(x, y, (long)n) : run_scan<2, 4>(x, y, (long)n);
+        } else {
+            if (S == 1) hipLaunchKernelGGL(iir_seq_kernel<1>, dim3(1), dim3(64), 0, ctx().stream, x, y, (long)n, seq, (float *)seq_xs.p, (float *)seq_ys.p);
+            else hipLaunchKernelGGL(iir_seq_kernel<2>, dim3(1), dim3(64), 0, ctx().stream, x, y, (long)n, seq, (float *)seq_xs.p, (float *)seq_ys.p);
+            LR_LAUNCH_CHECK();
+        }
+        return rc ? rc : (long)n;
+    }
+};
+
+// P x P matrix helpers (double, host) for the transition powers
+static void matmul(const std::vector<double> &A, const std::vector<double> &B, std::vector<double> &C, int P)
+{
+    std::vector<double> T((size_t)P * P, 0.0);
+    for (int r = 0; r < P; r++)
+        for (int c = 0; c < P; c++) {
+            double acc = 0;
+            for (int k = 0; k < P; k++) acc += A[r * P + k] * B[k * P + c];
+            T[r * P + c] = acc;
+        }
+    C = T;
+}
+
+// =====================================================================================================
+// DFT / IDFT / PSD
+// =====================================================================================================
+struct FftStage : lrhip_stage {
+    int N = 0, inverse = 0, out_kind = FFT_OUT_COMPLEX, shift = 0, in_real = 0, fpw = 1;
+    float out_scale = 1.f;
+    bool has_window = false;
+    DeviceBuf tw, window;
+    const char *kind() const override { return "fft"; }
+    int reset() override { return 0; }
+    unsigned long max_output(unsigned long n) const override { return n - n % N; }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n % N) return set_error("fft: input length %lu is not a multiple of the frame length %d", n, N);
+        if (n > cap) return set_error("fft: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        long nframes = (long)(n / N);
+        unsigned grid = (unsigned)((nframes + fpw - 1) / fpw);
+        size_t lds = (size_t)2 * fpw * N * sizeof(float2);
+        const float *w = has_window ? (const float *)window.p : nullptr;
+        if (in_real) {
+            auto kern = fft_frames_kernel<true>;
+            if (lds > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, (const float *)in_dev, (float *)out_dev, nframes, N, fpw,
+                               (const float2 *)tw.p, w, inverse, out_kind, out_scale, shift);
+        } else {
+            auto kern = fft_frames_kernel<false>;
+            if (lds > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, (const float *)in_dev, (float *)out_dev, nframes, N, fpw,
+                               (const float2 *)tw.p, w, inverse, out_kind, out_scale, shift);
+        }
+        LR_LAUNCH_CHECK();
+        return (long)n;
+    }
+};
+
+static FftStage *fft_build(unsigned n)
+{
+    if (n < 8 || n > 4096 || (n & (n - 1))) { set_error("fft: frame length must be a power of two in [8, 4096] (got %u)", n); return nullptr; }
+    if (ensure_init()) return nullptr;
+    std::unique_ptr<FftStage> q(new (std::nothrow) FftStage());
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->N = (int)n;
+    q->fpw = n >= 512 ? 1 : (int)(512 / n);
+    std::vector<float> tw(n);   // n/2 complex
+    for (unsigned m = 0; m < n / 2; m++) {
+        double ang = -2.0 * 3.14159265358979323846 * m / n;
+        tw[2 * m] = (float)std::cos(ang);
+        tw[2 * m + 1] = (float)std::sin(ang);
+    }
+    if (upload(q->tw, tw.data(), tw.size() * sizeof(float))) return nullptr;
+    return q.release();
+}
+
+// =====================================================================================================
+// chain
+// =====================================================================================================
+struct lrhip_chain {
+    struct Op {
+        lrhip_stage *stage;
+        bool owned;
+    };
+    std::vector<Op> ops;
+    std::vector<std::unique_ptr<DeviceBuf>> edges;   // edges[i] = output of op i (all but the last)
+    PinnedBuf h_in, h_out;
+    DeviceBuf d_in, d_out;
+    int last_launches = 0;
+    ~lrhip_chain()
+    {
+        for (auto &o : ops)
+            if (o.owned) delete o.stage;
+    }
+};
+
+// host-pointer path shared by stages and chains: pinned staging in, run, pinned staging out
+template <typename Runner>
+static long host_execute(PinnedBuf &h_in, PinnedBuf &h_out, DeviceBuf &d_in, DeviceBuf &d_out, int in_size, int out_size,
+                         unsigned long max_out, const void *in_host, unsigned long n_in, void *out_host,
+                         unsigned long out_capacity, Runner run)
+{
+    if (n_in && !in_host) return set_error("null input buffer");
+    size_t in_bytes = (size_t)n_in * in_size;
+    unsigned long cap = max_out < out_capacity ? max_out : out_capacity;
+    if (max_out > out_capacity) return set_error("output capacity %lu < required %lu", out_capacity, max_out);
+    if (max_out && !out_host) return set_error("null output buffer");
+    if (h_in.reserve(in_bytes ? in_bytes : 16) || d_in.reserve(in_bytes ? in_bytes : 16)) return -1;
+    if (h_out.reserve((size_t)cap * out_size + 16) || d_out.reserve((size_t)cap * out_size + 16)) return -1;
+    if (in_bytes) {
+        memcpy(h_in.p, in_host, in_bytes);
+        LR_HIP(hipMemcpyAsync(d_in.p, h_in.p, in_bytes, hipMemcpyHostToDevice, ctx().stream));
+    }
+    long n_out = run(d_in.p, n_in, d_out.p, cap);
+    if (n_out < 0) return n_out;
+    if (n_out) LR_HIP(hipMemcpyAsync(h_out.p, d_out.p, (size_t)n_out * out_size, hipMemcpyDeviceToHost, ctx().stream));
+    LR_HIP(hipStreamSynchronize(ctx().stream));
+    if (n_out) memcpy(out_host, h_out.p, (size_t)n_out * out_size);
+    return n_out;
+}
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char *lrhip_version(void) { return "lrhip 0.1 (gfx950)"; }
+const char *lrhip_strerror(void) { return err_buf(); }
+
+int lrhip_init(int device)
+{
+    err_buf()[0] = 0;
+    return ensure_init(device);
+}
+
+int lrhip_device_count(void)
+{
+    int count = 0;
+    LR_HIP(hipGetDeviceCount(&count));
+    return count;
+}
+
+int lrhip_set_stream(void *hip_stream)
+{
+    if (ensure_init()) return -1;
+    ctx().stream = hip_stream ? (hipStream_t)hip_stream : ctx().own_stream;
+    return 0;
+}
+
+int lrhip_synchronize(void)
+{
+    if (ensure_init()) return -1;
+    LR_HIP(hipStreamSynchronize(ctx().stream));
+    return 0;
+}
+
+lrhip_stage_t *lrhip_fir_create(const float *taps, unsigned ntaps, int taps_complex, int input_complex, unsigned decim, int use_fft)
+{
+    return fir_build(taps, ntaps, taps_complex, input_complex, decim, use_fft, false, 0.0);
+}
+
+lrhip_stage_t *lrhip_rotator_create(double omega)
+{
+    if (!std::isfinite(omega)) { set_error("rotator: omega must be finite"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    RotatorStage *q = new (std::nothrow) RotatorStage();
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->omega = omega;
+    q->step = turns_fixed(omega);
+    q->in_size = q->out_size = 8;
+    return q;
+}
+
+lrhip_stage_t *lrhip_downsampler_create(unsigned factor, int elem_size)
+{
+    if (factor < 1) { set_error("downsampler: factor must be >= 1"); return nullptr; }
+    if (elem_size != 4 && elem_size != 8) { set_error("downsampler: element size must be 4 or 8"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    DownsamplerStage *q = new (std::nothrow) DownsamplerStage();
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->factor = factor;
+    q->in_size = q->out_size = elem_size;
+    return q;
+}
+
+lrhip_stage_t *lrhip_fmdiscrim_create(double gain)
+{
+    if (!(gain != 0.0) || !std::isfinite(gain)) { set_error("fmdiscrim: gain must be finite and non-zero"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    std::unique_ptr<FmDiscrimStage> q(new (std::nothrow) FmDiscrimStage());
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->gain = gain;
+    q->in_size = 8; q->out_size = 4;
+    if (q->reset()) return nullptr;
+    return q.release();
+}
+
+lrhip_stage_t *lrhip_iir_create(const float *b, unsigned nb, const float *a, unsigned na, int input_complex)
+{
+    if (!b || !a || nb < 1 || na < 1) { set_error("iir: need b_taps and at least one a_tap (iirfilter.lua:56)"); return nullptr; }
+    if (nb > IIR_SEQ_MAX || na > IIR_SEQ_MAX) { set_error("iir: at most %d taps supported", IIR_SEQ_MAX); return nullptr; }
+    if (a[0] == 0.0f) { set_error("iir: a[0] must be non-zero"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    std::unique_ptr<IirStage> q(new (std::nothrow) IirStage());
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->S = input_complex ? 2 : 1;
+    q->in_size = q->out_size = 4 * q->S;
+    q->nb = (int)nb; q->na = (int)na; q->P = (int)na - 1;
+    q->seq.nb = (int)nb; q->seq.na = (int)na;
+    for (unsigned i = 0; i < nb; i++) q->seq.b[i] = b[i];
+    for (unsigned i = 0; i < na; i++) q->seq.a[i] = a[i];
+    q->scan = q->P >= 1 && q->P <= IIR_MAX_P && nb <= IIR_MAX_NB;
+    if (q->scan) {
+        int P = q->P;
+        IirCoeffs &co = q->co;
+        memset(&co, 0, sizeof(co));
+        co.nb = (int)nb; co.P = P;
+        for (unsigned i = 0; i < nb; i++) co.b[i] = (float)((double)b[i] / (double)a[0]);
+        for (int i = 0; i < P; i++) co.a[i] = (float)((double)a[i + 1] / (double)a[0]);
+        // companion matrix of the homogeneous recurrence for the state (y[n-1], ..., y[n-P])
+        std::vector<double> A((size_t)P * P, 0.0), T;
+        for (int k = 0; k < P; k++) A[k] = -(double)co.a[k];
+        for (int r = 1; r < P; r++) A[r * P + r - 1] = 1.0;
+        T = A;
+        for (int s = 1; s < IIR_LC; s <<= 1) matmul(T, T, T, P);      // A^LC (LC is a power of two)
+        for (int k = 0; k <= 8; k++) {
+            for (int i = 0; i < P * P; i++) co.Tpow[k][i] = (float)T[i];
+            matmul(T, T, T, P);
+        }
+    }
+    if (q->reset()) return nullptr;
+    return q.release();
+}
+
+lrhip_stage_t *lrhip_psd_create(unsigned n, const float *window, double scale, int logarithmic, int input_complex, int fftshift)
+{
+    if (!(scale > 0.0)) { set_error("psd: scale must be positive"); return nullptr; }
+    FftStage *q = fft_build(n);
+    if (!q) return nullptr;
+    q->in_real = !input_complex;
+    q->in_size = input_complex ? 8 : 4;
+    q->out_size = 4;
+    q->out_kind = logarithmic ? FFT_OUT_PSD_LOG : FFT_OUT_PSD;
+    q->out_scale = (float)(1.0 / scale);
+    q->shift = fftshift != 0;
+    if (window) {
+        if (upload(q->window, window, n * sizeof(float))) { delete q; return nullptr; }
+        q->has_window = true;
+    }
+    return q;
+}
+
+lrhip_stage_t *lrhip_dft_create(unsigned n, int inverse, int real_side)
+{
+    FftStage *q = fft_build(n);
+    if (!q) return nullptr;
+    q->inverse = inverse != 0;
+    if (!inverse) {
+        q->in_real = real_side != 0;
+        q->in_size = real_side ? 4 : 8;
+        q->out_size = 8;
+        q->out_kind = FFT_OUT_COMPLEX;
+        q->out_scale = 1.0f;
+    } else {
+        q->in_real = 0;
+        q->in_size = 8;
+        q->out_size = real_side ? 4 : 8;
+        q->out_kind = real_side ? FFT_OUT_REAL : FFT_OUT_COMPLEX;
+        q->out_scale = (float)(1.0 / (double)n);      // spectrum_utils.lua:335-338
+    }
+    return q;
+}
+
+void lrhip_stage_destroy(lrhip_stage_t *q)
+{
+    if (!q) return;
+    if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+    delete q;
+}
+
+int lrhip_stage_reset(lrhip_stage_t *q) { return q ? q->reset() : set_error("null stage"); }
+int lrhip_stage_input_size(const lrhip_stage_t *q) { return q ? q->in_size : set_error("null stage"); }
+int lrhip_stage_output_size(const lrhip_stage_t *q) { return q ? q->out_size : set_error("null stage"); }
+unsigned long lrhip_stage_max_output(const lrhip_stage_t *q, unsigned long n_in) { return q ? q->max_output(n_in) : 0; }
+
+long lrhip_stage_execute_device(lrhip_stage_t *q, const void *in_dev, unsigned long n_in, void *out_dev, unsigned long out_capacity)
+{
+    if (!q) return set_error("null stage");
+    if (n_in && (!in_dev || !out_dev)) return set_error("null buffer");
+    return q->run(in_dev, n_in, out_dev, out_capacity);
+}
+
+long lrhip_stage_execute(lrhip_stage_t *q, const void *in_host, unsigned long n_in, void *out_host, unsigned long out_capacity)
+{
+    if (!q) return set_error("null stage");
+    return host_execute(q->h_in, q->h_out, q->d_in, q->d_out, q->in_size, q->out_size, q->max_output(n_in), in_host, n_in,
+                        out_host, out_capacity,
+                        [&](const void *di, unsigned long n, void *dout, unsigned long cap) { return q->run(di, n, dout, cap); });
+}
+
+// ---- chains ---------------------------------------------------------------------------------------------
+lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
+{
+    if (!stages || nstages < 1) { set_error("chain: need at least one stage"); return nullptr; }
+    for (unsigned i = 0; i < nstages; i++)
+        if (!stages[i]) { set_error("chain: stage %u is null", i); return nullptr; }
+    for (unsigned i = 0; i + 1 < nstages; i++)
+        if (stages[i]->out_size != stages[i + 1]->in_size) {
+            set_error("chain: stage %u (%s) emits %d-byte samples but stage %u (%s) takes %d-byte samples", i, stages[i]->kind(),
+                      stages[i]->out_size, i + 1, stages[i + 1]->kind(), stages[i + 1]->in_size);
+            return nullptr;
+        }
+    std::unique_ptr<lrhip_chain> c(new (std::nothrow) lrhip_chain());
+    if (!c) { set_error("out of memory"); return nullptr; }
+    unsigned i = 0;
+    while (i < nstages) {
+        // fusion: [rotator] fir(real taps, plain) [downsampler]  ->  one decimating Toeplitz-MFMA launch
+        RotatorStage *rot = dynamic_cast<RotatorStage *>(stages[i]);
+        unsigned j = rot ? i + 1 : i;
+        FirStage *fir = j < nstages ? dynamic_cast<FirStage *>(stages[j]) : nullptr;
+        bool fusable_fir = fir && !fir->taps_complex && !fir->use_fft && fir->D == 1 && !fir->rot;
+        DownsamplerStage *ds = (fusable_fir && j + 1 < nstages) ? dynamic_cast<DownsamplerStage *>(stages[j + 1]) : nullptr;
+        if (fusable_fir && (rot || ds)) {
+            unsigned D = ds ? (unsigned)ds->factor : 1;
+            std::vector<float> taps((size_t)fir->M);
+            for (int t = 0; t < fir->M; t++) taps[t] = fir->taps_rev[fir->M - 1 - t];
+            bool want_rot = rot && fir->S == 2;
+            FirStage *fused = nullptr;
+            if (FirStage::mfma_supported_decim(D))
+                fused = fir_build(taps.data(), (unsigned)fir->M, 0, fir->S == 2, D, 0, want_rot, want_rot ? rot->omega : 0.0);
+            if (fused) {
+                c->ops.push_back({fused, true});
+                i = j + (ds ? 2 : 1);
+                continue;
+            }
+            if (ds && !rot) {
+                // decimation not in the MFMA table: direct kernel still skips the discarded outputs
+                FirStage *f2 = fir_build(taps.data(), (unsigned)fir->M, 0, fir->S == 2, D, 0, false, 0.0);
+                if (f2) {
+                    c->ops.push_back({f2, true});
+                    i = j + 2;
+                    continue;
+                }
+            }
+        }
+        c->ops.push_back({stages[i], false});
+        i++;
+    }
+    for (size_t k = 0; k + 1 < c->ops.size(); k++) c->edges.emplace_back(new DeviceBuf());
+    return c.release();
+}
+
+void lrhip_chain_destroy(lrhip_chain_t *c)
+{
+    if (!c) return;
+    if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+    delete c;
+}
+
+unsigned long lrhip_chain_max_output(const lrhip_chain_t *c, unsigned long n_in)
+{
+    if (!c) return 0;
+    unsigned long n = n_in;
+    for (auto &o : c->ops) n = o.stage->max_output(n);
+    return n;
+}
+
+long lrhip_chain_execute_device(lrhip_chain_t *c, const void *in_dev, unsigned long n_in, void *out_dev, unsigned long out_capacity)
+{
+    if (!c) return set_error("null chain");
+    g_launches = 0;
+    const void *cur = in_dev;
+    unsigned long n = n_in;
+    for (size_t k = 0; k < c->ops.size(); k++) {
+        lrhip_stage *s = c->ops[k].stage;
+        bool last = k + 1 == c->ops.size();
+        unsigned long need = s->max_output(n);
+        void *dst;
+        unsigned long cap;
+        if (last) {
+            dst = out_dev;
+            cap = out_capacity;
+        } else {
+            if (c->edges[k]->reserve((size_t)need * s->out_size + 16)) return -1;
+            dst = c->edges[k]->p;
+            cap = need;
+        }
+        long got = s->run(cur, n, dst, cap);
+        if (got < 0) return got;
+        cur = dst;
+        n = (unsigned long)got;
+    }
+    c->last_launches = g_launches;
+    return (long)n;
+}
+
+long lrhip_chain_execute(lrhip_chain_t *c, const void *in_host, unsigned long n_in, void *out_host, unsigned long out_capacity)
+{
+    if (!c) return set_error("null chain");
+    return host_execute(c->h_in, c->h_out, c->d_in, c->d_out, c->ops.front().stage->in_size, c->ops.back().stage->out_size,
+                        lrhip_chain_max_output(c, n_in), in_host, n_in, out_host, out_capacity,
+                        [&](const void *di, unsigned long n, void *dout, unsigned long cap) { return lrhip_chain_execute_device(c, di, n, dout, cap); });
+}
+
+int lrhip_chain_last_launches(const lrhip_chain_t *c) { return c ? c->last_launches : set_error("null chain"); }
+
+// ---- memory helpers ----------------------------------------------------------------------------------------
+void *lrhip_malloc(unsigned long bytes)
+{
+    if (ensure_init()) return nullptr;
+    void *p = nullptr;
+    LR_HIP_NULL(hipMalloc(&p, bytes ? bytes : 4));
+    return p;
+}
+void lrhip_free(void *p)
+{
+    if (p) (void)hipFree(p);
+}
+int lrhip_memcpy_h2d(void *dst, const void *src, unsigned long bytes)
+{
+    if (ensure_init()) return -1;
+    LR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx().stream));
+    LR_HIP(hipStreamSynchronize(ctx().stream));
+    return 0;
+}
+int lrhip_memcpy_d2h(void *dst, const void *src, unsigned long bytes)
+{
+    if (ensure_init()) return -1;
+    LR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx().stream));
+    LR_HIP(hipStreamSynchronize(ctx().stream));
+    return 0;
+}
+void *lrhip_host_alloc(unsigned long bytes)
+{
+    if (ensure_init()) return nullptr;
+    void *p = nullptr;
+    LR_HIP_NULL(hipHostMalloc(&p, bytes ? bytes : 4, hipHostMallocDefault));
+    return p;
+}
+void lrhip_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+// ---- timers ----------------------------------------------------------------------------------------------------
+struct lrhip_timer {
+    hipEvent_t a, b;
+};
+lrhip_timer_t *lrhip_timer_create(void)
+{
+    if (ensure_init()) return nullptr;
+    lrhip_timer *t = new (std::nothrow) lrhip_timer();
+    if (!t) { set_error("out of memory"); return nullptr; }
+    if (hipEventCreate(&t->a) != hipSuccess || hipEventCreate(&t->b) != hipSuccess) {
+        set_error("hipEventCreate failed");
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+void lrhip_timer_destroy(lrhip_timer_t *t)
+{
+    if (!t) return;
+    (void)hipEventDestroy(t->a);
+    (void)hipEventDestroy(t->b);
+    delete t;
+}
+int lrhip_timer_start(lrhip_timer_t *t)
+{
+    if (!t) return set_error("null timer");
+    LR_HIP(hipEventRecord(t->a, ctx().stream));
+    return 0;
+}
+int lrhip_timer_stop(lrhip_timer_t *t)
+{
+    if (!t) return set_error("null timer");
+    LR_HIP(hipEventRecord(t->b, ctx().stream));
+    return 0;
+}
+double lrhip_timer_elapsed_ms(lrhip_timer_t *t)
+{
+    if (!t) return (double)set_error("null timer");
+    if (hipEventSynchronize(t->b) != hipSuccess) return (double)set_error("hipEventSynchronize failed");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t->a, t->b) != hipSuccess) return (double)set_error("hipEventElapsedTime failed");
+    return (double)ms;
+}
+
+}  // extern "C"

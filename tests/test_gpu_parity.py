@@ -1,0 +1,400 @@
+"""GPU parity: every hot-path block through the C ABI (liblrhip.so) against the reference's golden vectors and
+against the CPU oracle, in the two modes of tests/jigs.lua (whole vector / one sample per process() call),
+plus randomized chunkings, large sizes and size-independent properties.
+
+Tolerances: FIR (real taps) bit-exact vs the oracle's fmaf-chain mode and < 1e-6 vs golden / f64;
+rotator 1e-5 vs golden (reference epsilon) and 1e-6 vs closed form; discriminator 1e-6; downsampler
+bit-exact; IIR 1e-6; DFT 1e-5; PSD 1e-5 (lin) / 3 dB (log, reference epsilon)."""
+import numpy as np
+import pytest
+
+import luaradio_amd as lr
+from luaradio_amd import spectrum_utils, types
+from oracle import oracle as O
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+RATE = 2.0
+
+
+def make(cls, args, x, rate=RATE):
+    """tests/jigs.lua:62-86 create_block: instantiate, get_rate -> 2.0, differentiate, initialize"""
+    blk = cls(*args)
+    blk.rate = rate
+    blk.differentiate([types.type_of(x)])
+    blk.initialize()
+    return blk
+
+
+def rand_c(rng, n):
+    return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+
+
+def rand_r(rng, n):
+    return rng.uniform(-1, 1, n).astype(np.float32)
+
+
+def chunked(blk, x, cuts):
+    parts, a = [], 0
+    for b in list(cuts) + [len(x)]:
+        parts.append(blk.process(x[a:b]))
+        a = b
+    return np.concatenate(parts)
+
+
+def _golden_both_modes(cls, vec, eps, exact=False):
+    x, want = vec["inputs"][0], vec["outputs"][0]
+    whole, samplewise = G.run_whole_and_samplewise(lambda: make(cls, vec["args"], x), x)
+    assert len(whole) == len(want) and len(samplewise) == len(want), vec["desc"]
+    if exact:
+        assert np.array_equal(whole, want) and np.array_equal(samplewise, want), vec["desc"]
+    else:
+        assert G.max_abs_err(whole, want) < eps, vec["desc"]
+        assert G.max_abs_err(samplewise, want) < eps, vec["desc"]
+    return whole, samplewise
+
+
+# --------------------------------------------------------------------------------------------- golden vectors
+def test_golden_firfilter():
+    doc = G.load("firfilter_spec")
+    assert len(doc["vectors"]) == 24
+    for vec in doc["vectors"]:
+        whole, samplewise = _golden_both_modes(lr.FIRFilterBlock, vec, doc["epsilon"])
+        assert np.array_equal(whole, samplewise), vec["desc"]     # chunking never changes a bit
+
+
+@pytest.mark.parametrize("name,cls", [("lowpassfilter_spec", lr.LowpassFilterBlock), ("highpassfilter_spec", lr.HighpassFilterBlock),
+                                      ("bandpassfilter_spec", lr.BandpassFilterBlock), ("bandstopfilter_spec", lr.BandstopFilterBlock)])
+def test_golden_firwin_blocks(name, cls):
+    doc = G.load(name)
+    for vec in doc["vectors"]:
+        _golden_both_modes(cls, vec, doc["epsilon"])
+
+
+def test_golden_frequencytranslator():
+    doc = G.load("frequencytranslator_spec")
+    for vec in doc["vectors"]:
+        _golden_both_modes(lr.FrequencyTranslatorBlock, vec, doc["epsilon"])
+
+
+def test_golden_frequencydiscriminator():
+    doc = G.load("frequencydiscriminator_spec")
+    for vec in doc["vectors"]:
+        _golden_both_modes(lr.FrequencyDiscriminatorBlock, vec, doc["epsilon"])
+
+
+def test_golden_downsampler_bit_exact():
+    doc = G.load("downsampler_spec")
+    assert len(doc["vectors"]) == 20
+    for vec in doc["vectors"]:
+        _golden_both_modes(lr.DownsamplerBlock, vec, 0, exact=True)
+
+
+def test_golden_iir_family():
+    doc = G.load("iirfilter_spec")
+    for vec in doc["vectors"]:
+        _golden_both_modes(lr.IIRFilterBlock, vec, doc["epsilon"])
+    doc = G.load("singlepolelowpassfilter_spec")
+    for vec in doc["vectors"]:
+        _golden_both_modes(lr.SinglepoleLowpassFilterBlock, vec, doc["epsilon"])
+    doc = G.load("fmdeemphasisfilter_spec")
+    for vec in doc["vectors"]:
+        _golden_both_modes(lr.FMDeemphasisFilterBlock, vec, doc["epsilon"])
+
+
+def test_golden_decimator_and_tuner():
+    doc = G.load("decimator_spec")
+    for vec in doc["vectors"]:
+        _golden_both_modes(lr.DecimatorBlock, vec, doc["epsilon"])
+    doc = G.load("tuner_spec")
+    for vec in doc["vectors"]:
+        _golden_both_modes(lr.TunerBlock, vec, doc["epsilon"])
+
+
+def test_golden_spectrum_utils():
+    v = G.load("spectrum_utils_vectors")["values"]      # tests/utilities/spectrum_utils_spec.lua:58-91
+    cx, rx = v["complex_test_vector"], v["real_test_vector"]
+
+    def dft(x):
+        out = np.empty(len(x), np.complex64)
+        spectrum_utils.DFT(x, out).compute()
+        return out
+
+    def idft(X, t):
+        out = np.empty(len(X), t.dtype)
+        spectrum_utils.IDFT(X, out).compute()
+        return out
+
+    def psd(x, w, fs, log):
+        out = np.empty(len(x), np.float32)
+        spectrum_utils.PSD(x, out, w, fs, log).compute()
+        return out
+
+    assert G.max_abs_err(dft(cx), v["complex_test_vector_dft"]) < 1e-5
+    assert G.max_abs_err(dft(rx), v["real_test_vector_dft"]) < 1e-5
+    assert G.max_abs_err(idft(v["complex_test_vector_dft"], types.ComplexFloat32), cx) < 1e-5
+    assert G.max_abs_err(idft(v["real_test_vector_dft"], types.Float32), rx) < 1e-5
+    for x, nm in ((cx, "complex"), (rx, "real")):
+        for win in ("rectangular", "hamming"):
+            assert G.max_abs_err(psd(x, win, 44100, False), v["%s_test_vector_%s_psd" % (nm, win)]) < 1e-5
+            assert G.max_abs_err(psd(x, win, 44100, True), v["%s_test_vector_%s_psd_log" % (nm, win)]) < 3
+    y = cx.copy()
+    spectrum_utils.fftshift(y)
+    assert np.array_equal(y, v["complex_test_vector_fftshift"])
+
+
+# --------------------------------------------------------------------------------------------- FIR vs oracle
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("ntaps", [1, 2, 5, 16, 31, 64, 127, 128, 129, 255, 500])
+def test_fir_real_taps_bit_exact_vs_fma_oracle(cplx, ntaps):
+    rng = np.random.default_rng(ntaps * 2 + cplx)
+    n = 20000
+    x = rand_c(rng, n) if cplx else rand_r(rng, n)
+    taps = rand_r(rng, ntaps) / ntaps
+    want = O.FIR(taps, cplx, O.MODE_FMA).process(x)
+    blk = make(lr.FIRFilterBlock, [taps], x)
+    got = blk.process(x)
+    assert np.array_equal(got, want)
+    # random ragged chunking incl. empty and 1-sample chunks gives the same bits
+    cuts = sorted(set(rng.integers(0, n, 12).tolist() + [0, 1, 2, n - 1]))
+    blk2 = make(lr.FIRFilterBlock, [taps], x)
+    assert np.array_equal(chunked(blk2, x, cuts), want)
+    # and stays within the reference epsilon of the f64 accumulation
+    assert G.max_abs_err(got, O.FIR(taps, cplx, O.MODE_F64).process(x)) < 1e-6
+
+
+@pytest.mark.parametrize("ntaps", [1, 8, 33, 128])
+def test_fir_complex_taps_bit_exact_vs_fma_oracle(ntaps):
+    rng = np.random.default_rng(100 + ntaps)
+    x = rand_c(rng, 5000)
+    taps = rand_c(rng, ntaps) / ntaps
+    want = O.FIR(taps, True, O.MODE_FMA).process(x)
+    blk = make(lr.FIRFilterBlock, [taps], x)
+    assert np.array_equal(chunked(blk, x, [1, 2, 700, 701, 4000]), want)
+    assert G.max_abs_err(want, O.FIR(taps, True, O.MODE_F64).process(x)) < 1e-6
+
+
+def test_fir_long_filter_uses_fallback_and_matches():
+    rng = np.random.default_rng(5)
+    x = rand_c(rng, 6000)
+    taps = rand_r(rng, 1500) / 1500
+    blk = make(lr.FIRFilterBlock, [taps], x)
+    assert np.array_equal(blk.process(x), O.FIR(taps, True, O.MODE_FMA).process(x))
+
+
+def test_fir_unaligned_host_and_device_views():
+    """device pointers that are only sample-aligned (8 B / 4 B) take the alignment-slack path"""
+    import torch
+    rng = np.random.default_rng(6)
+    taps = O.firwin_lowpass(128, 0.136).astype(np.float32)
+    for cplx in (True, False):
+        n = 70000
+        x = rand_c(rng, n + 3) if cplx else rand_r(rng, n + 3)
+        xt = torch.from_numpy(x.view(np.float32)).cuda()
+        for off in (0, 1, 2, 3):
+            xs = x[off:off + n]
+            blk = make(lr.FIRFilterBlock, [taps], xs)
+            yt = torch.empty(n * (2 if cplx else 1) + 8, dtype=torch.float32, device="cuda")
+            es = 8 if cplx else 4
+            for yoff in (0, 1):
+                blk.reset()
+                got_n = blk.process_device(xt.data_ptr() + off * es, n, yt.data_ptr() + yoff * es, n)
+                lr._lib.load().lrhip_synchronize()
+                assert got_n == n
+                y = yt.cpu().numpy()[yoff * (es // 4):][:n * (es // 4)]
+                y = y.view(np.complex64) if cplx else y
+                assert np.array_equal(y, O.FIR(taps, cplx, O.MODE_FMA).process(xs)), (cplx, off, yoff)
+
+
+def test_fir_overlap_save_framing_matches_reference_emission():
+    """use_fft=True: emits floor((fill+n)/L)*L samples per call, values of the direct form (firfilter.lua:451-485)"""
+    rng = np.random.default_rng(8)
+    x = rand_c(rng, 5000)
+    taps = rand_r(rng, 32) / 32
+    blk = make(lr.FIRFilterBlock, [taps, True], x)
+    orc = O.FIRFFT(taps, True)
+    a = 0
+    for b in (100, 224, 225, 226, 1000, 1001, 5000):
+        got, want = blk.process(x[a:b]), orc.process(x[a:b])
+        assert len(got) == len(want)
+        assert G.max_abs_err(got, want) < 1e-6
+        a = b
+
+
+# --------------------------------------------------------------------------------------------- other blocks vs oracle
+def test_rotator_vs_closed_form_long_and_chunked():
+    rng = np.random.default_rng(9)
+    n = 300000
+    x = rand_c(rng, n)
+    for offset in (0.2, -0.7318, 1e-4):
+        omega = 2 * np.pi * offset / RATE
+        want = O.Rotator(omega, O.MODE_F64).process(x)
+        blk = make(lr.FrequencyTranslatorBlock, [offset], x)
+        assert G.max_abs_err(chunked(blk, x, [1, 77, 4096, 100000]), want) < 1e-6
+        # the reference's double-accumulator formulation stays within its epsilon over the whole run
+        assert G.max_abs_err(want, O.Rotator(omega, O.MODE_LUA).process(x)) < 1e-5
+
+
+def test_discriminator_vs_oracle():
+    rng = np.random.default_rng(10)
+    x = rand_c(rng, 200000)
+    for k in (1.25, 5.0):
+        blk = make(lr.FrequencyDiscriminatorBlock, [k], x)
+        want = O.FMDiscriminator(k).process(x)
+        assert G.max_abs_err(chunked(blk, x, [1, 2, 65536, 65537]), want) < 1e-6
+
+
+@pytest.mark.parametrize("factor", [1, 2, 5, 7, 256, 1000])
+def test_downsampler_vs_oracle_bit_exact(factor):
+    rng = np.random.default_rng(11 + factor)
+    for x in (rand_c(rng, 100003), rand_r(rng, 100003)):
+        blk = make(lr.DownsamplerBlock, [factor], x)
+        orc = O.Downsampler(factor, np.iscomplexobj(x))
+        a = 0
+        for b in (0, 1, 3, 999, 1000, 50000, 100003):     # includes an empty chunk
+            got, want = blk.process(x[a:b]), orc.process(x[a:b])
+            assert np.array_equal(got, want)
+            a = b
+
+
+def test_deemphasis_scan_vs_sequential_oracle_large():
+    rng = np.random.default_rng(12)
+    for x in (rand_r(rng, 300001), rand_c(rng, 50001)):
+        blk = make(lr.FMDeemphasisFilterBlock, [75e-6], x, rate=220500.0)
+        b, a = O.fm_deemphasis_taps(75e-6, 220500.0)
+        for mode in (O.MODE_LUA, O.MODE_F64):
+            want = O.IIR(b, a, np.iscomplexobj(x), mode).process(x)
+            blk.reset()
+            assert G.max_abs_err(chunked(blk, x, [1, 2, 4095, 4096, 4097, 20000]), want) < 1e-6
+
+
+def test_iir_second_and_fourth_order_scan_large():
+    rng = np.random.default_rng(13)
+    x = rand_r(rng, 100000)
+    doc = G.load("iirfilter_spec")
+    for vec in doc["vectors"][:2]:
+        b, a = vec["args"]
+        blk = make(lr.IIRFilterBlock, [b, a], x)
+        want = O.IIR(b, a, False, O.MODE_F64).process(x)
+        assert G.max_abs_err(chunked(blk, x, [5, 4096, 8192, 8193]), want) < 2e-6
+
+
+# --------------------------------------------------------------------------------------------- fused composites
+@pytest.mark.parametrize("factor", [2, 3, 4, 5, 6, 7, 8, 10, 9, 25])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_decimator_fused_bit_exact_vs_unfused_oracle(factor, cplx):
+    rng = np.random.default_rng(20 + factor)
+    n = 50000
+    x = rand_c(rng, n) if cplx else rand_r(rng, n)
+    dec = make(lr.DecimatorBlock, [factor], x)
+    want = O.decimator(factor, RATE, cplx, mode=O.MODE_FMA).process(x)
+    got = chunked(dec, x, [1, 2, 3, 1000, 1001, 30000])
+    assert np.array_equal(got, want)
+    assert dec.chain.last_launches <= 2          # decimating FIR (+ history carry): the downsampler is fused away
+
+
+def test_tuner_fused_rotator_fir_downsampler():
+    rng = np.random.default_rng(30)
+    x = rand_c(rng, 120000)
+    rate = 1102500.0
+    tun = make(lr.TunerBlock, [-250e3, 200e3, 5], x, rate=rate)
+    want = O.tuner(-250e3, 200e3, 5, rate, mode=O.MODE_FMA, rot_mode=O.MODE_F64).process(x)
+    got = chunked(tun, x, [1, 5, 6, 4097, 65536])
+    assert len(got) == len(want)
+    assert G.max_abs_err(got, want) < 1e-6
+    assert tun.chain.last_launches <= 2          # one fused kernel + history carry
+    # fused == unfused device blocks, bit for bit
+    rot = make(lr.FrequencyTranslatorBlock, [-250e3], x, rate=rate)
+    lpf = make(lr.LowpassFilterBlock, [128, 100e3], x, rate=rate)
+    ds = make(lr.DownsamplerBlock, [5], x, rate=rate)
+    assert np.array_equal(got, ds.process(lpf.process(rot.process(x))))
+
+
+def test_wbfm_mono_chain_rms_within_1e5():
+    """BASELINE.json configs[2] at a size the oracle finishes in seconds: synthetic FM (SURVEY.md 8d C3 recipe),
+    chain = examples/rtlsdr_wbfm_mono.lua:12-17,28.  Bar: RMS error <= 1e-5 vs the per-block-pinned oracle."""
+    fs, n = 1102500.0, 1 << 20
+    rng = np.random.default_rng(3)
+    t = np.arange(n) / fs
+    m = 0.5 * np.sin(2 * np.pi * 1e3 * t) + 0.5 * np.sin(2 * np.pi * 5e3 * t)
+    ph = 2 * np.pi * 250e3 * t + 2 * np.pi * 75e3 / fs * np.cumsum(m)
+    x = (np.exp(1j * ph) + 0.01 * (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n))).astype(np.complex64)
+    rx = lr.wbfm_mono_receiver(fs, -250e3)
+    got = chunked(rx, x, [8192, 8193, 500000])
+    for mode in (O.MODE_LUA, O.MODE_F64):
+        want = O.wbfm_mono_chain(fs, -250e3, mode=mode, rot_mode=O.MODE_F64).process(x)
+        assert len(got) == len(want) == (n // 5 + 4) // 5 or len(got) == len(want)
+        err = got.astype(np.float64) - want.astype(np.float64)
+        rms = float(np.sqrt(np.mean(err ** 2)))
+        assert rms <= 1e-5, (mode, rms)
+        assert float(np.max(np.abs(err))) < 1e-4
+    # the demodulated audio really is the two tones (sanity: the chain is doing FM demodulation)
+    spec = np.abs(np.fft.rfft(got[2000:] * np.hanning(len(got) - 2000)))
+    freqs = np.fft.rfftfreq(len(got) - 2000, 1 / 44100.0)
+    top2 = sorted(freqs[np.argsort(spec)[-2:]])
+    assert abs(top2[0] - 1e3) < 20 and abs(top2[1] - 5e3) < 20
+
+
+# --------------------------------------------------------------------------------------------- properties at size
+def test_fir_properties_at_full_tile_sizes():
+    """size-independent checks on 2^24 samples (the oracle is too slow there): impulse response == taps,
+    linearity, and DC gain of the unity-gain lowpass."""
+    import torch
+    n = 1 << 24
+    taps = O.firwin_lowpass(128, 15e3 / 110250).astype(np.float32)
+    blk = make(lr.FIRFilterBlock, [taps], np.zeros(1, np.complex64))
+    L = lr._lib.load()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = torch.rand(2 * n, device="cuda", generator=g) * 2 - 1
+    b = torch.rand(2 * n, device="cuda", generator=g) * 2 - 1
+    ya, yb, yab = (torch.empty(2 * n, device="cuda") for _ in range(3))
+    for src, dst in ((a, ya), (b, yb), (a + b, yab)):
+        blk.reset()
+        assert blk.process_device(src.data_ptr(), n, dst.data_ptr(), n) == n
+    L.lrhip_synchronize()
+    assert float((yab - (ya + yb)).abs().max()) < 2e-6          # linearity (f32 rounding only)
+    # impulses placed across tile boundaries reproduce the taps exactly
+    imp = torch.zeros(2 * n, device="cuda")
+    pos = [0, 4095, 4096, 4097, 1 << 20, n - 200]
+    for p in pos:
+        imp[2 * p] = 1.0
+    blk.reset()
+    y = torch.empty(2 * n, device="cuda")
+    blk.process_device(imp.data_ptr(), n, y.data_ptr(), n)
+    L.lrhip_synchronize()
+    yr = y.view(-1, 2)[:, 0].cpu().numpy()
+    for p in (4096, 1 << 20, n - 200):
+        assert np.array_equal(yr[p:p + 128], taps)
+    dc = torch.ones(2 * n, device="cuda")
+    blk.reset()
+    blk.process_device(dc.data_ptr(), n, y.data_ptr(), n)
+    L.lrhip_synchronize()
+    assert abs(float(y[2 * (n // 2)]) - 1.0) < 1e-6
+
+
+def test_psd_many_frames_vs_oracle():
+    rng = np.random.default_rng(40)
+    N, frames = 1024, 64
+    x = rand_c(rng, N * frames)
+    for log in (False, True):
+        out = np.empty(N * frames, np.float32)
+        spectrum_utils.PSD(x, out, "hamming", 1102500.0, log, frames=frames).compute()
+        want = np.concatenate([O.psd(x[i * N:(i + 1) * N], "hamming", 1102500.0, log) for i in range(frames)])
+        if log:
+            assert G.max_abs_err(out, want) < 1e-2          # dB
+        else:
+            assert np.max(np.abs(out - want) / np.max(want)) < 1e-5
+
+
+def test_error_paths_report_through_strerror():
+    L = lr._lib.load()
+    import ctypes as C
+    assert not L.lrhip_fir_create(None, 0, 0, 1, 1, 0)
+    assert b"tap" in L.lrhip_strerror()
+    assert not L.lrhip_downsampler_create(0, 8)
+    assert not L.lrhip_dft_create(100, 0, 0)
+    blk = make(lr.DownsamplerBlock, [2], np.zeros(4, np.float32))
+    out = np.empty(1, np.float32)
+    x = np.zeros(10, np.float32)
+    rc = L.lrhip_stage_execute(blk.stage_handle(), x.ctypes.data_as(C.c_void_p), 10, out.ctypes.data_as(C.c_void_p), 1)
+    assert rc < 0 and b"capacity" in L.lrhip_strerror()

@@ -1,0 +1,122 @@
+"""CPU-side tests of the product's host logic and of the C-ABI surface (no compute calls: no GPU here)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import luaradio_amd as lr
+from luaradio_amd import _lib, filter_utils, types, window_utils
+from tests import golden_util as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "lrhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lrhip_\w+)\s*\(", text)))
+
+
+def test_abi_exports_every_declared_symbol():
+    """liblrhip.so loads and exports exactly what include/lrhip.h declares (and _lib.py binds all of it)."""
+    L = _lib.load()
+    declared = _header_functions()
+    assert len(declared) >= 30
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r"\bT (lrhip_\w+)", out))
+    assert set(declared) <= exported, sorted(set(declared) - exported)
+    assert set(declared) == set(_lib.SIGNATURES), sorted(set(declared) ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert b"gfx950" in L.lrhip_version()
+
+
+def test_library_is_built_for_gfx950_only():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", "--input=" + _lib.LIB_PATH],
+                         capture_output=True, text=True).stdout
+    if out.strip():
+        gpu_targets = [l for l in out.split() if "amdgcn" in l]
+        assert gpu_targets and all("gfx950" in t for t in gpu_targets), gpu_targets
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: creating any stage without a device is an error with a message."""
+    L = _lib.load()
+    blk = lr.FrequencyTranslatorBlock(0.2)
+    blk.rate = 2.0
+    blk.differentiate([types.ComplexFloat32])
+    with pytest.raises(lr.LrhipError) as ei:
+        blk.initialize()
+    assert "rotator" in str(ei.value) and L.lrhip_strerror()
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "luaradio_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".lua")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "liblroracle" not in text, f
+
+
+def test_window_utils_mirror_matches_reference_vectors():
+    vals = G.load("window_utils_vectors")["values"]
+    for name, want in vals.items():
+        kind = name[len("window_"):]
+        periodic = kind.endswith("_periodic")
+        kind = kind[:-len("_periodic")] if periodic else kind
+        got = types.Float32.vector_from_array(window_utils.window(128, kind, periodic))
+        assert G.max_abs_err(got, want) < 1e-6, name
+    with pytest.raises(ValueError):
+        window_utils.window(8, "kaiser")
+
+
+def test_filter_utils_mirror_matches_reference_vectors():
+    vals = G.load("filter_utils_vectors")["values"]
+    f32 = types.Float32.vector_from_array
+    assert G.max_abs_err(f32(filter_utils.firwin_lowpass(128, 0.5)), vals["firwin_lowpass"]) < 1e-6
+    assert G.max_abs_err(f32(filter_utils.firwin_highpass(129, 0.5)), vals["firwin_highpass"]) < 1e-6
+    assert G.max_abs_err(f32(filter_utils.firwin_bandpass(129, [0.4, 0.6])), vals["firwin_bandpass"]) < 1e-6
+    assert G.max_abs_err(f32(filter_utils.firwin_bandstop(129, [0.4, 0.6])), vals["firwin_bandstop"]) < 1e-6
+
+
+def test_filter_utils_mirror_is_bit_identical_to_oracle_design():
+    """two independent restatements (C double, Python double) of filter_utils.lua give the same Float32 taps"""
+    from oracle import oracle as O
+    for M, c, w in [(128, 15e3 / 110250, "hamming"), (128, 0.2, "bartlett"), (16, 0.2, "hamming"), (33, 0.7, "blackman")]:
+        a = types.Float32.vector_from_array(filter_utils.firwin_lowpass(M, c, w))
+        b = O.firwin_lowpass(M, c, w).astype(np.float32)
+        assert np.array_equal(a, b), (M, c, w)
+
+
+def test_block_type_signatures_and_rates():
+    b = lr.FIRFilterBlock([1.0, 2.0])
+    b.differentiate([types.Float32])
+    assert b.get_output_type() is types.Float32
+    b.differentiate([types.ComplexFloat32])
+    assert b.get_output_type() is types.ComplexFloat32
+    c = lr.FIRFilterBlock(np.array([1 + 1j], dtype=np.complex64))
+    with pytest.raises(TypeError):
+        c.differentiate([types.Float32])          # complex taps need complex input (firfilter.lua:68-70)
+    d = lr.DownsamplerBlock(5)
+    d.rate = 1102500.0
+    assert d.get_rate() == 220500.0                # downsampler.lua:36-38
+    t = lr.TunerBlock(-250e3, 200e3, 5)
+    t.rate = 1102500.0
+    t.differentiate([types.ComplexFloat32])
+    t._propagate_rates()
+    assert t.get_rate() == 220500.0
+    with pytest.raises(AssertionError):
+        lr.LowpassFilterBlock(128, None)
+    with pytest.raises(RuntimeError):
+        lr.FrequencyTranslatorBlock(1.0).get_rate()
+
+
+def test_lua_glue_declares_the_same_abi():
+    """the ffi.cdef in lua/radio/core/lrhip.lua names every function of include/lrhip.h"""
+    path = os.path.join(ROOT, "lua", "radio", "core", "lrhip.lua")
+    text = open(path).read()
+    for name in _header_functions():
+        assert name in text, name
