@@ -117,12 +117,15 @@ struct FirMfmaGeom {
     __host__ __device__ static constexpr int phys(int a) { return a + PAD * (a / ROW); }
 };
 
-template <int S, int D, int NACC, bool ROT>
+// KS > 0: the number of MFMA steps is a compile-time constant (fully unrolled main loop, the headline M = 128
+// case); KS == 0: run-time `ksteps_rt`.
+template <int S, int D, int NACC, bool ROT, int KS>
 __global__ __launch_bounds__(256) void fir_mfma_kernel(
     const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ atab, float *__restrict__ y,
-    int M, long n, long n_out, long first, int e, int ksteps, int out_aligned,
+    int M, long n, long n_out, long first, int e, int ksteps_rt, int out_aligned,
     uint64_t rot_step_fx, uint64_t rot_count0)
 {
+    const int ksteps = KS > 0 ? KS : ksteps_rt;
     using G = FirMfmaGeom<S, D>;
     constexpr int TILE_OUT = G::tile_out(NACC);
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -198,19 +201,25 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int ngroups = ksteps / G::GROUP;
-    for (int g = 0; g < ngroups; g++) {
+    auto group = [&](int g) {
+        const float *ap = aptr + g * (G::GROUP * 64);
+        const float *bp = bptr + g * (G::ROW + G::PAD);
 #pragma unroll
         for (int j = 0; j < G::GROUP; j++) {
-            float av = aptr[j * 64];
+            float av = ap[j * 64];
 #pragma unroll
             for (int a = 0; a < NACC; a++) {
-                float bv = bptr[a * ACC_STRIDE + j * 4 * S];
+                float bv = bp[a * ACC_STRIDE + j * 4 * S];
                 acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[a], 0, 0, 0);
             }
         }
-        aptr += G::GROUP * 64;
-        bptr += G::ROW + G::PAD;
+    };
+    if constexpr (KS > 0) {
+#pragma unroll
+        for (int g = 0; g < KS / G::GROUP; g++) group(g);
+    } else {
+        const int ngroups = ksteps / G::GROUP;
+        for (int g = 0; g < ngroups; g++) group(g);
     }
 
     // ---- epilogue: accumulator lane (col, kq) holds rows 4*kq .. 4*kq+3 of column col
@@ -230,12 +239,12 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
             // even lane = re column, odd lane = im column of the same block: trade halves so each lane owns
             // two whole ComplexFloat32 outputs (rows 4kq+{0,1} on the even lane, 4kq+{2,3} on the odd lane)
             const bool odd = col & 1;
-            float send0 = odd ? acc[a][0] : acc[a][2];
-            float send1 = odd ? acc[a][1] : acc[a][3];
+            const float a0 = acc[a][0], a1 = acc[a][1], a2 = acc[a][2], a3 = acc[a][3];
+            float send0 = odd ? a0 : a2;
+            float send1 = odd ? a1 : a3;
             float recv0 = __shfl_xor(send0, 1);
             float recv1 = __shfl_xor(send1, 1);
-            float4 o = odd ? make_float4(recv0, acc[a][2], recv1, acc[a][3])
-                           : make_float4(acc[a][0], recv0, acc[a][1], recv1);
+            float4 o = odd ? make_float4(recv0, a2, recv1, a3) : make_float4(a0, recv0, a1, recv1);
             long k = kblk + 4 * kq + (odd ? 2 : 0);
             if (out_aligned && k + 1 < n_out) {
                 *reinterpret_cast<float4 *>(y + 2 * k) = o;

@@ -84,6 +84,14 @@ struct FirStage : lrhip_stage {
     template <int SS, int DD, int NACC>
     int launch_mfma(const float *x, long n, float *y, long n_out)
     {
+        // the headline shape (M = 128 -> 36 MFMA steps at D = 1) gets the fully unrolled instantiation
+        if (DD == 1 && ksteps == 36 && !rot) return launch_mfma_ks<SS, DD, NACC, 36>(x, n, y, n_out);
+        return launch_mfma_ks<SS, DD, NACC, 0>(x, n, y, n_out);
+    }
+
+    template <int SS, int DD, int NACC, int KS>
+    int launch_mfma_ks(const float *x, long n, float *y, long n_out)
+    {
         using G = FirMfmaGeom<SS, DD>;
         constexpr int TILE_OUT = G::tile_out(NACC);
         // alignment slack so that the tile's first staged sample is 16-B aligned in global memory
@@ -101,7 +109,7 @@ struct FirStage : lrhip_stage {
         int out_aligned = ((uintptr_t)y % 16) == 0;
         if (rot) {
             if constexpr (SS == 2) {
-                auto kern = fir_mfma_kernel<2, DD, NACC, true>;
+                auto kern = fir_mfma_kernel<2, DD, NACC, true, 0>;
                 if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p, x, atab, y,
                                    M, n, n_out, (long)index, e, ksteps, out_aligned, rot_step, count);
@@ -109,7 +117,7 @@ struct FirStage : lrhip_stage {
                 return set_error("rotator fusion needs complex input");
             }
         } else {
-            auto kern = fir_mfma_kernel<SS, DD, NACC, false>;
+            auto kern = fir_mfma_kernel<SS, DD, NACC, false, KS>;
             if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p, x, atab, y,
                                M, n, n_out, (long)index, e, ksteps, out_aligned, (uint64_t)0, (uint64_t)0);

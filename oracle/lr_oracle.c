@@ -23,6 +23,9 @@
  *                      taps applied oldest-sample-first (firfilter.lua:272-280).
  *   LRO_MODE_FMA  (1)  the same order with each mul+add fused (fmaf chain) - this is bit-for-bit what
  *                      the HIP kernels compute (v_fma_f32 / v_mfma_f32_16x16x4_f32 are fmaf chains).
+ *   LRO_MODE_SIMD (3)  16 interleaved partial sums over the taps, what a SIMD dot product (VOLK's
+ *                      volk_32fc_32f_dot_prod_32fc / volk_32f_x2_dot_prod_32f, firfilter.lua:139-142,157-160) does;
+ *                      used as the timed CPU baseline (single thread, or OpenMP over output ranges).
  *   LRO_MODE_F64  (2)  products and sums in double, one final rounding - what scipy.signal.lfilter
  *                      (the generator of the golden vectors, tests/blocks/signal/firfilter_spec.py:7-9) does.
  */
@@ -34,6 +37,7 @@
 #define LRO_MODE_LUA 0
 #define LRO_MODE_FMA 1
 #define LRO_MODE_F64 2
+#define LRO_MODE_SIMD 3   /* VOLK-style: 16 partial sums across taps (order unspecified, as volk_32fc_32f_dot_prod_32fc) */
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -227,6 +231,46 @@ long lro_fir_process(lro_fir *q, const float *x, long n, float *y)
         else fir_dot_cc(s, q->taps_rev, M, q->mode, y + 2 * i);
     }
     /* keep the last M-1 samples of state (firfilter.lua:248: memmove from state.length-(M-1)) */
+    memmove(q->hist, q->state + (size_t)es * n, sizeof(float) * es * (M - 1));
+    return n;
+}
+
+/* VOLK-style dot product over a float stream z[0..len) with (possibly duplicated) taps hd[0..len):
+ * 16 independent partial sums so the compiler emits packed FMAs; even lanes / odd lanes are re / im when z is
+ * an interleaved complex stream and hd holds every tap twice. */
+static inline void dot16(const float *z, const float *hd, int len, float *even, float *odd)
+{
+    float acc[16] = {0};
+    int k = 0;
+    for (; k + 16 <= len; k += 16)
+        for (int l = 0; l < 16; l++) acc[l] += z[k + l] * hd[k + l];
+    for (; k < len; k++) acc[k & 15] += z[k] * hd[k];
+    float e = 0, o = 0;
+    for (int l = 0; l < 16; l += 2) { e += acc[l]; o += acc[l + 1]; }
+    *even = e; *odd = o;
+}
+
+/* Timed CPU baseline: same history handling as lro_fir_process, dot products in LRO_MODE_SIMD, optionally
+ * split over `nthreads` OpenMP threads (contiguous output ranges; the reference itself gives a block one core,
+ * docs/5.architecture.md:62-68, so nthreads = 1 is the reference-equivalent figure). Real taps only. */
+long lro_fir_process_simd(lro_fir *q, const float *x, long n, float *y, int nthreads)
+{
+    int M = q->ntaps, es = q->input_complex ? 2 : 1;
+    if (q->taps_complex) return -1;
+    long need = (long)(M - 1 + n) * es;
+    if (need > q->state_cap) { q->state = (float *)realloc(q->state, sizeof(float) * need); q->state_cap = need; }
+    memcpy(q->state, q->hist, sizeof(float) * es * (M - 1));
+    memcpy(q->state + (size_t)es * (M - 1), x, sizeof(float) * es * n);
+    float *hd = (float *)malloc(sizeof(float) * es * M);
+    for (int j = 0; j < M; j++) for (int c = 0; c < es; c++) hd[j * es + c] = q->taps_rev[j];
+    const float *state = q->state;
+#pragma omp parallel for schedule(static) num_threads(nthreads) if (nthreads > 1)
+    for (long i = 0; i < n; i++) {
+        float e, o;
+        dot16(state + (size_t)es * i, hd, M * es, &e, &o);
+        if (es == 2) { y[2 * i] = e; y[2 * i + 1] = o; } else y[i] = e + o;
+    }
+    free(hd);
     memmove(q->hist, q->state + (size_t)es * n, sizeof(float) * es * (M - 1));
     return n;
 }

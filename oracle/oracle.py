@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liblroracle.so")
 
-MODE_LUA, MODE_FMA, MODE_F64 = 0, 1, 2
+MODE_LUA, MODE_FMA, MODE_F64, MODE_SIMD = 0, 1, 2, 3
 
 
 def build(force=False):
@@ -41,6 +41,8 @@ def lib():
         L.lro_fir_process.restype = C.c_long
         L.lro_fir_process.argtypes = [vp, fp, C.c_long, fp]
         L.lro_fir_destroy.argtypes = [vp]
+        L.lro_fir_process_simd.restype = C.c_long
+        L.lro_fir_process_simd.argtypes = [vp, fp, C.c_long, fp, C.c_int]
         L.lro_firfft_create.restype = vp
         L.lro_firfft_create.argtypes = [fp, C.c_int, C.c_int, C.c_int]
         L.lro_firfft_process.restype = C.c_long
@@ -153,6 +155,19 @@ class FIR(_Stage):
         y = _out(len(x), xc)
         lib().lro_fir_process(self.q, _fp(xf), len(x), _fp(y.view(np.float32)))
         return y
+
+
+def _fir_process_simd(self, x, nthreads=1, out=None):
+    """VOLK-style SIMD dot products (the timed CPU baseline), optionally OpenMP-threaded."""
+    xf, xc = _as_f32(x)
+    assert xc == self.input_complex
+    y = out if out is not None else _out(len(x), xc)
+    n = lib().lro_fir_process_simd(self.q, _fp(xf), len(x), _fp(y.view(np.float32)), int(nthreads))
+    assert n == len(x)
+    return y
+
+
+FIR.process_simd = _fir_process_simd
 
 
 class FIRFFT(_Stage):

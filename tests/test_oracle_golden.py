@@ -200,3 +200,21 @@ def test_fir_modes_agree_long():
     whole = O.FIR(taps, True, O.MODE_FMA).process(x)
     parts = np.concatenate([f.process(x[a:b]) for a, b in ((0, 1), (1, 130), (130, 131), (131, 4000), (4000, 5000))])
     assert np.array_equal(whole, parts)
+
+
+def test_simd_baseline_kernel_matches_golden_and_other_modes():
+    """the timed CPU baseline (VOLK-style partial sums, optional OpenMP) is held to the same vectors"""
+    doc = G.load("lowpassfilter_spec")
+    for vec in doc["vectors"][:3] + doc["vectors"][6:9]:
+        x, want = vec["inputs"][0], vec["outputs"][0]
+        cplx = np.iscomplexobj(x)
+        f = O.lowpass(vec["args"][0], vec["args"][1], RATE, cplx)
+        assert G.max_abs_err(f.process_simd(x, 1), want) < doc["epsilon"]
+    rng = np.random.default_rng(3)
+    x = (rng.uniform(-1, 1, 40000) + 1j * rng.uniform(-1, 1, 40000)).astype(np.complex64)
+    taps = O.firwin_lowpass(128, 0.136).astype(np.float32)
+    ref = O.FIR(taps, True, O.MODE_F64).process(x)
+    a, b = O.FIR(taps, True), O.FIR(taps, True)
+    y1 = np.concatenate([a.process_simd(x[:777], 1), a.process_simd(x[777:], 1)])
+    y4 = b.process_simd(x, 4)
+    assert G.max_abs_err(y1, ref) < 1e-6 and np.array_equal(y1, y4)
