@@ -22,6 +22,17 @@ namespace lrhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// resident workgroups (= waves per SIMD, 256-thread workgroups) the persistent FIR kernel is register-budgeted for
+#ifndef LRHIP_FIR_SETPRIO
+#define LRHIP_FIR_SETPRIO 0
+#endif
+#ifndef LRHIP_FIR_SCHED
+#define LRHIP_FIR_SCHED 0
+#endif
+#ifndef LRHIP_FIR_WAVES_PER_SIMD
+#define LRHIP_FIR_WAVES_PER_SIMD 3
+#endif
+
 // s(p): the "state" vector of firfilter.lua:244-250 without materialising it:
 // p < M-1 -> hist[p] (carried), else x[p-(M-1)]; beyond the chunk reads as 0 (never used by a valid output).
 template <int S>
@@ -117,90 +128,77 @@ struct FirMfmaGeom {
     __host__ __device__ static constexpr int phys(int a) { return a + PAD * (a / ROW); }
 };
 
-// KS > 0: the number of MFMA steps is a compile-time constant (fully unrolled main loop, the headline M = 128
-// case); KS == 0: run-time `ksteps_rt`.
-template <int S, int D, int NACC, bool ROT, int KS>
-__global__ __launch_bounds__(256) void fir_mfma_kernel(
-    const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ atab, float *__restrict__ y,
-    int M, long n, long n_out, long first, int e, int ksteps_rt, int out_aligned,
-    uint64_t rot_step_fx, uint64_t rot_count0)
+// ---- shared device pieces ---------------------------------------------------------------------------------
+
+// fused FrequencyTranslatorBlock: rotate the two ComplexFloat32 samples of a float4 whose first sample has
+// absolute index cnt
+__device__ __forceinline__ float4 rotate_pair(float4 v, uint64_t step_fx, uint64_t cnt)
 {
-    const int ksteps = KS > 0 ? KS : ksteps_rt;
+    float c0, s0, c1, s1;
+    phasor_from_turns(step_fx * cnt, c0, s0);
+    phasor_from_turns(step_fx * (cnt + 1), c1, s1);
+    double xr = v.x, xi = v.y;
+    v.x = (float)(xr * (double)c0 - xi * (double)s0);
+    v.y = (float)(xr * (double)s0 + xi * (double)c0);
+    xr = v.z; xi = v.w;
+    v.z = (float)(xr * (double)c1 - xi * (double)s1);
+    v.w = (float)(xr * (double)s1 + xi * (double)c1);
+    return v;
+}
+
+// one float4 of staged samples (logical float index 4*i4) -> padded LDS rows
+template <int S, int D>
+__device__ __forceinline__ void lds_put4(float *ldsX, int i4, float4 v)
+{
     using G = FirMfmaGeom<S, D>;
-    constexpr int TILE_OUT = G::tile_out(NACC);
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *ldsA = lds;                       // ksteps * 64 floats
-    float *ldsX = lds + ksteps * 64;         // staged samples (padded rows)
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long tile_k0 = (long)blockIdx.x * TILE_OUT;
-    const long base = first + tile_k0 * D - e;               // stream position of r = 0
-    const int span = G::span(NACC, ksteps);                   // samples to stage
-    const int nflt = span * S;
-
-    // ---- A fragments (Toeplitz table for this launch's e) -> LDS
-    for (int i = tid; i < ksteps * 64; i += 256) ldsA[i] = atab[i];
-
-    // ---- stage the tile: global -> LDS (padded rows)
-    const long xlo = base - (M - 1);                          // x index of r = 0
-    const bool interior = (xlo >= 0) && (xlo + span <= n) && ((nflt & 3) == 0);
-    if (interior) {
-        const float4 *src = reinterpret_cast<const float4 *>(x + xlo * S);   // 16-B aligned by choice of e
-        for (int i4 = tid; i4 < nflt / 4; i4 += 256) {
-            float4 v = src[i4];
-            if (ROT) {   // fused FrequencyTranslatorBlock: rotate on the way in (S == 2)
-                float c0, s0, c1, s1;
-                uint64_t cnt = rot_count0 + (uint64_t)(xlo + 2 * (long)i4);
-                phasor_from_turns(rot_step_fx * cnt, c0, s0);
-                phasor_from_turns(rot_step_fx * (cnt + 1), c1, s1);
-                double xr = v.x, xi = v.y;
-                v.x = (float)(xr * (double)c0 - xi * (double)s0);
-                v.y = (float)(xr * (double)s0 + xi * (double)c0);
-                xr = v.z; xi = v.w;
-                v.z = (float)(xr * (double)c1 - xi * (double)s1);
-                v.w = (float)(xr * (double)s1 + xi * (double)c1);
-            }
-            int p = G::phys(4 * i4);
-            if (S == 2) {
-                *reinterpret_cast<float4 *>(ldsX + p) = v;
-            } else {
-                *reinterpret_cast<float2 *>(ldsX + p) = make_float2(v.x, v.y);
-                *reinterpret_cast<float2 *>(ldsX + p + 2) = make_float2(v.z, v.w);
-            }
-        }
+    int p = G::phys(4 * i4);
+    if (S == 2) {
+        *reinterpret_cast<float4 *>(ldsX + p) = v;
     } else {
-        for (int r = tid; r < span; r += 256) {
-            long p = base + r;
-            float v0 = stream_at<S>(hist, x, p, 0, M, n);
-            float v1 = S == 2 ? stream_at<S>(hist, x, p, 1, M, n) : 0.f;
-            if (ROT) {
-                float c0, s0;
-                // absolute sample index of stream position p is rot_count0 + p - (M-1); history before the
-                // start of the stream is zero, so its phase is irrelevant
-                phasor_from_turns(rot_step_fx * (rot_count0 + (uint64_t)(p - (M - 1))), c0, s0);
-                double xr = v0, xi = v1;
-                v0 = (float)(xr * (double)c0 - xi * (double)s0);
-                v1 = (float)(xr * (double)s0 + xi * (double)c0);
-            }
-            int pa = G::phys(S * r);
-            ldsX[pa] = v0;
-            if (S == 2) ldsX[pa + 1] = v1;
-        }
+        *reinterpret_cast<float2 *>(ldsX + p) = make_float2(v.x, v.y);
+        *reinterpret_cast<float2 *>(ldsX + p + 2) = make_float2(v.z, v.w);
     }
-    __syncthreads();
+}
 
-    // ---- MFMA main loop
+// edge tiles (touch the carried history, the end of the chunk, or an unaligned source): per-sample staging
+template <int S, int D, bool ROT>
+__device__ __forceinline__ void stage_edge(float *ldsX, const float *__restrict__ hist, const float *__restrict__ x,
+                                           long base, int span, int M, long n, uint64_t rot_step_fx, uint64_t rot_count0)
+{
+    using G = FirMfmaGeom<S, D>;
+    for (int r = threadIdx.x; r < span; r += 256) {
+        long p = base + r;
+        float v0 = stream_at<S>(hist, x, p, 0, M, n);
+        float v1 = S == 2 ? stream_at<S>(hist, x, p, 1, M, n) : 0.f;
+        if (ROT) {
+            float c0, s0;
+            // absolute sample index of stream position p is rot_count0 + p - (M-1); history before the
+            // start of the stream is zero, so its phase is irrelevant
+            phasor_from_turns(rot_step_fx * (rot_count0 + (uint64_t)(p - (M - 1))), c0, s0);
+            double xr = v0, xi = v1;
+            v0 = (float)(xr * (double)c0 - xi * (double)s0);
+            v1 = (float)(xr * (double)s0 + xi * (double)c0);
+        }
+        int pa = G::phys(S * r);
+        ldsX[pa] = v0;
+        if (S == 2) ldsX[pa + 1] = v1;
+    }
+}
+
+// the MFMA main loop over one staged tile; KS > 0 => fully unrolled
+template <int S, int D, int NACC, int KS>
+__device__ __forceinline__ void mfma_tile(const float *ldsA, const float *ldsX, int ksteps, f32x4 (&acc)[NACC])
+{
+    using G = FirMfmaGeom<S, D>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int blk_in_acc = S == 2 ? (col >> 1) : col;
     const int comp = S == 2 ? (col & 1) : 0;
     constexpr int ACC_STRIDE = (G::ROW + G::PAD) * G::BPA;    // floats between consecutive accumulators' blocks
     const float *bptr = ldsX + (G::ROW + G::PAD) * ((wave * NACC) * G::BPA + blk_in_acc) + S * kq + comp;
     const float *aptr = ldsA + lane;
-
-    f32x4 acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     auto group = [&](int g) {
         const float *ap = aptr + g * (G::GROUP * 64);
         const float *bp = bptr + g * (G::ROW + G::PAD);
@@ -215,31 +213,55 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
         }
     };
     if constexpr (KS > 0) {
+#if LRHIP_FIR_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int g = 0; g < KS / G::GROUP; g++) group(g);
+#if LRHIP_FIR_SCHED
+        // ask the scheduler for a software pipeline: a dozen LDS reads up front, then 2 MFMA : 1 LDS read
+        __builtin_amdgcn_sched_group_barrier(0x100, LRHIP_FIR_SCHED, 0);
+#pragma unroll
+        for (int i = 0; i < KS * NACC / 2; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#endif
+#if LRHIP_FIR_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     } else {
         const int ngroups = ksteps / G::GROUP;
         for (int g = 0; g < ngroups; g++) group(g);
     }
+}
 
-    // ---- epilogue: accumulator lane (col, kq) holds rows 4*kq .. 4*kq+3 of column col
+// epilogue: accumulator lane (col, kq) holds rows 4*kq .. 4*kq+3 of column col
+template <int S, int D, int NACC>
+__device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, long n_out, int out_aligned, f32x4 (&acc)[NACC])
+{
+    using G = FirMfmaGeom<S, D>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int blk_in_acc = S == 2 ? (col >> 1) : col;
 #pragma unroll
     for (int a = 0; a < NACC; a++) {
         const long kblk = tile_k0 + 16 * (long)((wave * NACC + a) * G::BPA + blk_in_acc);
+        const float a0 = acc[a][0], a1 = acc[a][1], a2 = acc[a][2], a3 = acc[a][3];
         if (S == 1) {
             long k = kblk + 4 * kq;
             if (out_aligned && k + 3 < n_out) {
-                *reinterpret_cast<float4 *>(y + k) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+                *reinterpret_cast<float4 *>(y + k) = make_float4(a0, a1, a2, a3);
             } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if (k + r < n_out) y[k + r] = acc[a][r];
+                if (k < n_out) y[k] = a0;
+                if (k + 1 < n_out) y[k + 1] = a1;
+                if (k + 2 < n_out) y[k + 2] = a2;
+                if (k + 3 < n_out) y[k + 3] = a3;
             }
         } else {
             // even lane = re column, odd lane = im column of the same block: trade halves so each lane owns
             // two whole ComplexFloat32 outputs (rows 4kq+{0,1} on the even lane, 4kq+{2,3} on the odd lane)
             const bool odd = col & 1;
-            const float a0 = acc[a][0], a1 = acc[a][1], a2 = acc[a][2], a3 = acc[a][3];
             float send0 = odd ? a0 : a2;
             float send1 = odd ? a1 : a3;
             float recv0 = __shfl_xor(send0, 1);
@@ -253,6 +275,126 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
                 if (k + 1 < n_out) *reinterpret_cast<float2 *>(y + 2 * k + 2) = make_float2(o.z, o.w);
             }
         }
+    }
+}
+
+// ---- generic kernel: run-time number of MFMA steps, one tile per workgroup ----------------------------------------
+template <int S, int D, int NACC, bool ROT>
+__global__ __launch_bounds__(256) void fir_mfma_kernel(
+    const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ atab, float *__restrict__ y,
+    int M, long n, long n_out, long first, int e, int ksteps, int out_aligned,
+    uint64_t rot_step_fx, uint64_t rot_count0)
+{
+    using G = FirMfmaGeom<S, D>;
+    constexpr int TILE_OUT = G::tile_out(NACC);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ldsA = lds;                       // ksteps * 64 floats
+    float *ldsX = lds + ksteps * 64;         // staged samples (padded rows)
+    const int tid = threadIdx.x;
+    const long tile_k0 = (long)blockIdx.x * TILE_OUT;
+    const long base = first + tile_k0 * D - e;               // stream position of r = 0
+    const int span = G::span(NACC, ksteps);                   // samples to stage
+    const int nf4 = span * S / 4;
+
+    const float4 *a4 = reinterpret_cast<const float4 *>(atab);
+    for (int i = tid; i < ksteps * 16; i += 256) *reinterpret_cast<float4 *>(ldsA + 4 * i) = a4[i];
+
+    const long xlo = base - (M - 1);                          // x index of r = 0
+    const bool interior = (xlo >= 0) && (xlo + span <= n);
+    if (interior) {
+        const float4 *src = reinterpret_cast<const float4 *>(x + xlo * S);   // 16-B aligned by choice of e
+        constexpr int UX = 4;                                  // loads in flight per thread per batch
+        for (int i0 = tid; i0 < nf4; i0 += 256 * UX) {
+            float4 vv[UX];
+#pragma unroll
+            for (int u = 0; u < UX; u++) {
+                int idx = i0 + u * 256;
+                vv[u] = src[idx < nf4 ? idx : nf4 - 1];       // clamped, unconditional: no branch between loads
+            }
+#pragma unroll
+            for (int u = 0; u < UX; u++) {
+                const int i4 = i0 + u * 256;
+                if (i4 < nf4) lds_put4<S, D>(ldsX, i4, ROT ? rotate_pair(vv[u], rot_step_fx, rot_count0 + (uint64_t)(xlo + 2 * (long)i4)) : vv[u]);
+            }
+        }
+    } else {
+        stage_edge<S, D, ROT>(ldsX, hist, x, base, span, M, n, rot_step_fx, rot_count0);
+    }
+    __syncthreads();
+    f32x4 acc[NACC];
+    mfma_tile<S, D, NACC, 0>(ldsA, ldsX, ksteps, acc);
+    store_tile<S, D, NACC>(y, tile_k0, n_out, out_aligned, acc);
+}
+
+// ---- persistent kernel: compile-time number of MFMA steps KS -----------------------------------------------------------
+// One workgroup per resident slot walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The Toeplitz table is
+// loaded into LDS once.  The NEXT tile's samples are fetched into registers (UX float4 per thread) right before
+// the current tile's MFMA loop, so HBM latency hides under ~9k cycles of matrix work; they are written to LDS
+// after the loop.  Edge tiles (first tile: history; last tiles: end of chunk) are staged synchronously.
+template <int S, int D, int NACC, bool ROT, int KS>
+__global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persistent_kernel(
+    const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ atab, float *__restrict__ y,
+    int M, long n, long n_out, long first, int e, long ntiles, int out_aligned,
+    uint64_t rot_step_fx, uint64_t rot_count0)
+{
+    using G = FirMfmaGeom<S, D>;
+    constexpr int TILE_OUT = G::tile_out(NACC);
+    constexpr int SPAN = G::span(NACC, KS);
+    constexpr int NF4 = SPAN * S / 4;
+    constexpr int UX = (NF4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ldsA = lds;
+    float *ldsX = lds + KS * 64;
+    const int tid = threadIdx.x;
+
+    {
+        const float4 *a4 = reinterpret_cast<const float4 *>(atab);
+        for (int i = tid; i < KS * 16; i += 256) *reinterpret_cast<float4 *>(ldsA + 4 * i) = a4[i];
+    }
+
+    auto xlo_of = [&](long t) { return first + t * (long)TILE_OUT * D - e - (M - 1); };
+    auto interior = [&](long t) { long lo = xlo_of(t); return t < ntiles && lo >= 0 && lo + SPAN <= n; };
+
+    float4 pre[UX];
+    long t = blockIdx.x;
+    bool have = false;
+    if (interior(t)) {
+        const float4 *src = reinterpret_cast<const float4 *>(x + xlo_of(t) * S);
+#pragma unroll
+        for (int u = 0; u < UX; u++) {
+            int idx = tid + u * 256;
+            pre[u] = src[idx < NF4 ? idx : NF4 - 1];
+        }
+        have = true;
+    }
+    for (; t < ntiles; t += gridDim.x) {
+        const long tile_k0 = t * (long)TILE_OUT;
+        if (have) {
+            const long xlo = xlo_of(t);
+#pragma unroll
+            for (int u = 0; u < UX; u++) {
+                const int i4 = tid + u * 256;
+                if (i4 < NF4) lds_put4<S, D>(ldsX, i4, ROT ? rotate_pair(pre[u], rot_step_fx, rot_count0 + (uint64_t)(xlo + 2 * (long)i4)) : pre[u]);
+            }
+        } else {
+            stage_edge<S, D, ROT>(ldsX, hist, x, first + tile_k0 * D - e, SPAN, M, n, rot_step_fx, rot_count0);
+        }
+        __syncthreads();
+        // prefetch the next tile while this one is multiplied
+        const long tn = t + gridDim.x;
+        have = interior(tn);
+        if (have) {
+            const float4 *src = reinterpret_cast<const float4 *>(x + xlo_of(tn) * S);
+#pragma unroll
+            for (int u = 0; u < UX; u++) {
+                int idx = tid + u * 256;
+                pre[u] = src[idx < NF4 ? idx : NF4 - 1];
+            }
+        }
+        f32x4 acc[NACC];
+        mfma_tile<S, D, NACC, KS>(ldsA, ldsX, KS, acc);
+        store_tile<S, D, NACC>(y, tile_k0, n_out, out_aligned, acc);
+        __syncthreads();      // everyone is done reading ldsX before it is overwritten
     }
 }
 

@@ -84,9 +84,27 @@ struct FirStage : lrhip_stage {
     template <int SS, int DD, int NACC>
     int launch_mfma(const float *x, long n, float *y, long n_out)
     {
-        // the headline shape (M = 128 -> 36 MFMA steps at D = 1) gets the fully unrolled instantiation
-        if (DD == 1 && ksteps == 36 && !rot) return launch_mfma_ks<SS, DD, NACC, 36>(x, n, y, n_out);
+        // the shapes that matter most get the persistent, fully unrolled instantiation:
+        // M = 128 at D = 1 (36 MFMA steps, the headline) and M = 128 at D = 5 (60 steps, the WBFM tuner)
+        if constexpr (DD == 1) {
+            if (ksteps == 36) return launch_mfma_ks<SS, DD, NACC, 36>(x, n, y, n_out);
+        }
+        if constexpr (DD == 5) {
+            if (ksteps == 60) return launch_mfma_ks<SS, DD, NACC, 60>(x, n, y, n_out);
+        }
         return launch_mfma_ks<SS, DD, NACC, 0>(x, n, y, n_out);
+    }
+
+    template <typename K>
+    int prepare_kernel(K kern, size_t lds_bytes, int *blocks_per_cu)
+    {
+        if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (blocks_per_cu) {
+            int nb = 0;
+            LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds_bytes));
+            *blocks_per_cu = nb < 1 ? 1 : nb;
+        }
+        return 0;
     }
 
     template <int SS, int DD, int NACC, int KS>
@@ -95,32 +113,47 @@ struct FirStage : lrhip_stage {
         using G = FirMfmaGeom<SS, DD>;
         constexpr int TILE_OUT = G::tile_out(NACC);
         // alignment slack so that the tile's first staged sample is 16-B aligned in global memory
+        if (((uintptr_t)x % (4 * SS)) != 0) {
+            if (rot) return set_error("fir: fused rotator needs a sample-aligned input pointer");
+            return launch_direct(x, n, y, n_out);
+        }
         long sample_addr = (long)((uintptr_t)x / (4 * SS));
         int q = 4 / SS;
         long v = sample_addr + (long)index - (M - 1);
         int e = (int)(((v % q) + q) % q);
-        bool sample_aligned = ((uintptr_t)x % (4 * SS)) == 0;
-        if (!sample_aligned) return launch_direct(x, n, y, n_out);
         int span = G::span(NACC, ksteps);
         size_t lds_floats = (size_t)ksteps * 64 + (size_t)G::phys(SS * span) + G::PAD + 8;
         size_t lds_bytes = lds_floats * sizeof(float);
-        unsigned grid = (unsigned)((n_out + TILE_OUT - 1) / TILE_OUT);
+        long ntiles = (n_out + TILE_OUT - 1) / TILE_OUT;
         const float *atab = (const float *)d_atab.p + (size_t)e * ksteps * 64;
+        const float *h = (const float *)hist[cur].p;
         int out_aligned = ((uintptr_t)y % 16) == 0;
-        if (rot) {
-            if constexpr (SS == 2) {
-                auto kern = fir_mfma_kernel<2, DD, NACC, true, 0>;
-                if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p, x, atab, y,
-                                   M, n, n_out, (long)index, e, ksteps, out_aligned, rot_step, count);
-            } else {
-                return set_error("rotator fusion needs complex input");
-            }
+        uint64_t rs = rot ? rot_step : 0, rc = rot ? count : 0;
+        if constexpr (KS > 0) {
+            int bpc = 1;
+            auto launch = [&](auto kern) -> int {
+                if (prepare_kernel(kern, lds_bytes, &bpc)) return -1;
+                long slots = (long)ctx().num_cus * bpc;
+                unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, atab, y, M, n, n_out, (long)index, e,
+                                   ntiles, out_aligned, rs, rc);
+                return 0;
+            };
+            int rc2;
+            if constexpr (SS == 2) rc2 = rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS>);
+            else rc2 = rot ? set_error("rotator fusion needs complex input") : launch(fir_mfma_persistent_kernel<1, DD, NACC, false, KS>);
+            if (rc2) return rc2;
         } else {
-            auto kern = fir_mfma_kernel<SS, DD, NACC, false, KS>;
-            if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p, x, atab, y,
-                               M, n, n_out, (long)index, e, ksteps, out_aligned, (uint64_t)0, (uint64_t)0);
+            auto launch = [&](auto kern) -> int {
+                if (prepare_kernel(kern, lds_bytes, nullptr)) return -1;
+                hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds_bytes, ctx().stream, h, x, atab, y, M, n, n_out, (long)index, e,
+                                   ksteps, out_aligned, rs, rc);
+                return 0;
+            };
+            int rc2;
+            if constexpr (SS == 2) rc2 = rot ? launch(fir_mfma_kernel<2, DD, NACC, true>) : launch(fir_mfma_kernel<2, DD, NACC, false>);
+            else rc2 = rot ? set_error("rotator fusion needs complex input") : launch(fir_mfma_kernel<1, DD, NACC, false>);
+            if (rc2) return rc2;
         }
         LR_LAUNCH_CHECK();
         return 0;
