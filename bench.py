@@ -165,17 +165,20 @@ def main():
         x = torch.empty(2 * n, dtype=torch.float32, device=dev)
         if rank == 0:
             x.copy_(torch.rand(2 * n, dtype=torch.float32, device=dev, generator=gen) * 2 - 1)
-        tun = lr.TunerBlock(-350e3 + 100e3 * (rank % 8), 100e3, 5)
-        tun.rate = fs
-        tun.differentiate([types.ComplexFloat32])
-        tun.initialize()
-        cap = tun.max_output(n)
-        y = torch.empty(2 * cap + 16, dtype=torch.float32, device=dev)
+        from luaradio_amd import fanout
+        nbranches = world
+        offs = fanout.branch_offsets(8 if world <= 8 else world)
+        mine = {}
+        for b in fanout.local_branches(nbranches, world, rank):
+            tun = lr.TunerBlock(offs[b % len(offs)], 100e3, 5)
+            tun.rate = fs
+            tun.differentiate([types.ComplexFloat32])
+            tun.initialize()
+            mine[b] = fanout.DeviceBranch(tun, n)
+        fo = fanout.FanOut(dist, rank, world, nbranches, mine, src=0)
 
         def step():
-            if dist is not None:
-                dist.broadcast(x, src=0)
-            tun.process_device(x.data_ptr(), n, y.data_ptr(), cap)
+            fo.push(x)
 
         out_per_step = n
         alg_bytes = 9.6 * n

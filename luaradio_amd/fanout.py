@@ -1,0 +1,92 @@
+"""Graph fan-out across the GPUs of one node (BASELINE.json configs[3]).
+
+The reference's fan-out is one OutputPort writing the same vector to several pipes, each reader an independent
+process (radio/core/block.lua:119-166, radio/core/pipe.lua:617-627).  The MI355X form of that one pattern:
+the source GPU broadcasts each IQ slab to the other GPUs (RCCL over xGMI - `torch.distributed` backend "nccl"),
+and every rank runs its own branch chain (e.g. TunerBlock(offset_k, bw, D)) on its own GPU.  There is no other
+exchange: outputs stay per-GPU (each branch has its own sink).  One process per GPU.
+
+Nothing here computes on the CPU: a branch executor is a device block/chain.  The distributed plumbing
+(branch -> rank plan, slab broadcast, max-over-ranks timing) is backend-agnostic so it can be exercised with
+gloo on CPU tensors in the tests, where the branch executor is injected by the test.
+"""
+import time
+
+
+def branch_offsets(num_branches, step=100e3):
+    """Centre offsets of the fan-out branches: symmetric comb, -350 kHz .. +350 kHz for 8 branches."""
+    return [(-(num_branches - 1) / 2.0 + b) * step for b in range(num_branches)]
+
+
+def plan(num_branches, world_size):
+    """branch -> rank, round-robin (branch b on rank b when num_branches == world_size)."""
+    if num_branches < 1 or world_size < 1:
+        raise ValueError("need at least one branch and one rank")
+    return [b % world_size for b in range(num_branches)]
+
+
+def local_branches(num_branches, world_size, rank):
+    return [b for b, r in enumerate(plan(num_branches, world_size)) if r == rank]
+
+
+class DeviceBranch:
+    """A device-resident branch: wraps an initialized luaradio_amd block/composite and a preallocated output."""
+
+    def __init__(self, block, max_input_samples):
+        import torch
+        self.block = block
+        self.cap = block.max_output(max_input_samples)
+        self.out_floats = 2 if block.get_output_type().size == 8 else 1
+        self.out = torch.empty(self.cap * self.out_floats + 16, dtype=torch.float32, device="cuda")
+        self.produced = 0
+
+    def process(self, slab):
+        """slab: 1-D float32 CUDA tensor of interleaved ComplexFloat32 samples"""
+        if not slab.is_cuda:
+            raise RuntimeError("DeviceBranch needs a CUDA tensor: there is no CPU path in luaradio_amd")
+        n = slab.numel() // 2
+        got = self.block.process_device(slab.data_ptr(), n, self.out.data_ptr(), self.cap)
+        self.produced += got
+        return self.out[:got * self.out_floats]
+
+
+class FanOut:
+    """One source rank, `len(branches_by_index)` branches spread over the ranks of a process group.
+
+    dist      torch.distributed (initialised) or None for a single process
+    branches  {branch_index: executor} for the branches this rank owns (see local_branches()); an executor has
+              .process(slab_tensor)
+    """
+
+    def __init__(self, dist, rank, world_size, num_branches, branches, src=0):
+        self.dist, self.rank, self.world, self.src = dist, rank, world_size, src
+        self.num_branches = num_branches
+        mine = local_branches(num_branches, world_size, rank)
+        if sorted(branches) != mine:
+            raise ValueError("rank %d must own branches %s, got %s" % (rank, mine, sorted(branches)))
+        self.branches = branches
+        self.slabs = 0
+
+    def push(self, slab):
+        """Broadcast one slab from the source rank (in place into `slab` on the others) and run the local branches.
+        Returns {branch_index: output}."""
+        if self.dist is not None and self.world > 1:
+            self.dist.broadcast(slab, src=self.src)
+        self.slabs += 1
+        return {b: ex.process(slab) for b, ex in self.branches.items()}
+
+    def timed(self, fn, sync):
+        """max-over-ranks wall time of fn(), bracketed by sync() (barrier + device synchronize) on both sides"""
+        sync()
+        t0 = time.perf_counter()
+        fn()
+        sync()
+        dt = time.perf_counter() - t0
+        if self.dist is not None and self.world > 1:
+            import torch
+            t = torch.tensor([dt], dtype=torch.float64)
+            if self.dist.get_backend() == "nccl":
+                t = t.cuda()
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt

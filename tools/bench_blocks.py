@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Per-block throughput table on one MI355X (the reference's benchmark suite is per block:
+benchmarks/luaradio_benchmark.lua).  Device-resident vectors, HIP-event timing on the launch stream.
+Prints one JSON object per block: MS/s (input samples), algorithmic GB/s, fraction of 8 TB/s, and the same
+for a plain device-to-device copy as the achievable-bandwidth yardstick."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log2-samples", type=int, default=26)
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import luaradio_amd as lr
+    from luaradio_amd import spectrum_utils, types
+
+    lr.init(0)
+    L = lr._lib.load()
+    L.lrhip_set_stream(torch.cuda.current_stream().cuda_stream)
+    n = 1 << args.log2_samples
+    g = torch.Generator(device="cuda").manual_seed(1)
+    xc = torch.rand(2 * n, device="cuda", generator=g) * 2 - 1
+    xr = xc[:n]
+    out = torch.empty(2 * n + 64, device="cuda")
+
+    def timeit(fn, reps=args.reps):
+        fn()
+        torch.cuda.synchronize()
+        t = L.lrhip_timer_create()
+        L.lrhip_timer_start(t)
+        for _ in range(reps):
+            fn()
+        L.lrhip_timer_stop(t)
+        ms = L.lrhip_timer_elapsed_ms(t) / reps
+        L.lrhip_timer_destroy(t)
+        return ms
+
+    def mk(cls, args_, cplx, rate=1102500.0):
+        b = cls(*args_)
+        b.rate = rate
+        b.differentiate([types.ComplexFloat32 if cplx else types.Float32])
+        b.initialize()
+        return b
+
+    rows = []
+
+    def run(name, blk, cplx, alg_bytes_per_sample, flops=0.0):
+        x = xc if cplx else xr
+        cap = blk.max_output(n)
+        ms = timeit(lambda: blk.process_device(x.data_ptr(), n, out.data_ptr(), cap))
+        gbs = alg_bytes_per_sample * n / ms / 1e6
+        rows.append({"block": name, "MS/s": round(n / ms / 1e3, 1), "alg_GB/s": round(gbs, 1), "frac_8TB/s": round(gbs / 8000, 4),
+                     "ms": round(ms, 4), "TFLOP/s": round(flops * n / ms / 1e9, 2) if flops else None})
+
+    # yardstick: device-to-device copy of the cf32 vector (16 B/sample)
+    y = torch.empty_like(xc)
+    ms = timeit(lambda: y.copy_(xc))
+    rows.append({"block": "torch copy (yardstick)", "MS/s": round(n / ms / 1e3, 1), "alg_GB/s": round(16 * n / ms / 1e6, 1),
+                 "frac_8TB/s": round(16 * n / ms / 1e6 / 8000, 4), "ms": round(ms, 4), "TFLOP/s": None})
+
+    taps128 = lr.filter_utils.firwin_lowpass(128, 15e3 / 110250)
+    run("FIRFilter 128 real taps, cf32", mk(lr.FIRFilterBlock, [taps128], True), True, 16, 512)
+    run("FIRFilter 128 real taps, f32", mk(lr.FIRFilterBlock, [taps128], False), False, 8, 256)
+    run("FIRFilter 16 real taps, cf32", mk(lr.FIRFilterBlock, [taps128[:16]], True), True, 16, 64)
+    run("FIRFilter 128 complex taps, cf32 (direct kernel)", mk(lr.FIRFilterBlock, [np.asarray(taps128, np.complex64) * (1 + 0.5j)], True), True, 16, 1024)
+    run("FrequencyTranslator", mk(lr.FrequencyTranslatorBlock, [-250e3], True), True, 16)
+    run("FrequencyDiscriminator", mk(lr.FrequencyDiscriminatorBlock, [1.25], True), True, 12)
+    run("Downsampler(5) cf32", mk(lr.DownsamplerBlock, [5], True), True, 8 + 8 / 5)
+    run("Downsampler(5) f32", mk(lr.DownsamplerBlock, [5], False), False, 4 + 4 / 5)
+    run("FMDeemphasis f32", mk(lr.FMDeemphasisFilterBlock, [75e-6], False, 220500.0), False, 8)
+    run("Decimator(5) cf32 (fused FIR+downsample)", mk(lr.DecimatorBlock, [5], True), True, 8 + 8 / 5, 4 * 128 / 5)
+    run("Tuner(-250k,200k,5) (fused rot+FIR+downsample)", mk(lr.TunerBlock, [-250e3, 200e3, 5], True), True, 8 + 8 / 5, 4 * 128 / 5 + 6)
+    rx = lr.wbfm_mono_receiver(1102500.0, -250e3)
+    cap = rx.max_output(n)
+    ms = timeit(lambda: rx.process_device(xc.data_ptr(), n, out.data_ptr(), cap))
+    rows.append({"block": "WBFM mono chain (RF samples in)", "MS/s": round(n / ms / 1e3, 1), "alg_GB/s": round(8.16 * n / ms / 1e6, 1),
+                 "frac_8TB/s": round(8.16 * n / ms / 1e6 / 8000, 4), "ms": round(ms, 4), "TFLOP/s": None, "launches": rx.chain.last_launches})
+    # PSD: frames of 1024
+    N = 1024
+    frames = n // N
+    win = np.asarray(lr.window_utils.window(N, "hamming", True), np.float32)
+    import ctypes as C
+    st = L.lrhip_psd_create(N, win.ctypes.data_as(C.POINTER(C.c_float)), 1102500.0 * float(np.sum(win.astype(np.float64) ** 2)), 1, 1, 1)
+    ms = timeit(lambda: L.lrhip_stage_execute_device(st, xc.data_ptr(), frames * N, out.data_ptr(), frames * N))
+    rows.append({"block": "PSD N=1024 hamming log fftshift", "MS/s": round(n / ms / 1e3, 1), "alg_GB/s": round(12 * n / ms / 1e6, 1),
+                 "frac_8TB/s": round(12 * n / ms / 1e6 / 8000, 4), "ms": round(ms, 4), "TFLOP/s": None})
+    L.lrhip_stage_destroy(st)
+    for r in rows:
+        print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    main()
