@@ -134,16 +134,9 @@ struct FirMfmaGeom {
 // absolute index cnt
 __device__ __forceinline__ float4 rotate_pair(float4 v, uint64_t step_fx, uint64_t cnt)
 {
-    float c0, s0, c1, s1;
-    phasor_from_turns(step_fx * cnt, c0, s0);
-    phasor_from_turns(step_fx * (cnt + 1), c1, s1);
-    double xr = v.x, xi = v.y;
-    v.x = (float)(xr * (double)c0 - xi * (double)s0);
-    v.y = (float)(xr * (double)s0 + xi * (double)c0);
-    xr = v.z; xi = v.w;
-    v.z = (float)(xr * (double)c1 - xi * (double)s1);
-    v.w = (float)(xr * (double)s1 + xi * (double)c1);
-    return v;
+    float2 a = rotate_sample(make_float2(v.x, v.y), step_fx * cnt);
+    float2 b = rotate_sample(make_float2(v.z, v.w), step_fx * (cnt + 1));
+    return make_float4(a.x, a.y, b.x, b.y);
 }
 
 // one float4 of staged samples (logical float index 4*i4) -> padded LDS rows
@@ -171,13 +164,11 @@ __device__ __forceinline__ void stage_edge(float *ldsX, const float *__restrict_
         float v0 = stream_at<S>(hist, x, p, 0, M, n);
         float v1 = S == 2 ? stream_at<S>(hist, x, p, 1, M, n) : 0.f;
         if (ROT) {
-            float c0, s0;
             // absolute sample index of stream position p is rot_count0 + p - (M-1); history before the
             // start of the stream is zero, so its phase is irrelevant
-            phasor_from_turns(rot_step_fx * (rot_count0 + (uint64_t)(p - (M - 1))), c0, s0);
-            double xr = v0, xi = v1;
-            v0 = (float)(xr * (double)c0 - xi * (double)s0);
-            v1 = (float)(xr * (double)s0 + xi * (double)c0);
+            float2 o = rotate_sample(make_float2(v0, v1), rot_step_fx * (rot_count0 + (uint64_t)(p - (M - 1))));
+            v0 = o.x;
+            v1 = o.y;
         }
         int pa = G::phys(S * r);
         ldsX[pa] = v0;

@@ -184,22 +184,75 @@ __global__ __launch_bounds__(256) void iir_scan_kernel(const float *__restrict__
     }
 }
 
-// pass 2: sequential carry across tiles.  state_in/out: [S][P] carried output state (ping-pong).
+// pass 2: carry across tiles, s_t = E_{t-1} + A^TILE s_{t-1}, as a 256-thread scan: every thread owns a
+// contiguous segment of `seg` tiles (sequential inside the segment, twice), segment end states are combined with a
+// Kogge-Stone scan using A^(TILE*seg*2^k) (computed on the host per launch in double).
+struct IirCarryPowers {
+    float Tseg[8][IIR_MAX_P * IIR_MAX_P];
+};
 template <int S, int P>
-__global__ void iir_carry_kernel(const float *__restrict__ tile_end, float *__restrict__ tile_start, long ntiles,
-                                 const float *__restrict__ state_in, IirCoeffs co)
+__global__ __launch_bounds__(256) void iir_carry_kernel(const float *__restrict__ tile_end, float *__restrict__ tile_start, long ntiles,
+                                                        long seg, const float *__restrict__ state_in, IirCoeffs co, IirCarryPowers pw)
 {
-    int c = threadIdx.x;
-    if (c >= S) return;
-    float s[P], tmp[P];
+    __shared__ float sst[2][S][256][P];
+    const int tid = threadIdx.x;
+    const long t0 = (long)tid * seg, t1 = (t0 + seg < ntiles) ? t0 + seg : ntiles;
+    float z[S][P], tmp[P];
 #pragma unroll
-    for (int k = 0; k < P; k++) s[k] = state_in[c * P + k];
-    for (long t = 0; t < ntiles; t++) {
+    for (int c = 0; c < S; c++) {
 #pragma unroll
-        for (int k = 0; k < P; k++) tile_start[(t * S + c) * P + k] = s[k];
-        mat_apply<P>(co.Tpow[8], s, tmp);
+        for (int k = 0; k < P; k++) z[c][k] = 0.f;
+        for (long t = t0; t < t1; t++) {
+            mat_apply<P>(co.Tpow[8], z[c], tmp);
 #pragma unroll
-        for (int k = 0; k < P; k++) s[k] = tile_end[(t * S + c) * P + k] + tmp[k];
+            for (int k = 0; k < P; k++) z[c][k] = tile_end[(t * S + c) * P + k] + tmp[k];
+        }
+        if (tid == 0) {      // fold the carried state into segment 0: S_0 = z_0 + A^(TILE*seg) * carried
+            float ci[P];
+#pragma unroll
+            for (int k = 0; k < P; k++) ci[k] = state_in[c * P + k];
+            mat_apply<P>(pw.Tseg[0], ci, tmp);
+#pragma unroll
+            for (int k = 0; k < P; k++) z[c][k] += tmp[k];
+        }
+#pragma unroll
+        for (int k = 0; k < P; k++) sst[0][c][tid][k] = z[c][k];
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int lvl = 0; lvl < 8; lvl++) {
+        int off = 1 << lvl;
+#pragma unroll
+        for (int c = 0; c < S; c++) {
+            float cur[P];
+#pragma unroll
+            for (int k = 0; k < P; k++) cur[k] = sst[buf][c][tid][k];
+            if (tid >= off) {
+                float prev[P];
+#pragma unroll
+                for (int k = 0; k < P; k++) prev[k] = sst[buf][c][tid - off][k];
+                mat_apply<P>(pw.Tseg[lvl], prev, tmp);
+#pragma unroll
+                for (int k = 0; k < P; k++) cur[k] += tmp[k];
+            }
+#pragma unroll
+            for (int k = 0; k < P; k++) sst[buf ^ 1][c][tid][k] = cur[k];
+        }
+        buf ^= 1;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < S; c++) {
+        float s[P];
+#pragma unroll
+        for (int k = 0; k < P; k++) s[k] = tid ? sst[buf][c][tid - 1][k] : state_in[c * P + k];
+        for (long t = t0; t < t1; t++) {
+#pragma unroll
+            for (int k = 0; k < P; k++) tile_start[(t * S + c) * P + k] = s[k];
+            mat_apply<P>(co.Tpow[8], s, tmp);
+#pragma unroll
+            for (int k = 0; k < P; k++) s[k] = tile_end[(t * S + c) * P + k] + tmp[k];
+        }
     }
 }
 

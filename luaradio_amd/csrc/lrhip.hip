@@ -306,7 +306,10 @@ struct RotatorStage : lrhip_stage {
         if (n > cap) return set_error("rotator: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
         unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
-        hipLaunchKernelGGL(rotator_kernel, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n, step, count);
+        if ((((uintptr_t)in_dev | (uintptr_t)out_dev) & 15) == 0)
+            hipLaunchKernelGGL(rotator_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n, step, count);
+        else
+            hipLaunchKernelGGL(rotator_kernel<1>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n, step, count);
         LR_LAUNCH_CHECK();
         count += n;
         return (long)n;
@@ -361,6 +364,19 @@ struct FmDiscrimStage : lrhip_stage {
     }
 };
 
+// P x P matrix helpers (double, host) for the transition powers
+static void matmul(const std::vector<double> &A, const std::vector<double> &B, std::vector<double> &C, int P)
+{
+    std::vector<double> T((size_t)P * P, 0.0);
+    for (int r = 0; r < P; r++)
+        for (int c = 0; c < P; c++) {
+            double acc = 0;
+            for (int k = 0; k < P; k++) acc += A[r * P + k] * B[k * P + c];
+            T[r * P + c] = acc;
+        }
+    C = T;
+}
+
 // =====================================================================================================
 // IIRFilterBlock
 // =====================================================================================================
@@ -369,6 +385,7 @@ struct IirStage : lrhip_stage {
     bool scan = false;
     IirCoeffs co;
     IirSeqCoeffs seq;
+    std::vector<double> Ttile;            // A^TILE in double (row-major PxP) for the per-launch carry powers
     DeviceBuf xhist[2], state[2], tile_end, tile_start, seq_xs, seq_ys;
     int cur = 0;
     const char *kind() const override { return "iir"; }
@@ -393,8 +410,23 @@ struct IirStage : lrhip_stage {
                                (const float *)nullptr, (float *)tile_end.p, co);
             LR_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL((iir_carry_kernel<SS, PP>), dim3(1), dim3(64), 0, ctx().stream, (const float *)tile_end.p, (float *)tile_start.p,
-                           ntiles > 1 ? ntiles : 1, st, co);
+        // carry scan: 256 segments of `seg` tiles; powers A^(TILE*seg*2^k) in double on the host
+        long nt = ntiles > 1 ? ntiles : 1, seg = (nt + 255) / 256;
+        IirCarryPowers pw;
+        {
+            std::vector<double> T = Ttile, R((size_t)PP * PP, 0.0);
+            for (int i = 0; i < PP; i++) R[i * PP + i] = 1.0;
+            for (long e = seg; e > 0; e >>= 1) {          // R = Ttile^seg by repeated squaring
+                if (e & 1) matmul(R, T, R, PP);
+                matmul(T, T, T, PP);
+            }
+            for (int k = 0; k < 8; k++) {
+                for (int i = 0; i < PP * PP; i++) pw.Tseg[k][i] = (float)R[i];
+                matmul(R, R, R, PP);
+            }
+        }
+        hipLaunchKernelGGL((iir_carry_kernel<SS, PP>), dim3(1), dim3(256), 0, ctx().stream, (const float *)tile_end.p, (float *)tile_start.p,
+                           nt, seg, st, co, pw);
         LR_LAUNCH_CHECK();
         hipLaunchKernelGGL((iir_scan_kernel<SS, PP, true>), dim3((unsigned)ntiles), dim3(256), 0, ctx().stream, x, y, n, xh,
                            (const float *)tile_start.p, (float *)nullptr, co);
@@ -424,19 +456,6 @@ struct IirStage : lrhip_stage {
         return rc ? rc : (long)n;
     }
 };
-
-// P x P matrix helpers (double, host) for the transition powers
-static void matmul(const std::vector<double> &A, const std::vector<double> &B, std::vector<double> &C, int P)
-{
-    std::vector<double> T((size_t)P * P, 0.0);
-    for (int r = 0; r < P; r++)
-        for (int c = 0; c < P; c++) {
-            double acc = 0;
-            for (int k = 0; k < P; k++) acc += A[r * P + k] * B[k * P + c];
-            T[r * P + c] = acc;
-        }
-    C = T;
-}
 
 // =====================================================================================================
 // DFT / IDFT / PSD
@@ -643,6 +662,7 @@ lrhip_stage_t *lrhip_iir_create(const float *b, unsigned nb, const float *a, uns
         for (int s = 1; s < IIR_LC; s <<= 1) matmul(T, T, T, P);      // A^LC (LC is a power of two)
         for (int k = 0; k <= 8; k++) {
             for (int i = 0; i < P * P; i++) co.Tpow[k][i] = (float)T[i];
+            if (k == 8) q->Ttile = T;
             matmul(T, T, T, P);
         }
     }
