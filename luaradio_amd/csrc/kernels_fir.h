@@ -176,9 +176,11 @@ __device__ __forceinline__ void stage_edge(float *ldsX, const float *__restrict_
     }
 }
 
-// the MFMA main loop over one staged tile; KS > 0 => fully unrolled
-template <int S, int D, int NACC, int KS>
-__device__ __forceinline__ void mfma_tile(const float *ldsA, const float *ldsX, int ksteps, f32x4 (&acc)[NACC])
+// the MFMA main loop over one staged tile; KS > 0 => fully unrolled.
+// NOUT = 2: two Toeplitz tables (ldsA, ldsA + ksteps*64) applied to the same B fragments -> two accumulator sets
+// (the re and im outputs of a complex-taps filter over the interleaved float stream).
+template <int S, int D, int NACC, int KS, int NOUT>
+__device__ __forceinline__ void mfma_tile(const float *ldsA, const float *ldsX, int ksteps, f32x4 (&acc)[NOUT][NACC])
 {
     using G = FirMfmaGeom<S, D>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -188,18 +190,24 @@ __device__ __forceinline__ void mfma_tile(const float *ldsA, const float *ldsX, 
     constexpr int ACC_STRIDE = (G::ROW + G::PAD) * G::BPA;    // floats between consecutive accumulators' blocks
     const float *bptr = ldsX + (G::ROW + G::PAD) * ((wave * NACC) * G::BPA + blk_in_acc) + S * kq + comp;
     const float *aptr = ldsA + lane;
+    const int astride = ksteps * 64;
 #pragma unroll
-    for (int a = 0; a < NACC; a++) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int o = 0; o < NOUT; o++)
+#pragma unroll
+        for (int a = 0; a < NACC; a++) acc[o][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto group = [&](int g) {
         const float *ap = aptr + g * (G::GROUP * 64);
         const float *bp = bptr + g * (G::ROW + G::PAD);
 #pragma unroll
         for (int j = 0; j < G::GROUP; j++) {
-            float av = ap[j * 64];
+            float av[NOUT];
+#pragma unroll
+            for (int o = 0; o < NOUT; o++) av[o] = ap[o * astride + j * 64];
 #pragma unroll
             for (int a = 0; a < NACC; a++) {
                 float bv = bp[a * ACC_STRIDE + j * 4 * S];
-                acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[a], 0, 0, 0);
+#pragma unroll
+                for (int o = 0; o < NOUT; o++) acc[o][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[o], bv, acc[o][a], 0, 0, 0);
             }
         }
     };
@@ -209,15 +217,6 @@ __device__ __forceinline__ void mfma_tile(const float *ldsA, const float *ldsX, 
 #endif
 #pragma unroll
         for (int g = 0; g < KS / G::GROUP; g++) group(g);
-#if LRHIP_FIR_SCHED
-        // ask the scheduler for a software pipeline: a dozen LDS reads up front, then 2 MFMA : 1 LDS read
-        __builtin_amdgcn_sched_group_barrier(0x100, LRHIP_FIR_SCHED, 0);
-#pragma unroll
-        for (int i = 0; i < KS * NACC / 2; i++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#endif
 #if LRHIP_FIR_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -228,8 +227,8 @@ __device__ __forceinline__ void mfma_tile(const float *ldsA, const float *ldsX, 
 }
 
 // epilogue: accumulator lane (col, kq) holds rows 4*kq .. 4*kq+3 of column col
-template <int S, int D, int NACC>
-__device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, long n_out, int out_aligned, f32x4 (&acc)[NACC])
+template <int S, int D, int NACC, int NOUT>
+__device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, long n_out, int out_aligned, f32x4 (&acc)[NOUT][NACC])
 {
     using G = FirMfmaGeom<S, D>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -238,8 +237,21 @@ __device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, 
 #pragma unroll
     for (int a = 0; a < NACC; a++) {
         const long kblk = tile_k0 + 16 * (long)((wave * NACC + a) * G::BPA + blk_in_acc);
-        const float a0 = acc[a][0], a1 = acc[a][1], a2 = acc[a][2], a3 = acc[a][3];
-        if (S == 1) {
+        const float a0 = acc[0][a][0], a1 = acc[0][a][1], a2 = acc[0][a][2], a3 = acc[0][a][3];
+        if (NOUT == 2) {
+            // complex taps over the float stream: set 0 = re, set 1 = im of the same four outputs
+            const float b0 = acc[NOUT - 1][a][0], b1 = acc[NOUT - 1][a][1], b2 = acc[NOUT - 1][a][2], b3 = acc[NOUT - 1][a][3];
+            long k = kblk + 4 * kq;
+            if (out_aligned && k + 3 < n_out) {
+                *reinterpret_cast<float4 *>(y + 2 * k) = make_float4(a0, b0, a1, b1);
+                *reinterpret_cast<float4 *>(y + 2 * k + 4) = make_float4(a2, b2, a3, b3);
+            } else {
+                if (k < n_out) *reinterpret_cast<float2 *>(y + 2 * k) = make_float2(a0, b0);
+                if (k + 1 < n_out) *reinterpret_cast<float2 *>(y + 2 * k + 2) = make_float2(a1, b1);
+                if (k + 2 < n_out) *reinterpret_cast<float2 *>(y + 2 * k + 4) = make_float2(a2, b2);
+                if (k + 3 < n_out) *reinterpret_cast<float2 *>(y + 2 * k + 6) = make_float2(a3, b3);
+            }
+        } else if (S == 1) {
             long k = kblk + 4 * kq;
             if (out_aligned && k + 3 < n_out) {
                 *reinterpret_cast<float4 *>(y + k) = make_float4(a0, a1, a2, a3);
@@ -270,7 +282,8 @@ __device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, 
 }
 
 // ---- generic kernel: run-time number of MFMA steps, one tile per workgroup ----------------------------------------
-template <int S, int D, int NACC, bool ROT>
+// NOUT = 2 (S = 1 geometry over the interleaved float stream, two Toeplitz tables): complex taps.
+template <int S, int D, int NACC, bool ROT, int NOUT>
 __global__ __launch_bounds__(256) void fir_mfma_kernel(
     const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ atab, float *__restrict__ y,
     int M, long n, long n_out, long first, int e, int ksteps, int out_aligned,
@@ -279,8 +292,8 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
     using G = FirMfmaGeom<S, D>;
     constexpr int TILE_OUT = G::tile_out(NACC);
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *ldsA = lds;                       // ksteps * 64 floats
-    float *ldsX = lds + ksteps * 64;         // staged samples (padded rows)
+    float *ldsA = lds;                       // NOUT * ksteps * 64 floats
+    float *ldsX = lds + NOUT * ksteps * 64;  // staged samples (padded rows)
     const int tid = threadIdx.x;
     const long tile_k0 = (long)blockIdx.x * TILE_OUT;
     const long base = first + tile_k0 * D - e;               // stream position of r = 0
@@ -288,7 +301,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
     const int nf4 = span * S / 4;
 
     const float4 *a4 = reinterpret_cast<const float4 *>(atab);
-    for (int i = tid; i < ksteps * 16; i += 256) *reinterpret_cast<float4 *>(ldsA + 4 * i) = a4[i];
+    for (int i = tid; i < NOUT * ksteps * 16; i += 256) *reinterpret_cast<float4 *>(ldsA + 4 * i) = a4[i];
 
     const long xlo = base - (M - 1);                          // x index of r = 0
     const bool interior = (xlo >= 0) && (xlo + span <= n);
@@ -312,9 +325,9 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
         stage_edge<S, D, ROT>(ldsX, hist, x, base, span, M, n, rot_step_fx, rot_count0);
     }
     __syncthreads();
-    f32x4 acc[NACC];
-    mfma_tile<S, D, NACC, 0>(ldsA, ldsX, ksteps, acc);
-    store_tile<S, D, NACC>(y, tile_k0, n_out, out_aligned, acc);
+    f32x4 acc[NOUT][NACC];
+    mfma_tile<S, D, NACC, 0, NOUT>(ldsA, ldsX, ksteps, acc);
+    store_tile<S, D, NACC, NOUT>(y, tile_k0, n_out, out_aligned, acc);
 }
 
 // ---- persistent kernel: compile-time number of MFMA steps KS -----------------------------------------------------------
@@ -382,9 +395,9 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
                 pre[u] = src[idx < NF4 ? idx : NF4 - 1];
             }
         }
-        f32x4 acc[NACC];
-        mfma_tile<S, D, NACC, KS>(ldsA, ldsX, KS, acc);
-        store_tile<S, D, NACC>(y, tile_k0, n_out, out_aligned, acc);
+        f32x4 acc[1][NACC];
+        mfma_tile<S, D, NACC, KS, 1>(ldsA, ldsX, KS, acc);
+        store_tile<S, D, NACC, 1>(y, tile_k0, n_out, out_aligned, acc);
         __syncthreads();      // everyone is done reading ldsX before it is overwritten
     }
 }
@@ -392,9 +405,9 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
 // Host: build the Toeplitz A-fragment tables, one per alignment slack e in [0, 4/S):
 //   tab[e][step][lane] = A[m = lane&15][t = 4*step + (lane>>4)] = taps_rev[t - e - m*D]  (0 outside [0, M))
 // ksteps = (emax + 15*D + M) rounded up to a multiple of 4*D steps (zero rows; fma(0,b,acc) == acc).
-inline int fir_mfma_ksteps(int M, int D, int S)
+inline int fir_mfma_ksteps(int M, int D, int S, int emax_override = -1)
 {
-    int emax = 4 / S - 1;
+    int emax = emax_override >= 0 ? emax_override : 4 / S - 1;
     int K = emax + 15 * D + M;
     int ks = (K + 3) / 4;
     int group = 4 * D;

@@ -58,6 +58,7 @@ struct FirStage : lrhip_stage {
     std::vector<float> taps_rev;          // host copy, reversed (firfilter.lua:234-238)
     DeviceBuf d_taps, d_atab;
     int ksteps = 0;                       // 0 => MFMA path unavailable for this (M, D)
+    int hist_pad = 0;                     // leading pad floats in the history buffers (1 for complex taps, see launch_mfma_cc)
     DeviceBuf hist[2];
     int cur = 0;
     unsigned long index = 0;              // carried downsampler index (downsampler.lua:53)
@@ -76,7 +77,7 @@ struct FirStage : lrhip_stage {
     int reset() override
     {
         cur = 0; index = 0; count = 0; fill = 0;
-        size_t hb = (size_t)(M > 1 ? M - 1 : 1) * S * sizeof(float);
+        size_t hb = ((size_t)(M > 1 ? M - 1 : 1) * S + hist_pad) * sizeof(float);
         if (zero_fill(hist[0], hb) || zero_fill(hist[1], hb)) return -1;
         return 0;
     }
@@ -126,7 +127,7 @@ struct FirStage : lrhip_stage {
         size_t lds_bytes = lds_floats * sizeof(float);
         long ntiles = (n_out + TILE_OUT - 1) / TILE_OUT;
         const float *atab = (const float *)d_atab.p + (size_t)e * ksteps * 64;
-        const float *h = (const float *)hist[cur].p;
+        const float *h = (const float *)hist[cur].p + hist_pad;
         int out_aligned = ((uintptr_t)y % 16) == 0;
         uint64_t rs = rot ? rot_step : 0, rc = rot ? count : 0;
         if constexpr (KS > 0) {
@@ -151,19 +152,58 @@ struct FirStage : lrhip_stage {
                 return 0;
             };
             int rc2;
-            if constexpr (SS == 2) rc2 = rot ? launch(fir_mfma_kernel<2, DD, NACC, true>) : launch(fir_mfma_kernel<2, DD, NACC, false>);
-            else rc2 = rot ? set_error("rotator fusion needs complex input") : launch(fir_mfma_kernel<1, DD, NACC, false>);
+            if constexpr (SS == 2) rc2 = rot ? launch(fir_mfma_kernel<2, DD, NACC, true, 1>) : launch(fir_mfma_kernel<2, DD, NACC, false, 1>);
+            else rc2 = rot ? set_error("rotator fusion needs complex input") : launch(fir_mfma_kernel<1, DD, NACC, false, 1>);
             if (rc2) return rc2;
         }
         LR_LAUNCH_CHECK();
         return 0;
     }
 
+    // complex taps: two real Toeplitz filters (re / im) of 2M taps over the interleaved float stream, decimation 2D,
+    // sharing every B fragment.  Stream position of output k in float units is 2*q_k + 1 once the float stream is
+    // given one leading pad float (so the history is the 2M-1 floats the S = 1 kernel expects).
+    template <int DD2, int NACC>
+    int launch_mfma_cc(const float *x, long n, float *y, long n_out)
+    {
+        using G = FirMfmaGeom<1, DD2>;
+        constexpr int TILE_OUT = G::tile_out(NACC);
+        if (((uintptr_t)x % 8) != 0) return launch_direct(x, n, y, n_out);
+        const int M2 = 2 * M;
+        const long first2 = 2 * (long)index + 1, n2 = 2 * n;
+        long v = (long)((uintptr_t)x / 4) + first2 - (M2 - 1);
+        int e = (int)(((v % 4) + 4) % 4);
+        int span = G::span(NACC, ksteps);
+        size_t lds_bytes = ((size_t)2 * ksteps * 64 + (size_t)G::phys(span) + G::PAD + 8) * sizeof(float);
+        long ntiles = (n_out + TILE_OUT - 1) / TILE_OUT;
+        const float *atab = (const float *)d_atab.p + (size_t)e * 2 * ksteps * 64;
+        const float *h = (const float *)hist[cur].p;          // includes the pad float
+        int out_aligned = ((uintptr_t)y % 16) == 0;
+        auto kern = fir_mfma_kernel<1, DD2, NACC, false, 2>;
+        if (prepare_kernel(kern, lds_bytes, nullptr)) return -1;
+        hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds_bytes, ctx().stream, h, x, atab, y, M2, n2, n_out, first2, e,
+                           ksteps, out_aligned, (uint64_t)0, (uint64_t)0);
+        LR_LAUNCH_CHECK();
+        return 0;
+    }
+
+    int dispatch_mfma_cc(const float *x, long n, float *y, long n_out)
+    {
+        switch (D) {
+            case 1: return launch_mfma_cc<2, 4>(x, n, y, n_out);
+            case 2: return launch_mfma_cc<4, 2>(x, n, y, n_out);
+            case 3: return launch_mfma_cc<6, 1>(x, n, y, n_out);
+            case 4: return launch_mfma_cc<8, 1>(x, n, y, n_out);
+            case 5: return launch_mfma_cc<10, 1>(x, n, y, n_out);
+            default: return launch_direct(x, n, y, n_out);
+        }
+    }
+
     int launch_direct(const float *x, long n, float *y, long n_out)
     {
         if (rot) return set_error("internal: direct FIR kernel has no fused rotator");
         unsigned grid = grid_for((unsigned long)n_out, 256);
-        const float *h = (const float *)hist[cur].p, *t = (const float *)d_taps.p;
+        const float *h = (const float *)hist[cur].p + hist_pad, *t = (const float *)d_taps.p;
         if (S == 1)
             hipLaunchKernelGGL(fir_direct_kernel<0>, dim3(grid), dim3(256), 0, ctx().stream, h, x, t, y, M, n, n_out, (long)index, (long)D);
         else if (!taps_complex)
@@ -200,16 +240,19 @@ struct FirStage : lrhip_stage {
         long n_out = (unsigned long)n > index ? (long)((n - index + D - 1) / D) : 0;
         if ((unsigned long)n_out > cap) return set_error("fir: output capacity %lu < %ld", cap, n_out);
         if (n_out > 0) {
-            int rc = ksteps ? (S == 1 ? dispatch_mfma<1>(x, n, y, n_out) : dispatch_mfma<2>(x, n, y, n_out))
-                            : launch_direct(x, n, y, n_out);
+            int rc = !ksteps ? launch_direct(x, n, y, n_out)
+                     : taps_complex ? dispatch_mfma_cc(x, n, y, n_out)
+                     : S == 1 ? dispatch_mfma<1>(x, n, y, n_out) : dispatch_mfma<2>(x, n, y, n_out);
             if (rc) return rc;
         }
         if (M > 1) {
             unsigned grid = grid_for((unsigned long)(M - 1) * S, 256);
+            const float *hi = (const float *)hist[cur].p + hist_pad;
+            float *ho = (float *)hist[cur ^ 1].p + hist_pad;
             if (S == 1)
-                hipLaunchKernelGGL(fir_history_kernel<1>, dim3(grid), dim3(256), 0, ctx().stream, (const float *)hist[cur].p, x, (float *)hist[cur ^ 1].p, M, n);
+                hipLaunchKernelGGL(fir_history_kernel<1>, dim3(grid), dim3(256), 0, ctx().stream, hi, x, ho, M, n);
             else
-                hipLaunchKernelGGL(fir_history_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, (const float *)hist[cur].p, x, (float *)hist[cur ^ 1].p, M, n);
+                hipLaunchKernelGGL(fir_history_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, hi, x, ho, M, n);
             LR_LAUNCH_CHECK();
             cur ^= 1;
         }
@@ -269,6 +312,31 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
             fir_mfma_build_tables(q->taps_rev.data(), q->M, (int)decim, q->S, ks, tab);
             if (upload(q->d_atab, tab.data(), tab.size() * sizeof(float))) return nullptr;
             q->ksteps = ks;
+        }
+    }
+    if (taps_complex && decim <= 5) {
+        // taps'_re = interleave(hr_rev, -hi_rev), taps'_im = interleave(hi_rev, hr_rev) over the float stream
+        int M2 = 2 * q->M, D2 = 2 * (int)decim;
+        int ks = fir_mfma_ksteps(M2, D2, 1, 2);          // 8-B aligned complex input => float slack e in {0, 2}
+        if ((size_t)2 * ks * 64 * sizeof(float) <= 80 * 1024) {
+            std::vector<float> tre((size_t)M2), tim((size_t)M2), tab, one;
+            for (int j = 0; j < q->M; j++) {
+                float hr = q->taps_rev[2 * j], hi = q->taps_rev[2 * j + 1];
+                tre[2 * j] = hr; tre[2 * j + 1] = -hi;
+                tim[2 * j] = hi; tim[2 * j + 1] = hr;
+            }
+            std::vector<float> are, aim;
+            fir_mfma_build_tables(tre.data(), M2, D2, 1, ks, are);     // [e = 0..3][ks][64]
+            fir_mfma_build_tables(tim.data(), M2, D2, 1, ks, aim);
+            tab.resize(are.size() + aim.size());
+            size_t per = (size_t)ks * 64;
+            for (int e = 0; e < 4; e++) {
+                std::copy(are.begin() + e * per, are.begin() + (e + 1) * per, tab.begin() + (size_t)e * 2 * per);
+                std::copy(aim.begin() + e * per, aim.begin() + (e + 1) * per, tab.begin() + (size_t)e * 2 * per + per);
+            }
+            if (upload(q->d_atab, tab.data(), tab.size() * sizeof(float))) return nullptr;
+            q->ksteps = ks;
+            q->hist_pad = 1;
         }
     }
     if (rot) {
@@ -756,29 +824,28 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
         RotatorStage *rot = dynamic_cast<RotatorStage *>(stages[i]);
         unsigned j = rot ? i + 1 : i;
         FirStage *fir = j < nstages ? dynamic_cast<FirStage *>(stages[j]) : nullptr;
-        bool fusable_fir = fir && !fir->taps_complex && !fir->use_fft && fir->D == 1 && !fir->rot;
+        bool fusable_fir = fir && !fir->use_fft && fir->D == 1 && !fir->rot;
+        if (rot && fusable_fir && fir->taps_complex) {      // rotator folding is implemented for real taps only
+            c->ops.push_back({stages[i], false});
+            i++;
+            continue;
+        }
         DownsamplerStage *ds = (fusable_fir && j + 1 < nstages) ? dynamic_cast<DownsamplerStage *>(stages[j + 1]) : nullptr;
         if (fusable_fir && (rot || ds)) {
             unsigned D = ds ? (unsigned)ds->factor : 1;
-            std::vector<float> taps((size_t)fir->M);
-            for (int t = 0; t < fir->M; t++) taps[t] = fir->taps_rev[fir->M - 1 - t];
+            int ts = fir->taps_complex ? 2 : 1;
+            std::vector<float> taps((size_t)fir->M * ts);
+            for (int t = 0; t < fir->M; t++)
+                for (int cc = 0; cc < ts; cc++) taps[(size_t)t * ts + cc] = fir->taps_rev[(size_t)(fir->M - 1 - t) * ts + cc];
             bool want_rot = rot && fir->S == 2;
             FirStage *fused = nullptr;
-            if (FirStage::mfma_supported_decim(D))
-                fused = fir_build(taps.data(), (unsigned)fir->M, 0, fir->S == 2, D, 0, want_rot, want_rot ? rot->omega : 0.0);
+            if (FirStage::mfma_supported_decim(D) || !rot)
+                fused = fir_build(taps.data(), (unsigned)fir->M, fir->taps_complex, fir->S == 2, D, 0, want_rot, want_rot ? rot->omega : 0.0);
+            if (fused && rot && !want_rot) { delete fused; fused = nullptr; }
             if (fused) {
                 c->ops.push_back({fused, true});
                 i = j + (ds ? 2 : 1);
                 continue;
-            }
-            if (ds && !rot) {
-                // decimation not in the MFMA table: direct kernel still skips the discarded outputs
-                FirStage *f2 = fir_build(taps.data(), (unsigned)fir->M, 0, fir->S == 2, D, 0, false, 0.0);
-                if (f2) {
-                    c->ops.push_back({f2, true});
-                    i = j + 2;
-                    continue;
-                }
             }
         }
         c->ops.push_back({stages[i], false});

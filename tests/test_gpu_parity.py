@@ -174,6 +174,26 @@ def test_fir_complex_taps_bit_exact_vs_fma_oracle(ntaps):
     assert G.max_abs_err(want, O.FIR(taps, True, O.MODE_F64).process(x)) < 1e-6
 
 
+@pytest.mark.parametrize("factor", [1, 2, 3, 5, 6])
+def test_fir_complex_taps_large_and_decimated(factor):
+    """complex taps run as two real Toeplitz filters over the interleaved float stream (MFMA path), incl. a
+    fused downsampler; ragged chunks exercise history / index carry"""
+    rng = np.random.default_rng(200 + factor)
+    n = 60000
+    x = rand_c(rng, n)
+    taps = rand_c(rng, 128) / 128
+    fir = make(lr.FIRFilterBlock, [taps], x)
+    want = O.FIR(taps, True, O.MODE_FMA).process(x)
+    if factor == 1:
+        assert np.array_equal(chunked(fir, x, [1, 4095, 4096, 4097, 30001]), want)
+        return
+    ds = make(lr.DownsamplerBlock, [factor], x)
+    chain = lr.Chain([fir, ds])
+    got = np.concatenate([chain.process(x[a:b]) for a, b in ((0, 1), (1, 2), (2, 5000), (5000, 5001), (5001, n))])
+    assert np.array_equal(got, O.Downsampler(factor, True).process(want))
+    assert chain.last_launches <= 2
+
+
 def test_fir_long_filter_uses_fallback_and_matches():
     rng = np.random.default_rng(5)
     x = rand_c(rng, 6000)
