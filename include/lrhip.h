@@ -52,8 +52,11 @@ const char *lrhip_version(void);
  * ComplexFloat32 or Float32 samples; complex taps require complex input (:69-74).
  * decim >= 1 fuses a following DownsamplerBlock(decim) (radio/composites/decimator.lua:37-39): only every
  * decim-th filter output is computed and emitted, with the downsampler's carried phase index.
- * use_fft != 0 reproduces the overlap-save emission framing (:451: only whole L = N-M+1 blocks are
- * emitted, N = 2^floor(log2(8M)); the tail is retained) - sample values are the same. */
+ * use_fft: 0 = direct form (bit-identical to the fmaf chain in the reference's tap order);
+ *          1 = overlap-save as the reference runs it (:320-398): only whole L = N-M+1 blocks are emitted,
+ *              N = 2^floor(log2(8M)), the tail is retained; arithmetic by the fused FFT kernel for 32 <= M <= 512;
+ *          2 = overlap-save arithmetic (fused 1024-point FFT kernel, 32 <= M <= 512) with sample-exact emission
+ *              (every call returns one output per input, like the direct form) - the fast path. */
 lrhip_stage_t *lrhip_fir_create(const float *taps, unsigned ntaps, int taps_complex, int input_complex,
                                 unsigned decim, int use_fft);
 /* FrequencyTranslatorBlock (radio/blocks/signal/frequencytranslator.lua:26-53, :93-110):

@@ -13,14 +13,15 @@ from .block import Block, Input, Output, _fptr, as_taps
 class FIRFilterBlock(Block):
     """radio/blocks/signal/firfilter.lua.  FIRFilterBlock(taps[, use_fft]).
 
-    use_fft=True reproduces the overlap-save emission framing of firfilter.lua:361-398 (only whole
-    L = N-M+1 blocks are emitted); the default here is False - there is no FFTW on the device path and the
-    direct form is what the MFMA kernel computes."""
+    use_fft=True is the reference's overlap-save (firfilter.lua:320-398: only whole L = N-M+1 blocks are
+    emitted, tail retained); use_fft="fast" runs the same overlap-save arithmetic (fused FFT kernel) but emits one
+    output per input; the default (False) is the direct form on the f32 matrix cores, bit-identical to the fmaf
+    chain in the reference's tap order."""
     name = "FIRFilterBlock"
 
     def instantiate(self, taps, use_fft=None):
         self.taps = as_taps(taps)
-        self.use_fft = bool(use_fft) if use_fft is not None else False
+        self.use_fft = 2 if use_fft == "fast" else (1 if use_fft else 0)
         self.decimation = 1
         if self.taps.dtype == np.complex64:      # firfilter.lua:68-74
             self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])

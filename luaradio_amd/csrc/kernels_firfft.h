@@ -1,0 +1,228 @@
+// kernels_firfft.h - FIRFilterBlock by FFT overlap-save (the reference's production default,
+// radio/blocks/signal/firfilter.lua:320-398: N = 2^floor(log2(8M)), L = N-M+1, per block: DFT, multiply by the
+// taps' DFT, IDFT, keep the last L outputs) as ONE fused kernel: load -> 1024-point FFT -> x H -> inverse FFT ->
+// store, everything between the global load and the global store in registers and LDS.
+//
+// Why: direct form is 4M flop per cf32 sample (512 at M = 128; matrix-pipe bound at ~39 % of the HBM roof);
+// overlap-save is ~125 flop per sample, which makes the block HBM-bound.
+//
+// One wave (64 lanes x 16 points) transforms one N = 1024 block; a 256-thread workgroup runs four blocks at a
+// time and walks the block list persistently.  1024 = 16 x 16 x 4:
+//   forward (decimation in frequency), lane t holds x[64*n1 + t]:
+//     radix-16 over n1 -> k1;  x W_1024^(t*k1);   exchange E1;   lane (t2,k1) holds [4*t1 + t2]
+//     radix-16 over t1 -> k2;  x W_64^(t2*k2);    exchange E2;   lane (q,k1) holds k2 = 4j+q, t2 = 0..3
+//     radix-4  over t2 -> k3:  X[k1 + 16*k2 + 256*k3]
+//   multiply by H (host-permuted to this register/lane order, 1/N folded in)
+//   inverse = the mirror image with conjugated twiddles; the result lands as y[64*n1 + t] in natural order,
+//   so loads and stores are both coalesced and no bit-reversal pass exists.
+// Exchanges go through a per-wave LDS buffer (no workgroup barrier: a wave's DS operations execute in order).
+// LDS layouts are padded so every ds_read_b64 / ds_write_b64 is conflict-free:
+//     E1 element(k1, t)      = 66*k1 + t
+//     E2 element(k1, k2, t2) = 70*k1 + 17*t2 + k2
+// Twiddles and H live in LDS tables indexed [register][lane] (or broadcast), loaded once per workgroup.
+//
+// Accuracy: f32 FFT arithmetic, not the fmaf chain of the direct form; error vs the f64 oracle is ~3e-7 for
+// |x| <= 1 and unity-gain taps (tests hold it to the reference's 1e-6).
+#pragma once
+#include "common.h"
+#include "kernels_fir.h"
+
+namespace lrhip {
+
+constexpr int FFTN = 1024;
+constexpr int FFT_E1_ROW = 66;
+constexpr int FFT_E2_ROW = 70;
+constexpr int FFT_EX_ELEMS = 16 * FFT_E2_ROW;          // per-wave exchange buffer (float2 elements)
+// LDS map (float2 units): [4 waves x FFT_EX_ELEMS | tw1 16x64 | H 16x64 | tw2 64]
+constexpr int FFT_LDS_TW1 = 4 * FFT_EX_ELEMS;
+constexpr int FFT_LDS_H = FFT_LDS_TW1 + 16 * 64;
+constexpr int FFT_LDS_TW2 = FFT_LDS_H + 16 * 64;
+constexpr int FFT_LDS_ELEMS = FFT_LDS_TW2 + 64;
+constexpr int FFT_TABLE_ELEMS = 16 * 64 + 16 * 64 + 64;   // tw1 | Hperm | tw2, as uploaded by the host
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+// a * conj(b)
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+}
+
+// DIR = +1: forward (kernel e^{-j...}), -1: inverse.  In-place 4-point DFT, natural order out.
+template <int DIR>
+__device__ __forceinline__ void radix4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
+{
+    float2 b0 = cadd(a0, a2), b1 = csub(a0, a2), b2 = cadd(a1, a3), d = csub(a1, a3);
+    float2 b3 = DIR > 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);   // d * (-j) or d * (+j)
+    a0 = cadd(b0, b2);
+    a2 = csub(b0, b2);
+    a1 = cadd(b1, b3);
+    a3 = csub(b1, b3);
+}
+
+// multiply by W_16^(DIR*p), p in {1,2,3,4,6,9}
+template <int DIR, int P>
+__device__ __forceinline__ float2 mul_w16(float2 a)
+{
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
+    if constexpr (P == 1) return DIR > 0 ? cmul(a, make_float2(C1, -S1)) : cmul(a, make_float2(C1, S1));
+    if constexpr (P == 2) return DIR > 0 ? make_float2((a.x + a.y) * R, (a.y - a.x) * R) : make_float2((a.x - a.y) * R, (a.y + a.x) * R);
+    if constexpr (P == 3) return DIR > 0 ? cmul(a, make_float2(S1, -C1)) : cmul(a, make_float2(S1, C1));
+    if constexpr (P == 4) return DIR > 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+    if constexpr (P == 6) return DIR > 0 ? make_float2((a.y - a.x) * R, -(a.x + a.y) * R) : make_float2(-(a.x + a.y) * R, (a.x - a.y) * R);
+    if constexpr (P == 9) return DIR > 0 ? cmul(a, make_float2(-C1, S1)) : cmul(a, make_float2(-C1, -S1));
+    return a;
+}
+
+// 16-point DFT of v[0..15] (index n = 4a + b), result in natural order: v[k] = sum_n v[n] W_16^(DIR*n*k)
+template <int DIR>
+__device__ __forceinline__ void dft16(float2 (&v)[16])
+{
+    // radix-4 over a for every b: afterwards position 4c+b holds u[b][c]
+#pragma unroll
+    for (int b = 0; b < 4; b++) radix4<DIR>(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    // twiddle W_16^(b*c)
+    v[4 * 1 + 1] = mul_w16<DIR, 1>(v[4 * 1 + 1]);
+    v[4 * 1 + 2] = mul_w16<DIR, 2>(v[4 * 1 + 2]);
+    v[4 * 1 + 3] = mul_w16<DIR, 3>(v[4 * 1 + 3]);
+    v[4 * 2 + 1] = mul_w16<DIR, 2>(v[4 * 2 + 1]);
+    v[4 * 2 + 2] = mul_w16<DIR, 4>(v[4 * 2 + 2]);
+    v[4 * 2 + 3] = mul_w16<DIR, 6>(v[4 * 2 + 3]);
+    v[4 * 3 + 1] = mul_w16<DIR, 3>(v[4 * 3 + 1]);
+    v[4 * 3 + 2] = mul_w16<DIR, 6>(v[4 * 3 + 2]);
+    v[4 * 3 + 3] = mul_w16<DIR, 9>(v[4 * 3 + 3]);
+    // radix-4 over b for every c: position 4c+d holds X[c + 4d]
+#pragma unroll
+    for (int c = 0; c < 4; c++) radix4<DIR>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    // un-permute (compile-time renaming): natural[c + 4d] = v[4c + d]
+    float2 t;
+    t = v[1]; v[1] = v[4]; v[4] = t;
+    t = v[2]; v[2] = v[8]; v[8] = t;
+    t = v[3]; v[3] = v[12]; v[12] = t;
+    t = v[6]; v[6] = v[9]; v[9] = t;
+    t = v[7]; v[7] = v[13]; v[13] = t;
+    t = v[11]; v[11] = v[14]; v[14] = t;
+}
+
+// One overlap-save block per wave.  S = 2: ComplexFloat32 stream.  S = 1: Float32 stream with REAL taps, two
+// consecutive blocks packed as re/im of one complex FFT (h real => IFFT(H*(Xa + jXb)) = h*xa + j h*xb).
+template <int S>
+__global__ __launch_bounds__(256, 3) void fir_fft_kernel(const float *__restrict__ hist, const float *__restrict__ x,
+                                                          const float2 *__restrict__ tables, float *__restrict__ y,
+                                                          int M, long n, long n_out, long nblocks)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 fl[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2 *ex = fl + wave * FFT_EX_ELEMS;
+    const float2 *tw1 = fl + FFT_LDS_TW1, *Hp = fl + FFT_LDS_H, *tw2 = fl + FFT_LDS_TW2;
+
+    for (int i = tid; i < FFT_TABLE_ELEMS; i += 256) fl[FFT_LDS_TW1 + i] = tables[i];
+    __syncthreads();
+
+    const int L = FFTN - M + 1;
+    const int hi4 = lane >> 4, lo16 = lane & 15;      // (t2 | q, k1) numbering of stages 2 and 3
+    constexpr int BPW = S == 2 ? 1 : 2;               // stream blocks per FFT
+
+    for (long fb = (long)blockIdx.x * 4 + wave; fb * BPW < nblocks; fb += (long)gridDim.x * 4) {
+        float2 v[16];
+        // ---- load: stream positions p0 + 64*i + lane  (stream = [M-1 history | chunk])
+        if (S == 2) {
+            const long p0 = fb * L;
+            const long xlo = p0 - (M - 1);
+            if (xlo >= 0 && xlo + FFTN <= n) {
+                const float2 *src = reinterpret_cast<const float2 *>(x) + xlo + lane;
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = src[64 * i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    long p = p0 + 64 * i + lane;
+                    v[i] = make_float2(stream_at<2>(hist, x, p, 0, M, n), stream_at<2>(hist, x, p, 1, M, n));
+                }
+            }
+        } else {
+            const long pa = (fb * 2) * L, pb = pa + L;
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                v[i] = make_float2(stream_at<1>(hist, x, pa + 64 * i + lane, 0, M, n), stream_at<1>(hist, x, pb + 64 * i + lane, 0, M, n));
+        }
+
+        // ---- forward stage 1: radix-16 over n1, twiddle W_1024^(t*k1)
+        dft16<1>(v);
+#pragma unroll
+        for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw1[k * 64 + lane]);
+        // E1: write (k1, t), read (k1 = lo16, 4*t1 + t2), t2 = hi4
+#pragma unroll
+        for (int k = 0; k < 16; k++) ex[k * FFT_E1_ROW + lane] = v[k];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = ex[lo16 * FFT_E1_ROW + 4 * i + hi4];
+        // ---- forward stage 2: radix-16 over t1, twiddle W_64^(t2*k2)
+        dft16<1>(v);
+#pragma unroll
+        for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw2[k * 4 + hi4]);
+        // E2: write (k1 = lo16, k2, t2 = hi4), read (k1 = lo16, k2 = 4j + q, t2 = 0..3), q = hi4; register 4j + t2
+#pragma unroll
+        for (int k = 0; k < 16; k++) ex[lo16 * FFT_E2_ROW + 17 * hi4 + k] = v[k];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int t2 = 0; t2 < 4; t2++) v[4 * j + t2] = ex[lo16 * FFT_E2_ROW + 17 * t2 + 4 * j + hi4];
+        // ---- forward stage 3: radix-4 over t2 -> k3; multiply by H; inverse stage 3: radix-4 over k3 -> t2
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            radix4<1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+#pragma unroll
+            for (int k3 = 0; k3 < 4; k3++) v[4 * j + k3] = cmul(v[4 * j + k3], Hp[(4 * j + k3) * 64 + lane]);
+            radix4<-1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+            // conj twiddle W_64^(-t2*k2), k2 = 4j + q
+#pragma unroll
+            for (int t2 = 1; t2 < 4; t2++) v[4 * j + t2] = cmulc(v[4 * j + t2], tw2[(4 * j + hi4) * 4 + t2]);
+        }
+        // E2 back: write (k1, k2 = 4j + q, t2), read (k1 = lo16, k2 = 0..15, t2 = hi4)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int t2 = 0; t2 < 4; t2++) ex[lo16 * FFT_E2_ROW + 17 * t2 + 4 * j + hi4] = v[4 * j + t2];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = ex[lo16 * FFT_E2_ROW + 17 * hi4 + k];
+        // ---- inverse stage 2: radix-16 over k2 -> t1
+        dft16<-1>(v);
+        // E1 back: write (k1 = lo16, 4*t1 + t2), read (k1, t = lane)
+#pragma unroll
+        for (int i = 0; i < 16; i++) ex[lo16 * FFT_E1_ROW + 4 * i + hi4] = v[i];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = ex[k * FFT_E1_ROW + lane];
+        // ---- inverse stage 1: conj twiddle, radix-16 over k1 -> n1
+#pragma unroll
+        for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], tw1[k * 64 + lane]);
+        dft16<-1>(v);
+
+        // ---- store: outputs of this block are positions M-1 .. N-1 (firfilter.lua:379 copies output_block[M-1 ..])
+        if (S == 2) {
+            const long o0 = fb * L - (M - 1);
+            float2 *dst = reinterpret_cast<float2 *>(y);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                int nn = 64 * i + lane;
+                long o = o0 + nn;
+                if (nn >= M - 1 && o < n_out) dst[o] = v[i];
+            }
+        } else {
+            const long oa = (fb * 2) * L - (M - 1), ob = oa + L;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                int nn = 64 * i + lane;
+                if (nn >= M - 1) {
+                    if (oa + nn < n_out) y[oa + nn] = v[i].x;
+                    if (ob + nn < n_out) y[ob + nn] = v[i].y;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace lrhip

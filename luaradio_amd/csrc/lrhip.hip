@@ -9,6 +9,7 @@
 #include "kernels_elem.h"
 #include "kernels_fft.h"
 #include "kernels_fir.h"
+#include "kernels_firfft.h"
 #include "kernels_iir.h"
 
 using namespace lrhip;
@@ -67,6 +68,10 @@ struct FirStage : lrhip_stage {
     // overlap-save emission framing (firfilter.lua:451-485)
     long L = 0, fill = 0;
     DeviceBuf pending, work;
+    // overlap-save ARITHMETIC (fused 1024-point FFT kernel); independent of the emission framing
+    bool fft_arith = false;
+    DeviceBuf d_fft_tables;
+    int fft_blocks_per_cu = 0;
 
     const char *kind() const override { return "fir"; }
     unsigned long max_output(unsigned long n) const override
@@ -199,6 +204,27 @@ struct FirStage : lrhip_stage {
         }
     }
 
+    int launch_fft(const float *x, long n, float *y, long n_out)
+    {
+        const long Lf = FFTN - M + 1;
+        long nblocks = (n_out + Lf - 1) / Lf;
+        long nffts = S == 2 ? nblocks : (nblocks + 1) / 2;
+        size_t lds_bytes = (size_t)FFT_LDS_ELEMS * sizeof(float2);
+        const float *h = (const float *)hist[cur].p + hist_pad;
+        auto go = [&](auto kern) -> int {
+            if (!fft_blocks_per_cu && prepare_kernel(kern, lds_bytes, &fft_blocks_per_cu)) return -1;
+            long slots = (long)ctx().num_cus * fft_blocks_per_cu;
+            long want = (nffts + 3) / 4;
+            unsigned grid = (unsigned)(want < slots ? want : slots);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, (const float2 *)d_fft_tables.p, y, M, n, n_out, nblocks);
+            return 0;
+        };
+        int rc = S == 2 ? go(fir_fft_kernel<2>) : go(fir_fft_kernel<1>);
+        if (rc) return rc;
+        LR_LAUNCH_CHECK();
+        return 0;
+    }
+
     int launch_direct(const float *x, long n, float *y, long n_out)
     {
         if (rot) return set_error("internal: direct FIR kernel has no fused rotator");
@@ -240,7 +266,8 @@ struct FirStage : lrhip_stage {
         long n_out = (unsigned long)n > index ? (long)((n - index + D - 1) / D) : 0;
         if ((unsigned long)n_out > cap) return set_error("fir: output capacity %lu < %ld", cap, n_out);
         if (n_out > 0) {
-            int rc = !ksteps ? launch_direct(x, n, y, n_out)
+            int rc = fft_arith ? launch_fft(x, n, y, n_out)
+                     : !ksteps ? launch_direct(x, n, y, n_out)
                      : taps_complex ? dispatch_mfma_cc(x, n, y, n_out)
                      : S == 1 ? dispatch_mfma<1>(x, n, y, n_out) : dispatch_mfma<2>(x, n, y, n_out);
             if (rc) return rc;
@@ -292,13 +319,14 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
     if (!taps || ntaps < 1) { set_error("fir: need at least one tap"); return nullptr; }
     if (taps_complex && !input_complex) { set_error("fir: complex taps require ComplexFloat32 input (firfilter.lua:69-74)"); return nullptr; }
     if (decim < 1) { set_error("fir: decimation must be >= 1"); return nullptr; }
-    if (use_fft && decim != 1) { set_error("fir: overlap-save framing cannot be combined with decimation"); return nullptr; }
+    if (use_fft && decim != 1) { set_error("fir: overlap-save cannot be combined with decimation"); return nullptr; }
+    if (use_fft < 0 || use_fft > 2) { set_error("fir: use_fft must be 0 (direct form), 1 (overlap-save as the reference: block emission) or 2 (overlap-save arithmetic, sample-exact emission)"); return nullptr; }
     if (ntaps > (1u << 20)) { set_error("fir: too many taps"); return nullptr; }
     if (ensure_init()) return nullptr;
     std::unique_ptr<FirStage> q(new (std::nothrow) FirStage());
     if (!q) { set_error("out of memory"); return nullptr; }
     q->M = (int)ntaps; q->S = input_complex ? 2 : 1; q->taps_complex = taps_complex; q->D = decim;
-    q->use_fft = use_fft != 0; q->rot = rot;
+    q->use_fft = use_fft == 1; q->rot = rot;     // 1: reference emission framing; 2: FFT arithmetic, sample-exact emission
     q->in_size = q->out_size = 4 * q->S;
     int ts = taps_complex ? 2 : 1;
     q->taps_rev.resize((size_t)ntaps * ts);
@@ -344,6 +372,47 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
         long double turns = (long double)omega / (2.0L * 3.14159265358979323846264338327950288L);
         turns -= floorl(turns);
         q->rot_step = (uint64_t)(turns * 18446744073709551616.0L);
+    }
+    if (use_fft && decim == 1 && !rot && ntaps >= 32 && ntaps <= 512 && (input_complex || !taps_complex)) {
+        // fused overlap-save kernel tables: tw1[k1][t] | Hperm[4j+k3][lane] | tw2[k2][t2]
+        const double PI2 = 6.283185307179586476925286766559;
+        std::vector<float> tab((size_t)FFT_TABLE_ELEMS * 2);
+        for (int k1 = 0; k1 < 16; k1++)
+            for (int t = 0; t < 64; t++) {
+                double a = -PI2 * (double)((k1 * t) % FFTN) / FFTN;
+                tab[2 * (k1 * 64 + t)] = (float)std::cos(a);
+                tab[2 * (k1 * 64 + t) + 1] = (float)std::sin(a);
+            }
+        std::vector<double> Hr(FFTN, 0.0), Hi(FFTN, 0.0);
+        for (int k = 0; k < FFTN; k++) {
+            double sr = 0, si = 0;
+            for (unsigned m = 0; m < ntaps; m++) {
+                double a = -PI2 * (double)((k * (long)m) % FFTN) / FFTN, c = std::cos(a), sn = std::sin(a);
+                double hr = taps_complex ? taps[2 * m] : taps[m], hi = taps_complex ? taps[2 * m + 1] : 0.0;
+                sr += hr * c - hi * sn;
+                si += hr * sn + hi * c;
+            }
+            Hr[k] = sr / FFTN;      // the 1/N of the inverse transform (spectrum_utils.lua:335-338) folded in
+            Hi[k] = si / FFTN;
+        }
+        for (int j = 0; j < 4; j++)
+            for (int k3 = 0; k3 < 4; k3++)
+                for (int lane = 0; lane < 64; lane++) {
+                    int qq = lane >> 4, k1 = lane & 15;
+                    int k = k1 + 16 * (4 * j + qq) + 256 * k3;
+                    size_t o = (size_t)16 * 64 + (size_t)(4 * j + k3) * 64 + lane;
+                    tab[2 * o] = (float)Hr[k];
+                    tab[2 * o + 1] = (float)Hi[k];
+                }
+        for (int k2 = 0; k2 < 16; k2++)
+            for (int t2 = 0; t2 < 4; t2++) {
+                double a = -PI2 * (double)((k2 * t2) % 64) / 64.0;
+                size_t o = (size_t)2 * 16 * 64 + k2 * 4 + t2;
+                tab[2 * o] = (float)std::cos(a);
+                tab[2 * o + 1] = (float)std::sin(a);
+            }
+        if (upload(q->d_fft_tables, tab.data(), tab.size() * sizeof(float))) return nullptr;
+        q->fft_arith = true;
     }
     if (q->use_fft) {
         long N = 1L << (long)std::floor(std::log(8.0 * ntaps) / std::log(2.0));   // firfilter.lua:329

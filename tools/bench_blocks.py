@@ -68,9 +68,12 @@ def main():
 
     taps128 = lr.filter_utils.firwin_lowpass(128, 15e3 / 110250)
     run("FIRFilter 128 real taps, cf32", mk(lr.FIRFilterBlock, [taps128], True), True, 16, 512)
+    run("FIRFilter 128 real taps, cf32, overlap-save (use_fft=fast)", mk(lr.FIRFilterBlock, [taps128, "fast"], True), True, 16, 125)
     run("FIRFilter 128 real taps, f32", mk(lr.FIRFilterBlock, [taps128], False), False, 8, 256)
+    run("FIRFilter 128 real taps, f32, overlap-save (use_fft=fast)", mk(lr.FIRFilterBlock, [taps128, "fast"], False), False, 8, 63)
     run("FIRFilter 16 real taps, cf32", mk(lr.FIRFilterBlock, [taps128[:16]], True), True, 16, 64)
     run("FIRFilter 128 complex taps, cf32", mk(lr.FIRFilterBlock, [np.asarray(taps128, np.complex64) * (1 + 0.5j)], True), True, 16, 1024)
+    run("FIRFilter 128 complex taps, cf32, overlap-save (use_fft=fast)", mk(lr.FIRFilterBlock, [np.asarray(taps128, np.complex64) * (1 + 0.5j), "fast"], True), True, 16, 125)
     run("FrequencyTranslator", mk(lr.FrequencyTranslatorBlock, [-250e3], True), True, 16)
     run("FrequencyDiscriminator", mk(lr.FrequencyDiscriminatorBlock, [1.25], True), True, 12)
     run("Downsampler(5) cf32", mk(lr.DownsamplerBlock, [5], True), True, 8 + 8 / 5)
