@@ -16,9 +16,11 @@
 //   inverse = the mirror image with conjugated twiddles; the result lands as y[64*n1 + t] in natural order,
 //   so loads and stores are both coalesced and no bit-reversal pass exists.
 // Exchanges go through a per-wave LDS buffer (no workgroup barrier: a wave's DS operations execute in order).
-// LDS layouts are padded so every ds_read_b64 / ds_write_b64 is conflict-free:
-//     E1 element(k1, t)      = 66*k1 + t
-//     E2 element(k1, k2, t2) = 70*k1 + 17*t2 + k2
+// Stages 2 and 3 number their lanes (k1 = lane >> 2, t2 or q = lane & 3).  LDS layouts are padded so that every
+// ds_read_b64 (32-lane groups, 32 bank pairs) AND every ds_write_b64 (16-lane groups, 16 bank pairs) is
+// conflict-free:
+//     E1 element(k1, t)      = 68*k1 + t
+//     E2 element(k1, k2, t2) = 68*k1 + 17*t2 + k2
 // Twiddles and H live in LDS tables indexed [register][lane] (or broadcast), loaded once per workgroup.
 //
 // Accuracy: f32 FFT arithmetic, not the fmaf chain of the direct form; error vs the f64 oracle is ~3e-7 for
@@ -27,11 +29,18 @@
 #include "common.h"
 #include "kernels_fir.h"
 
+#ifndef LRHIP_FFT_EXP
+#define LRHIP_FFT_EXP 0
+#endif
+#ifndef LRHIP_FFT_PREFETCH
+#define LRHIP_FFT_PREFETCH 0
+#endif
+
 namespace lrhip {
 
 constexpr int FFTN = 1024;
-constexpr int FFT_E1_ROW = 66;
-constexpr int FFT_E2_ROW = 70;
+constexpr int FFT_E1_ROW = 68;
+constexpr int FFT_E2_ROW = 68;
 constexpr int FFT_EX_ELEMS = 16 * FFT_E2_ROW;          // per-wave exchange buffer (float2 elements)
 // LDS map (float2 units): [4 waves x FFT_EX_ELEMS | tw1 16x64 | H 16x64 | tw2 64]
 constexpr int FFT_LDS_TW1 = 4 * FFT_EX_ELEMS;
@@ -123,20 +132,36 @@ __global__ __launch_bounds__(256, 3) void fir_fft_kernel(const float *__restrict
     for (int i = tid; i < FFT_TABLE_ELEMS; i += 256) fl[FFT_LDS_TW1 + i] = tables[i];
     __syncthreads();
 
-    const int L = FFTN - M + 1;
-    const int hi4 = lane >> 4, lo16 = lane & 15;      // (t2 | q, k1) numbering of stages 2 and 3
+    // block advance: the overlap is rounded up to a multiple of 64 samples (V >= M-1) so that every block's load window
+    // AND its stored rows start on 512-B boundaries relative to x / y (L = 897 would misalign every row)
+    const int V = ((M - 1 + 63) / 64) * 64;
+    const int L = FFTN - V;
+    const int sub = lane & 3, k1s = lane >> 2;       // stages 2 and 3: sub = t2 or q, k1s = k1
     constexpr int BPW = S == 2 ? 1 : 2;               // stream blocks per FFT
 
-    for (long fb = (long)blockIdx.x * 4 + wave; fb * BPW < nblocks; fb += (long)gridDim.x * 4) {
-        float2 v[16];
-        // ---- load: stream positions p0 + 64*i + lane  (stream = [M-1 history | chunk])
-        if (S == 2) {
-            const long p0 = fb * L;
-            const long xlo = p0 - (M - 1);
-            if (xlo >= 0 && xlo + FFTN <= n) {
-                const float2 *src = reinterpret_cast<const float2 *>(x) + xlo + lane;
+    const long fstep = (long)gridDim.x * 4;
+#if LRHIP_FFT_PREFETCH
+    // register prefetch (S = 2): the next block's 16 loads are issued before this block's arithmetic
+    float2 pre[16];
+    bool have = false;
+    auto interior = [&](long b) { long lo = b * L - V; return b * BPW < nblocks && lo >= 0 && lo + FFTN <= n; };
+    if (S == 2 && interior((long)blockIdx.x * 4 + wave)) {
+        const float2 *src = reinterpret_cast<const float2 *>(x) + (((long)blockIdx.x * 4 + wave) * L - V) + lane;
 #pragma unroll
-                for (int i = 0; i < 16; i++) v[i] = src[64 * i];
+        for (int i = 0; i < 16; i++) pre[i] = src[64 * i];
+        have = true;
+    }
+#endif
+    for (long fb = (long)blockIdx.x * 4 + wave; fb * BPW < nblocks; fb += fstep) {
+        float2 v[16];
+        // ---- load: window position 64*i + lane  (stream = [M-1 history | chunk])
+        if (S == 2) {
+            const long xlo = fb * L - V;                  // x index of window position 0
+            const long p0 = xlo + (M - 1);                // the same in stream coordinates
+#if LRHIP_FFT_PREFETCH
+            if (have) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = pre[i];
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
@@ -144,8 +169,32 @@ __global__ __launch_bounds__(256, 3) void fir_fft_kernel(const float *__restrict
                     v[i] = make_float2(stream_at<2>(hist, x, p, 0, M, n), stream_at<2>(hist, x, p, 1, M, n));
                 }
             }
+            have = interior(fb + fstep);
+            if (have) {
+                const float2 *src = reinterpret_cast<const float2 *>(x) + ((fb + fstep) * L - V) + lane;
+#pragma unroll
+                for (int i = 0; i < 16; i++) pre[i] = src[64 * i];
+            }
+#else
+            if (xlo >= 0 && xlo + FFTN <= n) {
+#if LRHIP_FFT_EXP == 2      /* experiment: no global loads */
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = make_float2((float)(lane + i) * 1e-3f, (float)(fb & 1023) * 1e-3f);
+#else
+                const float2 *src = reinterpret_cast<const float2 *>(x) + xlo + lane;
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = src[64 * i];
+#endif
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    long p = p0 + 64 * i + lane;
+                    v[i] = make_float2(stream_at<2>(hist, x, p, 0, M, n), stream_at<2>(hist, x, p, 1, M, n));
+                }
+            }
+#endif
         } else {
-            const long pa = (fb * 2) * L, pb = pa + L;
+            const long pa = (fb * 2) * L - V + (M - 1), pb = pa + L;
 #pragma unroll
             for (int i = 0; i < 16; i++)
                 v[i] = make_float2(stream_at<1>(hist, x, pa + 64 * i + lane, 0, M, n), stream_at<1>(hist, x, pb + 64 * i + lane, 0, M, n));
@@ -155,22 +204,22 @@ __global__ __launch_bounds__(256, 3) void fir_fft_kernel(const float *__restrict
         dft16<1>(v);
 #pragma unroll
         for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw1[k * 64 + lane]);
-        // E1: write (k1, t), read (k1 = lo16, 4*t1 + t2), t2 = hi4
+        // E1: write (k1, t), read (k1 = k1s, 4*t1 + t2), t2 = sub
 #pragma unroll
         for (int k = 0; k < 16; k++) ex[k * FFT_E1_ROW + lane] = v[k];
 #pragma unroll
-        for (int i = 0; i < 16; i++) v[i] = ex[lo16 * FFT_E1_ROW + 4 * i + hi4];
+        for (int i = 0; i < 16; i++) v[i] = ex[k1s * FFT_E1_ROW + 4 * i + sub];
         // ---- forward stage 2: radix-16 over t1, twiddle W_64^(t2*k2)
         dft16<1>(v);
 #pragma unroll
-        for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw2[k * 4 + hi4]);
-        // E2: write (k1 = lo16, k2, t2 = hi4), read (k1 = lo16, k2 = 4j + q, t2 = 0..3), q = hi4; register 4j + t2
+        for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw2[k * 4 + sub]);
+        // E2: write (k1 = k1s, k2, t2 = sub), read (k1 = k1s, k2 = 4j + q, t2 = 0..3), q = sub; register 4j + t2
 #pragma unroll
-        for (int k = 0; k < 16; k++) ex[lo16 * FFT_E2_ROW + 17 * hi4 + k] = v[k];
+        for (int k = 0; k < 16; k++) ex[k1s * FFT_E2_ROW + 17 * sub + k] = v[k];
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int t2 = 0; t2 < 4; t2++) v[4 * j + t2] = ex[lo16 * FFT_E2_ROW + 17 * t2 + 4 * j + hi4];
+            for (int t2 = 0; t2 < 4; t2++) v[4 * j + t2] = ex[k1s * FFT_E2_ROW + 17 * t2 + 4 * j + sub];
         // ---- forward stage 3: radix-4 over t2 -> k3; multiply by H; inverse stage 3: radix-4 over k3 -> t2
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -180,20 +229,20 @@ __global__ __launch_bounds__(256, 3) void fir_fft_kernel(const float *__restrict
             radix4<-1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
             // conj twiddle W_64^(-t2*k2), k2 = 4j + q
 #pragma unroll
-            for (int t2 = 1; t2 < 4; t2++) v[4 * j + t2] = cmulc(v[4 * j + t2], tw2[(4 * j + hi4) * 4 + t2]);
+            for (int t2 = 1; t2 < 4; t2++) v[4 * j + t2] = cmulc(v[4 * j + t2], tw2[(4 * j + sub) * 4 + t2]);
         }
-        // E2 back: write (k1, k2 = 4j + q, t2), read (k1 = lo16, k2 = 0..15, t2 = hi4)
+        // E2 back: write (k1, k2 = 4j + q, t2), read (k1 = k1s, k2 = 0..15, t2 = sub)
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int t2 = 0; t2 < 4; t2++) ex[lo16 * FFT_E2_ROW + 17 * t2 + 4 * j + hi4] = v[4 * j + t2];
+            for (int t2 = 0; t2 < 4; t2++) ex[k1s * FFT_E2_ROW + 17 * t2 + 4 * j + sub] = v[4 * j + t2];
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = ex[lo16 * FFT_E2_ROW + 17 * hi4 + k];
+        for (int k = 0; k < 16; k++) v[k] = ex[k1s * FFT_E2_ROW + 17 * sub + k];
         // ---- inverse stage 2: radix-16 over k2 -> t1
         dft16<-1>(v);
-        // E1 back: write (k1 = lo16, 4*t1 + t2), read (k1, t = lane)
+        // E1 back: write (k1 = k1s, 4*t1 + t2), read (k1, t = lane)
 #pragma unroll
-        for (int i = 0; i < 16; i++) ex[lo16 * FFT_E1_ROW + 4 * i + hi4] = v[i];
+        for (int i = 0; i < 16; i++) ex[k1s * FFT_E1_ROW + 4 * i + sub] = v[i];
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = ex[k * FFT_E1_ROW + lane];
         // ---- inverse stage 1: conj twiddle, radix-16 over k1 -> n1
@@ -201,22 +250,36 @@ __global__ __launch_bounds__(256, 3) void fir_fft_kernel(const float *__restrict
         for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], tw1[k * 64 + lane]);
         dft16<-1>(v);
 
-        // ---- store: outputs of this block are positions M-1 .. N-1 (firfilter.lua:379 copies output_block[M-1 ..])
+        // ---- store: window positions V .. N-1 are this block's L outputs (positions < M-1 are the circular wrap,
+        // firfilter.lua:379 copies output_block[M-1 ..]; we drop up to 63 more so the rows stay aligned)
         if (S == 2) {
-            const long o0 = fb * L - (M - 1);
-            float2 *dst = reinterpret_cast<float2 *>(y);
+            const long o0 = fb * L - V;
+            float2 *dst = reinterpret_cast<float2 *>(y) + o0 + lane;
+#if LRHIP_FFT_EXP == 1          /* experiment: no global stores (value-dependent, never true) */
+            if (v[3].x == 1.2345e30f)
+#else
+            if (o0 + FFTN <= n_out)
+#endif
+            {
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                int nn = 64 * i + lane;
-                long o = o0 + nn;
-                if (nn >= M - 1 && o < n_out) dst[o] = v[i];
+                for (int i = 0; i < 16; i++)
+                    if (64 * i >= V) dst[64 * i] = v[i];            // wave-uniform: whole rows only
             }
+#if LRHIP_FFT_EXP != 1
+            else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    int nn = 64 * i + lane;
+                    if (nn >= V && o0 + nn < n_out) dst[64 * i] = v[i];
+                }
+            }
+#endif
         } else {
-            const long oa = (fb * 2) * L - (M - 1), ob = oa + L;
+            const long oa = (fb * 2) * L - V, ob = oa + L;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 int nn = 64 * i + lane;
-                if (nn >= M - 1) {
+                if (nn >= V) {
                     if (oa + nn < n_out) y[oa + nn] = v[i].x;
                     if (ob + nn < n_out) y[ob + nn] = v[i].y;
                 }

@@ -206,7 +206,7 @@ struct FirStage : lrhip_stage {
 
     int launch_fft(const float *x, long n, float *y, long n_out)
     {
-        const long Lf = FFTN - M + 1;
+        const long Lf = FFTN - ((M - 1 + 63) / 64) * 64;      // block advance of the fused kernel (overlap rounded to 64)
         long nblocks = (n_out + Lf - 1) / Lf;
         long nffts = S == 2 ? nblocks : (nblocks + 1) / 2;
         size_t lds_bytes = (size_t)FFT_LDS_ELEMS * sizeof(float2);
@@ -398,7 +398,7 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
         for (int j = 0; j < 4; j++)
             for (int k3 = 0; k3 < 4; k3++)
                 for (int lane = 0; lane < 64; lane++) {
-                    int qq = lane >> 4, k1 = lane & 15;
+                    int qq = lane & 3, k1 = lane >> 2;
                     int k = k1 + 16 * (4 * j + qq) + 256 * k3;
                     size_t o = (size_t)16 * 64 + (size_t)(4 * j + k3) * 64 + lane;
                     tab[2 * o] = (float)Hr[k];
