@@ -161,7 +161,9 @@ def wbfm_mono_receiver(rate=1102500.0, tune_offset=-250e3):
     """The compute blocks of examples/rtlsdr_wbfm_mono.lua:12-17,28 as one composite:
     Tuner(-250e3, 200e3, 5) -> FrequencyDiscriminator(1.25) -> Lowpass(128, 15e3) -> FMDeemphasis(75e-6) -> Downsampler(5)."""
     top = CompositeBlock()
-    top.connect(TunerBlock(tune_offset, 200e3, 5), B.FrequencyDiscriminatorBlock(1.25), B.LowpassFilterBlock(128, 15e3),
+    af_filter = B.LowpassFilterBlock(128, 15e3)
+    af_filter.use_fft = 2        # overlap-save arithmetic, one output per input (the reference's default FIR form is FFT too)
+    top.connect(TunerBlock(tune_offset, 200e3, 5), B.FrequencyDiscriminatorBlock(1.25), af_filter,
                 B.FMDeemphasisFilterBlock(75e-6), B.DownsamplerBlock(5))
     top.rate = rate
     top.differentiate([types.ComplexFloat32])

@@ -29,11 +29,13 @@
 #include "common.h"
 #include "kernels_fir.h"
 
-#ifndef LRHIP_FFT_EXP
-#define LRHIP_FFT_EXP 0
-#endif
 #ifndef LRHIP_FFT_PREFETCH
 #define LRHIP_FFT_PREFETCH 0
+#endif
+// 1: exchange re and im planes one after the other through a half-size per-wave buffer (34 KB of LDS per
+//    workgroup -> 4 workgroups = 16 waves per CU); 0: one ds_*_b64 pass (52 KB -> 12 waves per CU)
+#ifndef LRHIP_FFT_SPLIT
+#define LRHIP_FFT_SPLIT 0
 #endif
 
 namespace lrhip {
@@ -41,7 +43,8 @@ namespace lrhip {
 constexpr int FFTN = 1024;
 constexpr int FFT_E1_ROW = 68;
 constexpr int FFT_E2_ROW = 68;
-constexpr int FFT_EX_ELEMS = 16 * FFT_E2_ROW;          // per-wave exchange buffer (float2 elements)
+constexpr int FFT_EX_ELEMS = LRHIP_FFT_SPLIT ? 16 * FFT_E2_ROW / 2 : 16 * FFT_E2_ROW;   // per-wave exchange buffer (float2 units)
+constexpr int FFT_WAVES_PER_SIMD = LRHIP_FFT_SPLIT ? 4 : 3;
 // LDS map (float2 units): [4 waves x FFT_EX_ELEMS | tw1 16x64 | H 16x64 | tw2 64]
 constexpr int FFT_LDS_TW1 = 4 * FFT_EX_ELEMS;
 constexpr int FFT_LDS_H = FFT_LDS_TW1 + 16 * 64;
@@ -117,10 +120,33 @@ __device__ __forceinline__ void dft16(float2 (&v)[16])
     t = v[11]; v[11] = v[14]; v[14] = t;
 }
 
+// register <-> LDS transpose: lane writes v[k] to element widx(k), then reads element ridx(i) into v[i]
+template <typename WI, typename RI>
+__device__ __forceinline__ void exchange(float2 *ex, float2 (&v)[16], WI widx, RI ridx)
+{
+#if LRHIP_FFT_SPLIT
+    float *exf = reinterpret_cast<float *>(ex);
+    float re[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) exf[widx(k)] = v[k].x;
+#pragma unroll
+    for (int i = 0; i < 16; i++) re[i] = exf[ridx(i)];
+#pragma unroll
+    for (int k = 0; k < 16; k++) exf[widx(k)] = v[k].y;      // in-order DS queue: the re reads above are already issued
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = make_float2(re[i], exf[ridx(i)]);
+#else
+#pragma unroll
+    for (int k = 0; k < 16; k++) ex[widx(k)] = v[k];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = ex[ridx(i)];
+#endif
+}
+
 // One overlap-save block per wave.  S = 2: ComplexFloat32 stream.  S = 1: Float32 stream with REAL taps, two
 // consecutive blocks packed as re/im of one complex FFT (h real => IFFT(H*(Xa + jXb)) = h*xa + j h*xb).
 template <int S>
-__global__ __launch_bounds__(256, 3) void fir_fft_kernel(const float *__restrict__ hist, const float *__restrict__ x,
+__global__ __launch_bounds__(256, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const float *__restrict__ hist, const float *__restrict__ x,
                                                           const float2 *__restrict__ tables, float *__restrict__ y,
                                                           int M, long n, long n_out, long nblocks)
 {
@@ -177,14 +203,9 @@ __global__ __launch_bounds__(256, 3) void fir_fft_kernel(const float *__restrict
             }
 #else
             if (xlo >= 0 && xlo + FFTN <= n) {
-#if LRHIP_FFT_EXP == 2      /* experiment: no global loads */
-#pragma unroll
-                for (int i = 0; i < 16; i++) v[i] = make_float2((float)(lane + i) * 1e-3f, (float)(fb & 1023) * 1e-3f);
-#else
                 const float2 *src = reinterpret_cast<const float2 *>(x) + xlo + lane;
 #pragma unroll
                 for (int i = 0; i < 16; i++) v[i] = src[64 * i];
-#endif
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
@@ -205,21 +226,14 @@ __global__ __launch_bounds__(256, 3) void fir_fft_kernel(const float *__restrict
 #pragma unroll
         for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw1[k * 64 + lane]);
         // E1: write (k1, t), read (k1 = k1s, 4*t1 + t2), t2 = sub
-#pragma unroll
-        for (int k = 0; k < 16; k++) ex[k * FFT_E1_ROW + lane] = v[k];
-#pragma unroll
-        for (int i = 0; i < 16; i++) v[i] = ex[k1s * FFT_E1_ROW + 4 * i + sub];
+        exchange(ex, v, [&](int k) { return k * FFT_E1_ROW + lane; }, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; });
         // ---- forward stage 2: radix-16 over t1, twiddle W_64^(t2*k2)
         dft16<1>(v);
 #pragma unroll
         for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw2[k * 4 + sub]);
         // E2: write (k1 = k1s, k2, t2 = sub), read (k1 = k1s, k2 = 4j + q, t2 = 0..3), q = sub; register 4j + t2
-#pragma unroll
-        for (int k = 0; k < 16; k++) ex[k1s * FFT_E2_ROW + 17 * sub + k] = v[k];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int t2 = 0; t2 < 4; t2++) v[4 * j + t2] = ex[k1s * FFT_E2_ROW + 17 * t2 + 4 * j + sub];
+        exchange(ex, v, [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; },
+                 [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; });       // r = 4j + t2
         // ---- forward stage 3: radix-4 over t2 -> k3; multiply by H; inverse stage 3: radix-4 over k3 -> t2
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -232,19 +246,12 @@ __global__ __launch_bounds__(256, 3) void fir_fft_kernel(const float *__restrict
             for (int t2 = 1; t2 < 4; t2++) v[4 * j + t2] = cmulc(v[4 * j + t2], tw2[(4 * j + sub) * 4 + t2]);
         }
         // E2 back: write (k1, k2 = 4j + q, t2), read (k1 = k1s, k2 = 0..15, t2 = sub)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int t2 = 0; t2 < 4; t2++) ex[k1s * FFT_E2_ROW + 17 * t2 + 4 * j + sub] = v[4 * j + t2];
-#pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = ex[k1s * FFT_E2_ROW + 17 * sub + k];
+        exchange(ex, v, [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; },
+                 [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; });
         // ---- inverse stage 2: radix-16 over k2 -> t1
         dft16<-1>(v);
         // E1 back: write (k1 = k1s, 4*t1 + t2), read (k1, t = lane)
-#pragma unroll
-        for (int i = 0; i < 16; i++) ex[k1s * FFT_E1_ROW + 4 * i + sub] = v[i];
-#pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = ex[k * FFT_E1_ROW + lane];
+        exchange(ex, v, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; }, [&](int k) { return k * FFT_E1_ROW + lane; });
         // ---- inverse stage 1: conj twiddle, radix-16 over k1 -> n1
 #pragma unroll
         for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], tw1[k * 64 + lane]);
@@ -255,25 +262,17 @@ __global__ __launch_bounds__(256, 3) void fir_fft_kernel(const float *__restrict
         if (S == 2) {
             const long o0 = fb * L - V;
             float2 *dst = reinterpret_cast<float2 *>(y) + o0 + lane;
-#if LRHIP_FFT_EXP == 1          /* experiment: no global stores (value-dependent, never true) */
-            if (v[3].x == 1.2345e30f)
-#else
-            if (o0 + FFTN <= n_out)
-#endif
-            {
+            if (o0 + FFTN <= n_out) {
 #pragma unroll
                 for (int i = 0; i < 16; i++)
                     if (64 * i >= V) dst[64 * i] = v[i];            // wave-uniform: whole rows only
-            }
-#if LRHIP_FFT_EXP != 1
-            else {
+            } else {
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     int nn = 64 * i + lane;
                     if (nn >= V && o0 + nn < n_out) dst[64 * i] = v[i];
                 }
             }
-#endif
         } else {
             const long oa = (fb * 2) * L - V, ob = oa + L;
 #pragma unroll

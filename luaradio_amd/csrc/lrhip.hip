@@ -93,7 +93,8 @@ struct FirStage : lrhip_stage {
         // the shapes that matter most get the persistent, fully unrolled instantiation:
         // M = 128 at D = 1 (36 MFMA steps, the headline) and M = 128 at D = 5 (60 steps, the WBFM tuner)
         if constexpr (DD == 1) {
-            if (ksteps == 36) return launch_mfma_ks<SS, DD, NACC, 36>(x, n, y, n_out);
+            if (ksteps == 36) return launch_mfma_ks<SS, DD, NACC, 36>(x, n, y, n_out);     // M = 128, cf32
+            if (ksteps == 40) return launch_mfma_ks<SS, DD, NACC, 40>(x, n, y, n_out);     // M = 128, f32 (slack up to 3 samples)
         }
         if constexpr (DD == 5) {
             if (ksteps == 60) return launch_mfma_ks<SS, DD, NACC, 60>(x, n, y, n_out);
@@ -248,7 +249,7 @@ struct FirStage : lrhip_stage {
             case 2: return launch_mfma<SS, 2, 4>(x, n, y, n_out);
             case 3: return launch_mfma<SS, 3, 2>(x, n, y, n_out);
             case 4: return launch_mfma<SS, 4, 2>(x, n, y, n_out);
-            case 5: return launch_mfma<SS, 5, 2>(x, n, y, n_out);
+            case 5: return launch_mfma<SS, 5, 1>(x, n, y, n_out);
             case 6: return launch_mfma<SS, 6, 1>(x, n, y, n_out);
             case 7: return launch_mfma<SS, 7, 1>(x, n, y, n_out);
             case 8: return launch_mfma<SS, 8, 1>(x, n, y, n_out);
