@@ -287,4 +287,112 @@ __global__ __launch_bounds__(256, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// spectrum_utils.DFT / IDFT / PSD for N = 1024 frames on the same one-wave-per-frame engine
+// (radio/utilities/spectrum_utils.lua:25-113, :259-349, :522-640; fftshift :654-667 folded into the store index).
+// Forward: natural-order load (x window) -> 3 stages -> lane (k1 = lane>>2, q = lane&3), register 4j + k3 holds
+// X[k1 + 16*(4j + q) + 256*k3]; for one register the 64 lanes cover 64 consecutive bins (permuted), so the
+// scattered store is still one full segment per instruction.  Inverse: gather-load in that layout, mirror stages,
+// natural-order store.  LDS: [4 waves x exchange | tw1 16x64 | tw2 64] float2.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SPEC_LDS_TW1 = 4 * FFT_EX_ELEMS;
+constexpr int SPEC_LDS_TW2 = SPEC_LDS_TW1 + 16 * 64;
+constexpr int SPEC_LDS_ELEMS = SPEC_LDS_TW2 + 64;
+constexpr int SPEC_TABLE_ELEMS = 16 * 64 + 64;        // tw1 | tw2 as uploaded by the host
+
+enum { SPEC_FWD_COMPLEX = 0, SPEC_FWD_PSD = 1, SPEC_FWD_PSD_LOG = 2, SPEC_INV_COMPLEX = 3, SPEC_INV_REAL = 4 };
+
+template <bool IN_REAL>
+__global__ __launch_bounds__(256, 3) void spectrum1024_kernel(const float *__restrict__ x, float *__restrict__ y, long nframes,
+                                                               const float2 *__restrict__ tables, const float *__restrict__ window,
+                                                               int mode, float out_scale, int shift)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 fl[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2 *ex = fl + wave * FFT_EX_ELEMS;
+    const float2 *tw1 = fl + SPEC_LDS_TW1, *tw2 = fl + SPEC_LDS_TW2;
+    for (int i = tid; i < SPEC_TABLE_ELEMS; i += 256) fl[SPEC_LDS_TW1 + i] = tables[i];
+    __syncthreads();
+    const int sub = lane & 3, k1s = lane >> 2;
+
+    for (long f = (long)blockIdx.x * 4 + wave; f < nframes; f += (long)gridDim.x * 4) {
+        float2 v[16];
+        if (mode <= SPEC_FWD_PSD_LOG) {
+            // ---- forward
+            if (IN_REAL) {
+                const float *src = x + f * FFTN + lane;
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = make_float2(src[64 * i], 0.f);
+            } else {
+                const float2 *src = reinterpret_cast<const float2 *>(x) + f * FFTN + lane;
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = src[64 * i];
+            }
+            if (window) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    float w = window[64 * i + lane];
+                    v[i].x *= w;
+                    v[i].y *= w;
+                }
+            }
+            dft16<1>(v);
+#pragma unroll
+            for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw1[k * 64 + lane]);
+            exchange(ex, v, [&](int k) { return k * FFT_E1_ROW + lane; }, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; });
+            dft16<1>(v);
+#pragma unroll
+            for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw2[k * 4 + sub]);
+            exchange(ex, v, [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; },
+                     [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; });
+#pragma unroll
+            for (int j = 0; j < 4; j++) radix4<1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+            // ---- store bin k = k1 + 16*(4j + q) + 256*k3 at position (k + N/2) mod N when shifting
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int k3 = 0; k3 < 4; k3++) {
+                    int k = k1s + 16 * (4 * j + sub) + 256 * k3;
+                    int pos = shift ? ((k + FFTN / 2) & (FFTN - 1)) : k;
+                    float2 X = v[4 * j + k3];
+                    if (mode == SPEC_FWD_COMPLEX) {
+                        reinterpret_cast<float2 *>(y)[f * FFTN + pos] = make_float2(X.x * out_scale, X.y * out_scale);
+                    } else {
+                        float p = fmaf(X.x, X.x, X.y * X.y) * out_scale;       // spectrum_utils.lua:631-638
+                        y[f * FFTN + pos] = mode == SPEC_FWD_PSD_LOG ? 10.0f * log10f(p) : p;
+                    }
+                }
+        } else {
+            // ---- inverse: gather the spectrum in the stage-3 layout, mirror the stages
+            const float2 *src = reinterpret_cast<const float2 *>(x) + f * FFTN;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int k3 = 0; k3 < 4; k3++) v[4 * j + k3] = src[k1s + 16 * (4 * j + sub) + 256 * k3];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                radix4<-1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+#pragma unroll
+                for (int t2 = 1; t2 < 4; t2++) v[4 * j + t2] = cmulc(v[4 * j + t2], tw2[(4 * j + sub) * 4 + t2]);
+            }
+            exchange(ex, v, [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; },
+                     [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; });
+            dft16<-1>(v);
+            exchange(ex, v, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; }, [&](int k) { return k * FFT_E1_ROW + lane; });
+#pragma unroll
+            for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], tw1[k * 64 + lane]);
+            dft16<-1>(v);
+            if (mode == SPEC_INV_COMPLEX) {
+                float2 *dst = reinterpret_cast<float2 *>(y) + f * FFTN + lane;
+#pragma unroll
+                for (int i = 0; i < 16; i++) dst[64 * i] = make_float2(v[i].x * out_scale, v[i].y * out_scale);
+            } else {
+                float *dst = y + f * FFTN + lane;
+#pragma unroll
+                for (int i = 0; i < 16; i++) dst[64 * i] = v[i].x * out_scale;    // real part (spectrum_utils.lua:499-503)
+            }
+        }
+    }
+}
+
 }  // namespace lrhip

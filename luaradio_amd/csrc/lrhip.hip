@@ -602,7 +602,8 @@ struct FftStage : lrhip_stage {
     int N = 0, inverse = 0, out_kind = FFT_OUT_COMPLEX, shift = 0, in_real = 0, fpw = 1;
     float out_scale = 1.f;
     bool has_window = false;
-    DeviceBuf tw, window;
+    DeviceBuf tw, window, spec_tables;    // spec_tables: tw1 | tw2 of the one-wave-per-frame N = 1024 engine
+    int spec_blocks_per_cu = 0;
     const char *kind() const override { return "fft"; }
     int reset() override { return 0; }
     unsigned long max_output(unsigned long n) const override { return n - n % N; }
@@ -612,6 +613,29 @@ struct FftStage : lrhip_stage {
         if (n > cap) return set_error("fft: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
         long nframes = (long)(n / N);
+        if (N == FFTN) {
+            size_t lds_bytes = (size_t)SPEC_LDS_ELEMS * sizeof(float2);
+            int mode = inverse ? (out_kind == FFT_OUT_REAL ? SPEC_INV_REAL : SPEC_INV_COMPLEX)
+                               : (out_kind == FFT_OUT_PSD ? SPEC_FWD_PSD : out_kind == FFT_OUT_PSD_LOG ? SPEC_FWD_PSD_LOG : SPEC_FWD_COMPLEX);
+            const float *wp = has_window ? (const float *)window.p : nullptr;
+            auto go = [&](auto kern) -> int {
+                if (!spec_blocks_per_cu) {
+                    if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                    int nb = 0;
+                    LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds_bytes));
+                    spec_blocks_per_cu = nb < 1 ? 1 : nb;
+                }
+                long slots = (long)ctx().num_cus * spec_blocks_per_cu, want = (nframes + 3) / 4;
+                unsigned g = (unsigned)(want < slots ? want : slots);
+                hipLaunchKernelGGL(kern, dim3(g), dim3(256), lds_bytes, ctx().stream, (const float *)in_dev, (float *)out_dev, nframes,
+                                   (const float2 *)spec_tables.p, wp, mode, out_scale, shift);
+                return 0;
+            };
+            int rc = in_real ? go(spectrum1024_kernel<true>) : go(spectrum1024_kernel<false>);
+            if (rc) return rc;
+            LR_LAUNCH_CHECK();
+            return (long)n;
+        }
         unsigned grid = (unsigned)((nframes + fpw - 1) / fpw);
         size_t lds = (size_t)2 * fpw * N * sizeof(float2);
         const float *w = has_window ? (const float *)window.p : nullptr;
@@ -646,6 +670,24 @@ static FftStage *fft_build(unsigned n)
         tw[2 * m + 1] = (float)std::sin(ang);
     }
     if (upload(q->tw, tw.data(), tw.size() * sizeof(float))) return nullptr;
+    if (n == FFTN) {
+        const double PI2 = 6.283185307179586476925286766559;
+        std::vector<float> tab((size_t)SPEC_TABLE_ELEMS * 2);
+        for (int k1 = 0; k1 < 16; k1++)
+            for (int t = 0; t < 64; t++) {
+                double a = -PI2 * (double)((k1 * t) % FFTN) / FFTN;
+                tab[2 * (k1 * 64 + t)] = (float)std::cos(a);
+                tab[2 * (k1 * 64 + t) + 1] = (float)std::sin(a);
+            }
+        for (int k2 = 0; k2 < 16; k2++)
+            for (int t2 = 0; t2 < 4; t2++) {
+                double a = -PI2 * (double)((k2 * t2) % 64) / 64.0;
+                size_t o = (size_t)16 * 64 + k2 * 4 + t2;
+                tab[2 * o] = (float)std::cos(a);
+                tab[2 * o + 1] = (float)std::sin(a);
+            }
+        if (upload(q->spec_tables, tab.data(), tab.size() * sizeof(float))) return nullptr;
+    }
     return q.release();
 }
 
