@@ -82,6 +82,14 @@ lrhip_stage_t *lrhip_psd_create(unsigned n, const float *window, double scale, i
  * for inverse transforms a Float32 output (real part, :499-503).  Complex side is ComplexFloat32. */
 lrhip_stage_t *lrhip_dft_create(unsigned n, int inverse, int real_side);
 
+/* IQFileSource / RealFileSource sample conversion (radio/blocks/sources/iqfile.lua:99-113, realfile.lua:99-110,
+ * formats table radio/utilities/format_utils.lua:82-97): raw file samples -> (value - offset)/scale.
+ * format: "u8","s8","u16le","u16be","s16le","s16be","u32le","u32be","s32le","s32be","f32le","f32be","f64le","f64be".
+ * complex_out != 0: input is interleaved I/Q (2 raw scalars per sample), output ComplexFloat32; else Float32.
+ * Input samples are the RAW file records (lrhip_stage_input_size() bytes each), so the bytes read from the file
+ * are handed over unchanged and converted on the device. */
+lrhip_stage_t *lrhip_format_convert_create(const char *format, int complex_out);
+
 void lrhip_stage_destroy(lrhip_stage_t *q);
 /* Back to the just-created state (zero history, phase 0, index 0). */
 int lrhip_stage_reset(lrhip_stage_t *q);

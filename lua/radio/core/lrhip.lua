@@ -34,6 +34,7 @@ lrhip_stage_t *lrhip_fmdiscrim_create(double gain);
 lrhip_stage_t *lrhip_iir_create(const float *b, unsigned nb, const float *a, unsigned na, int input_complex);
 lrhip_stage_t *lrhip_psd_create(unsigned n, const float *window, double scale, int logarithmic, int input_complex, int fftshift);
 lrhip_stage_t *lrhip_dft_create(unsigned n, int inverse, int real_side);
+lrhip_stage_t *lrhip_format_convert_create(const char *format, int complex_out);
 void lrhip_stage_destroy(lrhip_stage_t *q);
 int lrhip_stage_reset(lrhip_stage_t *q);
 int lrhip_stage_input_size(const lrhip_stage_t *q);

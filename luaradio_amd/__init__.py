@@ -9,6 +9,7 @@ from .block import Block, Input, Output  # noqa: F401
 from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock, FIRFilterBlock,  # noqa: F401
                      FMDeemphasisFilterBlock, FrequencyDiscriminatorBlock, FrequencyTranslatorBlock,
                      HighpassFilterBlock, IIRFilterBlock, LowpassFilterBlock, SinglepoleLowpassFilterBlock)
+from .sources import IQFileSource, RealFileSource  # noqa: F401
 from .composites import (Chain, CompositeBlock, DecimatorBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401
                          wbfm_mono_receiver)
 

@@ -105,4 +105,37 @@ __global__ __launch_bounds__(256) void downsample_kernel(const T *__restrict__ x
         y[i] = x[index + i * factor];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// IQFileSource / RealFileSource sample-format conversion
+// (reference: radio/blocks/sources/iqfile.lua:99-113, realfile.lua:99-110, radio/utilities/format_utils.lua:82-97):
+//   out = (raw.value - offset) / scale   after an optional byte swap, evaluated in double and rounded once.
+// Doing it on the device lets an RTL-SDR style u8 file cross PCIe at 2 B per complex sample instead of 8.
+// One thread converts one scalar (the interleaved I/Q stream of a complex file is 2n scalars).
+// Traffic: sizeof(T) in + 4 out per scalar.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T byteswap_raw(T v)
+{
+    if constexpr (sizeof(T) == 2) return (T)__builtin_bswap16((uint16_t)v);
+    else if constexpr (sizeof(T) == 4) return (T)__builtin_bswap32((uint32_t)v);
+    else if constexpr (sizeof(T) == 8) return (T)__builtin_bswap64((uint64_t)v);
+    else return v;
+}
+
+// RAW = storage integer type, VAL = the value type it is reinterpreted as (int8_t ... double)
+template <typename RAW, typename VAL, bool SWAP>
+__global__ __launch_bounds__(256) void format_convert_kernel(const RAW *__restrict__ in, float *__restrict__ out, unsigned long n,
+                                                             double offset, double scale)
+{
+    unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        RAW r = in[i];
+        if (SWAP) r = byteswap_raw(r);
+        VAL v;
+        __builtin_memcpy(&v, &r, sizeof(v));
+        out[i] = (float)(((double)v - offset) / scale);
+    }
+}
+
 }  // namespace lrhip

@@ -692,6 +692,63 @@ static FftStage *fft_build(unsigned n)
 }
 
 // =====================================================================================================
+// IQFileSource / RealFileSource format conversion
+// =====================================================================================================
+struct FormatStage : lrhip_stage {
+    int fmt = 0;          // index into kFormats
+    int scalars = 1;      // raw scalars per sample (2 for I/Q)
+    const char *kind() const override { return "format"; }
+    int reset() override { return 0; }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override;
+};
+
+struct FormatDesc {
+    const char *name;
+    int bytes;        // per scalar
+    int cls;          // 0 u8, 1 s8, 2 u16, 3 s16, 4 u32, 5 s32, 6 f32, 7 f64
+    bool swap;        // file byte order differs from the (little-endian) device
+    double offset, scale;
+};
+// radio/utilities/format_utils.lua:82-97
+static const FormatDesc kFormats[] = {
+    {"u8", 1, 0, false, 127.5, 127.5},           {"s8", 1, 1, false, 0.0, 127.5},
+    {"u16le", 2, 2, false, 32767.5, 32767.5},    {"u16be", 2, 2, true, 32767.5, 32767.5},
+    {"s16le", 2, 3, false, 0.0, 32767.5},        {"s16be", 2, 3, true, 0.0, 32767.5},
+    {"u32le", 4, 4, false, 2147483647.5, 2147483647.5}, {"u32be", 4, 4, true, 2147483647.5, 2147483647.5},
+    {"s32le", 4, 5, false, 0.0, 2147483647.5},   {"s32be", 4, 5, true, 0.0, 2147483647.5},
+    {"f32le", 4, 6, false, 0.0, 1.0},            {"f32be", 4, 6, true, 0.0, 1.0},
+    {"f64le", 8, 7, false, 0.0, 1.0},            {"f64be", 8, 7, true, 0.0, 1.0},
+};
+
+long FormatStage::run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap)
+{
+    if (n > cap) return set_error("format: output capacity %lu < %lu", cap, n);
+    if (!n) return 0;
+    const FormatDesc &f = kFormats[fmt];
+    unsigned long ns = n * scalars;
+    unsigned grid = grid_for(ns, 256, ctx().num_cus * 16);
+    float *out = (float *)out_dev;
+#define LR_FMT(RAW, VAL)                                                                                                   \
+    do {                                                                                                                   \
+        if (f.swap) hipLaunchKernelGGL((format_convert_kernel<RAW, VAL, true>), dim3(grid), dim3(256), 0, ctx().stream, (const RAW *)in_dev, out, ns, f.offset, f.scale); \
+        else hipLaunchKernelGGL((format_convert_kernel<RAW, VAL, false>), dim3(grid), dim3(256), 0, ctx().stream, (const RAW *)in_dev, out, ns, f.offset, f.scale);      \
+    } while (0)
+    switch (f.cls) {
+        case 0: LR_FMT(uint8_t, uint8_t); break;
+        case 1: LR_FMT(uint8_t, int8_t); break;
+        case 2: LR_FMT(uint16_t, uint16_t); break;
+        case 3: LR_FMT(uint16_t, int16_t); break;
+        case 4: LR_FMT(uint32_t, uint32_t); break;
+        case 5: LR_FMT(uint32_t, int32_t); break;
+        case 6: LR_FMT(uint32_t, float); break;
+        default: LR_FMT(uint64_t, double); break;
+    }
+#undef LR_FMT
+    LR_LAUNCH_CHECK();
+    return (long)n;
+}
+
+// =====================================================================================================
 // chain
 // =====================================================================================================
 struct lrhip_chain {
@@ -886,6 +943,23 @@ lrhip_stage_t *lrhip_dft_create(unsigned n, int inverse, int real_side)
         q->out_kind = real_side ? FFT_OUT_REAL : FFT_OUT_COMPLEX;
         q->out_scale = (float)(1.0 / (double)n);      // spectrum_utils.lua:335-338
     }
+    return q;
+}
+
+lrhip_stage_t *lrhip_format_convert_create(const char *format, int complex_out)
+{
+    if (!format) { set_error("format: missing format name"); return nullptr; }
+    int idx = -1;
+    for (size_t i = 0; i < sizeof(kFormats) / sizeof(kFormats[0]); i++)
+        if (!strcmp(kFormats[i].name, format)) idx = (int)i;
+    if (idx < 0) { set_error("Unsupported format (\"%s\")", format); return nullptr; }     // iqfile.lua:48
+    if (ensure_init()) return nullptr;
+    FormatStage *q = new (std::nothrow) FormatStage();
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->fmt = idx;
+    q->scalars = complex_out ? 2 : 1;
+    q->in_size = kFormats[idx].bytes * q->scalars;
+    q->out_size = 4 * q->scalars;
     return q;
 }
 

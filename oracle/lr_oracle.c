@@ -607,3 +607,39 @@ void lro_multiply_conjugate(const float *a, const float *b, long n, float *y)
         y[2 * i + 1] = (float)(ar * bi + ai * br);
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * IQFileSource / RealFileSource conversion: radio/blocks/sources/iqfile.lua:99-113, realfile.lua:99-110 with the
+ * formats table radio/utilities/format_utils.lua:82-97: optional byte swap, then (value - offset)/scale in double,
+ * rounded to float on store.  `nscalars` raw scalars in, floats out.  Returns -1 for an unknown format.
+ * ---------------------------------------------------------------------------------------- */
+long lro_format_convert(const char *format, const unsigned char *raw, long nscalars, float *out)
+{
+    static const struct { const char *name; int bytes, cls, be; double offset, scale; } F[] = {
+        {"u8", 1, 0, 0, 127.5, 127.5}, {"s8", 1, 1, 0, 0, 127.5},
+        {"u16le", 2, 2, 0, 32767.5, 32767.5}, {"u16be", 2, 2, 1, 32767.5, 32767.5},
+        {"s16le", 2, 3, 0, 0, 32767.5}, {"s16be", 2, 3, 1, 0, 32767.5},
+        {"u32le", 4, 4, 0, 2147483647.5, 2147483647.5}, {"u32be", 4, 4, 1, 2147483647.5, 2147483647.5},
+        {"s32le", 4, 5, 0, 0, 2147483647.5}, {"s32be", 4, 5, 1, 0, 2147483647.5},
+        {"f32le", 4, 6, 0, 0, 1.0}, {"f32be", 4, 6, 1, 0, 1.0}, {"f64le", 8, 7, 0, 0, 1.0}, {"f64be", 8, 7, 1, 0, 1.0}};
+    int k = -1;
+    for (unsigned i = 0; i < sizeof(F) / sizeof(F[0]); i++) if (!strcmp(F[i].name, format)) k = (int)i;
+    if (k < 0) return -1;
+    for (long i = 0; i < nscalars; i++) {
+        unsigned char b[8];
+        for (int j = 0; j < F[k].bytes; j++) b[j] = raw[i * F[k].bytes + (F[k].be ? F[k].bytes - 1 - j : j)];   /* host is little-endian */
+        double v;
+        switch (F[k].cls) {
+            case 0: v = b[0]; break;
+            case 1: v = (int8_t)b[0]; break;
+            case 2: { uint16_t t; memcpy(&t, b, 2); v = t; break; }
+            case 3: { int16_t t; memcpy(&t, b, 2); v = t; break; }
+            case 4: { uint32_t t; memcpy(&t, b, 4); v = t; break; }
+            case 5: { int32_t t; memcpy(&t, b, 4); v = t; break; }
+            case 6: { float t; memcpy(&t, b, 4); v = t; break; }
+            default: { double t; memcpy(&t, b, 8); v = t; break; }
+        }
+        out[i] = (float)((v - F[k].offset) / F[k].scale);
+    }
+    return nscalars;
+}

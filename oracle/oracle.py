@@ -75,6 +75,8 @@ def lib():
         L.lro_psd.argtypes = [fp, C.c_int, C.c_int, C.c_char_p, C.c_double, C.c_int, fp]
         L.lro_fftshift.argtypes = [fp, C.c_int, C.c_int]
         L.lro_multiply_conjugate.argtypes = [fp, fp, C.c_long, fp]
+        L.lro_format_convert.restype = C.c_long
+        L.lro_format_convert.argtypes = [C.c_char_p, C.c_char_p, C.c_long, fp]
         _lib = L
     return _lib
 
@@ -307,6 +309,20 @@ def multiply_conjugate(a, b):
     y = np.empty(len(a), np.complex64)
     lib().lro_multiply_conjugate(_fp(af), _fp(bf), len(a), _fp(y.view(np.float32)))
     return y
+
+
+FORMAT_BYTES = {"u8": 1, "s8": 1, "u16le": 2, "u16be": 2, "s16le": 2, "s16be": 2, "u32le": 4, "u32be": 4,
+                "s32le": 4, "s32be": 4, "f32le": 4, "f32be": 4, "f64le": 8, "f64be": 8}
+
+
+def format_convert(fmt, raw, complex_out):
+    """IQFileSource / RealFileSource conversion of raw file bytes (iqfile.lua:99-113, realfile.lua:99-110)."""
+    nscalars = len(raw) // FORMAT_BYTES[fmt]
+    out = np.empty(nscalars, np.float32)
+    n = lib().lro_format_convert(fmt.encode(), bytes(raw), nscalars, _fp(out))
+    if n < 0:
+        raise ValueError('Unsupported format ("%s")' % fmt)
+    return out.view(np.complex64) if complex_out else out
 
 
 # ---------------------------------------------------------------- composites (composition of the pinned blocks)

@@ -43,6 +43,8 @@ SPECS = [
     "blocks/signal/singlepolelowpassfilter_spec",
     "blocks/signal/fmdeemphasisfilter_spec",
     "blocks/signal/multiplyconjugate_spec",
+    "blocks/sources/iqfile_spec",
+    "blocks/sources/realfile_spec",
     "composites/decimator_spec",
     "composites/tuner_spec",
     "utilities/filter_utils_vectors",
@@ -95,6 +97,15 @@ class LuaLiteralParser:
                 return False
             if val == "nil":
                 return None
+            if val == "require":
+                # require('tests.buffer').open("\x..") - an in-memory file (tests/buffer.lua); keep the bytes
+                m2 = re.compile(r"\s*\(\s*'tests\.buffer'\s*\)\s*\.open\s*\(").match(self.text, self.pos)
+                if not m2:
+                    raise ValueError("unsupported require at %d" % self.pos)
+                self.pos = m2.end()
+                data = self.value()
+                self.take(")")
+                return data
             m = re.match(r"radio\.types\.(\w+)\.vector_from_array$", val)
             if m:
                 self.take("(")

@@ -218,3 +218,15 @@ def test_simd_baseline_kernel_matches_golden_and_other_modes():
     y1 = np.concatenate([a.process_simd(x[:777], 1), a.process_simd(x[777:], 1)])
     y4 = b.process_simd(x, 4)
     assert G.max_abs_err(y1, ref) < 1e-6 and np.array_equal(y1, y4)
+
+
+def test_file_source_formats():
+    """IQFileSource / RealFileSource conversion (14 formats each) against the reference's vectors"""
+    for name, cplx in (("iqfile_spec", True), ("realfile_spec", False)):
+        doc = G.load(name)
+        assert len(doc["vectors"]) == 14
+        for vec in doc["vectors"]:
+            raw, fmt = vec["args"][0], vec["args"][1]
+            got = O.format_convert(fmt, raw, cplx)
+            want = vec["outputs"][0]
+            assert len(got) == len(want) and G.max_abs_err(got, want) < doc["epsilon"], vec["desc"]
