@@ -90,6 +90,12 @@ lrhip_stage_t *lrhip_dft_create(unsigned n, int inverse, int real_side);
  * are handed over unchanged and converted on the device. */
 lrhip_stage_t *lrhip_format_convert_create(const char *format, int complex_out);
 
+/* Two-input element-wise blocks: op = "multiply" (radio/blocks/signal/multiply.lua:43-76), "multiplyconjugate"
+ * (multiplyconjugate.lua:41-59, complex only), "add" (add.lua), "subtract" (subtract.lua).  Replaces
+ * volk_32fc_x2_multiply_32fc_a / volk_32f_x2_multiply_32f_a / volk_32fc_x2_multiply_conjugate_32fc_a.
+ * Executed with lrhip_stage_execute2*(). */
+lrhip_stage_t *lrhip_binary_create(const char *op, int input_complex);
+
 void lrhip_stage_destroy(lrhip_stage_t *q);
 /* Back to the just-created state (zero history, phase 0, index 0). */
 int lrhip_stage_reset(lrhip_stage_t *q);
@@ -109,6 +115,12 @@ long lrhip_stage_execute(lrhip_stage_t *q, const void *in_host, unsigned long n_
  * known on the host without a device round-trip.  This is what chains and bench.py use. */
 long lrhip_stage_execute_device(lrhip_stage_t *q, const void *in_dev, unsigned long n_in,
                                 void *out_dev, unsigned long out_capacity);
+
+/* Two-input variants for lrhip_binary_create() stages (both inputs n_in samples). */
+long lrhip_stage_execute2(lrhip_stage_t *q, const void *in1_host, const void *in2_host, unsigned long n_in,
+                          void *out_host, unsigned long out_capacity);
+long lrhip_stage_execute2_device(lrhip_stage_t *q, const void *in1_dev, const void *in2_dev, unsigned long n_in,
+                                 void *out_dev, unsigned long out_capacity);
 
 /* ---- chains: several blocks, device-resident edges ------------------------------------------------------ */
 /* A maximal linear run of device-capable blocks collapsed into one object (what CompositeBlock's

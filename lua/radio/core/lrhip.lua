@@ -35,6 +35,7 @@ lrhip_stage_t *lrhip_iir_create(const float *b, unsigned nb, const float *a, uns
 lrhip_stage_t *lrhip_psd_create(unsigned n, const float *window, double scale, int logarithmic, int input_complex, int fftshift);
 lrhip_stage_t *lrhip_dft_create(unsigned n, int inverse, int real_side);
 lrhip_stage_t *lrhip_format_convert_create(const char *format, int complex_out);
+lrhip_stage_t *lrhip_binary_create(const char *op, int input_complex);
 void lrhip_stage_destroy(lrhip_stage_t *q);
 int lrhip_stage_reset(lrhip_stage_t *q);
 int lrhip_stage_input_size(const lrhip_stage_t *q);
@@ -42,6 +43,8 @@ int lrhip_stage_output_size(const lrhip_stage_t *q);
 unsigned long lrhip_stage_max_output(const lrhip_stage_t *q, unsigned long n_in);
 long lrhip_stage_execute(lrhip_stage_t *q, const void *in_host, unsigned long n_in, void *out_host, unsigned long out_capacity);
 long lrhip_stage_execute_device(lrhip_stage_t *q, const void *in_dev, unsigned long n_in, void *out_dev, unsigned long out_capacity);
+long lrhip_stage_execute2(lrhip_stage_t *q, const void *in1_host, const void *in2_host, unsigned long n_in, void *out_host, unsigned long out_capacity);
+long lrhip_stage_execute2_device(lrhip_stage_t *q, const void *in1_dev, const void *in2_dev, unsigned long n_in, void *out_dev, unsigned long out_capacity);
 
 lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages);
 void lrhip_chain_destroy(lrhip_chain_t *c);

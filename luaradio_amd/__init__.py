@@ -8,7 +8,8 @@ from ._lib import LrhipError, init  # noqa: F401
 from .block import Block, Input, Output  # noqa: F401
 from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock, FIRFilterBlock,  # noqa: F401
                      FMDeemphasisFilterBlock, FrequencyDiscriminatorBlock, FrequencyTranslatorBlock,
-                     HighpassFilterBlock, IIRFilterBlock, LowpassFilterBlock, SinglepoleLowpassFilterBlock)
+                     HighpassFilterBlock, IIRFilterBlock, LowpassFilterBlock, SinglepoleLowpassFilterBlock,
+                     MultiplyBlock, MultiplyConjugateBlock, AddBlock, SubtractBlock)
 from .sources import IQFileSource, RealFileSource  # noqa: F401
 from .composites import (Chain, CompositeBlock, DecimatorBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401
                          wbfm_mono_receiver)

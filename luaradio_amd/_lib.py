@@ -35,6 +35,9 @@ SIGNATURES = {
     "lrhip_psd_create": (_vp, [C.c_uint, _fp, C.c_double, C.c_int, C.c_int, C.c_int]),
     "lrhip_dft_create": (_vp, [C.c_uint, C.c_int, C.c_int]),
     "lrhip_format_convert_create": (_vp, [C.c_char_p, C.c_int]),
+    "lrhip_binary_create": (_vp, [C.c_char_p, C.c_int]),
+    "lrhip_stage_execute2": (C.c_long, [_vp, _vp, _vp, _ul, _vp, _ul]),
+    "lrhip_stage_execute2_device": (C.c_long, [_vp, _vp, _vp, _ul, _vp, _ul]),
     "lrhip_stage_destroy": (None, [_vp]),
     "lrhip_stage_reset": (C.c_int, [_vp]),
     "lrhip_stage_input_size": (C.c_int, [_vp]),

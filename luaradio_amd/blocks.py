@@ -188,3 +188,51 @@ class FMDeemphasisFilterBlock(SinglepoleLowpassFilterBlock):
     def instantiate(self, tau):
         assert tau, "Missing argument #1 (tau)"
         SinglepoleLowpassFilterBlock.instantiate(self, 1 / (2 * math.pi * tau))
+
+
+class _BinaryBlock(Block):
+    """Two-input element-wise blocks (MultiplyBlock, MultiplyConjugateBlock, AddBlock, SubtractBlock)."""
+    _op = "multiply"
+    _complex_only = False
+
+    def instantiate(self):
+        self.add_type_signature([Input("in1", types.ComplexFloat32), Input("in2", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+        if not self._complex_only:
+            self.add_type_signature([Input("in1", types.Float32), Input("in2", types.Float32)], [Output("out", types.Float32)])
+
+    def initialize(self):
+        self._set_stage(_lib.load().lrhip_binary_create(self._op.encode(), int(self.get_input_type() is types.ComplexFloat32)),
+                        "Creating lrhip %s object" % self._op)
+
+    def process(self, x, y):
+        import ctypes as C
+        L = _lib.load()
+        x, y = np.ascontiguousarray(x), np.ascontiguousarray(y)
+        dt = self.get_input_type().dtype
+        if x.dtype != dt or y.dtype != dt or len(x) != len(y):
+            raise TypeError("Block %s expects two %s vectors of equal length" % (self.name, self.get_input_type()))
+        out = np.empty(len(x), dtype=dt)
+        n = L.lrhip_stage_execute2(self._stage, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), len(x),
+                                   out.ctypes.data_as(C.c_void_p), len(out))
+        _lib.check(n, "%s:process" % self.name)
+        return out[:n]
+
+
+class MultiplyBlock(_BinaryBlock):
+    """radio/blocks/signal/multiply.lua"""
+    name, _op = "MultiplyBlock", "multiply"
+
+
+class MultiplyConjugateBlock(_BinaryBlock):
+    """radio/blocks/signal/multiplyconjugate.lua"""
+    name, _op, _complex_only = "MultiplyConjugateBlock", "multiplyconjugate", True
+
+
+class AddBlock(_BinaryBlock):
+    """radio/blocks/signal/add.lua"""
+    name, _op = "AddBlock", "add"
+
+
+class SubtractBlock(_BinaryBlock):
+    """radio/blocks/signal/subtract.lua"""
+    name, _op = "SubtractBlock", "subtract"

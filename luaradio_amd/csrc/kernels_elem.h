@@ -138,4 +138,41 @@ __global__ __launch_bounds__(256) void format_convert_kernel(const RAW *__restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Two-input element-wise blocks: MultiplyBlock (radio/blocks/signal/multiply.lua:43-76), MultiplyConjugateBlock
+// (multiplyconjugate.lua:41-59), AddBlock (add.lua), SubtractBlock (subtract.lua).  Complex products follow the
+// Lua arithmetic: each component evaluated in double and rounded once (radio/types/complexfloat32.lua:79-81).
+// Traffic: 3 x sample size per sample.
+// ------------------------------------------------------------------------------------------------
+enum { BIN_MULTIPLY = 0, BIN_MULTIPLY_CONJ = 1, BIN_ADD = 2, BIN_SUBTRACT = 3 };
+
+template <int OP>
+__global__ __launch_bounds__(256) void binary_complex_kernel(const float2 *__restrict__ a, const float2 *__restrict__ b,
+                                                             float2 *__restrict__ y, unsigned long n)
+{
+    unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float2 p = a[i], q = b[i], o;
+        if (OP == BIN_ADD) o = make_float2(p.x + q.x, p.y + q.y);
+        else if (OP == BIN_SUBTRACT) o = make_float2(p.x - q.x, p.y - q.y);
+        else {
+            double ar = p.x, ai = p.y, br = q.x, bi = OP == BIN_MULTIPLY_CONJ ? -(double)q.y : (double)q.y;
+            o = make_float2((float)(ar * br - ai * bi), (float)(ar * bi + ai * br));
+        }
+        y[i] = o;
+    }
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void binary_real_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                          float *__restrict__ y, unsigned long n)
+{
+    unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float p = a[i], q = b[i];
+        y[i] = OP == BIN_ADD ? p + q : OP == BIN_SUBTRACT ? p - q : p * q;
+    }
+}
+
 }  // namespace lrhip

@@ -32,6 +32,7 @@ struct lrhip_stage {
     virtual ~lrhip_stage() {}
     virtual unsigned long max_output(unsigned long n_in) const { return n_in; }
     virtual long run(const void *in_dev, unsigned long n_in, void *out_dev, unsigned long cap) = 0;
+    virtual long run2(const void *, const void *, unsigned long, void *, unsigned long) { return set_error("%s is not a two-input stage", kind()); }
     virtual int reset() = 0;
     virtual const char *kind() const = 0;
 };
@@ -749,6 +750,42 @@ long FormatStage::run(const void *in_dev, unsigned long n, void *out_dev, unsign
 }
 
 // =====================================================================================================
+// MultiplyBlock / MultiplyConjugateBlock / AddBlock / SubtractBlock
+// =====================================================================================================
+struct BinaryStage : lrhip_stage {
+    int op = BIN_MULTIPLY;
+    PinnedBuf h_in2;
+    DeviceBuf d_in2;
+    const char *kind() const override { return "binary"; }
+    int reset() override { return 0; }
+    long run(const void *, unsigned long, void *, unsigned long) override { return set_error("binary stage needs two inputs: use lrhip_stage_execute2"); }
+    long run2(const void *a, const void *b, unsigned long n, void *y, unsigned long cap) override
+    {
+        if (n > cap) return set_error("binary: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+#define LR_BIN(K, OP, T) hipLaunchKernelGGL((K<OP>), dim3(grid), dim3(256), 0, ctx().stream, (const T *)a, (const T *)b, (T *)y, n)
+        if (in_size == 8) {
+            switch (op) {
+                case BIN_MULTIPLY: LR_BIN(binary_complex_kernel, BIN_MULTIPLY, float2); break;
+                case BIN_MULTIPLY_CONJ: LR_BIN(binary_complex_kernel, BIN_MULTIPLY_CONJ, float2); break;
+                case BIN_ADD: LR_BIN(binary_complex_kernel, BIN_ADD, float2); break;
+                default: LR_BIN(binary_complex_kernel, BIN_SUBTRACT, float2); break;
+            }
+        } else {
+            switch (op) {
+                case BIN_MULTIPLY: LR_BIN(binary_real_kernel, BIN_MULTIPLY, float); break;
+                case BIN_ADD: LR_BIN(binary_real_kernel, BIN_ADD, float); break;
+                default: LR_BIN(binary_real_kernel, BIN_SUBTRACT, float); break;
+            }
+        }
+#undef LR_BIN
+        LR_LAUNCH_CHECK();
+        return (long)n;
+    }
+};
+
+// =====================================================================================================
 // chain
 // =====================================================================================================
 struct lrhip_chain {
@@ -963,6 +1000,21 @@ lrhip_stage_t *lrhip_format_convert_create(const char *format, int complex_out)
     return q;
 }
 
+lrhip_stage_t *lrhip_binary_create(const char *op, int input_complex)
+{
+    if (!op) { set_error("binary: missing operation name"); return nullptr; }
+    int code = !strcmp(op, "multiply") ? BIN_MULTIPLY : !strcmp(op, "multiplyconjugate") ? BIN_MULTIPLY_CONJ
+             : !strcmp(op, "add") ? BIN_ADD : !strcmp(op, "subtract") ? BIN_SUBTRACT : -1;
+    if (code < 0) { set_error("binary: unknown operation \"%s\"", op); return nullptr; }
+    if (code == BIN_MULTIPLY_CONJ && !input_complex) { set_error("binary: multiplyconjugate takes ComplexFloat32 inputs (multiplyconjugate.lua:26)"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    BinaryStage *q = new (std::nothrow) BinaryStage();
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->op = code;
+    q->in_size = q->out_size = input_complex ? 8 : 4;
+    return q;
+}
+
 void lrhip_stage_destroy(lrhip_stage_t *q)
 {
     if (!q) return;
@@ -988,6 +1040,31 @@ long lrhip_stage_execute(lrhip_stage_t *q, const void *in_host, unsigned long n_
     return host_execute(q->h_in, q->h_out, q->d_in, q->d_out, q->in_size, q->out_size, q->max_output(n_in), in_host, n_in,
                         out_host, out_capacity,
                         [&](const void *di, unsigned long n, void *dout, unsigned long cap) { return q->run(di, n, dout, cap); });
+}
+
+long lrhip_stage_execute2_device(lrhip_stage_t *q, const void *in1_dev, const void *in2_dev, unsigned long n_in, void *out_dev,
+                                 unsigned long out_capacity)
+{
+    if (!q) return set_error("null stage");
+    if (n_in && (!in1_dev || !in2_dev || !out_dev)) return set_error("null buffer");
+    return q->run2(in1_dev, in2_dev, n_in, out_dev, out_capacity);
+}
+
+long lrhip_stage_execute2(lrhip_stage_t *q, const void *in1_host, const void *in2_host, unsigned long n_in, void *out_host,
+                          unsigned long out_capacity)
+{
+    if (!q) return set_error("null stage");
+    BinaryStage *b = dynamic_cast<BinaryStage *>(q);
+    if (!b) return set_error("%s is not a two-input stage", q->kind());
+    if (n_in && !in2_host) return set_error("null input buffer");
+    size_t bytes = (size_t)n_in * q->in_size;
+    if (b->h_in2.reserve(bytes ? bytes : 16) || b->d_in2.reserve(bytes ? bytes : 16)) return -1;
+    if (bytes) {
+        memcpy(b->h_in2.p, in2_host, bytes);
+        LR_HIP(hipMemcpyAsync(b->d_in2.p, b->h_in2.p, bytes, hipMemcpyHostToDevice, ctx().stream));
+    }
+    return host_execute(q->h_in, q->h_out, q->d_in, q->d_out, q->in_size, q->out_size, n_in, in1_host, n_in, out_host, out_capacity,
+                        [&](const void *di, unsigned long n, void *dout, unsigned long cap) { return q->run2(di, b->d_in2.p, n, dout, cap); });
 }
 
 // ---- chains ---------------------------------------------------------------------------------------------

@@ -43,6 +43,9 @@ SPECS = [
     "blocks/signal/singlepolelowpassfilter_spec",
     "blocks/signal/fmdeemphasisfilter_spec",
     "blocks/signal/multiplyconjugate_spec",
+    "blocks/signal/multiply_spec",
+    "blocks/signal/add_spec",
+    "blocks/signal/subtract_spec",
     "blocks/sources/iqfile_spec",
     "blocks/sources/realfile_spec",
     "composites/decimator_spec",

@@ -519,6 +519,54 @@ def test_file_sources_convert_on_device():
         lr.IQFileSource(raw, "u24le", 1.0)
 
 
+def test_golden_binary_blocks():
+    for name, cls in (("multiply_spec", lr.MultiplyBlock), ("multiplyconjugate_spec", lr.MultiplyConjugateBlock),
+                      ("add_spec", lr.AddBlock), ("subtract_spec", lr.SubtractBlock)):
+        doc = G.load(name)
+        for vec in doc["vectors"]:
+            a, b = vec["inputs"]
+            blk = cls()
+            blk.differentiate([types.type_of(a), types.type_of(b)])
+            blk.initialize()
+            want = vec["outputs"][0]
+            assert G.max_abs_err(blk.process(a, b), want) < doc["epsilon"], vec["desc"]
+            one = np.concatenate([blk.process(a[i:i + 1], b[i:i + 1]) for i in range(len(a))])
+            assert G.max_abs_err(one, want) < doc["epsilon"]
+    a = make(lr.MultiplyConjugateBlock, [], np.zeros(1, np.complex64)) if False else None
+    rng = np.random.default_rng(60)
+    x, y = rand_c(rng, 100001), rand_c(rng, 100001)
+    blk = lr.MultiplyConjugateBlock()
+    blk.differentiate([types.ComplexFloat32, types.ComplexFloat32])
+    blk.initialize()
+    assert np.array_equal(blk.process(x, y), O.multiply_conjugate(x, y))      # same single-rounding arithmetic
+
+
+def test_reference_top_level_chain_on_device():
+    """tests/top_spec.lua:13-54, the reference's own end-to-end graph, against tests/top_vectors.gen.lua (eps 1e-6):
+    IQFileSource(f32le) x2 -> MultiplyConjugate -> Lowpass(16, 100e3) -> FrequencyDiscriminator(5) ->
+    Decimator(25, {num_taps = 16}) at 1 MHz - every block on the device, sources converting on the device."""
+    v = G.load("top_vectors")["values"]
+    want = np.frombuffer(v["SNK_TEST_VECTOR"], np.float32)
+    for chunking in ("whole", "ragged"):
+        s1 = lr.IQFileSource(v["SRC1_TEST_VECTOR"], "f32le", 1000000)
+        s2 = lr.IQFileSource(v["SRC2_TEST_VECTOR"], "f32le", 1000000)
+        s1.initialize()
+        s2.initialize()
+        a, b = s1.read_all(), s2.read_all()
+        mc = lr.MultiplyConjugateBlock()
+        mc.differentiate([types.ComplexFloat32, types.ComplexFloat32])
+        mc.initialize()
+        rest = lr.CompositeBlock()
+        rest.connect(lr.LowpassFilterBlock(16, 100e3), lr.FrequencyDiscriminatorBlock(5.0), lr.DecimatorBlock(25, {"num_taps": 16}))
+        rest.rate = s1.get_rate()
+        rest.differentiate([types.ComplexFloat32])
+        rest.initialize()
+        cuts = [] if chunking == "whole" else [1, 7, 100, 101, 400]
+        got = chunked(rest, mc.process(a, b), cuts)
+        assert len(got) == len(want)
+        assert G.max_abs_err(got, want) < 1e-6, chunking
+
+
 def test_error_paths_report_through_strerror():
     L = lr._lib.load()
     import ctypes as C
