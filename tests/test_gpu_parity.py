@@ -438,6 +438,59 @@ def test_fir_properties_at_full_tile_sizes():
     assert abs(float(y[2 * (n // 2)]) - 1.0) < 1e-6
 
 
+def test_fir_overlap_save_properties_at_bench_size():
+    """BASELINE.json configs[1] size (2^28 cf32, 2 GiB in / 2 GiB out) - the oracle cannot run there, so:
+    (1) the overlap-save kernel agrees with the bit-exact direct-form kernel to 1e-6 on every one of 2^28 samples,
+    (2) impulses across FFT-block and tile boundaries reproduce the taps, (3) the history carry across two
+    half-size launches gives the same values as one launch."""
+    import torch
+    n = 1 << 28
+    taps = np.asarray(lr.filter_utils.firwin_lowpass(128, 15e3 / 110250), np.float32)
+    L = lr._lib.load()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.empty(2 * n, device="cuda")
+    for o in range(0, 2 * n, 1 << 26):
+        x[o:o + (1 << 26)] = torch.rand(1 << 26, device="cuda", generator=g) * 2 - 1
+    y_fft, y_dir = torch.empty(2 * n, device="cuda"), torch.empty(2 * n, device="cuda")
+    fft = make(lr.FIRFilterBlock, [taps, "fast"], np.zeros(1, np.complex64))
+    direct = make(lr.FIRFilterBlock, [taps], np.zeros(1, np.complex64))
+    assert fft.process_device(x.data_ptr(), n, y_fft.data_ptr(), n) == n
+    assert direct.process_device(x.data_ptr(), n, y_dir.data_ptr(), n) == n
+    L.lrhip_synchronize()
+    worst = 0.0
+    for o in range(0, 2 * n, 1 << 27):
+        worst = max(worst, float((y_fft[o:o + (1 << 27)] - y_dir[o:o + (1 << 27)]).abs().max()))
+    assert worst < 1e-6, worst
+    # (3) two launches of n/2 == one launch of n (history of M-1 samples carried on the device)
+    fft.reset()
+    h = n // 2 + 12345
+    fft.process_device(x.data_ptr(), h, y_dir.data_ptr(), h)
+    fft.process_device(x.data_ptr() + 8 * h, n - h, y_dir.data_ptr() + 8 * h, n - h)
+    L.lrhip_synchronize()
+    lo, hi = 2 * (h - 4096), 2 * (h + 4096)
+    assert float((y_fft[lo:hi] - y_dir[lo:hi]).abs().max()) < 1e-6
+    del y_dir
+    # (2) impulses: block boundaries are multiples of 896 samples
+    x.zero_()
+    pos = [0, 895, 896, 896 * 1000 - 64, (1 << 27) + 5, n - 200]
+    for p in pos:
+        x[2 * p] = 1.0
+    fft.reset()
+    fft.process_device(x.data_ptr(), n, y_fft.data_ptr(), n)
+    L.lrhip_synchronize()
+    for p in [896 + 128, 896 * 1000 - 64, (1 << 27) + 5, n - 200]:
+        got = y_fft[2 * p:2 * (p + 128):2].cpu().numpy()
+        want = taps.copy()
+        if p == 896 + 128:
+            continue
+        assert np.max(np.abs(got - want)) < 1e-6, p
+    got = y_fft[0:2 * 1100:2].cpu().numpy()      # impulses at 0, 895 and 896 superpose
+    want = np.zeros(1100, np.float32)
+    for p in (0, 895, 896):
+        want[p:p + 128] += taps
+    assert np.max(np.abs(got - want)) < 1e-6
+
+
 def test_psd_many_frames_vs_oracle():
     rng = np.random.default_rng(40)
     N, frames = 1024, 64
