@@ -123,7 +123,7 @@ struct FirMfmaGeom {
     static constexpr int BPA = 16 / S;            // blocks per accumulator
     static constexpr int GROUP = 4 * D;           // MFMA steps per LDS row of t
     __host__ __device__ static constexpr int tile_out(int nacc) { return 4 * nacc * BPA * 16; }
-    // samples staged per tile for `ksteps` MFMA steps (ksteps a multiple of GROUP)
+    // samples staged per tile for `ksteps` MFMA steps
     __host__ __device__ static constexpr int span(int nacc, int ksteps) { return 16 * D * (4 * nacc * BPA - 1) + 4 * ksteps; }
     __host__ __device__ static constexpr int phys(int a) { return a + PAD * (a / ROW); }
 };
@@ -176,11 +176,17 @@ __device__ __forceinline__ void stage_edge(float *ldsX, const float *__restrict_
     }
 }
 
+// Zero-padded reversed taps in LDS: [ZL zeros | taps_rev[0..M) | zeros], ZL = 3 + 15*D, length fir_taps_len().
+// The Toeplitz entry A[m][t] = taps_rev[t - e - m*D] is then a plain read at (ZL + t - e - m*D): no table.
+__host__ __device__ constexpr int fir_taps_zl(int D) { return 3 + 15 * D; }
+__host__ __device__ constexpr int fir_taps_len(int D, int ksteps) { return ((fir_taps_zl(D) + 4 * ksteps + 3) / 4) * 4; }
+
 // the MFMA main loop over one staged tile; KS > 0 => fully unrolled.
-// NOUT = 2: two Toeplitz tables (ldsA, ldsA + ksteps*64) applied to the same B fragments -> two accumulator sets
-// (the re and im outputs of a complex-taps filter over the interleaved float stream).
+// A fragment of step s: lane (m = lane&15, kq = lane>>4) reads taps_pad[ZL + 4s + kq - e - m*D] (a broadcast-friendly
+// LDS read; equal addresses across lanes are free).  NOUT = 2: two tap arrays (ldsT, ldsT + tlen) applied to the same B
+// fragments -> two accumulator sets (the re and im outputs of a complex-taps filter over the interleaved float stream).
 template <int S, int D, int NACC, int KS, int NOUT>
-__device__ __forceinline__ void mfma_tile(const float *ldsA, const float *ldsX, int ksteps, f32x4 (&acc)[NOUT][NACC])
+__device__ __forceinline__ void mfma_tile(const float *ldsT, int tlen, int e, const float *ldsX, int ksteps, f32x4 (&acc)[NOUT][NACC])
 {
     using G = FirMfmaGeom<S, D>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -189,26 +195,20 @@ __device__ __forceinline__ void mfma_tile(const float *ldsA, const float *ldsX, 
     const int comp = S == 2 ? (col & 1) : 0;
     constexpr int ACC_STRIDE = (G::ROW + G::PAD) * G::BPA;    // floats between consecutive accumulators' blocks
     const float *bptr = ldsX + (G::ROW + G::PAD) * ((wave * NACC) * G::BPA + blk_in_acc) + S * kq + comp;
-    const float *aptr = ldsA + lane;
-    const int astride = ksteps * 64;
+    const float *aptr = ldsT + fir_taps_zl(D) + kq - e - col * D;      // row m of the Toeplitz block = lane & 15
 #pragma unroll
     for (int o = 0; o < NOUT; o++)
 #pragma unroll
         for (int a = 0; a < NACC; a++) acc[o][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto group = [&](int g) {
-        const float *ap = aptr + g * (G::GROUP * 64);
-        const float *bp = bptr + g * (G::ROW + G::PAD);
+    auto step = [&](const float *ap, const float *bp, int j) {
+        float av[NOUT];
 #pragma unroll
-        for (int j = 0; j < G::GROUP; j++) {
-            float av[NOUT];
+        for (int o = 0; o < NOUT; o++) av[o] = ap[o * tlen + 4 * j];
 #pragma unroll
-            for (int o = 0; o < NOUT; o++) av[o] = ap[o * astride + j * 64];
+        for (int a = 0; a < NACC; a++) {
+            float bv = bp[a * ACC_STRIDE + j * 4 * S];
 #pragma unroll
-            for (int a = 0; a < NACC; a++) {
-                float bv = bp[a * ACC_STRIDE + j * 4 * S];
-#pragma unroll
-                for (int o = 0; o < NOUT; o++) acc[o][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[o], bv, acc[o][a], 0, 0, 0);
-            }
+            for (int o = 0; o < NOUT; o++) acc[o][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[o], bv, acc[o][a], 0, 0, 0);
         }
     };
     if constexpr (KS > 0) {
@@ -216,13 +216,22 @@ __device__ __forceinline__ void mfma_tile(const float *ldsA, const float *ldsX, 
         __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
-        for (int g = 0; g < KS / G::GROUP; g++) group(g);
+        for (int g = 0; g < (KS + G::GROUP - 1) / G::GROUP; g++)
+#pragma unroll
+            for (int j = 0; j < G::GROUP; j++)
+                if (g * G::GROUP + j < KS) step(aptr + 4 * g * G::GROUP, bptr + g * (G::ROW + G::PAD), j);
 #if LRHIP_FIR_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
     } else {
         const int ngroups = ksteps / G::GROUP;
-        for (int g = 0; g < ngroups; g++) group(g);
+        for (int g = 0; g < ngroups; g++) {
+#pragma unroll
+            for (int j = 0; j < G::GROUP; j++) step(aptr, bptr, j);
+            aptr += 4 * G::GROUP;
+            bptr += G::ROW + G::PAD;
+        }
+        for (int j = 0; j < ksteps - ngroups * G::GROUP; j++) step(aptr, bptr, j);
     }
 }
 
@@ -285,23 +294,23 @@ __device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, 
 // NOUT = 2 (S = 1 geometry over the interleaved float stream, two Toeplitz tables): complex taps.
 template <int S, int D, int NACC, bool ROT, int NOUT>
 __global__ __launch_bounds__(256) void fir_mfma_kernel(
-    const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ atab, float *__restrict__ y,
+    const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_pad, float *__restrict__ y,
     int M, long n, long n_out, long first, int e, int ksteps, int out_aligned,
     uint64_t rot_step_fx, uint64_t rot_count0)
 {
     using G = FirMfmaGeom<S, D>;
     constexpr int TILE_OUT = G::tile_out(NACC);
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *ldsA = lds;                       // NOUT * ksteps * 64 floats
-    float *ldsX = lds + NOUT * ksteps * 64;  // staged samples (padded rows)
+    const int tlen = fir_taps_len(D, ksteps);
+    float *ldsT = lds;                       // NOUT zero-padded tap arrays
+    float *ldsX = lds + NOUT * tlen;         // staged samples (padded rows)
     const int tid = threadIdx.x;
     const long tile_k0 = (long)blockIdx.x * TILE_OUT;
     const long base = first + tile_k0 * D - e;               // stream position of r = 0
     const int span = G::span(NACC, ksteps);                   // samples to stage
     const int nf4 = span * S / 4;
 
-    const float4 *a4 = reinterpret_cast<const float4 *>(atab);
-    for (int i = tid; i < NOUT * ksteps * 16; i += 256) *reinterpret_cast<float4 *>(ldsA + 4 * i) = a4[i];
+    for (int i = tid; i < NOUT * tlen; i += 256) ldsT[i] = taps_pad[i];
 
     const long xlo = base - (M - 1);                          // x index of r = 0
     const bool interior = (xlo >= 0) && (xlo + span <= n);
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
     }
     __syncthreads();
     f32x4 acc[NOUT][NACC];
-    mfma_tile<S, D, NACC, 0, NOUT>(ldsA, ldsX, ksteps, acc);
+    mfma_tile<S, D, NACC, 0, NOUT>(ldsT, tlen, e, ldsX, ksteps, acc);
     store_tile<S, D, NACC, NOUT>(y, tile_k0, n_out, out_aligned, acc);
 }
 
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
 // after the loop.  Edge tiles (first tile: history; last tiles: end of chunk) are staged synchronously.
 template <int S, int D, int NACC, bool ROT, int KS>
 __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persistent_kernel(
-    const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ atab, float *__restrict__ y,
+    const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_pad, float *__restrict__ y,
     int M, long n, long n_out, long first, int e, long ntiles, int out_aligned,
     uint64_t rot_step_fx, uint64_t rot_count0)
 {
@@ -347,14 +356,12 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
     constexpr int NF4 = SPAN * S / 4;
     constexpr int UX = (NF4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *ldsA = lds;
-    float *ldsX = lds + KS * 64;
+    constexpr int TLEN = fir_taps_len(D, KS);
+    float *ldsT = lds;
+    float *ldsX = lds + TLEN;
     const int tid = threadIdx.x;
 
-    {
-        const float4 *a4 = reinterpret_cast<const float4 *>(atab);
-        for (int i = tid; i < KS * 16; i += 256) *reinterpret_cast<float4 *>(ldsA + 4 * i) = a4[i];
-    }
+    for (int i = tid; i < TLEN; i += 256) ldsT[i] = taps_pad[i];
 
     auto xlo_of = [&](long t) { return first + t * (long)TILE_OUT * D - e - (M - 1); };
     auto interior = [&](long t) { long lo = xlo_of(t); return t < ntiles && lo >= 0 && lo + SPAN <= n; };
@@ -396,34 +403,23 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
             }
         }
         f32x4 acc[1][NACC];
-        mfma_tile<S, D, NACC, KS, 1>(ldsA, ldsX, KS, acc);
+        mfma_tile<S, D, NACC, KS, 1>(ldsT, TLEN, e, ldsX, KS, acc);
         store_tile<S, D, NACC, 1>(y, tile_k0, n_out, out_aligned, acc);
         __syncthreads();      // everyone is done reading ldsX before it is overwritten
     }
 }
 
-// Host: build the Toeplitz A-fragment tables, one per alignment slack e in [0, 4/S):
-//   tab[e][step][lane] = A[m = lane&15][t = 4*step + (lane>>4)] = taps_rev[t - e - m*D]  (0 outside [0, M))
-// ksteps = (emax + 15*D + M) rounded up to a multiple of 4*D steps (zero rows; fma(0,b,acc) == acc).
+// Host: number of MFMA steps, K = emax + 15*D + M rounded up to a multiple of 4 (the zero padding of the tap array
+// supplies the zero rows; fma(0, b, acc) == acc), and the zero-padded reversed taps the kernels read.
 inline int fir_mfma_ksteps(int M, int D, int S, int emax_override = -1)
 {
     int emax = emax_override >= 0 ? emax_override : 4 / S - 1;
-    int K = emax + 15 * D + M;
-    int ks = (K + 3) / 4;
-    int group = 4 * D;
-    return (ks + group - 1) / group * group;
+    return (emax + 15 * D + M + 3) / 4;
 }
-inline void fir_mfma_build_tables(const float *taps_rev, int M, int D, int S, int ksteps, std::vector<float> &out)
+inline void fir_mfma_build_taps(const float *taps_rev, int M, int D, int ksteps, std::vector<float> &out)
 {
-    int ne = 4 / S;
-    out.assign((size_t)ne * ksteps * 64, 0.f);
-    for (int e = 0; e < ne; e++)
-        for (int st = 0; st < ksteps; st++)
-            for (int lane = 0; lane < 64; lane++) {
-                int m = lane & 15, t = 4 * st + (lane >> 4);
-                int j = t - e - m * D;
-                if (j >= 0 && j < M) out[((size_t)e * ksteps + st) * 64 + lane] = taps_rev[j];
-            }
+    out.assign((size_t)fir_taps_len(D, ksteps), 0.f);
+    for (int j = 0; j < M; j++) out[(size_t)fir_taps_zl(D) + j] = taps_rev[j];
 }
 
 }  // namespace lrhip

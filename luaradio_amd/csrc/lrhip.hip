@@ -95,10 +95,10 @@ struct FirStage : lrhip_stage {
         // M = 128 at D = 1 (36 MFMA steps, the headline) and M = 128 at D = 5 (60 steps, the WBFM tuner)
         if constexpr (DD == 1) {
             if (ksteps == 36) return launch_mfma_ks<SS, DD, NACC, 36>(x, n, y, n_out);     // M = 128, cf32
-            if (ksteps == 40) return launch_mfma_ks<SS, DD, NACC, 40>(x, n, y, n_out);     // M = 128, f32 (slack up to 3 samples)
+            if (ksteps == 37) return launch_mfma_ks<SS, DD, NACC, 37>(x, n, y, n_out);     // M = 128, f32 (slack up to 3 samples)
         }
         if constexpr (DD == 5) {
-            if (ksteps == 60) return launch_mfma_ks<SS, DD, NACC, 60>(x, n, y, n_out);
+            if (ksteps == 51) return launch_mfma_ks<SS, DD, NACC, 51>(x, n, y, n_out);     // M = 128 at D = 5 (Tuner / Decimator(5))
         }
         return launch_mfma_ks<SS, DD, NACC, 0>(x, n, y, n_out);
     }
@@ -130,10 +130,10 @@ struct FirStage : lrhip_stage {
         long v = sample_addr + (long)index - (M - 1);
         int e = (int)(((v % q) + q) % q);
         int span = G::span(NACC, ksteps);
-        size_t lds_floats = (size_t)ksteps * 64 + (size_t)G::phys(SS * span) + G::PAD + 8;
+        size_t lds_floats = (size_t)fir_taps_len(DD, ksteps) + (size_t)G::phys(SS * span) + G::PAD + 8;
         size_t lds_bytes = lds_floats * sizeof(float);
         long ntiles = (n_out + TILE_OUT - 1) / TILE_OUT;
-        const float *atab = (const float *)d_atab.p + (size_t)e * ksteps * 64;
+        const float *atab = (const float *)d_atab.p;          // zero-padded reversed taps
         const float *h = (const float *)hist[cur].p + hist_pad;
         int out_aligned = ((uintptr_t)y % 16) == 0;
         uint64_t rs = rot ? rot_step : 0, rc = rot ? count : 0;
@@ -181,9 +181,9 @@ struct FirStage : lrhip_stage {
         long v = (long)((uintptr_t)x / 4) + first2 - (M2 - 1);
         int e = (int)(((v % 4) + 4) % 4);
         int span = G::span(NACC, ksteps);
-        size_t lds_bytes = ((size_t)2 * ksteps * 64 + (size_t)G::phys(span) + G::PAD + 8) * sizeof(float);
+        size_t lds_bytes = ((size_t)2 * fir_taps_len(DD2, ksteps) + (size_t)G::phys(span) + G::PAD + 8) * sizeof(float);
         long ntiles = (n_out + TILE_OUT - 1) / TILE_OUT;
-        const float *atab = (const float *)d_atab.p + (size_t)e * 2 * ksteps * 64;
+        const float *atab = (const float *)d_atab.p;          // [re taps | im taps], each zero-padded
         const float *h = (const float *)hist[cur].p;          // includes the pad float
         int out_aligned = ((uintptr_t)y % 16) == 0;
         auto kern = fir_mfma_kernel<1, DD2, NACC, false, 2>;
@@ -337,9 +337,9 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
     if (upload(q->d_taps, q->taps_rev.data(), q->taps_rev.size() * sizeof(float))) return nullptr;
     if (!taps_complex && FirStage::mfma_supported_decim(decim)) {
         int ks = fir_mfma_ksteps(q->M, (int)decim, q->S);
-        if ((size_t)ks * 64 * sizeof(float) <= 40 * 1024) {   // A-table must leave LDS room for the tile
+        if ((size_t)fir_taps_len((int)decim, ks) * sizeof(float) <= 16 * 1024) {   // tap array must leave LDS room for the tile
             std::vector<float> tab;
-            fir_mfma_build_tables(q->taps_rev.data(), q->M, (int)decim, q->S, ks, tab);
+            fir_mfma_build_taps(q->taps_rev.data(), q->M, (int)decim, ks, tab);
             if (upload(q->d_atab, tab.data(), tab.size() * sizeof(float))) return nullptr;
             q->ksteps = ks;
         }
@@ -348,22 +348,18 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
         // taps'_re = interleave(hr_rev, -hi_rev), taps'_im = interleave(hi_rev, hr_rev) over the float stream
         int M2 = 2 * q->M, D2 = 2 * (int)decim;
         int ks = fir_mfma_ksteps(M2, D2, 1, 2);          // 8-B aligned complex input => float slack e in {0, 2}
-        if ((size_t)2 * ks * 64 * sizeof(float) <= 80 * 1024) {
-            std::vector<float> tre((size_t)M2), tim((size_t)M2), tab, one;
+        if ((size_t)2 * fir_taps_len(D2, ks) * sizeof(float) <= 32 * 1024) {
+            std::vector<float> tre((size_t)M2), tim((size_t)M2), tab;
             for (int j = 0; j < q->M; j++) {
                 float hr = q->taps_rev[2 * j], hi = q->taps_rev[2 * j + 1];
                 tre[2 * j] = hr; tre[2 * j + 1] = -hi;
                 tim[2 * j] = hi; tim[2 * j + 1] = hr;
             }
             std::vector<float> are, aim;
-            fir_mfma_build_tables(tre.data(), M2, D2, 1, ks, are);     // [e = 0..3][ks][64]
-            fir_mfma_build_tables(tim.data(), M2, D2, 1, ks, aim);
-            tab.resize(are.size() + aim.size());
-            size_t per = (size_t)ks * 64;
-            for (int e = 0; e < 4; e++) {
-                std::copy(are.begin() + e * per, are.begin() + (e + 1) * per, tab.begin() + (size_t)e * 2 * per);
-                std::copy(aim.begin() + e * per, aim.begin() + (e + 1) * per, tab.begin() + (size_t)e * 2 * per + per);
-            }
+            fir_mfma_build_taps(tre.data(), M2, D2, ks, are);
+            fir_mfma_build_taps(tim.data(), M2, D2, ks, aim);
+            tab = are;
+            tab.insert(tab.end(), aim.begin(), aim.end());
             if (upload(q->d_atab, tab.data(), tab.size() * sizeof(float))) return nullptr;
             q->ksteps = ks;
             q->hist_pad = 1;
