@@ -134,6 +134,21 @@ long lrhip_chain_execute(lrhip_chain_t *c, const void *in_host, unsigned long n_
                          void *out_host, unsigned long out_capacity);
 long lrhip_chain_execute_device(lrhip_chain_t *c, const void *in_dev, unsigned long n_in,
                                 void *out_dev, unsigned long out_capacity);
+/* Pipelined host path: the chain owns a RING of `depth` slots, each a pinned host input/output buffer plus device
+ * input/output buffers sized for `max_chunk` input samples.  submit() copies the caller's vector into the next
+ * pinned slot and enqueues H2D (copy-in stream) -> the chain's kernels (compute stream) -> D2H (copy-out stream),
+ * chained by events, and returns at once; collect() waits for the OLDEST submitted chunk and hands back its output.
+ * With depth >= 2 the PCIe transfers of neighbouring chunks overlap the kernels, and the block's process() can return
+ * chunk k-depth+1 while chunk k is in flight (the reference's own FFT FIR also delays its output, firfilter.lua:361-398).
+ * Block state is advanced at submit time, so results are identical to lrhip_chain_execute() chunk for chunk.
+ * submit() returns the number of output samples the chunk WILL produce (>= 0) or < 0; collect() returns the number of
+ * samples written, or < 0 (-2: nothing in flight).  This is what radio/core/pipe.lua's read/write loop
+ * (pipe.lua:495-533, :252-262) becomes for a device chain. */
+int  lrhip_chain_set_ring(lrhip_chain_t *c, unsigned depth, unsigned long max_chunk);
+long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_in);
+long lrhip_chain_collect(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
+/* Chunks submitted and not yet collected. */
+int  lrhip_chain_in_flight(const lrhip_chain_t *c);
 /* Number of kernels launched by the last chain execute (diagnostic for the fusion tests). */
 int lrhip_chain_last_launches(const lrhip_chain_t *c);
 

@@ -52,6 +52,10 @@ unsigned long lrhip_chain_max_output(const lrhip_chain_t *c, unsigned long n_in)
 long lrhip_chain_execute(lrhip_chain_t *c, const void *in_host, unsigned long n_in, void *out_host, unsigned long out_capacity);
 long lrhip_chain_execute_device(lrhip_chain_t *c, const void *in_dev, unsigned long n_in, void *out_dev, unsigned long out_capacity);
 int lrhip_chain_last_launches(const lrhip_chain_t *c);
+int lrhip_chain_set_ring(lrhip_chain_t *c, unsigned depth, unsigned long max_chunk);
+long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_in);
+long lrhip_chain_collect(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
+int lrhip_chain_in_flight(const lrhip_chain_t *c);
 
 void *lrhip_malloc(unsigned long bytes);
 void lrhip_free(void *dev_ptr);

@@ -57,6 +57,35 @@ class Chain:
     def last_launches(self):
         return _lib.load().lrhip_chain_last_launches(self._chain)
 
+    # ---- pipelined host path (ring of pinned + device slots; H2D / kernels / D2H of neighbouring chunks overlap)
+    def set_ring(self, depth, max_chunk):
+        _lib.check(_lib.load().lrhip_chain_set_ring(self._chain, depth, max_chunk), "chain:set_ring")
+        self._ring_out = np.empty(max_chunk + 64, dtype=self.out_type.dtype)
+
+    def submit(self, x):
+        x = np.ascontiguousarray(x)
+        if x.dtype != self.in_type.dtype:
+            raise TypeError("chain expects %s input, got %s" % (self.in_type, x.dtype))
+        return _lib.check(_lib.load().lrhip_chain_submit(self._chain, x.ctypes.data_as(C.c_void_p), len(x)), "chain:submit")
+
+    def collect(self):
+        n = _lib.load().lrhip_chain_collect(self._chain, self._ring_out.ctypes.data_as(C.c_void_p), len(self._ring_out))
+        _lib.check(n, "chain:collect")
+        return self._ring_out[:n].copy()
+
+    @property
+    def in_flight(self):
+        return _lib.load().lrhip_chain_in_flight(self._chain)
+
+    def stream(self, chunks, depth=3):
+        """Run an iterable of input vectors through the ring, yielding the outputs in order."""
+        for x in chunks:
+            if self.in_flight == depth:
+                yield self.collect()
+            self.submit(x)
+        while self.in_flight:
+            yield self.collect()
+
 
 class CompositeBlock(Block):
     """Linear composite: connect(b1, b2, ...) then differentiate / initialize / process like a block.

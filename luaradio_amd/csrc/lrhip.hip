@@ -794,8 +794,27 @@ struct lrhip_chain {
     PinnedBuf h_in, h_out;
     DeviceBuf d_in, d_out;
     int last_launches = 0;
+    // ---- pipelined ring (lrhip_chain_set_ring)
+    struct Slot {
+        PinnedBuf h_in, h_out;
+        DeviceBuf d_in, d_out;
+        hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;   // H2D done, kernels done, D2H done
+        bool used = false;          // events have been recorded at least once
+        long n_out = 0;
+    };
+    std::vector<std::unique_ptr<Slot>> ring;
+    unsigned long ring_chunk = 0;
+    unsigned head = 0, inflight = 0;       // next slot to submit into; chunks submitted and not collected
+    hipStream_t s_in = nullptr, s_out = nullptr;
     ~lrhip_chain()
     {
+        for (auto &sl : ring) {
+            if (sl->ev_in) (void)hipEventDestroy(sl->ev_in);
+            if (sl->ev_done) (void)hipEventDestroy(sl->ev_done);
+            if (sl->ev_out) (void)hipEventDestroy(sl->ev_out);
+        }
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_out) (void)hipStreamDestroy(s_out);
         for (auto &o : ops)
             if (o.owned) delete o.stage;
     }
@@ -1167,6 +1186,89 @@ long lrhip_chain_execute(lrhip_chain_t *c, const void *in_host, unsigned long n_
 }
 
 int lrhip_chain_last_launches(const lrhip_chain_t *c) { return c ? c->last_launches : set_error("null chain"); }
+
+int lrhip_chain_in_flight(const lrhip_chain_t *c) { return c ? (int)c->inflight : set_error("null chain"); }
+
+int lrhip_chain_set_ring(lrhip_chain_t *c, unsigned depth, unsigned long max_chunk)
+{
+    if (!c) return set_error("null chain");
+    if (depth < 1 || depth > 16) return set_error("ring depth must be 1..16");
+    if (max_chunk < 1) return set_error("ring: max_chunk must be >= 1");
+    if (c->inflight) return set_error("ring: %u chunks still in flight", c->inflight);
+    if (ensure_init()) return -1;
+    if (!c->s_in) LR_HIP(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+    if (!c->s_out) LR_HIP(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+    LR_HIP(hipStreamSynchronize(ctx().stream));
+    c->ring.clear();
+    int in_size = c->ops.front().stage->in_size, out_size = c->ops.back().stage->out_size;
+    // bound on the output of one chunk whatever the carried state (rate-changing stages may emit one extra sample)
+    unsigned long max_out = max_chunk + 64;
+    for (unsigned i = 0; i < depth; i++) {
+        std::unique_ptr<lrhip_chain::Slot> sl(new (std::nothrow) lrhip_chain::Slot());
+        if (!sl) return set_error("out of memory");
+        if (sl->h_in.reserve((size_t)max_chunk * in_size) || sl->d_in.reserve((size_t)max_chunk * in_size)) return -1;
+        if (sl->h_out.reserve((size_t)max_out * out_size) || sl->d_out.reserve((size_t)max_out * out_size)) return -1;
+        LR_HIP(hipEventCreateWithFlags(&sl->ev_in, hipEventDisableTiming));
+        LR_HIP(hipEventCreateWithFlags(&sl->ev_done, hipEventDisableTiming));
+        LR_HIP(hipEventCreateWithFlags(&sl->ev_out, hipEventDisableTiming));
+        c->ring.push_back(std::move(sl));
+    }
+    // size the device-resident edges once, so no reallocation happens while chunks are in flight
+    unsigned long nmax = max_chunk;
+    for (size_t k = 0; k + 1 < c->ops.size(); k++) {
+        nmax = nmax + 64;
+        if (c->edges[k]->reserve((size_t)nmax * c->ops[k].stage->out_size + 16)) return -1;
+    }
+    c->ring_chunk = max_chunk;
+    c->head = 0;
+    c->inflight = 0;
+    return 0;
+}
+
+long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_in)
+{
+    if (!c) return set_error("null chain");
+    if (c->ring.empty()) return set_error("chain has no ring: call lrhip_chain_set_ring first");
+    if (n_in > c->ring_chunk) return set_error("chunk of %lu samples exceeds the ring's max_chunk %lu", n_in, c->ring_chunk);
+    if (n_in && !in_host) return set_error("null input buffer");
+    if (c->inflight == c->ring.size()) return set_error("ring full: collect a chunk first (%u in flight)", c->inflight);
+    lrhip_chain::Slot &sl = *c->ring[c->head];
+    int in_size = c->ops.front().stage->in_size, out_size = c->ops.back().stage->out_size;
+    size_t bytes = (size_t)n_in * in_size;
+    // the slot was collected (ev_out waited) before it can be reused, so its buffers are free on host and device
+    if (bytes) {
+        memcpy(sl.h_in.p, in_host, bytes);
+        LR_HIP(hipMemcpyAsync(sl.d_in.p, sl.h_in.p, bytes, hipMemcpyHostToDevice, c->s_in));
+    }
+    LR_HIP(hipEventRecord(sl.ev_in, c->s_in));
+    LR_HIP(hipStreamWaitEvent(ctx().stream, sl.ev_in, 0));
+    unsigned long cap = (unsigned long)(sl.d_out.cap / out_size);
+    long n_out = lrhip_chain_execute_device(c, sl.d_in.p, n_in, sl.d_out.p, cap);
+    if (n_out < 0) return n_out;
+    LR_HIP(hipEventRecord(sl.ev_done, ctx().stream));
+    LR_HIP(hipStreamWaitEvent(c->s_out, sl.ev_done, 0));
+    if (n_out) LR_HIP(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, (size_t)n_out * out_size, hipMemcpyDeviceToHost, c->s_out));
+    LR_HIP(hipEventRecord(sl.ev_out, c->s_out));
+    sl.n_out = n_out;
+    sl.used = true;
+    c->head = (c->head + 1) % c->ring.size();
+    c->inflight++;
+    return n_out;
+}
+
+long lrhip_chain_collect(lrhip_chain_t *c, void *out_host, unsigned long out_capacity)
+{
+    if (!c) return set_error("null chain");
+    if (!c->inflight) { set_error("nothing in flight"); return -2; }
+    unsigned tail = (c->head + (unsigned)c->ring.size() - c->inflight) % c->ring.size();
+    lrhip_chain::Slot &sl = *c->ring[tail];
+    if ((unsigned long)sl.n_out > out_capacity) return set_error("output capacity %lu < %ld", out_capacity, sl.n_out);
+    if (sl.n_out && !out_host) return set_error("null output buffer");
+    LR_HIP(hipEventSynchronize(sl.ev_out));
+    if (sl.n_out) memcpy(out_host, sl.h_out.p, (size_t)sl.n_out * c->ops.back().stage->out_size);
+    c->inflight--;
+    return sl.n_out;
+}
 
 // ---- memory helpers ----------------------------------------------------------------------------------------
 void *lrhip_malloc(unsigned long bytes)

@@ -620,6 +620,41 @@ def test_reference_top_level_chain_on_device():
         assert G.max_abs_err(got, want) < 1e-6, chunking
 
 
+def test_chain_ring_pipelined_equals_synchronous():
+    """submit()/collect() through the pinned ring gives, chunk for chunk, what lrhip_chain_execute() gives"""
+    rng = np.random.default_rng(70)
+    fs = 1102500.0
+    x = rand_c(rng, 710000)
+    sizes = [8192, 1, 131072, 4096, 0, 65536, 100000, 8192, 131072, 50000, 131072, 70913]
+    assert sum(sizes) <= len(x)
+    chunks, a = [], 0
+    for sz in sizes:
+        chunks.append(x[a:a + sz])
+        a += sz
+    ref = lr.wbfm_mono_receiver(fs, -250e3)
+    want = [ref.process(c) for c in chunks]
+    for depth in (1, 2, 4):
+        rx = lr.wbfm_mono_receiver(fs, -250e3)
+        rx.chain.set_ring(depth, 131072)
+        got = list(rx.chain.stream(chunks, depth=depth))
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+        assert rx.chain.in_flight == 0
+    # error paths: oversize chunk, collect with nothing in flight, ring full
+    L = lr._lib.load()
+    import ctypes as C
+    rx = lr.wbfm_mono_receiver(fs, -250e3)
+    rx.chain.set_ring(2, 1000)
+    with pytest.raises(lr.LrhipError):
+        rx.chain.submit(x[:1001])
+    assert L.lrhip_chain_collect(rx.chain._chain, None, 0) == -2
+    rx.chain.submit(x[:1000]); rx.chain.submit(x[:1000])
+    with pytest.raises(lr.LrhipError):
+        rx.chain.submit(x[:10])
+    rx.chain.collect(); rx.chain.collect()
+
+
 def test_error_paths_report_through_strerror():
     L = lr._lib.load()
     import ctypes as C
