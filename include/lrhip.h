@@ -96,6 +96,12 @@ lrhip_stage_t *lrhip_format_convert_create(const char *format, int complex_out);
  * Executed with lrhip_stage_execute2*(). */
 lrhip_stage_t *lrhip_binary_create(const char *op, int input_complex);
 
+/* MultiplyConstantBlock (radio/blocks/signal/multiplyconstant.lua:28-71): real constant (constant_complex = 0, `im`
+ * ignored) on Float32 or ComplexFloat32 input, or a complex constant on ComplexFloat32 input only (:42-44). */
+lrhip_stage_t *lrhip_multiply_constant_create(float re, float im, int constant_complex, int input_complex);
+/* UpsamplerBlock (radio/blocks/signal/upsampler.lua:26-53): zero-stuffing by `factor`. elem_size = 8 or 4. */
+lrhip_stage_t *lrhip_upsampler_create(unsigned factor, int elem_size);
+
 void lrhip_stage_destroy(lrhip_stage_t *q);
 /* Back to the just-created state (zero history, phase 0, index 0). */
 int lrhip_stage_reset(lrhip_stage_t *q);

@@ -9,9 +9,10 @@ from .block import Block, Input, Output  # noqa: F401
 from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock, FIRFilterBlock,  # noqa: F401
                      FMDeemphasisFilterBlock, FrequencyDiscriminatorBlock, FrequencyTranslatorBlock,
                      HighpassFilterBlock, IIRFilterBlock, LowpassFilterBlock, SinglepoleLowpassFilterBlock,
-                     MultiplyBlock, MultiplyConjugateBlock, AddBlock, SubtractBlock)
+                     MultiplyBlock, MultiplyConjugateBlock, AddBlock, SubtractBlock, ComplexBandpassFilterBlock,
+                     ComplexBandstopFilterBlock, RootRaisedCosineFilterBlock, MultiplyConstantBlock, UpsamplerBlock)
 from .sources import IQFileSource, RealFileSource  # noqa: F401
-from .composites import (Chain, CompositeBlock, DecimatorBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401
+from .composites import (Chain, CompositeBlock, DecimatorBlock, InterpolatorBlock, RationalResamplerBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401
                          wbfm_mono_receiver)
 
 version = "0.1.0"

@@ -36,6 +36,8 @@ SIGNATURES = {
     "lrhip_dft_create": (_vp, [C.c_uint, C.c_int, C.c_int]),
     "lrhip_format_convert_create": (_vp, [C.c_char_p, C.c_int]),
     "lrhip_binary_create": (_vp, [C.c_char_p, C.c_int]),
+    "lrhip_multiply_constant_create": (_vp, [C.c_float, C.c_float, C.c_int, C.c_int]),
+    "lrhip_upsampler_create": (_vp, [C.c_uint, C.c_int]),
     "lrhip_stage_execute2": (C.c_long, [_vp, _vp, _vp, _ul, _vp, _ul]),
     "lrhip_stage_execute2_device": (C.c_long, [_vp, _vp, _vp, _ul, _vp, _ul]),
     "lrhip_stage_destroy": (None, [_vp]),

@@ -236,3 +236,90 @@ class AddBlock(_BinaryBlock):
 class SubtractBlock(_BinaryBlock):
     """radio/blocks/signal/subtract.lua"""
     name, _op = "SubtractBlock", "subtract"
+
+
+class ComplexBandpassFilterBlock(FIRFilterBlock):
+    """radio/blocks/signal/complexbandpassfilter.lua. ComplexBandpassFilterBlock(num_taps, cutoffs[, nyquist[, window]])."""
+    name = "ComplexBandpassFilterBlock"
+    _design = staticmethod(filter_utils.firwin_complex_bandpass)
+
+    def instantiate(self, num_taps, cutoffs, nyquist=None, window=None):
+        assert num_taps, "Missing argument #1 (num_taps)"
+        assert cutoffs is not None, "Missing argument #2 (cutoffs)"
+        self.cutoffs, self.window, self.nyquist = cutoffs, window or "hamming", nyquist
+        FIRFilterBlock.instantiate(self, types.ComplexFloat32.vector(num_taps))
+
+    def initialize(self):
+        nyquist = self.nyquist or (self.get_rate() / 2)
+        taps = self._design(len(self.taps), [self.cutoffs[0] / nyquist, self.cutoffs[1] / nyquist], self.window)
+        self.taps = types.ComplexFloat32.vector_from_array(taps)
+        FIRFilterBlock.initialize(self)
+
+
+class ComplexBandstopFilterBlock(ComplexBandpassFilterBlock):
+    """radio/blocks/signal/complexbandstopfilter.lua"""
+    name = "ComplexBandstopFilterBlock"
+    _design = staticmethod(filter_utils.firwin_complex_bandstop)
+
+
+class RootRaisedCosineFilterBlock(FIRFilterBlock):
+    """radio/blocks/signal/rootraisedcosinefilter.lua. RootRaisedCosineFilterBlock(num_taps, beta, symbol_rate)."""
+    name = "RootRaisedCosineFilterBlock"
+
+    def instantiate(self, num_taps, beta, symbol_rate):
+        assert num_taps, "Missing argument #1 (num_taps)"
+        assert beta is not None, "Missing argument #2 (beta)"
+        assert symbol_rate, "Missing argument #3 (symbol_rate)"
+        self.beta, self.symbol_rate = beta, symbol_rate
+        FIRFilterBlock.instantiate(self, types.Float32.vector(num_taps))
+
+    def initialize(self):
+        taps = filter_utils.fir_root_raised_cosine(len(self.taps), self.get_rate(), self.beta, 1 / self.symbol_rate)
+        self.taps = types.Float32.vector_from_array(taps)
+        FIRFilterBlock.initialize(self)
+
+
+class MultiplyConstantBlock(Block):
+    """radio/blocks/signal/multiplyconstant.lua. MultiplyConstantBlock(constant): number / Float32 or a complex constant."""
+    name = "MultiplyConstantBlock"
+
+    def instantiate(self, constant):
+        assert constant is not None, "Missing argument #1 (constant)"
+        if isinstance(constant, (complex, np.complexfloating)):
+            self.constant = np.complex64(constant)
+            self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+        elif isinstance(constant, (int, float, np.floating, np.integer)):
+            self.constant = np.float32(constant)
+            self.add_type_signature([Input("in", types.Float32)], [Output("out", types.Float32)])
+            self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+        else:
+            raise TypeError("Unsupported constant type")
+
+    def initialize(self):
+        cc = isinstance(self.constant, np.complexfloating)
+        self._set_stage(_lib.load().lrhip_multiply_constant_create(float(np.real(self.constant)), float(np.imag(self.constant)), int(cc),
+                                                                   int(self.get_input_type() is types.ComplexFloat32)),
+                        "Creating lrhip multiplyconstant object")
+
+    def process(self, x):
+        return self._execute(x, self.get_output_type().dtype)
+
+
+class UpsamplerBlock(Block):
+    """radio/blocks/signal/upsampler.lua. UpsamplerBlock(factor)."""
+    name = "UpsamplerBlock"
+
+    def instantiate(self, factor):
+        assert factor, "Missing argument #1 (factor)"
+        self.factor = int(factor)
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+        self.add_type_signature([Input("in", types.Float32)], [Output("out", types.Float32)])
+
+    def get_rate(self):
+        return Block.get_rate(self) * self.factor          # upsampler.lua:41-43
+
+    def initialize(self):
+        self._set_stage(_lib.load().lrhip_upsampler_create(self.factor, self.get_input_type().size), "Creating lrhip upsampler object")
+
+    def process(self, x):
+        return self._execute(x, self.get_output_type().dtype)

@@ -157,6 +157,37 @@ class DecimatorBlock(CompositeBlock):
         self.add_type_signature([Input("in", types.Float32)], [Output("out", types.Float32)])
 
 
+class InterpolatorBlock(CompositeBlock):
+    """radio/composites/interpolator.lua:24-42. InterpolatorBlock(interpolation[, {num_taps=, window=}])."""
+    name = "InterpolatorBlock"
+
+    def instantiate(self, interpolation, options=None):
+        CompositeBlock.instantiate(self)
+        assert interpolation, "Missing argument #1 (interpolation)"
+        options = options or {}
+        self.connect(B.MultiplyConstantBlock(interpolation), B.UpsamplerBlock(interpolation),
+                     B.LowpassFilterBlock(options.get("num_taps") or 128, 1 / interpolation, 1.0, options.get("window")))
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+        self.add_type_signature([Input("in", types.Float32)], [Output("out", types.Float32)])
+
+
+class RationalResamplerBlock(CompositeBlock):
+    """radio/composites/rationalresampler.lua:25-49. RationalResamplerBlock(interpolation, decimation[, options])."""
+    name = "RationalResamplerBlock"
+
+    def instantiate(self, interpolation, decimation, options=None):
+        CompositeBlock.instantiate(self)
+        assert interpolation, "Missing argument #1 (interpolation)"
+        assert decimation, "Missing argument #2 (decimation)"
+        options = options or {}
+        cutoff = 1 / interpolation if (1 / interpolation < 1 / decimation) else 1 / decimation
+        self.connect(B.MultiplyConstantBlock(interpolation), B.UpsamplerBlock(interpolation),
+                     B.LowpassFilterBlock(options.get("num_taps") or 128, cutoff, 1.0, options.get("window")),
+                     B.DownsamplerBlock(decimation))
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+        self.add_type_signature([Input("in", types.Float32)], [Output("out", types.Float32)])
+
+
 class TunerBlock(CompositeBlock):
     """radio/composites/tuner.lua:32-48. TunerBlock(offset, bandwidth, decimation[, options])."""
     name = "TunerBlock"

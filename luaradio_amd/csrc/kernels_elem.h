@@ -175,4 +175,43 @@ __global__ __launch_bounds__(256) void binary_real_kernel(const float *__restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// MultiplyConstantBlock (radio/blocks/signal/multiplyconstant.lua:52-71) and UpsamplerBlock
+// (radio/blocks/signal/upsampler.lua:45-53, zero-stuffing: y[i*L] = x[i], 0 elsewhere) - the two small blocks the
+// Interpolator / RationalResampler composites add around the FIR (radio/composites/interpolator.lua:31-34).
+// MODE 0: real x real constant, 1: complex x real constant (scalar_mul), 2: complex x complex constant.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void multiply_constant_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned long n,
+                                                                float cr, float ci)
+{
+    unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (MODE == 0) {
+            y[i] = x[i] * cr;
+        } else {
+            float2 v = reinterpret_cast<const float2 *>(x)[i], o;
+            if (MODE == 1) o = make_float2(v.x * cr, v.y * cr);
+            else {
+                double ar = v.x, ai = v.y;
+                o = make_float2((float)(ar * (double)cr - ai * (double)ci), (float)(ar * (double)ci + ai * (double)cr));
+            }
+            reinterpret_cast<float2 *>(y)[i] = o;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_kernel(const T *__restrict__ x, T *__restrict__ y, unsigned long n_out, unsigned long factor)
+{
+    unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += stride) {
+        unsigned long q = i / factor;
+        T v = {};
+        if (q * factor == i) v = x[q];
+        y[i] = v;
+    }
+}
+
 }  // namespace lrhip

@@ -782,6 +782,49 @@ struct BinaryStage : lrhip_stage {
 };
 
 // =====================================================================================================
+// MultiplyConstantBlock, UpsamplerBlock
+// =====================================================================================================
+struct MulConstStage : lrhip_stage {
+    float cr = 1.f, ci = 0.f;
+    int mode = 0;
+    const char *kind() const override { return "multiplyconstant"; }
+    int reset() override { return 0; }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n > cap) return set_error("multiplyconstant: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+        const float *x = (const float *)in_dev;
+        float *y = (float *)out_dev;
+        if (mode == 0) hipLaunchKernelGGL(multiply_constant_kernel<0>, dim3(grid), dim3(256), 0, ctx().stream, x, y, n, cr, ci);
+        else if (mode == 1) hipLaunchKernelGGL(multiply_constant_kernel<1>, dim3(grid), dim3(256), 0, ctx().stream, x, y, n, cr, ci);
+        else hipLaunchKernelGGL(multiply_constant_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, x, y, n, cr, ci);
+        LR_LAUNCH_CHECK();
+        return (long)n;
+    }
+};
+
+struct UpsamplerStage : lrhip_stage {
+    unsigned long factor = 1;
+    const char *kind() const override { return "upsampler"; }
+    int reset() override { return 0; }
+    unsigned long max_output(unsigned long n) const override { return n * factor; }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        unsigned long n_out = n * factor;                 // upsampler.lua:46
+        if (n_out > cap) return set_error("upsampler: output capacity %lu < %lu", cap, n_out);
+        if (!n_out) return 0;
+        unsigned grid = grid_for(n_out, 256, ctx().num_cus * 16);
+        if (in_size == 8)
+            hipLaunchKernelGGL(upsample_kernel<float2>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n_out, factor);
+        else
+            hipLaunchKernelGGL(upsample_kernel<float>, dim3(grid), dim3(256), 0, ctx().stream, (const float *)in_dev, (float *)out_dev, n_out, factor);
+        LR_LAUNCH_CHECK();
+        return (long)n_out;
+    }
+};
+
+// =====================================================================================================
 // chain
 // =====================================================================================================
 struct lrhip_chain {
@@ -1015,6 +1058,30 @@ lrhip_stage_t *lrhip_format_convert_create(const char *format, int complex_out)
     return q;
 }
 
+lrhip_stage_t *lrhip_multiply_constant_create(float re, float im, int constant_complex, int input_complex)
+{
+    if (constant_complex && !input_complex) { set_error("multiplyconstant: a complex constant takes ComplexFloat32 input only (multiplyconstant.lua:42-44)"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    MulConstStage *q = new (std::nothrow) MulConstStage();
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->cr = re; q->ci = constant_complex ? im : 0.f;
+    q->mode = !input_complex ? 0 : (constant_complex ? 2 : 1);
+    q->in_size = q->out_size = input_complex ? 8 : 4;
+    return q;
+}
+
+lrhip_stage_t *lrhip_upsampler_create(unsigned factor, int elem_size)
+{
+    if (factor < 1) { set_error("upsampler: factor must be >= 1"); return nullptr; }
+    if (elem_size != 4 && elem_size != 8) { set_error("upsampler: element size must be 4 or 8"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    UpsamplerStage *q = new (std::nothrow) UpsamplerStage();
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->factor = factor;
+    q->in_size = q->out_size = elem_size;
+    return q;
+}
+
 lrhip_stage_t *lrhip_binary_create(const char *op, int input_complex)
 {
     if (!op) { set_error("binary: missing operation name"); return nullptr; }
@@ -1202,7 +1269,8 @@ int lrhip_chain_set_ring(lrhip_chain_t *c, unsigned depth, unsigned long max_chu
     c->ring.clear();
     int in_size = c->ops.front().stage->in_size, out_size = c->ops.back().stage->out_size;
     // bound on the output of one chunk whatever the carried state (rate-changing stages may emit one extra sample)
-    unsigned long max_out = max_chunk + 64;
+    unsigned long max_out = lrhip_chain_max_output(c, max_chunk) + 64;
+    if (max_out < max_chunk + 64) max_out = max_chunk + 64;
     for (unsigned i = 0; i < depth; i++) {
         std::unique_ptr<lrhip_chain::Slot> sl(new (std::nothrow) lrhip_chain::Slot());
         if (!sl) return set_error("out of memory");
@@ -1216,7 +1284,8 @@ int lrhip_chain_set_ring(lrhip_chain_t *c, unsigned depth, unsigned long max_chu
     // size the device-resident edges once, so no reallocation happens while chunks are in flight
     unsigned long nmax = max_chunk;
     for (size_t k = 0; k + 1 < c->ops.size(); k++) {
-        nmax = nmax + 64;
+        unsigned long grow = c->ops[k].stage->max_output(nmax);
+        nmax = (grow > nmax ? grow : nmax) + 64;
         if (c->edges[k]->reserve((size_t)nmax * c->ops[k].stage->out_size + 16)) return -1;
     }
     c->ring_chunk = max_chunk;

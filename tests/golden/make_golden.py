@@ -46,6 +46,13 @@ SPECS = [
     "blocks/signal/multiply_spec",
     "blocks/signal/add_spec",
     "blocks/signal/subtract_spec",
+    "blocks/signal/multiplyconstant_spec",
+    "blocks/signal/upsampler_spec",
+    "blocks/signal/complexbandpassfilter_spec",
+    "blocks/signal/complexbandstopfilter_spec",
+    "blocks/signal/rootraisedcosinefilter_spec",
+    "composites/interpolator_spec",
+    "composites/rationalresampler_spec",
     "blocks/sources/iqfile_spec",
     "blocks/sources/realfile_spec",
     "composites/decimator_spec",

@@ -17,6 +17,10 @@ def _vec(v):
         if v["type"] == "Float32":
             return np.array(v["data"], dtype=np.float64).astype(np.float32)
         return np.array(v["data"])
+    if isinstance(v, dict) and "scalar" in v:
+        if v["type"] == "ComplexFloat32":
+            return np.complex64(complex(v["scalar"][0], v["scalar"][1]))
+        return np.float32(v["scalar"][0])
     if isinstance(v, dict) and v.get("type") == "bytes":
         return bytes.fromhex(v["hex"])
     return v

@@ -572,6 +572,18 @@ def test_file_sources_convert_on_device():
         lr.IQFileSource(raw, "u24le", 1.0)
 
 
+@pytest.mark.parametrize("name,cls", [("multiplyconstant_spec", "MultiplyConstantBlock"), ("upsampler_spec", "UpsamplerBlock"),
+                                      ("complexbandpassfilter_spec", "ComplexBandpassFilterBlock"),
+                                      ("complexbandstopfilter_spec", "ComplexBandstopFilterBlock"),
+                                      ("rootraisedcosinefilter_spec", "RootRaisedCosineFilterBlock"),
+                                      ("interpolator_spec", "InterpolatorBlock"), ("rationalresampler_spec", "RationalResamplerBlock")])
+def test_golden_rank2_blocks(name, cls):
+    """§8(f) rank 2: the remaining FIR subclasses and the Interpolator / RationalResampler composites, same jig"""
+    doc = G.load(name)
+    for vec in doc["vectors"]:
+        _golden_both_modes(getattr(lr, cls), vec, doc["epsilon"], exact=(cls == "UpsamplerBlock"))
+
+
 def test_golden_binary_blocks():
     for name, cls in (("multiply_spec", lr.MultiplyBlock), ("multiplyconjugate_spec", lr.MultiplyConjugateBlock),
                       ("add_spec", lr.AddBlock), ("subtract_spec", lr.SubtractBlock)):

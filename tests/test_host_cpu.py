@@ -82,6 +82,19 @@ def test_filter_utils_mirror_matches_reference_vectors():
     assert G.max_abs_err(f32(filter_utils.firwin_bandstop(129, [0.4, 0.6])), vals["firwin_bandstop"]) < 1e-6
 
 
+def test_filter_utils_complex_rrc_hilbert_match_reference_vectors():
+    vals = G.load("filter_utils_vectors")["values"]      # args: tests/utilities/filter_utils_spec.lua:29-57
+    c64 = types.ComplexFloat32.vector_from_array
+    f32 = types.Float32.vector_from_array
+    for cut, key in (([0.1, 0.3], "positive"), ([-0.1, -0.3], "negative"), ([-0.2, 0.2], "zero")):
+        assert G.max_abs_err(c64(filter_utils.firwin_complex_bandpass(129, cut)), vals["firwin_complex_bandpass_" + key]) < 1e-6
+        assert G.max_abs_err(c64(filter_utils.firwin_complex_bandstop(129, cut)), vals["firwin_complex_bandstop_" + key]) < 1e-6
+    assert G.max_abs_err(f32(filter_utils.fir_root_raised_cosine(101, 1e6, 0.5, 1e3)), vals["fir_root_raised_cosine"]) < 1e-6
+    assert G.max_abs_err(f32(filter_utils.fir_hilbert_transform(129)), vals["fir_hilbert_transform"]) < 1e-6
+    with pytest.raises(ValueError):
+        filter_utils.fir_hilbert_transform(128)
+
+
 def test_filter_utils_mirror_is_bit_identical_to_oracle_design():
     """two independent restatements (C double, Python double) of filter_utils.lua give the same Float32 taps"""
     from oracle import oracle as O
