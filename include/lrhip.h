@@ -102,6 +102,13 @@ lrhip_stage_t *lrhip_multiply_constant_create(float re, float im, int constant_c
 /* UpsamplerBlock (radio/blocks/signal/upsampler.lua:26-53): zero-stuffing by `factor`. elem_size = 8 or 4. */
 lrhip_stage_t *lrhip_upsampler_create(unsigned factor, int elem_size);
 
+/* Critically sampled K-channel analysis filterbank (BASELINE.json configs[4]; not a block of the reference: defined as
+ * K parallel chains FrequencyTranslatorBlock(-c*fs/K) -> FIRFilterBlock(taps) -> DownsamplerBlock(K), c = 0..K-1).
+ * ComplexFloat32 in; one output frame of K ComplexFloat32 values (channel-major within the frame) per K input
+ * samples, with the downsampler's carried index.  Computed as one dense GEMM on the f32 matrix cores.
+ * nchannels in {32, 64}; ntaps a multiple of 32. */
+lrhip_stage_t *lrhip_channelizer_create(const float *taps, unsigned ntaps, unsigned nchannels);
+
 void lrhip_stage_destroy(lrhip_stage_t *q);
 /* Back to the just-created state (zero history, phase 0, index 0). */
 int lrhip_stage_reset(lrhip_stage_t *q);

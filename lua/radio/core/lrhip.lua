@@ -38,6 +38,7 @@ lrhip_stage_t *lrhip_format_convert_create(const char *format, int complex_out);
 lrhip_stage_t *lrhip_binary_create(const char *op, int input_complex);
 lrhip_stage_t *lrhip_multiply_constant_create(float re, float im, int constant_complex, int input_complex);
 lrhip_stage_t *lrhip_upsampler_create(unsigned factor, int elem_size);
+lrhip_stage_t *lrhip_channelizer_create(const float *taps, unsigned ntaps, unsigned nchannels);
 void lrhip_stage_destroy(lrhip_stage_t *q);
 int lrhip_stage_reset(lrhip_stage_t *q);
 int lrhip_stage_input_size(const lrhip_stage_t *q);

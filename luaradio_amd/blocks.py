@@ -323,3 +323,30 @@ class UpsamplerBlock(Block):
 
     def process(self, x):
         return self._execute(x, self.get_output_type().dtype)
+
+
+class PolyphaseChannelizerBlock(Block):
+    """Critically sampled K-channel analysis filterbank (BASELINE.json configs[4]).  Not a block of the reference: it is
+    K parallel chains FrequencyTranslatorBlock(-c*rate/K) -> FIRFilterBlock(taps) -> DownsamplerBlock(K), evaluated as
+    one dense GEMM on the f32 matrix cores.  PolyphaseChannelizerBlock(num_channels[, taps]); default prototype =
+    firwin_lowpass(16*K, 1/K).  Output: frames of K ComplexFloat32 (channel c at position c), one per K inputs."""
+    name = "PolyphaseChannelizerBlock"
+
+    def instantiate(self, num_channels, taps=None):
+        assert num_channels, "Missing argument #1 (num_channels)"
+        self.num_channels = int(num_channels)
+        if taps is None:
+            taps = filter_utils.firwin_lowpass(16 * self.num_channels, 1.0 / self.num_channels)
+        self.taps = types.Float32.vector_from_array(taps)
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+
+    def get_rate(self):
+        return Block.get_rate(self)      # K values per K input samples; each channel runs at rate/K
+
+    def initialize(self):
+        self._set_stage(_lib.load().lrhip_channelizer_create(_fptr(self.taps), len(self.taps), self.num_channels),
+                        "Creating lrhip channelizer object")
+
+    def process(self, x):
+        """returns an array of shape (frames, K)"""
+        return self._execute(x, np.complex64).reshape(-1, self.num_channels)

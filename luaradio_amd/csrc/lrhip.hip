@@ -10,6 +10,7 @@
 #include "kernels_fft.h"
 #include "kernels_fir.h"
 #include "kernels_firfft.h"
+#include "kernels_channelizer.h"
 #include "kernels_iir.h"
 
 using namespace lrhip;
@@ -825,6 +826,57 @@ struct UpsamplerStage : lrhip_stage {
 };
 
 // =====================================================================================================
+// polyphase channelizer as a dense MFMA GEMM
+// =====================================================================================================
+struct ChannelizerStage : lrhip_stage {
+    int M = 0, K = 0;
+    DeviceBuf W, hist[2];
+    int cur = 0;
+    unsigned long index = 0;
+    const char *kind() const override { return "channelizer"; }
+    unsigned long max_output(unsigned long n) const override { return (n / K + 1) * K; }
+    int reset() override
+    {
+        cur = 0; index = 0;
+        size_t hb = (size_t)(M - 1) * 2 * sizeof(float);
+        return (zero_fill(hist[0], hb) || zero_fill(hist[1], hb)) ? -1 : 0;
+    }
+    template <int NCT>
+    int launch(const float *x, long n, float *y, long nframes)
+    {
+        constexpr int K2 = 16 * NCT;
+        int nflt = 2 * ((CHAN_MT - 1) * K + M);
+        size_t dsize = (size_t)((nflt + 2 * (nflt / K2) + 2 + 3) / 4) * 4;
+        size_t lds_bytes = (dsize + (size_t)2 * CHAN_KSLAB * (K2 + 16)) * sizeof(float);
+        auto kern = channelizer_kernel<NCT>;
+        if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        unsigned grid = (unsigned)((nframes + CHAN_MT - 1) / CHAN_MT);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p, x, (const float *)W.p, y, M, n,
+                           nframes, (long)index);
+        LR_LAUNCH_CHECK();
+        return 0;
+    }
+    long run(const void *in_dev, unsigned long n_in, void *out_dev, unsigned long cap) override
+    {
+        long n = (long)n_in;
+        if (n <= 0) return 0;
+        long nframes = n_in > index ? (long)((n_in - index + K - 1) / K) : 0;
+        if ((unsigned long)(nframes * K) > cap) return set_error("channelizer: output capacity %lu < %ld", cap, nframes * K);
+        const float *x = (const float *)in_dev;
+        if (nframes > 0) {
+            int rc = K == 32 ? launch<4>(x, n, (float *)out_dev, nframes) : launch<8>(x, n, (float *)out_dev, nframes);
+            if (rc) return rc;
+        }
+        unsigned grid = grid_for((unsigned long)(M - 1) * 2, 256);
+        hipLaunchKernelGGL(fir_history_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, (const float *)hist[cur].p, x, (float *)hist[cur ^ 1].p, M, n);
+        LR_LAUNCH_CHECK();
+        cur ^= 1;
+        index = index + (unsigned long)nframes * K - n_in;
+        return nframes * K;
+    }
+};
+
+// =====================================================================================================
 // chain
 // =====================================================================================================
 struct lrhip_chain {
@@ -1080,6 +1132,35 @@ lrhip_stage_t *lrhip_upsampler_create(unsigned factor, int elem_size)
     q->factor = factor;
     q->in_size = q->out_size = elem_size;
     return q;
+}
+
+lrhip_stage_t *lrhip_channelizer_create(const float *taps, unsigned ntaps, unsigned nchannels)
+{
+    if (!taps || ntaps < 32 || (ntaps % 32) != 0 || ntaps > 8192) { set_error("channelizer: ntaps must be a multiple of 32 in [32, 8192]"); return nullptr; }
+    if (nchannels != 32 && nchannels != 64) { set_error("channelizer: nchannels must be 32 or 64"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    std::unique_ptr<ChannelizerStage> q(new (std::nothrow) ChannelizerStage());
+    if (!q) { set_error("out of memory"); return nullptr; }
+    int M = (int)ntaps, K = (int)nchannels, K2 = 2 * K;
+    q->M = M; q->K = K;
+    q->in_size = q->out_size = 8;
+    // W[2i][2c] = Re g, W[2i+1][2c] = -Im g, W[2i][2c+1] = Im g, W[2i+1][2c+1] = Re g,
+    // g_c[i] = h[M-1-i] * exp(+j*2*pi*c*(M-1-i)/K)   (kernels_channelizer.h)
+    std::vector<float> W((size_t)2 * M * K2);
+    const double PI2 = 6.283185307179586476925286766559;
+    for (int i = 0; i < M; i++)
+        for (int c = 0; c < K; c++) {
+            int j = M - 1 - i;
+            double a = PI2 * (double)(((long)c * j) % K) / K, h = taps[j];
+            float gr = (float)(h * std::cos(a)), gi = (float)(h * std::sin(a));
+            W[(size_t)(2 * i) * K2 + 2 * c] = gr;
+            W[(size_t)(2 * i + 1) * K2 + 2 * c] = -gi;
+            W[(size_t)(2 * i) * K2 + 2 * c + 1] = gi;
+            W[(size_t)(2 * i + 1) * K2 + 2 * c + 1] = gr;
+        }
+    if (upload(q->W, W.data(), W.size() * sizeof(float))) return nullptr;
+    if (q->reset()) return nullptr;
+    return q.release();
 }
 
 lrhip_stage_t *lrhip_binary_create(const char *op, int input_complex)

@@ -584,6 +584,29 @@ def test_golden_rank2_blocks(name, cls):
         _golden_both_modes(getattr(lr, cls), vec, doc["epsilon"], exact=(cls == "UpsamplerBlock"))
 
 
+@pytest.mark.parametrize("K,M", [(64, 1024), (32, 256), (64, 96)])
+def test_channelizer_gemm_vs_reference_chains(K, M):
+    """BASELINE.json configs[4]: the K-channel filterbank as a dense MFMA GEMM equals K parallel reference chains
+    FrequencyTranslator(-c/K) -> FIRFilter(h) -> Downsampler(K) (oracle restatements of the pinned blocks).
+    No golden vector exists in the reference for this (parity unpinned); tolerance 2e-6."""
+    rng = np.random.default_rng(K + M)
+    n = K * 150 + 17
+    x = rand_c(rng, n)
+    taps = O.firwin_lowpass(M, 1.0 / K).astype(np.float32)
+    blk = make(lr.PolyphaseChannelizerBlock, [K, taps], x)
+    cuts = [1, K - 1, K, K + 1, 40 * K + 3]
+    parts, a = [], 0
+    for b in cuts + [n]:
+        parts.append(blk.process(x[a:b]))
+        a = b
+    got = np.concatenate(parts)
+    frames = (n + K - 1) // K
+    assert got.shape == (frames, K)
+    for c in range(K):
+        want = O.Chain([O.Rotator(-2 * np.pi * c / K, O.MODE_F64), O.FIR(taps, True, O.MODE_F64), O.Downsampler(K, True)]).process(x)
+        assert G.max_abs_err(got[:, c], want) < 2e-6, c
+
+
 def test_golden_binary_blocks():
     for name, cls in (("multiply_spec", lr.MultiplyBlock), ("multiplyconjugate_spec", lr.MultiplyConjugateBlock),
                       ("add_spec", lr.AddBlock), ("subtract_spec", lr.SubtractBlock)):

@@ -96,6 +96,16 @@ def main():
     rows.append({"block": "PSD N=1024 hamming log fftshift", "MS/s": round(n / ms / 1e3, 1), "alg_GB/s": round(12 * n / ms / 1e6, 1),
                  "frac_8TB/s": round(12 * n / ms / 1e6 / 8000, 4), "ms": round(ms, 4), "TFLOP/s": None})
     L.lrhip_stage_destroy(st)
+    # configs[4]: 64-channel filterbank, 1024-tap prototype, as a dense GEMM on the f32 matrix cores
+    ch = mk(lr.PolyphaseChannelizerBlock, [64], True)
+    nch = min(n, 1 << 24)
+    cap = ch.max_output(nch)
+    big = torch.empty(2 * cap + 64, device="cuda")
+    ms = timeit(lambda: ch.process_device(xc.data_ptr(), nch, big.data_ptr(), cap), reps=3)
+    tf = 8.0 * 1024 * nch / ms / 1e9
+    rows.append({"block": "PolyphaseChannelizer K=64, 1024 taps (dense MFMA GEMM)", "MS/s": round(nch / ms / 1e3, 1),
+                 "alg_GB/s": round(16 * nch / ms / 1e6, 1), "frac_8TB/s": round(16 * nch / ms / 1e6 / 8000, 4), "ms": round(ms, 4),
+                 "TFLOP/s": round(tf, 2), "mfma_util_vs_157.3TF": round(tf / 157.3, 4)})
     for r in rows:
         print(json.dumps(r))
 
