@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--fir-mode", default="auto", choices=["auto", "direct", "fft"],
                     help="fir workload arithmetic: direct = Toeplitz MFMA (bit-exact fmaf chain); fft = fused overlap-save kernel; "
                          "auto = fft (the faster one; both are parity-tested)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs of the multi-rank plumbing)")
+    ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (seconds of CPU work)")
     return ap.parse_args()
@@ -97,11 +100,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     lr.init(local_rank)
     L = lr._lib.load()
     # launch on torch's current stream so torch.cuda.synchronize()/barriers and the library's HIP events agree
@@ -215,7 +223,7 @@ def main():
     ev_ms = L.lrhip_timer_elapsed_ms(timer)
     L.lrhip_timer_destroy(timer)
     if dist is not None:
-        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
 
