@@ -2,6 +2,7 @@
 //
 //   y[n] = ( sum_{j<nb} b[j] x[n-j]  -  sum_{1<=i<na} a[i] y[n-i] ) / a[0]
 //
+// (rewritten in round 1: direct 16-B global access per thread instead of an LDS transposition; optional fused downsampler)
 // The WBFM chain needs the first-order case (FMDeemphasisFilterBlock = SinglepoleLowpassFilterBlock,
 // singlepolelowpassfilter.lua:55-67: nb = na = 2).  A linear recurrence is a scan over affine maps of the
 // P = na-1 element output state, so it is done in three data-parallel passes:
@@ -45,57 +46,73 @@ __device__ __forceinline__ void mat_apply(const float *T, const float *v, float 
     }
 }
 
-// LDS layout: component plane cpl, chunk c, offset i -> cpl*PLANE + c*(LC+1) + i   (+1: conflict-free column walks)
-template <int S, int P, bool FINAL>
+// Each thread owns LC = 16 consecutive samples and reads them straight from global memory as 16-B vectors (a wave
+// covers 64 x 64 B = 4 KB contiguous; the four loads of a thread reuse its L1 lines), plus the NBT-1 samples before its
+// chunk for the feed-forward taps; LDS is used only for the scan over chunk end states.
+// NBT = compile-time bound on the number of feed-forward taps (2: single-pole filters; 16: general).
+// FINAL pass only: `dec`/`dfirst` fuse a following DownsamplerBlock (radio/blocks/signal/downsampler.lua:45-56):
+// only samples with (index - dfirst) % dec == 0 are stored, at (index - dfirst) / dec; it also publishes the last P
+// outputs of the chunk as the carried state.
+template <int S, int P, bool FINAL, int NBT>
 __global__ __launch_bounds__(256) void iir_scan_kernel(const float *__restrict__ x, float *__restrict__ y, long n,
                                                        const float *__restrict__ xhist,      // nb-1 samples before x[0]
                                                        const float *__restrict__ tile_start, // FINAL: [tile][S][P]
                                                        float *__restrict__ tile_end,         // !FINAL: [tile][S][P]
-                                                       IirCoeffs co)
+                                                       const float *__restrict__ state_in, float *__restrict__ state_out,
+                                                       long dec, long dfirst, IirCoeffs co)
 {
-    constexpr int LC = IIR_LC, TILE = IIR_TILE, HALO = IIR_MAX_NB - 1;
-    constexpr int PLANE = 256 * (LC + 1) + HALO + 1;
-    __shared__ float sx[S * PLANE];          // inputs: [HALO history | tile]; reused for outputs
+    constexpr int LC = IIR_LC, TILE = IIR_TILE, PV = NBT - 1;
     __shared__ float sst[2][S][256][P];      // chunk end states (double-buffered scan)
 
     const int tid = threadIdx.x;
     const long t0 = (long)blockIdx.x * TILE;
+    const long c0 = t0 + (long)tid * LC;     // first sample of this thread's chunk
     const int nb = co.nb;
-    const long cnt = (n - t0) < TILE ? (n - t0) : TILE;
 
-    // stage: history (nb-1 samples before the tile) at plane offsets [HALO-(nb-1), HALO), tile after it
-    for (int i = tid; i < (nb - 1) * S; i += 256) {
-        int r = i / S, c = i % S;                 // r-th history sample, oldest first
-        long g = t0 - (nb - 1) + r;               // global sample index
-        float v = g >= 0 ? x[g * S + c] : xhist[(g + (nb - 1)) * S + c];
-        sx[c * PLANE + HALO - (nb - 1) + r] = v;
+    // ---- load: xs[c][PV + i] = x[c0 + i], xs[c][PV - j] = x[c0 - j]
+    float xs[S][PV + LC];
+    const bool vec = (c0 + LC <= n) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    if (vec) {
+        const float4 *src = reinterpret_cast<const float4 *>(x + c0 * S);
+#pragma unroll
+        for (int q = 0; q < LC * S / 4; q++) {
+            float4 v = src[q];
+            if (S == 1) {
+                xs[0][PV + 4 * q] = v.x; xs[0][PV + 4 * q + 1] = v.y; xs[0][PV + 4 * q + 2] = v.z; xs[0][PV + 4 * q + 3] = v.w;
+            } else {
+                xs[0][PV + 2 * q] = v.x; xs[S - 1][PV + 2 * q] = v.y; xs[0][PV + 2 * q + 1] = v.z; xs[S - 1][PV + 2 * q + 1] = v.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < LC; i++)
+#pragma unroll
+            for (int c = 0; c < S; c++) xs[c][PV + i] = (c0 + i < n) ? x[(c0 + i) * S + c] : 0.f;
     }
-    for (int i = tid; i < TILE * S; i += 256) {
-        int r = i / S, c = i % S;
-        float v = r < cnt ? x[(t0 + r) * S + c] : 0.f;
-        sx[c * PLANE + HALO + (r / LC) * (LC + 1) + (r % LC)] = v;
-    }
-    __syncthreads();
+#pragma unroll
+    for (int j = 1; j <= PV; j++)
+#pragma unroll
+        for (int c = 0; c < S; c++) {
+            long g = c0 - j;
+            float v = 0.f;
+            if (j < nb && c0 < n) v = g >= 0 ? x[g * S + c] : xhist[(g + (nb - 1)) * S + c];
+            xs[c][PV - j] = v;
+        }
 
-    // feed-forward part for this thread's chunk, u[i] = sum_j b[j] x[n-j]; previous chunk's tail is at
-    // (c-1)*(LC+1) + LC-1-..., i.e. not contiguous because of the +1 pad: fetch through a helper.
+    // ---- feed-forward part u[i] = sum_j b[j] x[i-j]
     float u[S][LC];
 #pragma unroll
-    for (int c = 0; c < S; c++) {
-        const float *pl = sx + c * PLANE + HALO;
+    for (int c = 0; c < S; c++)
 #pragma unroll
         for (int i = 0; i < LC; i++) {
             float acc = 0.f;
-            for (int j = 0; j < nb; j++) {
-                int r = tid * LC + i - j;          // tile-relative sample index, may be negative (history)
-                float xv = r >= 0 ? pl[(r / LC) * (LC + 1) + (r % LC)] : pl[r];
-                acc = fmaf(co.b[j], xv, acc);
-            }
+#pragma unroll
+            for (int j = 0; j < NBT; j++)
+                if (j < nb) acc = fmaf(co.b[j], xs[c][PV + i - j], acc);
             u[c][i] = acc;
         }
-    }
 
-    // zero-state run over the chunk -> chunk end state
+    // ---- zero-state run over the chunk -> chunk end state
     float st[S][P];
 #pragma unroll
     for (int c = 0; c < S; c++) {
@@ -112,7 +129,7 @@ __global__ __launch_bounds__(256) void iir_scan_kernel(const float *__restrict__
         }
     }
 
-    // inclusive Kogge-Stone scan of chunk end states: S_c = z_c + A^LC S_{c-1}  (S_{-1} = tile start state)
+    // ---- inclusive Kogge-Stone scan of chunk end states: S_c = z_c + A^LC S_{c-1}  (S_{-1} = tile start state)
     int buf = 0;
 #pragma unroll
     for (int c = 0; c < S; c++) {
@@ -159,13 +176,12 @@ __global__ __launch_bounds__(256) void iir_scan_kernel(const float *__restrict__
         return;
     }
 
-    // true start state of this chunk = scanned end state of the previous chunk (or the tile start state)
+    // ---- true start state of this chunk = scanned end state of the previous chunk (or the tile start state); re-run
 #pragma unroll
     for (int c = 0; c < S; c++) {
 #pragma unroll
         for (int k = 0; k < P; k++)
             st[c][k] = tid ? sst[buf][c][tid - 1][k] : tile_start[((long)blockIdx.x * S + c) * P + k];
-        float *pl = sx + c * PLANE + HALO + tid * (LC + 1);
 #pragma unroll
         for (int i = 0; i < LC; i++) {
             float v = u[c][i];
@@ -174,13 +190,45 @@ __global__ __launch_bounds__(256) void iir_scan_kernel(const float *__restrict__
 #pragma unroll
             for (int k = P - 1; k > 0; k--) st[c][k] = st[c][k - 1];
             st[c][0] = v;
-            pl[i] = v;       // every thread only overwrites its own chunk; u[] already holds what it needed
+            u[c][i] = v;                       // u now holds y
+            long g = c0 + i;
+            if (g < n && g >= n - P) state_out[c * P + (int)(n - 1 - g)] = v;       // carried state y[n-1-k]
         }
     }
-    __syncthreads();
-    for (int i = tid; i < TILE * S; i += 256) {
-        int r = i / S, c = i % S;
-        if (r < cnt) y[(t0 + r) * S + c] = sx[c * PLANE + HALO + (r / LC) * (LC + 1) + (r % LC)];
+    if (blockIdx.x == 0 && tid == 0 && n < P)       // tiny chunk: older state entries shift down
+#pragma unroll
+        for (int c = 0; c < S; c++)
+            for (int k = (int)n; k < P; k++) state_out[c * P + k] = state_in[c * P + k - (int)n];
+
+    // ---- store
+    if (dec == 1) {
+        if (vec && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+            float4 *dst = reinterpret_cast<float4 *>(y + c0 * S);
+#pragma unroll
+            for (int q = 0; q < LC * S / 4; q++)
+                dst[q] = S == 1 ? make_float4(u[0][4 * q], u[0][4 * q + 1], u[0][4 * q + 2], u[0][4 * q + 3])
+                                : make_float4(u[0][2 * q], u[S - 1][2 * q], u[0][2 * q + 1], u[S - 1][2 * q + 1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < LC; i++)
+#pragma unroll
+                for (int c = 0; c < S; c++)
+                    if (c0 + i < n) y[(c0 + i) * S + c] = u[c][i];
+        }
+    } else {
+        // first kept index >= c0:  dfirst + ceil((c0 - dfirst)/dec)*dec
+        long k0 = c0 <= dfirst ? 0 : (c0 - dfirst + dec - 1) / dec;
+        long g0 = dfirst + k0 * dec;
+#pragma unroll
+        for (int i = 0; i < LC; i++) {
+            long g = c0 + i;
+            if (g == g0 && g < n) {
+#pragma unroll
+                for (int c = 0; c < S; c++) y[k0 * S + c] = u[c][i];
+                k0++;
+                g0 += dec;
+            }
+        }
     }
 }
 
@@ -256,22 +304,15 @@ __global__ __launch_bounds__(256) void iir_carry_kernel(const float *__restrict_
     }
 }
 
-// carried state after the chunk: y[n-1-i] (zero-extended by the previous state when n < P) and the last nb-1 inputs
+// carried feed-forward history after the chunk: the last nb-1 inputs (the output state is published by the final pass)
 template <int S>
-__global__ void iir_state_kernel(const float *__restrict__ x, const float *__restrict__ y, long n, int nb, int P,
-                                 const float *__restrict__ xhist_in, float *__restrict__ xhist_out,
-                                 const float *__restrict__ state_in, float *__restrict__ state_out)
+__global__ void iir_state_kernel(const float *__restrict__ x, long n, int nb, const float *__restrict__ xhist_in,
+                                 float *__restrict__ xhist_out)
 {
-    int tid = threadIdx.x;
-    for (int i = tid; i < (nb - 1) * S; i += blockDim.x) {
+    for (int i = threadIdx.x; i < (nb - 1) * S; i += blockDim.x) {
         int r = i / S, c = i % S;                 // r-th oldest of the nb-1 retained inputs
         long g = n - (nb - 1) + r;
         xhist_out[i] = g >= 0 ? x[g * S + c] : xhist_in[(g + (nb - 1)) * S + c];
-    }
-    for (int i = tid; i < P * S; i += blockDim.x) {
-        int c = i / P, k = i % P;                 // state[c][k] = y[n-1-k]
-        long g = n - 1 - k;
-        state_out[i] = g >= 0 ? y[g * S + c] : state_in[c * P + (int)(-g - 1)];
     }
 }
 

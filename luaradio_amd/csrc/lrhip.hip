@@ -524,10 +524,12 @@ struct IirStage : lrhip_stage {
     std::vector<double> Ttile;            // A^TILE in double (row-major PxP) for the per-launch carry powers
     DeviceBuf xhist[2], state[2], tile_end, tile_start, seq_xs, seq_ys;
     int cur = 0;
+    unsigned long D = 1, index = 0;       // fused DownsamplerBlock behind the filter (chains)
     const char *kind() const override { return "iir"; }
+    unsigned long max_output(unsigned long n) const override { return D == 1 ? n : n / D + 1; }
     int reset() override
     {
-        cur = 0;
+        cur = 0; index = 0;
         for (int i = 0; i < 2; i++) {
             if (zero_fill(xhist[i], sizeof(float) * S * IIR_MAX_NB)) return -1;
             if (zero_fill(state[i], sizeof(float) * S * (IIR_MAX_P + 1))) return -1;
@@ -535,15 +537,16 @@ struct IirStage : lrhip_stage {
         if (zero_fill(seq_xs, sizeof(float) * S * IIR_SEQ_MAX) || zero_fill(seq_ys, sizeof(float) * S * IIR_SEQ_MAX)) return -1;
         return 0;
     }
-    template <int SS, int PP>
-    int run_scan(const float *x, float *y, long n)
+    template <int SS, int PP, int NBT>
+    int run_scan_nb(const float *x, float *y, long n)
     {
         long ntiles = (n + IIR_TILE - 1) / IIR_TILE;
         if (tile_end.reserve(sizeof(float) * ntiles * SS * PP) || tile_start.reserve(sizeof(float) * ntiles * SS * PP)) return -1;
         const float *xh = (const float *)xhist[cur].p, *st = (const float *)state[cur].p;
+        float *st_out = (float *)state[cur ^ 1].p;
         if (ntiles > 1) {
-            hipLaunchKernelGGL((iir_scan_kernel<SS, PP, false>), dim3((unsigned)ntiles), dim3(256), 0, ctx().stream, x, (float *)nullptr, n, xh,
-                               (const float *)nullptr, (float *)tile_end.p, co);
+            hipLaunchKernelGGL((iir_scan_kernel<SS, PP, false, NBT>), dim3((unsigned)ntiles), dim3(256), 0, ctx().stream, x, (float *)nullptr, n, xh,
+                               (const float *)nullptr, (float *)tile_end.p, st, st_out, 1L, 0L, co);
             LR_LAUNCH_CHECK();
         }
         // carry scan: 256 segments of `seg` tiles; powers A^(TILE*seg*2^k) in double on the host
@@ -564,19 +567,26 @@ struct IirStage : lrhip_stage {
         hipLaunchKernelGGL((iir_carry_kernel<SS, PP>), dim3(1), dim3(256), 0, ctx().stream, (const float *)tile_end.p, (float *)tile_start.p,
                            nt, seg, st, co, pw);
         LR_LAUNCH_CHECK();
-        hipLaunchKernelGGL((iir_scan_kernel<SS, PP, true>), dim3((unsigned)ntiles), dim3(256), 0, ctx().stream, x, y, n, xh,
-                           (const float *)tile_start.p, (float *)nullptr, co);
+        hipLaunchKernelGGL((iir_scan_kernel<SS, PP, true, NBT>), dim3((unsigned)ntiles), dim3(256), 0, ctx().stream, x, y, n, xh,
+                           (const float *)tile_start.p, (float *)nullptr, st, st_out, (long)D, (long)index, co);
         LR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(iir_state_kernel<SS>, dim3(1), dim3(64), 0, ctx().stream, x, (const float *)y, n, nb, PP, xh, (float *)xhist[cur ^ 1].p,
-                           st, (float *)state[cur ^ 1].p);
-        LR_LAUNCH_CHECK();
+        if (nb > 1) {
+            hipLaunchKernelGGL(iir_state_kernel<SS>, dim3(1), dim3(64), 0, ctx().stream, x, n, nb, xh, (float *)xhist[cur ^ 1].p);
+            LR_LAUNCH_CHECK();
+        }
         cur ^= 1;
         return 0;
     }
+    template <int SS, int PP>
+    int run_scan(const float *x, float *y, long n)
+    {
+        return nb <= 2 ? run_scan_nb<SS, PP, 2>(x, y, n) : run_scan_nb<SS, PP, 16>(x, y, n);
+    }
     long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
     {
-        if (n > cap) return set_error("iir: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
+        unsigned long n_out = D == 1 ? n : (n > index ? (n - index + D - 1) / D : 0);
+        if (n_out > cap) return set_error("iir: output capacity %lu < %lu", cap, n_out);
         const float *x = (const float *)in_dev;
         float *y = (float *)out_dev;
         int rc = 0;
@@ -589,7 +599,9 @@ struct IirStage : lrhip_stage {
             else hipLaunchKernelGGL(iir_seq_kernel<2>, dim3(1), dim3(64), 0, ctx().stream, x, y, (long)n, seq, (float *)seq_xs.p, (float *)seq_ys.p);
             LR_LAUNCH_CHECK();
         }
-        return rc ? rc : (long)n;
+        if (rc) return rc;
+        if (D > 1) index = index + n_out * D - n;       // downsampler.lua:53
+        return (long)n_out;
     }
 };
 
@@ -1272,6 +1284,20 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
                 c->ops.push_back({fused, true});
                 i = j + (ds ? 2 : 1);
                 continue;
+            }
+        }
+        // fusion: iir (scan path) -> downsampler: the final scan pass stores only the kept samples
+        {
+            IirStage *iir = dynamic_cast<IirStage *>(stages[i]);
+            DownsamplerStage *ds2 = (iir && iir->scan && iir->D == 1 && i + 1 < nstages) ? dynamic_cast<DownsamplerStage *>(stages[i + 1]) : nullptr;
+            if (ds2 && ds2->factor > 1) {
+                IirStage *f = (IirStage *)lrhip_iir_create(iir->seq.b, (unsigned)iir->nb, iir->seq.a, (unsigned)iir->na, iir->S == 2);
+                if (f) {
+                    f->D = ds2->factor;
+                    c->ops.push_back({f, true});
+                    i += 2;
+                    continue;
+                }
             }
         }
         c->ops.push_back({stages[i], false});

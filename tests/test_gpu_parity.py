@@ -330,6 +330,25 @@ def test_deemphasis_scan_vs_sequential_oracle_large():
             assert G.max_abs_err(chunked(blk, x, [1, 2, 4095, 4096, 4097, 20000]), want) < 1e-6
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+def test_iir_downsampler_chain_fusion(cplx):
+    """[IIR -> Downsampler] in a chain stores only the kept samples from the final scan pass: same bits as unfused"""
+    rng = np.random.default_rng(14 + cplx)
+    n = 90001
+    x = rand_c(rng, n) if cplx else rand_r(rng, n)
+    for factor in (2, 5, 4096, 5000):
+        iir = make(lr.FMDeemphasisFilterBlock, [75e-6], x, rate=220500.0)
+        ds = make(lr.DownsamplerBlock, [factor], x)
+        chain = lr.Chain([iir, ds])
+        cuts = [(0, 1), (1, 2), (2, 4097), (4097, 4098), (4098, 50000), (50000, n)]
+        got = np.concatenate([chain.process(x[a:b]) for a, b in cuts])
+        ref_iir = make(lr.FMDeemphasisFilterBlock, [75e-6], x, rate=220500.0)
+        ref_ds = make(lr.DownsamplerBlock, [factor], x)
+        want = np.concatenate([ref_ds.process(ref_iir.process(x[a:b])) for a, b in cuts])
+        assert np.array_equal(got, want), factor
+        assert len(got) == (n + factor - 1) // factor
+
+
 def test_iir_second_and_fourth_order_scan_large():
     rng = np.random.default_rng(13)
     x = rand_r(rng, 100000)
