@@ -145,10 +145,37 @@ __device__ __forceinline__ void exchange(float2 *ex, float2 (&v)[16], WI widx, R
 
 // One overlap-save block per wave.  S = 2: ComplexFloat32 stream.  S = 1: Float32 stream with REAL taps, two
 // consecutive blocks packed as re/im of one complex FFT (h real => IFFT(H*(Xa + jXb)) = h*xa + j h*xb).
-template <int S>
+// PRE = 1 (S = 1 only): fused FrequencyDiscriminatorBlock in front of the filter (frequencydiscriminator.lua:68-88): x is
+// the ComplexFloat32 stream c, the filtered real stream is r[i] = arg(c[i] conj(c[i-1])) / gain with c[-1] = *disc_prev;
+// `hist` then holds the last M-1 values of r.
+template <int PRE>
+__device__ __forceinline__ float fft_real_sample(const float *__restrict__ hist, const float *__restrict__ x, long p, int M, long n,
+                                                 double inv_gain, const float2 *__restrict__ disc_prev)
+{
+    if (p < 0) return 0.f;
+    if (p < M - 1) return hist[p];
+    long xi = p - (M - 1);
+    if (xi >= n) return 0.f;
+    if (PRE == 0) return x[xi];
+    const float2 *c = reinterpret_cast<const float2 *>(x);
+    return discriminate(c[xi], xi ? c[xi - 1] : *disc_prev, inv_gain);
+}
+
+// history carry of the fused discriminator + FIR stage: last M-1 values of r, and the last complex sample
+__global__ __launch_bounds__(256) void fir_fft_pre_history_kernel(const float *__restrict__ hist_in, const float *__restrict__ x,
+                                                                  float *__restrict__ hist_out, int M, long n, double inv_gain,
+                                                                  const float2 *__restrict__ prev_in, float2 *__restrict__ prev_out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M - 1) hist_out[i] = fft_real_sample<1>(hist_in, x, n + i, M, n, inv_gain, prev_in);
+    if (i == 0 && n > 0) *prev_out = reinterpret_cast<const float2 *>(x)[n - 1];
+}
+
+template <int S, int PRE>
 __global__ __launch_bounds__(256, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const float *__restrict__ hist, const float *__restrict__ x,
                                                           const float2 *__restrict__ tables, float *__restrict__ y,
-                                                          int M, long n, long n_out, long nblocks)
+                                                          int M, long n, long n_out, long nblocks,
+                                                          double inv_gain, const float2 *__restrict__ disc_prev)
 {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -215,10 +242,27 @@ __global__ __launch_bounds__(256, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const 
             }
 #endif
         } else {
-            const long pa = (fb * 2) * L - V + (M - 1), pb = pa + L;
+            const long pa = (fb * 2) * L - V + (M - 1), pb = pa + L;      // stream positions of the two packed blocks
+            const long xa = pa - (M - 1), xb = pb - (M - 1);               // their x indices
+            if (xa >= PRE && xb + FFTN <= n) {
+                // both windows inside the chunk: coalesced loads, no history
+                if (PRE == 0) {
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                v[i] = make_float2(stream_at<1>(hist, x, pa + 64 * i + lane, 0, M, n), stream_at<1>(hist, x, pb + 64 * i + lane, 0, M, n));
+                    for (int i = 0; i < 16; i++) v[i] = make_float2(x[xa + 64 * i + lane], x[xb + 64 * i + lane]);
+                } else {
+                    const float2 *c = reinterpret_cast<const float2 *>(x);
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        long ia = xa + 64 * i + lane, ib = xb + 64 * i + lane;
+                        v[i] = make_float2(discriminate(c[ia], c[ia - 1], inv_gain), discriminate(c[ib], c[ib - 1], inv_gain));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    v[i] = make_float2(fft_real_sample<PRE>(hist, x, pa + 64 * i + lane, M, n, inv_gain, disc_prev),
+                                       fft_real_sample<PRE>(hist, x, pb + 64 * i + lane, M, n, inv_gain, disc_prev));
+            }
         }
 
         // ---- forward stage 1: radix-16 over n1, twiddle W_1024^(t*k1)

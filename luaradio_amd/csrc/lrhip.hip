@@ -74,6 +74,11 @@ struct FirStage : lrhip_stage {
     bool fft_arith = false;
     DeviceBuf d_fft_tables;
     int fft_blocks_per_cu = 0;
+    // fused FrequencyDiscriminatorBlock in front (chains): input is ComplexFloat32, the filter runs on arg(c[i] conj c[i-1])/gain
+    bool pre_disc = false;
+    double disc_gain = 1.0;
+    DeviceBuf disc_prev;
+    int disc_cur = 0;
 
     const char *kind() const override { return "fir"; }
     unsigned long max_output(unsigned long n) const override
@@ -83,7 +88,8 @@ struct FirStage : lrhip_stage {
     }
     int reset() override
     {
-        cur = 0; index = 0; count = 0; fill = 0;
+        cur = 0; index = 0; count = 0; fill = 0; disc_cur = 0;
+        if (pre_disc && zero_fill(disc_prev, 4 * sizeof(float))) return -1;
         size_t hb = ((size_t)(M > 1 ? M - 1 : 1) * S + hist_pad) * sizeof(float);
         if (zero_fill(hist[0], hb) || zero_fill(hist[1], hb)) return -1;
         return 0;
@@ -219,10 +225,12 @@ struct FirStage : lrhip_stage {
             long slots = (long)ctx().num_cus * fft_blocks_per_cu;
             long want = (nffts + 3) / 4;
             unsigned grid = (unsigned)(want < slots ? want : slots);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, (const float2 *)d_fft_tables.p, y, M, n, n_out, nblocks);
+            const float2 *dp = pre_disc ? (const float2 *)disc_prev.p + disc_cur : nullptr;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, (const float2 *)d_fft_tables.p, y, M, n, n_out, nblocks,
+                               1.0 / disc_gain, dp);
             return 0;
         };
-        int rc = S == 2 ? go(fir_fft_kernel<2>) : go(fir_fft_kernel<1>);
+        int rc = S == 2 ? go(fir_fft_kernel<2, 0>) : pre_disc ? go(fir_fft_kernel<1, 1>) : go(fir_fft_kernel<1, 0>);
         if (rc) return rc;
         LR_LAUNCH_CHECK();
         return 0;
@@ -275,7 +283,15 @@ struct FirStage : lrhip_stage {
                      : S == 1 ? dispatch_mfma<1>(x, n, y, n_out) : dispatch_mfma<2>(x, n, y, n_out);
             if (rc) return rc;
         }
-        if (M > 1) {
+        if (pre_disc) {
+            unsigned grid = grid_for((unsigned long)(M > 1 ? M - 1 : 1), 256);
+            float2 *dp = (float2 *)disc_prev.p;
+            hipLaunchKernelGGL(fir_fft_pre_history_kernel, dim3(grid), dim3(256), 0, ctx().stream, (const float *)hist[cur].p, x, (float *)hist[cur ^ 1].p, M, n,
+                               1.0 / disc_gain, (const float2 *)(dp + disc_cur), dp + (disc_cur ^ 1));
+            LR_LAUNCH_CHECK();
+            cur ^= 1;
+            disc_cur ^= 1;
+        } else if (M > 1) {
             unsigned grid = grid_for((unsigned long)(M - 1) * S, 256);
             const float *hi = (const float *)hist[cur].p + hist_pad;
             float *ho = (float *)hist[cur ^ 1].p + hist_pad;
@@ -1284,6 +1300,25 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
                 c->ops.push_back({fused, true});
                 i = j + (ds ? 2 : 1);
                 continue;
+            }
+        }
+        // fusion: discriminator -> overlap-save FIR on the real stream: the discriminator runs in the FFT kernel's load stage
+        {
+            FmDiscrimStage *dsc = dynamic_cast<FmDiscrimStage *>(stages[i]);
+            FirStage *f1 = (dsc && i + 1 < nstages) ? dynamic_cast<FirStage *>(stages[i + 1]) : nullptr;
+            if (f1 && f1->fft_arith && !f1->use_fft && f1->S == 1 && f1->D == 1 && !f1->rot && !f1->pre_disc) {
+                std::vector<float> taps((size_t)f1->M);
+                for (int t = 0; t < f1->M; t++) taps[t] = f1->taps_rev[f1->M - 1 - t];
+                FirStage *fused = fir_build(taps.data(), (unsigned)f1->M, 0, 0, 1, 2, false, 0.0);
+                if (fused) {
+                    fused->pre_disc = true;
+                    fused->disc_gain = dsc->gain;
+                    fused->in_size = 8;                 // ComplexFloat32 in, Float32 out
+                    if (fused->reset()) { delete fused; return nullptr; }
+                    c->ops.push_back({fused, true});
+                    i += 2;
+                    continue;
+                }
             }
         }
         // fusion: iir (scan path) -> downsampler: the final scan pass stores only the kept samples

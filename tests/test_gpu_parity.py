@@ -330,6 +330,28 @@ def test_deemphasis_scan_vs_sequential_oracle_large():
             assert G.max_abs_err(chunked(blk, x, [1, 2, 4095, 4096, 4097, 20000]), want) < 1e-6
 
 
+def test_discriminator_fir_chain_fusion():
+    """[FrequencyDiscriminator -> overlap-save FIR] in a chain runs the discriminator in the FFT kernel's load stage:
+    same bits as the two blocks run separately, for ragged chunks (history of r and the previous complex sample carry)"""
+    rng = np.random.default_rng(15)
+    n = 150001
+    x = rand_c(rng, n)
+    taps = np.asarray(lr.filter_utils.firwin_lowpass(128, 15e3 / 110250), np.float32)
+    cuts = [(0, 1), (1, 2), (2, 897), (897, 1793), (1793, 1794), (1794, 70000), (70000, n)]
+    disc = make(lr.FrequencyDiscriminatorBlock, [1.25], x)
+    fir = make(lr.FIRFilterBlock, [taps, "fast"], np.zeros(1, np.float32))
+    chain = lr.Chain([disc, fir])
+    got = np.concatenate([chain.process(x[a:b]) for a, b in cuts])
+    assert chain.last_launches == 2               # fused FFT kernel + history carry
+    d2 = make(lr.FrequencyDiscriminatorBlock, [1.25], x)
+    f2 = make(lr.FIRFilterBlock, [taps, "fast"], np.zeros(1, np.float32))
+    want = np.concatenate([f2.process(d2.process(x[a:b])) for a, b in cuts])
+    assert len(got) == n
+    assert G.max_abs_err(got, want) < 1e-6
+    whole = O.FIR(taps, False, O.MODE_F64).process(O.FMDiscriminator(1.25).process(x))
+    assert G.max_abs_err(got, whole) < 1e-6
+
+
 @pytest.mark.parametrize("cplx", [False, True])
 def test_iir_downsampler_chain_fusion(cplx):
     """[IIR -> Downsampler] in a chain stores only the kept samples from the final scan pass: same bits as unfused"""
