@@ -259,7 +259,7 @@ struct FirStage : lrhip_stage {
             case 2: return launch_mfma<SS, 2, 4>(x, n, y, n_out);
             case 3: return launch_mfma<SS, 3, 2>(x, n, y, n_out);
             case 4: return launch_mfma<SS, 4, 2>(x, n, y, n_out);
-            case 5: return launch_mfma<SS, 5, 1>(x, n, y, n_out);
+            case 5: return launch_mfma<SS, 5, 2>(x, n, y, n_out);
             case 6: return launch_mfma<SS, 6, 1>(x, n, y, n_out);
             case 7: return launch_mfma<SS, 7, 1>(x, n, y, n_out);
             case 8: return launch_mfma<SS, 8, 1>(x, n, y, n_out);
