@@ -102,6 +102,17 @@ lrhip_stage_t *lrhip_multiply_constant_create(float re, float im, int constant_c
 /* UpsamplerBlock (radio/blocks/signal/upsampler.lua:26-53): zero-stuffing by `factor`. elem_size = 8 or 4. */
 lrhip_stage_t *lrhip_upsampler_create(unsigned factor, int elem_size);
 
+/* One-input element-wise blocks. op: "complexmagnitude", "complexphase", "complextoreal", "complextoimag",
+ * "complexconjugate" (ComplexFloat32 in), "realtocomplex", "absolutevalue" (Float32 in), and "addconstant"
+ * (radio/blocks/signal/addconstant.lua:26-75: constant (re, im); constant_complex / input_complex as for
+ * lrhip_multiply_constant_create).  For the ops with a fixed input type input_complex is ignored. */
+lrhip_stage_t *lrhip_unary_create(const char *op, float re, float im, int constant_complex, int input_complex);
+/* DelayBlock (radio/blocks/signal/delay.lua:26-72): delay by num_samples (> 0), zero initial state. elem_size 8 or 4. */
+lrhip_stage_t *lrhip_delay_create(unsigned num_samples, int elem_size);
+/* HilbertTransformBlock (radio/blocks/signal/hilberttransform.lua:25-37, :100-160): Float32 in, ComplexFloat32 out =
+ * (input delayed by (M-1)/2, input filtered by the M Hilbert taps).  taps: M (odd) floats from fir_hilbert_transform. */
+lrhip_stage_t *lrhip_hilbert_create(const float *taps, unsigned ntaps);
+
 /* Critically sampled K-channel analysis filterbank (BASELINE.json configs[4]; not a block of the reference: defined as
  * K parallel chains FrequencyTranslatorBlock(-c*fs/K) -> FIRFilterBlock(taps) -> DownsamplerBlock(K), c = 0..K-1).
  * ComplexFloat32 in; one output frame of K ComplexFloat32 values (channel-major within the frame) per K input

@@ -70,4 +70,55 @@ function M.patch_iirfilter(IIRFilterBlock)
     IIRFilterBlock.process_real = process
 end
 
+-- One-input element-wise blocks (complexmagnitude.lua, complexphase.lua, complextoreal.lua, complextoimag.lua,
+-- complexconjugate.lua, realtocomplex.lua, absolutevalue.lua): M.patch_unary(ComplexMagnitudeBlock, "complexmagnitude")
+function M.patch_unary(Block, op)
+    function Block:process(x)
+        local stage = lazy(self, function ()
+            return lrhip.lib.lrhip_unary_create(op, 0, 0, 0, (self:get_input_type() == types.ComplexFloat32) and 1 or 0)
+        end)
+        return lrhip.execute(stage, x, self.out)
+    end
+end
+
+-- AddConstantBlock (addconstant.lua:26-75): the constant's type decides the arithmetic, as in the reference
+function M.patch_addconstant(AddConstantBlock)
+    local function process(self, x)
+        local stage = lazy(self, function ()
+            local c = self.constant
+            local cc = ffi.istype(types.ComplexFloat32, c)
+            return lrhip.lib.lrhip_unary_create("addconstant", cc and c.real or (type(c) == "number" and c or c.value),
+                                                cc and c.imag or 0, cc and 1 or 0,
+                                                (self:get_input_type() == types.ComplexFloat32) and 1 or 0)
+        end)
+        return lrhip.execute(stage, x, self.out)
+    end
+    AddConstantBlock.process_complex_by_complex = process
+    AddConstantBlock.process_complex_by_real = process
+    AddConstantBlock.process_real_by_real = process
+end
+
+-- DelayBlock (delay.lua:43-72), ComplexFloat32 / Float32 signatures
+function M.patch_delay(DelayBlock)
+    function DelayBlock:process(x)
+        local stage = lazy(self, function ()
+            return lrhip.lib.lrhip_delay_create(self.num_samples, ffi.sizeof(self:get_input_type()))
+        end)
+        return lrhip.execute(stage, x, self.out)
+    end
+end
+
+-- HilbertTransformBlock (hilberttransform.lua:100-160); self.hilbert_taps as computed by instantiate() (not reversed)
+function M.patch_hilberttransform(HilbertTransformBlock)
+    function HilbertTransformBlock:initialize()
+        self.out = types.ComplexFloat32.vector()
+    end
+    function HilbertTransformBlock:process(x)
+        local stage = lazy(self, function ()
+            return lrhip.lib.lrhip_hilbert_create(ffi.cast("const float *", self.hilbert_taps.data), self.hilbert_taps.length)
+        end)
+        return lrhip.execute(stage, x, self.out)
+    end
+end
+
 return M

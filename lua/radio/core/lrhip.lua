@@ -39,6 +39,9 @@ lrhip_stage_t *lrhip_binary_create(const char *op, int input_complex);
 lrhip_stage_t *lrhip_multiply_constant_create(float re, float im, int constant_complex, int input_complex);
 lrhip_stage_t *lrhip_upsampler_create(unsigned factor, int elem_size);
 lrhip_stage_t *lrhip_channelizer_create(const float *taps, unsigned ntaps, unsigned nchannels);
+lrhip_stage_t *lrhip_unary_create(const char *op, float re, float im, int constant_complex, int input_complex);
+lrhip_stage_t *lrhip_delay_create(unsigned num_samples, int elem_size);
+lrhip_stage_t *lrhip_hilbert_create(const float *taps, unsigned ntaps);
 void lrhip_stage_destroy(lrhip_stage_t *q);
 int lrhip_stage_reset(lrhip_stage_t *q);
 int lrhip_stage_input_size(const lrhip_stage_t *q);

@@ -10,7 +10,9 @@ from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock,
                      FMDeemphasisFilterBlock, FrequencyDiscriminatorBlock, FrequencyTranslatorBlock,
                      HighpassFilterBlock, IIRFilterBlock, LowpassFilterBlock, SinglepoleLowpassFilterBlock,
                      MultiplyBlock, MultiplyConjugateBlock, AddBlock, SubtractBlock, ComplexBandpassFilterBlock,
-                     ComplexBandstopFilterBlock, RootRaisedCosineFilterBlock, MultiplyConstantBlock, UpsamplerBlock, PolyphaseChannelizerBlock)
+                     ComplexBandstopFilterBlock, RootRaisedCosineFilterBlock, MultiplyConstantBlock, UpsamplerBlock, PolyphaseChannelizerBlock, ComplexMagnitudeBlock,
+                     ComplexPhaseBlock, ComplexToRealBlock, ComplexToImagBlock, ComplexConjugateBlock, RealToComplexBlock,
+                     AbsoluteValueBlock, AddConstantBlock, DelayBlock, HilbertTransformBlock)
 from .sources import IQFileSource, RealFileSource  # noqa: F401
 from .composites import (Chain, CompositeBlock, DecimatorBlock, InterpolatorBlock, RationalResamplerBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401
                          wbfm_mono_receiver)

@@ -350,3 +350,99 @@ class PolyphaseChannelizerBlock(Block):
     def process(self, x):
         """returns an array of shape (frames, K)"""
         return self._execute(x, np.complex64).reshape(-1, self.num_channels)
+
+
+class _UnaryBlock(Block):
+    """One-input element-wise blocks with fixed types."""
+    _op, _in, _out = "", types.ComplexFloat32, types.Float32
+
+    def instantiate(self):
+        self.add_type_signature([Input("in", self._in)], [Output("out", self._out)])
+
+    def initialize(self):
+        self._set_stage(_lib.load().lrhip_unary_create(self._op.encode(), 0.0, 0.0, 0, int(self._in is types.ComplexFloat32)),
+                        "Creating lrhip %s object" % self._op)
+
+    def process(self, x):
+        return self._execute(x, self._out.dtype)
+
+
+class ComplexMagnitudeBlock(_UnaryBlock):
+    """radio/blocks/signal/complexmagnitude.lua"""
+    name, _op = "ComplexMagnitudeBlock", "complexmagnitude"
+
+
+class ComplexPhaseBlock(_UnaryBlock):
+    """radio/blocks/signal/complexphase.lua"""
+    name, _op = "ComplexPhaseBlock", "complexphase"
+
+
+class ComplexToRealBlock(_UnaryBlock):
+    """radio/blocks/signal/complextoreal.lua"""
+    name, _op = "ComplexToRealBlock", "complextoreal"
+
+
+class ComplexToImagBlock(_UnaryBlock):
+    """radio/blocks/signal/complextoimag.lua"""
+    name, _op = "ComplexToImagBlock", "complextoimag"
+
+
+class ComplexConjugateBlock(_UnaryBlock):
+    """radio/blocks/signal/complexconjugate.lua"""
+    name, _op, _out = "ComplexConjugateBlock", "complexconjugate", types.ComplexFloat32
+
+
+class RealToComplexBlock(_UnaryBlock):
+    """radio/blocks/signal/realtocomplex.lua"""
+    name, _op, _in, _out = "RealToComplexBlock", "realtocomplex", types.Float32, types.ComplexFloat32
+
+
+class AbsoluteValueBlock(_UnaryBlock):
+    """radio/blocks/signal/absolutevalue.lua"""
+    name, _op, _in, _out = "AbsoluteValueBlock", "absolutevalue", types.Float32, types.Float32
+
+
+class AddConstantBlock(MultiplyConstantBlock):
+    """radio/blocks/signal/addconstant.lua. AddConstantBlock(constant)."""
+    name = "AddConstantBlock"
+
+    def initialize(self):
+        cc = isinstance(self.constant, np.complexfloating)
+        self._set_stage(_lib.load().lrhip_unary_create(b"addconstant", float(np.real(self.constant)), float(np.imag(self.constant)), int(cc),
+                                                       int(self.get_input_type() is types.ComplexFloat32)),
+                        "Creating lrhip addconstant object")
+
+
+class DelayBlock(Block):
+    """radio/blocks/signal/delay.lua. DelayBlock(num_samples) (ComplexFloat32 / Float32 signatures)."""
+    name = "DelayBlock"
+
+    def instantiate(self, num_samples):
+        assert num_samples is not None, "Missing argument #1 (num_samples)"
+        assert num_samples > 0, "Number of samples must be greater than 0"
+        self.num_samples = int(num_samples)
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+        self.add_type_signature([Input("in", types.Float32)], [Output("out", types.Float32)])
+
+    def initialize(self):
+        self._set_stage(_lib.load().lrhip_delay_create(self.num_samples, self.get_input_type().size), "Creating lrhip delay object")
+
+    def process(self, x):
+        return self._execute(x, self.get_output_type().dtype)
+
+
+class HilbertTransformBlock(Block):
+    """radio/blocks/signal/hilberttransform.lua. HilbertTransformBlock(num_taps[, window]): Float32 -> ComplexFloat32."""
+    name = "HilbertTransformBlock"
+
+    def instantiate(self, num_taps, window=None):
+        assert num_taps, "Missing argument #1 (num_taps)"
+        assert (num_taps % 2) == 1, "Number of taps must be odd"
+        self.hilbert_taps = types.Float32.vector_from_array(filter_utils.fir_hilbert_transform(num_taps, window or "hamming"))
+        self.add_type_signature([Input("in", types.Float32)], [Output("out", types.ComplexFloat32)])
+
+    def initialize(self):
+        self._set_stage(_lib.load().lrhip_hilbert_create(_fptr(self.hilbert_taps), len(self.hilbert_taps)), "Creating lrhip hilbert object")
+
+    def process(self, x):
+        return self._execute(x, np.complex64)

@@ -233,4 +233,62 @@ __global__ __launch_bounds__(256) void upsample_kernel(const T *__restrict__ x, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// One-input element-wise blocks (radio/blocks/signal/{complexmagnitude,complexphase,complextoreal,complextoimag,
+// complexconjugate,realtocomplex,absolutevalue,addconstant}.lua) - one sample per thread, HBM bound.
+// ------------------------------------------------------------------------------------------------
+enum { UN_CMAG = 0, UN_CPHASE = 1, UN_CREAL = 2, UN_CIMAG = 3, UN_CCONJ = 4, UN_R2C = 5, UN_ABS = 6,
+       UN_ADDC_REAL = 7, UN_ADDC_CPLX_BY_REAL = 8, UN_ADDC_CPLX = 9 };
+
+template <int OP>
+__global__ __launch_bounds__(256) void unary_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned long n, float cr, float ci)
+{
+    unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
+    const float2 *xc = reinterpret_cast<const float2 *>(x);
+    float2 *yc = reinterpret_cast<float2 *>(y);
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (OP == UN_CMAG) { float2 v = xc[i]; y[i] = sqrtf((float)((double)v.x * v.x + (double)v.y * v.y)); }   // complexfloat32.lua:163-165
+        else if (OP == UN_CPHASE) { float2 v = xc[i]; y[i] = atan2f(v.y, v.x); }                                   // :152-154
+        else if (OP == UN_CREAL) y[i] = xc[i].x;
+        else if (OP == UN_CIMAG) y[i] = xc[i].y;
+        else if (OP == UN_CCONJ) { float2 v = xc[i]; yc[i] = make_float2(v.x, -v.y); }
+        else if (OP == UN_R2C) yc[i] = make_float2(x[i], 0.f);
+        else if (OP == UN_ABS) y[i] = fabsf(x[i]);
+        else if (OP == UN_ADDC_REAL) y[i] = x[i] + cr;
+        else if (OP == UN_ADDC_CPLX_BY_REAL) { float2 v = xc[i]; yc[i] = make_float2(v.x + cr, v.y); }             // addconstant.lua:66-72
+        else { float2 v = xc[i]; yc[i] = make_float2(v.x + cr, v.y + ci); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DelayBlock (radio/blocks/signal/delay.lua:43-72): y[i] = s[i] with s = [state (D samples, zero initially) | x];
+// the new state is the last D samples of s.  Bit-exact copies; T = float or float2.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void delay_kernel(const T *__restrict__ state_in, const T *__restrict__ x, T *__restrict__ y,
+                                                    T *__restrict__ state_out, unsigned long n, unsigned long D)
+{
+    unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n + D; i += stride) {
+        T v = i < D ? state_in[i] : x[i - D];
+        if (i < n) y[i] = v;
+        if (i >= n) state_out[i - n] = v;
+    }
+}
+
+// HilbertTransformBlock output assembly (radio/blocks/signal/hilberttransform.lua:111-124):
+// out[i] = (s[(M-1)/2 + i], fir[i]) with s = [M-1 history | chunk]
+__global__ __launch_bounds__(256) void hilbert_combine_kernel(const float *__restrict__ hist, const float *__restrict__ x,
+                                                              const float *__restrict__ fir, float2 *__restrict__ y, unsigned long n, int M)
+{
+    unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
+    const long half = (M - 1) / 2;
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long p = half + (long)i;             // stream position of the delayed sample
+        float d = p < M - 1 ? hist[p] : x[p - (M - 1)];
+        y[i] = make_float2(d, fir[i]);
+    }
+}
+
 }  // namespace lrhip

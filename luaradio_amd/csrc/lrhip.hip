@@ -61,6 +61,7 @@ struct FirStage : lrhip_stage {
     std::vector<float> taps_rev;          // host copy, reversed (firfilter.lua:234-238)
     DeviceBuf d_taps, d_atab;
     int ksteps = 0;                       // 0 => MFMA path unavailable for this (M, D)
+    int mfma_blocks_per_cu = 0;           // resident workgroups of the persistent kernel (occupancy query, cached)
     int hist_pad = 0;                     // leading pad floats in the history buffers (1 for complex taps, see launch_mfma_cc)
     DeviceBuf hist[2];
     int cur = 0;
@@ -145,10 +146,9 @@ struct FirStage : lrhip_stage {
         int out_aligned = ((uintptr_t)y % 16) == 0;
         uint64_t rs = rot ? rot_step : 0, rc = rot ? count : 0;
         if constexpr (KS > 0) {
-            int bpc = 1;
             auto launch = [&](auto kern) -> int {
-                if (prepare_kernel(kern, lds_bytes, &bpc)) return -1;
-                long slots = (long)ctx().num_cus * bpc;
+                if (!mfma_blocks_per_cu && prepare_kernel(kern, lds_bytes, &mfma_blocks_per_cu)) return -1;     // queried once per stage
+                long slots = (long)ctx().num_cus * mfma_blocks_per_cu;
                 unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, atab, y, M, n, n_out, (long)index, e,
                                    ntiles, out_aligned, rs, rc);
@@ -905,6 +905,82 @@ struct ChannelizerStage : lrhip_stage {
 };
 
 // =====================================================================================================
+// one-input element-wise blocks, DelayBlock, HilbertTransformBlock
+// =====================================================================================================
+struct UnaryStage : lrhip_stage {
+    int op = 0;
+    float cr = 0.f, ci = 0.f;
+    const char *kind() const override { return "unary"; }
+    int reset() override { return 0; }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n > cap) return set_error("unary: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+        const float *x = (const float *)in_dev;
+        float *y = (float *)out_dev;
+#define LR_UN(OP) case OP: hipLaunchKernelGGL(unary_kernel<OP>, dim3(grid), dim3(256), 0, ctx().stream, x, y, n, cr, ci); break
+        switch (op) {
+            LR_UN(UN_CMAG); LR_UN(UN_CPHASE); LR_UN(UN_CREAL); LR_UN(UN_CIMAG); LR_UN(UN_CCONJ); LR_UN(UN_R2C); LR_UN(UN_ABS);
+            LR_UN(UN_ADDC_REAL); LR_UN(UN_ADDC_CPLX_BY_REAL); LR_UN(UN_ADDC_CPLX);
+            default: return set_error("unary: bad op");
+        }
+#undef LR_UN
+        LR_LAUNCH_CHECK();
+        return (long)n;
+    }
+};
+
+struct DelayStage : lrhip_stage {
+    unsigned long D = 1;
+    DeviceBuf state[2];
+    int cur = 0;
+    const char *kind() const override { return "delay"; }
+    int reset() override
+    {
+        cur = 0;
+        return (zero_fill(state[0], D * in_size) || zero_fill(state[1], D * in_size)) ? -1 : 0;
+    }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n > cap) return set_error("delay: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        unsigned grid = grid_for(n + D, 256, ctx().num_cus * 16);
+        if (in_size == 8)
+            hipLaunchKernelGGL(delay_kernel<float2>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)state[cur].p, (const float2 *)in_dev,
+                               (float2 *)out_dev, (float2 *)state[cur ^ 1].p, n, D);
+        else
+            hipLaunchKernelGGL(delay_kernel<float>, dim3(grid), dim3(256), 0, ctx().stream, (const float *)state[cur].p, (const float *)in_dev,
+                               (float *)out_dev, (float *)state[cur ^ 1].p, n, D);
+        LR_LAUNCH_CHECK();
+        cur ^= 1;
+        return (long)n;
+    }
+};
+
+struct HilbertStage : lrhip_stage {
+    std::unique_ptr<FirStage> fir;     // real taps, Float32 stream: the imaginary part
+    DeviceBuf tmp;
+    const char *kind() const override { return "hilbert"; }
+    int reset() override { return fir->reset(); }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n > cap) return set_error("hilbert: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        if (tmp.reserve(n * sizeof(float))) return -1;
+        long got = fir->core((const float *)in_dev, (long)n, (float *)tmp.p, n);
+        if (got < 0) return got;
+        // core() has swapped the ping-pong history: the history that was current for this chunk is the other one
+        const float *old_hist = (const float *)fir->hist[fir->cur ^ 1].p;
+        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+        hipLaunchKernelGGL(hilbert_combine_kernel, dim3(grid), dim3(256), 0, ctx().stream, old_hist, (const float *)in_dev, (const float *)tmp.p,
+                           (float2 *)out_dev, n, fir->M);
+        LR_LAUNCH_CHECK();
+        return (long)n;
+    }
+};
+
+// =====================================================================================================
 // chain
 // =====================================================================================================
 struct lrhip_chain {
@@ -1160,6 +1236,54 @@ lrhip_stage_t *lrhip_upsampler_create(unsigned factor, int elem_size)
     q->factor = factor;
     q->in_size = q->out_size = elem_size;
     return q;
+}
+
+lrhip_stage_t *lrhip_unary_create(const char *op, float re, float im, int constant_complex, int input_complex)
+{
+    if (!op) { set_error("unary: missing operation name"); return nullptr; }
+    struct { const char *name; int code, in, out; } T[] = {
+        {"complexmagnitude", UN_CMAG, 8, 4}, {"complexphase", UN_CPHASE, 8, 4}, {"complextoreal", UN_CREAL, 8, 4},
+        {"complextoimag", UN_CIMAG, 8, 4},   {"complexconjugate", UN_CCONJ, 8, 8}, {"realtocomplex", UN_R2C, 4, 8},
+        {"absolutevalue", UN_ABS, 4, 4}};
+    int code = -1, in = 0, out = 0;
+    for (auto &t : T)
+        if (!strcmp(t.name, op)) { code = t.code; in = t.in; out = t.out; }
+    if (!strcmp(op, "addconstant")) {
+        if (constant_complex && !input_complex) { set_error("addconstant: a complex constant takes ComplexFloat32 input only (addconstant.lua:42-44)"); return nullptr; }
+        code = !input_complex ? UN_ADDC_REAL : (constant_complex ? UN_ADDC_CPLX : UN_ADDC_CPLX_BY_REAL);
+        in = out = input_complex ? 8 : 4;
+    }
+    if (code < 0) { set_error("unary: unknown operation \"%s\"", op); return nullptr; }
+    if (ensure_init()) return nullptr;
+    UnaryStage *q = new (std::nothrow) UnaryStage();
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->op = code; q->cr = re; q->ci = im;
+    q->in_size = in; q->out_size = out;
+    return q;
+}
+
+lrhip_stage_t *lrhip_delay_create(unsigned num_samples, int elem_size)
+{
+    if (num_samples < 1) { set_error("Number of samples must be greater than 0"); return nullptr; }      // delay.lua:28
+    if (elem_size != 4 && elem_size != 8) { set_error("delay: element size must be 4 or 8"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    std::unique_ptr<DelayStage> q(new (std::nothrow) DelayStage());
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->D = num_samples;
+    q->in_size = q->out_size = elem_size;
+    if (q->reset()) return nullptr;
+    return q.release();
+}
+
+lrhip_stage_t *lrhip_hilbert_create(const float *taps, unsigned ntaps)
+{
+    if (!taps || (ntaps % 2) != 1) { set_error("Number of taps must be odd"); return nullptr; }          // hilberttransform.lua:29
+    std::unique_ptr<HilbertStage> q(new (std::nothrow) HilbertStage());
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->fir.reset(fir_build(taps, ntaps, 0, 0, 1, 0, false, 0.0));
+    if (!q->fir) return nullptr;
+    q->in_size = 4; q->out_size = 8;
+    return q.release();
 }
 
 lrhip_stage_t *lrhip_channelizer_create(const float *taps, unsigned ntaps, unsigned nchannels)

@@ -47,6 +47,16 @@ SPECS = [
     "blocks/signal/add_spec",
     "blocks/signal/subtract_spec",
     "blocks/signal/multiplyconstant_spec",
+    "blocks/signal/addconstant_spec",
+    "blocks/signal/complexmagnitude_spec",
+    "blocks/signal/complexphase_spec",
+    "blocks/signal/complextoreal_spec",
+    "blocks/signal/complextoimag_spec",
+    "blocks/signal/complexconjugate_spec",
+    "blocks/signal/realtocomplex_spec",
+    "blocks/signal/absolutevalue_spec",
+    "blocks/signal/delay_spec",
+    "blocks/signal/hilberttransform_spec",
     "blocks/signal/upsampler_spec",
     "blocks/signal/complexbandpassfilter_spec",
     "blocks/signal/complexbandstopfilter_spec",

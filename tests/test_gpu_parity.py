@@ -648,6 +648,21 @@ def test_channelizer_gemm_vs_reference_chains(K, M):
         assert G.max_abs_err(got[:, c], want) < 2e-6, c
 
 
+@pytest.mark.parametrize("name,cls,exact", [
+    ("addconstant_spec", "AddConstantBlock", False), ("complexmagnitude_spec", "ComplexMagnitudeBlock", False),
+    ("complexphase_spec", "ComplexPhaseBlock", False), ("complextoreal_spec", "ComplexToRealBlock", True),
+    ("complextoimag_spec", "ComplexToImagBlock", True), ("complexconjugate_spec", "ComplexConjugateBlock", True),
+    ("realtocomplex_spec", "RealToComplexBlock", True), ("absolutevalue_spec", "AbsoluteValueBlock", True),
+    ("delay_spec", "DelayBlock", True), ("hilberttransform_spec", "HilbertTransformBlock", False)])
+def test_golden_rank3_blocks(name, cls, exact):
+    """§8(f) rank 2/3 remainder: one-input element-wise blocks, Delay and the Hilbert transform, same jig"""
+    doc = G.load(name)
+    for vec in doc["vectors"]:
+        if any(getattr(v, "dtype", None) is not None and v.dtype.kind not in "fc" for v in vec["inputs"]):
+            continue          # Bit / Byte signatures of DelayBlock are protocol payloads, out of scope
+        _golden_both_modes(getattr(lr, cls), vec, doc["epsilon"], exact=exact)
+
+
 def test_golden_binary_blocks():
     for name, cls in (("multiply_spec", lr.MultiplyBlock), ("multiplyconjugate_spec", lr.MultiplyConjugateBlock),
                       ("add_spec", lr.AddBlock), ("subtract_spec", lr.SubtractBlock)):
