@@ -91,7 +91,8 @@ lrhip_stage_t *lrhip_dft_create(unsigned n, int inverse, int real_side);
 lrhip_stage_t *lrhip_format_convert_create(const char *format, int complex_out);
 
 /* Two-input element-wise blocks: op = "multiply" (radio/blocks/signal/multiply.lua:43-76), "multiplyconjugate"
- * (multiplyconjugate.lua:41-59, complex only), "add" (add.lua), "subtract" (subtract.lua).  Replaces
+ * (multiplyconjugate.lua:41-59, complex only), "add" (add.lua), "subtract" (subtract.lua), "floattocomplex" (floattocomplex.lua: two Float32 inputs ->
+ * ComplexFloat32 (in1, in2); input_complex ignored).  Replaces
  * volk_32fc_x2_multiply_32fc_a / volk_32f_x2_multiply_32f_a / volk_32fc_x2_multiply_conjugate_32fc_a.
  * Executed with lrhip_stage_execute2*(). */
 lrhip_stage_t *lrhip_binary_create(const char *op, int input_complex);
@@ -112,6 +113,15 @@ lrhip_stage_t *lrhip_delay_create(unsigned num_samples, int elem_size);
 /* HilbertTransformBlock (radio/blocks/signal/hilberttransform.lua:25-37, :100-160): Float32 in, ComplexFloat32 out =
  * (input delayed by (M-1)/2, input filtered by the M Hilbert taps).  taps: M (odd) floats from fir_hilbert_transform. */
 lrhip_stage_t *lrhip_hilbert_create(const float *taps, unsigned ntaps);
+
+/* Welch / Bartlett averaged power spectrum, the arithmetic of GnuplotSpectrumSink / GnuplotWaterfallSink
+ * (radio/blocks/sinks/gnuplotspectrum.lua:140-186): frames of n samples every (n - overlap) samples, each frame's PSD
+ * (arguments as lrhip_psd_create, spectrum fftshifted) accumulated on the device.  The stage is a sink:
+ * lrhip_stage_execute*() consumes the chunk and returns 0 outputs; partial frames are carried to the next call.
+ * lrhip_welch_read() writes the n-point average (sum / frames) to avg_host and returns the number of frames averaged
+ * (0: nothing accumulated, avg_host untouched); reset != 0 clears the accumulator (gnuplotspectrum.lua:189-191). */
+lrhip_stage_t *lrhip_welch_create(unsigned n, const float *window, double scale, int logarithmic, int input_complex, unsigned overlap);
+long lrhip_welch_read(lrhip_stage_t *q, float *avg_host, int reset);
 
 /* Critically sampled K-channel analysis filterbank (BASELINE.json configs[4]; not a block of the reference: defined as
  * K parallel chains FrequencyTranslatorBlock(-c*fs/K) -> FIRFilterBlock(taps) -> DownsamplerBlock(K), c = 0..K-1).

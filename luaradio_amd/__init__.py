@@ -12,9 +12,10 @@ from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock,
                      MultiplyBlock, MultiplyConjugateBlock, AddBlock, SubtractBlock, ComplexBandpassFilterBlock,
                      ComplexBandstopFilterBlock, RootRaisedCosineFilterBlock, MultiplyConstantBlock, UpsamplerBlock, PolyphaseChannelizerBlock, ComplexMagnitudeBlock,
                      ComplexPhaseBlock, ComplexToRealBlock, ComplexToImagBlock, ComplexConjugateBlock, RealToComplexBlock,
-                     AbsoluteValueBlock, AddConstantBlock, DelayBlock, HilbertTransformBlock)
+                     AbsoluteValueBlock, AddConstantBlock, DelayBlock, HilbertTransformBlock, SinglepoleHighpassFilterBlock,
+                     FMPreemphasisFilterBlock, FloatToComplexBlock, ComplexToFloatBlock)
 from .sources import IQFileSource, RealFileSource  # noqa: F401
 from .composites import (Chain, CompositeBlock, DecimatorBlock, InterpolatorBlock, RationalResamplerBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401
-                         wbfm_mono_receiver)
+                         NBFMDemodulator, AMEnvelopeDemodulator, SSBDemodulator, wbfm_mono_receiver)
 
 version = "0.1.0"

@@ -211,7 +211,7 @@ class _BinaryBlock(Block):
         dt = self.get_input_type().dtype
         if x.dtype != dt or y.dtype != dt or len(x) != len(y):
             raise TypeError("Block %s expects two %s vectors of equal length" % (self.name, self.get_input_type()))
-        out = np.empty(len(x), dtype=dt)
+        out = np.empty(len(x), dtype=self.get_output_type().dtype)
         n = L.lrhip_stage_execute2(self._stage, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), len(x),
                                    out.ctypes.data_as(C.c_void_p), len(out))
         _lib.check(n, "%s:process" % self.name)
@@ -446,3 +446,57 @@ class HilbertTransformBlock(Block):
 
     def process(self, x):
         return self._execute(x, np.complex64)
+
+
+class SinglepoleHighpassFilterBlock(IIRFilterBlock):
+    """radio/blocks/signal/singlepolehighpassfilter.lua:27-48. SinglepoleHighpassFilterBlock(cutoff)."""
+    name = "SinglepoleHighpassFilterBlock"
+
+    def instantiate(self, cutoff):
+        assert cutoff is not None, "Missing argument #1 (cutoff)"
+        self.cutoff = cutoff
+        super().instantiate(types.Float32.vector(2), types.Float32.vector(2))
+
+    def initialize(self):
+        rate = self.get_rate()
+        tau = 1 / (2 * math.pi * self.cutoff)                       # :36-37 warped time constant
+        tau = 1 / (2 * rate * math.tan(1 / (2 * rate * tau)))
+        self.b_taps[0] = (2 * tau * rate) / (1 + 2 * tau * rate)
+        self.b_taps[1] = -(2 * tau * rate) / (1 + 2 * tau * rate)
+        self.a_taps[0] = 1
+        self.a_taps[1] = (1 - 2 * tau * rate) / (1 + 2 * tau * rate)
+        super().initialize()
+
+
+class FMPreemphasisFilterBlock(SinglepoleHighpassFilterBlock):
+    """radio/blocks/signal/fmpreemphasisfilter.lua:30-33. FMPreemphasisFilterBlock(tau)."""
+    name = "FMPreemphasisFilterBlock"
+
+    def instantiate(self, tau):
+        assert tau is not None, "Missing argument #1 (tau)"
+        super().instantiate(1 / (2 * math.pi * tau))
+
+
+class FloatToComplexBlock(_BinaryBlock):
+    """radio/blocks/signal/floattocomplex.lua: (real, imag) Float32 inputs -> ComplexFloat32."""
+    name, _op = "FloatToComplexBlock", "floattocomplex"
+
+    def instantiate(self):
+        self.add_type_signature([Input("real", types.Float32), Input("imag", types.Float32)], [Output("out", types.ComplexFloat32)])
+
+
+class ComplexToFloatBlock(Block):
+    """radio/blocks/signal/complextofloat.lua: ComplexFloat32 -> (real, imag) Float32 outputs (two device passes)."""
+    name = "ComplexToFloatBlock"
+
+    def instantiate(self):
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("real", types.Float32), Output("imag", types.Float32)])
+
+    def initialize(self):
+        self._real, self._imag = ComplexToRealBlock(), ComplexToImagBlock()
+        for b in (self._real, self._imag):
+            b.differentiate([types.ComplexFloat32])
+            b.initialize()
+
+    def process(self, x):
+        return self._real.process(x), self._imag.process(x)

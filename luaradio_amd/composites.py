@@ -217,6 +217,44 @@ class WBFMMonoDemodulator(CompositeBlock):
         self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.Float32)])
 
 
+class NBFMDemodulator(CompositeBlock):
+    """radio/composites/nbfmdemodulator.lua:25-41. NBFMDemodulator([deviation=5e3[, bandwidth=4e3]])."""
+    name = "NBFMDemodulator"
+
+    def instantiate(self, deviation=None, bandwidth=None):
+        CompositeBlock.instantiate(self)
+        deviation = deviation or 5e3
+        bandwidth = bandwidth or 4e3
+        self.connect(B.LowpassFilterBlock(128, 2 * (deviation + bandwidth) / 2), B.FrequencyDiscriminatorBlock(deviation / bandwidth),
+                     B.LowpassFilterBlock(128, bandwidth))
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.Float32)])
+
+
+class AMEnvelopeDemodulator(CompositeBlock):
+    """radio/composites/amenvelopedemodulator.lua:24-38. AMEnvelopeDemodulator([bandwidth=5e3])."""
+    name = "AMEnvelopeDemodulator"
+
+    def instantiate(self, bandwidth=None):
+        CompositeBlock.instantiate(self)
+        bandwidth = bandwidth or 5e3
+        self.connect(B.ComplexMagnitudeBlock(), B.SinglepoleHighpassFilterBlock(100), B.LowpassFilterBlock(128, bandwidth))
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.Float32)])
+
+
+class SSBDemodulator(CompositeBlock):
+    """radio/composites/ssbdemodulator.lua:25-43. SSBDemodulator(sideband[, bandwidth=3e3])."""
+    name = "SSBDemodulator"
+
+    def instantiate(self, sideband, bandwidth=None):
+        CompositeBlock.instantiate(self)
+        assert sideband, "Missing argument #1 (sideband)"
+        assert sideband in ("lsb", "usb"), "Sideband should be 'lsb' or 'usb'"
+        bandwidth = bandwidth or 3e3
+        self.connect(B.ComplexBandpassFilterBlock(129, [0, -bandwidth] if sideband == "lsb" else [0, bandwidth]),
+                     B.ComplexToRealBlock(), B.LowpassFilterBlock(128, bandwidth))
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.Float32)])
+
+
 def wbfm_mono_receiver(rate=1102500.0, tune_offset=-250e3):
     """The compute blocks of examples/rtlsdr_wbfm_mono.lua:12-17,28 as one composite:
     Tuner(-250e3, 200e3, 5) -> FrequencyDiscriminator(1.25) -> Lowpass(128, 15e3) -> FMDeemphasis(75e-6) -> Downsampler(5)."""

@@ -95,6 +95,15 @@ __device__ __forceinline__ float discriminate(float2 a, float2 b, double inv_gai
 {
     // a * conj(b); f32 fused products: the residual (<= 1 ulp of the larger product) moves the angle by < 1e-7 rad
     float tr = fmaf(a.x, b.x, a.y * b.y), ti = fmaf(a.y, b.x, -a.x * b.y);
+    if (tr == 0.f && ti == 0.f) {
+        // zero product (first sample after the zero initial state, or an exactly silent input): the reference's angle is
+        // then decided by the SIGNS of the zeros, atan2(+-0, -0) = +-pi (frequencydiscriminator.lua:74 -> complexfloat32.lua:79-81
+        // operation order: re = ar*br - ai*(-bi), im = ar*(-bi) + ai*br)
+        float nb = -b.y;
+        float zr = __fsub_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, nb)), zi = __fadd_rn(__fmul_rn(a.x, nb), __fmul_rn(a.y, b.x));
+        float r = __builtin_signbit(zr) ? 3.14159265358979f : 0.f;
+        return copysignf(r, zi) * (float)inv_gain;
+    }
     return fast_atan2f(ti, tr) * (float)inv_gain;
 }
 
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256) void format_convert_kernel(const RAW *__restri
 // Lua arithmetic: each component evaluated in double and rounded once (radio/types/complexfloat32.lua:79-81).
 // Traffic: 3 x sample size per sample.
 // ------------------------------------------------------------------------------------------------
-enum { BIN_MULTIPLY = 0, BIN_MULTIPLY_CONJ = 1, BIN_ADD = 2, BIN_SUBTRACT = 3 };
+enum { BIN_MULTIPLY = 0, BIN_MULTIPLY_CONJ = 1, BIN_ADD = 2, BIN_SUBTRACT = 3, BIN_F2C = 4 };
 
 template <int OP>
 __global__ __launch_bounds__(256) void binary_complex_kernel(const float2 *__restrict__ a, const float2 *__restrict__ b,
@@ -289,6 +298,62 @@ __global__ __launch_bounds__(256) void hilbert_combine_kernel(const float *__res
         float d = p < M - 1 ? hist[p] : x[p - (M - 1)];
         y[i] = make_float2(d, fir[i]);
     }
+}
+
+// FloatToComplexBlock (radio/blocks/signal/floattocomplex.lua): y[i] = (a[i], b[i])
+__global__ __launch_bounds__(256) void float_to_complex_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                               float2 *__restrict__ y, unsigned long n)
+{
+    unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = make_float2(a[i], b[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Welch / Bartlett averaging of GnuplotSpectrumSink (radio/blocks/sinks/gnuplotspectrum.lua:140-186): the stream
+// s = [pending | chunk] is cut into frames of N samples every `hop` = N - overlap samples; every frame's (log) PSD is
+// fftshifted and accumulated.  welch_gather lays the overlapping frames out contiguously for the PSD kernel,
+// welch_partial / welch_final reduce the per-frame spectra in a fixed order (reproducible sums).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void welch_gather_kernel(const T *__restrict__ pending, unsigned long P, const T *__restrict__ x,
+                                                           T *__restrict__ frames, unsigned long nframes, int N, int hop)
+{
+    unsigned long total = nframes * (unsigned long)N, stride = (unsigned long)gridDim.x * blockDim.x;
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        unsigned long f = i / N, j = i % N, p = f * hop + j;
+        frames[i] = p < P ? pending[p] : x[p - P];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void welch_pending_kernel(const T *__restrict__ pending, unsigned long P, const T *__restrict__ x,
+                                                            unsigned long start, T *__restrict__ out, unsigned long count)
+{
+    unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        unsigned long p = start + i;
+        out[i] = p < P ? pending[p] : x[p - P];
+    }
+}
+
+constexpr int WELCH_CHUNK = 64;      // frames per partial sum
+__global__ __launch_bounds__(256) void welch_partial_kernel(const float *__restrict__ psd, float *__restrict__ partial, unsigned long nframes, int N)
+{
+    int j = blockIdx.x * 256 + threadIdx.x;
+    unsigned long c = blockIdx.y, f0 = c * WELCH_CHUNK, f1 = f0 + WELCH_CHUNK < nframes ? f0 + WELCH_CHUNK : nframes;
+    if (j >= N) return;
+    float acc = 0.f;
+    for (unsigned long f = f0; f < f1; f++) acc += psd[f * N + j];
+    partial[c * N + j] = acc;
+}
+
+__global__ __launch_bounds__(256) void welch_final_kernel(const float *__restrict__ partial, unsigned long nchunks, float *__restrict__ sum, int N)
+{
+    int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    float acc = sum[j];
+    for (unsigned long c = 0; c < nchunks; c++) acc += partial[c * N + j];
+    sum[j] = acc;
 }
 
 }  // namespace lrhip

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const 
     const int L = FFTN - V;
     // L is a multiple of 64 samples, so window and output rows keep the 16-B alignment of x and y
     const bool xy_aligned16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && ((V & 1) == 0);
+    (void)xy_aligned16;
     const int sub = lane & 3, k1s = lane >> 2;       // stages 2 and 3: sub = t2 or q, k1s = k1
     constexpr int BPW = S == 2 ? 1 : 2;               // stream blocks per FFT
 

@@ -718,6 +718,76 @@ static FftStage *fft_build(unsigned n)
 }
 
 // =====================================================================================================
+// Welch-averaged spectrum (the arithmetic of GnuplotSpectrumSink)
+// =====================================================================================================
+struct WelchStage : lrhip_stage {
+    std::unique_ptr<FftStage> psd;
+    int N = 0, hop = 0;
+    unsigned long P = 0;            // pending samples (< N once a frame could be cut)
+    long count = 0;                 // frames accumulated
+    DeviceBuf pending[2], frames, spectra, partial, sum;
+    PinnedBuf h_avg;
+    int cur = 0;
+    const char *kind() const override { return "welch"; }
+    unsigned long max_output(unsigned long) const override { return 0; }
+    int clear()
+    {
+        count = 0;
+        return zero_fill(sum, (size_t)N * sizeof(float));
+    }
+    int reset() override
+    {
+        P = 0; cur = 0;
+        if (pending[0].reserve((size_t)N * in_size) || pending[1].reserve((size_t)N * in_size)) return -1;
+        return clear();
+    }
+    template <typename T>
+    long run_t(const T *x, unsigned long n)
+    {
+        unsigned long total = P + n;
+        unsigned long nf = total >= (unsigned long)N ? (total - N) / hop + 1 : 0;
+        const T *pend = (const T *)pending[cur].p;
+        if (nf) {
+            const void *frames_in;
+            if (P == 0 && hop == N) frames_in = x;             // contiguous frames: no gather
+            else {
+                if (frames.reserve(nf * N * sizeof(T))) return -1;
+                hipLaunchKernelGGL(welch_gather_kernel<T>, dim3(grid_for(nf * N, 256, ctx().num_cus * 16)), dim3(256), 0, ctx().stream, pend, P, x,
+                                   (T *)frames.p, nf, N, hop);
+                LR_LAUNCH_CHECK();
+                frames_in = frames.p;
+            }
+            if (spectra.reserve(nf * N * sizeof(float))) return -1;
+            long got = psd->run(frames_in, nf * N, spectra.p, nf * N);
+            if (got < 0) return got;
+            unsigned long nchunks = (nf + WELCH_CHUNK - 1) / WELCH_CHUNK;
+            if (partial.reserve(nchunks * N * sizeof(float))) return -1;
+            if (nchunks > 65535) return set_error("welch: more than %d frames in one call", 65535 * WELCH_CHUNK);
+            dim3 g((N + 255) / 256, (unsigned)nchunks);
+            hipLaunchKernelGGL(welch_partial_kernel, g, dim3(256), 0, ctx().stream, (const float *)spectra.p, (float *)partial.p, nf, N);
+            hipLaunchKernelGGL(welch_final_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx().stream, (const float *)partial.p, nchunks, (float *)sum.p, N);
+            LR_LAUNCH_CHECK();
+            count += (long)nf;
+        }
+        // what is left after the last frame start + hop: the overlap of the last frame plus the unconsumed tail
+        unsigned long start = nf * hop, left = total - start;
+        if (left) {
+            hipLaunchKernelGGL(welch_pending_kernel<T>, dim3((unsigned)((left + 255) / 256)), dim3(256), 0, ctx().stream, pend, P, x, start,
+                               (T *)pending[cur ^ 1].p, left);
+            LR_LAUNCH_CHECK();
+        }
+        cur ^= 1;
+        P = left;
+        return 0;
+    }
+    long run(const void *in_dev, unsigned long n, void *, unsigned long) override
+    {
+        if (!n) return 0;
+        return in_size == 8 ? run_t<float2>((const float2 *)in_dev, n) : run_t<float>((const float *)in_dev, n);
+    }
+};
+
+// =====================================================================================================
 // IQFileSource / RealFileSource format conversion
 // =====================================================================================================
 struct FormatStage : lrhip_stage {
@@ -789,6 +859,11 @@ struct BinaryStage : lrhip_stage {
         if (n > cap) return set_error("binary: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
         unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+        if (op == BIN_F2C) {
+            hipLaunchKernelGGL(float_to_complex_kernel, dim3(grid), dim3(256), 0, ctx().stream, (const float *)a, (const float *)b, (float2 *)y, n);
+            LR_LAUNCH_CHECK();
+            return (long)n;
+        }
 #define LR_BIN(K, OP, T) hipLaunchKernelGGL((K<OP>), dim3(grid), dim3(256), 0, ctx().stream, (const T *)a, (const T *)b, (T *)y, n)
         if (in_size == 8) {
             switch (op) {
@@ -1176,6 +1251,38 @@ lrhip_stage_t *lrhip_psd_create(unsigned n, const float *window, double scale, i
     return q;
 }
 
+lrhip_stage_t *lrhip_welch_create(unsigned n, const float *window, double scale, int logarithmic, int input_complex, unsigned overlap)
+{
+    if (overlap >= n) { set_error("welch: overlap %u must be smaller than the frame length %u", overlap, n); return nullptr; }
+    std::unique_ptr<FftStage> psd((FftStage *)lrhip_psd_create(n, window, scale, logarithmic, input_complex, 1));
+    if (!psd) return nullptr;
+    std::unique_ptr<WelchStage> q(new (std::nothrow) WelchStage());
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->N = (int)n; q->hop = (int)(n - overlap);
+    q->in_size = input_complex ? 8 : 4; q->out_size = 4;
+    q->psd = std::move(psd);
+    if (q->reset()) return nullptr;
+    return q.release();
+}
+
+long lrhip_welch_read(lrhip_stage_t *q, float *avg_host, int reset)
+{
+    WelchStage *w = q ? dynamic_cast<WelchStage *>(q) : nullptr;
+    if (!w) return set_error("welch_read: not a welch stage");
+    long frames = w->count;
+    if (frames > 0) {
+        if (!avg_host) return set_error("null output buffer");
+        size_t bytes = (size_t)w->N * sizeof(float);
+        if (w->h_avg.reserve(bytes)) return -1;
+        LR_HIP(hipMemcpyAsync(w->h_avg.p, w->sum.p, bytes, hipMemcpyDeviceToHost, ctx().stream));
+        LR_HIP(hipStreamSynchronize(ctx().stream));
+        const float *src = (const float *)w->h_avg.p;
+        for (int i = 0; i < w->N; i++) avg_host[i] = src[i] / (float)frames;      // gnuplotspectrum.lua:179-181
+    }
+    if (reset && w->clear()) return -1;
+    return frames;
+}
+
 lrhip_stage_t *lrhip_dft_create(unsigned n, int inverse, int real_side)
 {
     FftStage *q = fft_build(n);
@@ -1319,7 +1426,7 @@ lrhip_stage_t *lrhip_binary_create(const char *op, int input_complex)
 {
     if (!op) { set_error("binary: missing operation name"); return nullptr; }
     int code = !strcmp(op, "multiply") ? BIN_MULTIPLY : !strcmp(op, "multiplyconjugate") ? BIN_MULTIPLY_CONJ
-             : !strcmp(op, "add") ? BIN_ADD : !strcmp(op, "subtract") ? BIN_SUBTRACT : -1;
+             : !strcmp(op, "add") ? BIN_ADD : !strcmp(op, "subtract") ? BIN_SUBTRACT : !strcmp(op, "floattocomplex") ? BIN_F2C : -1;
     if (code < 0) { set_error("binary: unknown operation \"%s\"", op); return nullptr; }
     if (code == BIN_MULTIPLY_CONJ && !input_complex) { set_error("binary: multiplyconjugate takes ComplexFloat32 inputs (multiplyconjugate.lua:26)"); return nullptr; }
     if (ensure_init()) return nullptr;
@@ -1327,6 +1434,7 @@ lrhip_stage_t *lrhip_binary_create(const char *op, int input_complex)
     if (!q) { set_error("out of memory"); return nullptr; }
     q->op = code;
     q->in_size = q->out_size = input_complex ? 8 : 4;
+    if (code == BIN_F2C) { q->in_size = 4; q->out_size = 8; }
     return q;
 }
 
@@ -1345,7 +1453,7 @@ unsigned long lrhip_stage_max_output(const lrhip_stage_t *q, unsigned long n_in)
 long lrhip_stage_execute_device(lrhip_stage_t *q, const void *in_dev, unsigned long n_in, void *out_dev, unsigned long out_capacity)
 {
     if (!q) return set_error("null stage");
-    if (n_in && (!in_dev || !out_dev)) return set_error("null buffer");
+    if (n_in && (!in_dev || (!out_dev && q->max_output(n_in)))) return set_error("null buffer");
     return q->run(in_dev, n_in, out_dev, out_capacity);
 }
 

@@ -99,3 +99,48 @@ def fftshift(samples):
     tmp = samples[:off].copy()
     samples[:off] = samples[off:2 * off]
     samples[off:2 * off] = tmp
+
+
+
+class WelchSpectrum(_Transform):
+    """The arithmetic of GnuplotSpectrumSink / GnuplotWaterfallSink (radio/blocks/sinks/gnuplotspectrum.lua:104-134,
+    140-193): frames of num_samples every num_samples - floor(overlap*num_samples) samples, log PSD of each frame,
+    fftshift, running average; the gnuplot text protocol itself stays on the host and is out of scope.
+
+    WelchSpectrum(data_type[, num_samples=1024[, window='hamming'[, sample_rate=2[, overlap=0.0[, reference_level=0.0]]]]])
+    process(x) consumes a chunk; average() returns (mean PSD - reference_level) and resets, or None if no frame is complete."""
+
+    def __init__(self, data_type, num_samples=1024, window=None, sample_rate=None, overlap=0.0, reference_level=0.0, logarithmic=True):
+        super().__init__()
+        if data_type not in (types.ComplexFloat32, types.Float32):
+            raise TypeError("Unsupported input samples data type.")
+        if num_samples % 2:
+            raise ValueError("PSD length must be even.")
+        self.data_type, self.num_samples = data_type, int(num_samples)
+        self.num_overlap = int(np.floor(overlap * num_samples))                  # gnuplotspectrum.lua:121
+        self.reference_level = reference_level
+        self.sample_rate = sample_rate or 2
+        self.window = types.Float32.vector_from_array(window_utils.window(self.num_samples, window or "hamming", True))
+        energy = 0.0
+        for v in self.window:
+            energy = energy + float(v) * float(v)
+        self._stage = _lib.check_ptr(
+            _lib.load().lrhip_welch_create(self.num_samples, self.window.ctypes.data_as(C.POINTER(C.c_float)), self.sample_rate * energy,
+                                           int(logarithmic), int(data_type is types.ComplexFloat32), self.num_overlap),
+            "Creating lrhip welch object")
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, dtype=self.data_type.dtype)
+        n = _lib.load().lrhip_stage_execute(self._stage, x.ctypes.data_as(C.c_void_p), len(x), None, 0)
+        _lib.check(n, "WelchSpectrum:process")
+
+    def process_device(self, in_ptr, n):
+        _lib.check(_lib.load().lrhip_stage_execute_device(self._stage, in_ptr, n, None, 0), "WelchSpectrum:process_device")
+
+    def average(self, reset=True):
+        out = np.empty(self.num_samples, np.float32)
+        frames = _lib.check(_lib.load().lrhip_welch_read(self._stage, out.ctypes.data_as(C.POINTER(C.c_float)), int(reset)), "WelchSpectrum:average")
+        if not frames:
+            return None
+        self.frames = int(frames)
+        return out - np.float32(self.reference_level)

@@ -303,6 +303,44 @@ def fftshift(x):
     return xf.view(np.complex64) if xc else xf
 
 
+class WelchSpectrum:
+    """GnuplotSpectrumSink's averaging loop, radio/blocks/sinks/gnuplotspectrum.lua:140-193, restated with the oracle's PSD:
+    fill a state buffer of num_samples, PSD (logarithmic) -> fftshift -> accumulate (Float32), keep num_overlap samples.
+    No golden vectors exist for the sink in the reference (it writes gnuplot text); this restatement is pinned only
+    through the PSD / fftshift vectors of tests/utilities/spectrum_utils_vectors.gen.lua."""
+
+    def __init__(self, is_complex, num_samples=1024, window_type="hamming", sample_rate=2.0, overlap=0.0, reference_level=0.0):
+        self.n, self.window_type, self.sample_rate = num_samples, window_type, sample_rate
+        self.num_overlap = int(np.floor(overlap * num_samples))          # :121
+        self.reference_level = reference_level
+        self.state = np.zeros(num_samples, np.complex64 if is_complex else np.float32)
+        self.state_index = 0
+        self.acc = np.zeros(num_samples, np.float32)
+        self.count = 0
+
+    def process(self, x):
+        i = 0
+        while i < len(x):                                                 # :149-172
+            num = min(self.n - self.state_index, len(x) - i)
+            self.state[self.state_index:self.state_index + num] = x[i:i + num]
+            self.state_index += num
+            i += num
+            if self.state_index == self.n:
+                p = fftshift(psd(self.state, self.window_type, self.sample_rate, True))
+                self.acc = (self.acc + p).astype(np.float32)              # Float32 accumulation, frame order
+                self.count += 1
+                self.state[:self.num_overlap] = self.state[self.n - self.num_overlap:].copy()
+                self.state_index = self.num_overlap
+
+    def average(self):
+        if not self.count:
+            return None
+        out = (self.acc / np.float32(self.count) - np.float32(self.reference_level)).astype(np.float32)   # :179-181
+        self.acc[:] = 0
+        self.count = 0
+        return out
+
+
 def multiply_conjugate(a, b):
     af, _ = _as_f32(np.asarray(a, np.complex64))
     bf, _ = _as_f32(np.asarray(b, np.complex64))

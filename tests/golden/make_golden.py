@@ -56,6 +56,10 @@ SPECS = [
     "blocks/signal/realtocomplex_spec",
     "blocks/signal/absolutevalue_spec",
     "blocks/signal/delay_spec",
+    "blocks/signal/singlepolehighpassfilter_spec",
+    "blocks/signal/fmpreemphasisfilter_spec",
+    "blocks/signal/floattocomplex_spec",
+    "blocks/signal/complextofloat_spec",
     "blocks/signal/hilberttransform_spec",
     "blocks/signal/upsampler_spec",
     "blocks/signal/complexbandpassfilter_spec",

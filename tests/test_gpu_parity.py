@@ -663,6 +663,115 @@ def test_golden_rank3_blocks(name, cls, exact):
         _golden_both_modes(getattr(lr, cls), vec, doc["epsilon"], exact=exact)
 
 
+@pytest.mark.parametrize("name,cls", [("singlepolehighpassfilter_spec", "SinglepoleHighpassFilterBlock"),
+                                      ("fmpreemphasisfilter_spec", "FMPreemphasisFilterBlock")])
+def test_golden_highpass_iir_blocks(name, cls):
+    doc = G.load(name)
+    for vec in doc["vectors"]:
+        _golden_both_modes(getattr(lr, cls), vec, doc["epsilon"])
+
+
+def test_golden_floattocomplex_complextofloat():
+    doc = G.load("floattocomplex_spec")
+    for vec in doc["vectors"]:
+        a, b = vec["inputs"]
+        blk = lr.FloatToComplexBlock()
+        blk.differentiate([types.Float32, types.Float32])
+        blk.initialize()
+        assert np.array_equal(blk.process(a, b), vec["outputs"][0])
+        one = np.concatenate([blk.process(a[i:i + 1], b[i:i + 1]) for i in range(len(a))])
+        assert np.array_equal(one, vec["outputs"][0])
+    doc = G.load("complextofloat_spec")
+    for vec in doc["vectors"]:
+        blk = make(lr.ComplexToFloatBlock, [], vec["inputs"][0])
+        re, im = blk.process(vec["inputs"][0])
+        assert np.array_equal(re, vec["outputs"][0]) and np.array_equal(im, vec["outputs"][1])
+
+
+@pytest.mark.parametrize("which", ["nbfm", "am", "ssb-usb", "ssb-lsb"])
+def test_feedforward_demodulators_vs_oracle_chain(which):
+    """radio/composites/{nbfmdemodulator,amenvelopedemodulator,ssbdemodulator}.lua as device chains, against the same
+    blocks chained in the oracle (LUA arithmetic), ragged chunks, RMS error <= 1e-5 of the output RMS"""
+    rate = 48000.0
+    rng = np.random.default_rng(77)
+    n = 60000
+    t = np.arange(n) / rate
+    audio = np.sin(2 * np.pi * 700 * t) + 0.5 * np.sin(2 * np.pi * 1900 * t)
+    if which == "nbfm":
+        x = np.exp(1j * 2 * np.pi * 5e3 * np.cumsum(audio) / rate)
+        blk = lr.NBFMDemodulator()
+        stages = [O.lowpass(128, 9e3, rate, True), O.FMDiscriminator(5e3 / 4e3), O.lowpass(128, 4e3, rate, False)]
+    elif which == "am":
+        x = (1 + 0.5 * audio) * np.exp(1j * 0.3)
+        blk = lr.AMEnvelopeDemodulator()
+        b, a = _singlepole_highpass_taps(100, rate)
+        stages = [_OracleFn(lambda v: np.abs(v.astype(np.complex128)).astype(np.float32)), O.IIR(b, a, False), O.lowpass(128, 5e3, rate, False)]
+    else:
+        sb = which[-3:]
+        x = (audio + 0j) * np.exp(1j * 2 * np.pi * 100 * t)
+        blk = lr.SSBDemodulator(sb)
+        taps = lr.filter_utils.firwin_complex_bandpass(129, [0, -3e3 / (rate / 2)] if sb == "lsb" else [0, 3e3 / (rate / 2)])
+        stages = [O.FIR(types.ComplexFloat32.vector_from_array(taps), True), _OracleFn(lambda v: np.ascontiguousarray(v.real)), O.lowpass(128, 3e3, rate, False)]
+    x = (x + 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    blk.rate = rate
+    blk.differentiate([types.ComplexFloat32])
+    blk.initialize()
+    got, want, pos = [], [], 0
+    for size in [1, 777, 4096, 20000, 13, n]:
+        chunk = x[pos:pos + size]
+        pos += len(chunk)
+        got.append(blk.process(chunk))
+        v = chunk
+        for st in stages:
+            v = st.process(v)
+        want.append(v)
+    got, want = np.concatenate(got), np.concatenate(want)
+    assert len(got) == len(want) == n
+    rms = float(np.sqrt(np.mean(want.astype(np.float64) ** 2)))
+    err = float(np.sqrt(np.mean((got.astype(np.float64) - want) ** 2)))
+    assert rms > 1e-3 and err <= 1e-5 * max(rms, 1.0), (which, err, rms)
+
+
+class _OracleFn:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def process(self, x):
+        return self.fn(x)
+
+
+def _singlepole_highpass_taps(cutoff, rate):
+    """singlepolehighpassfilter.lua:34-45 in double precision, rounded to Float32 like the reference's tap vectors"""
+    import math
+    tau = 1 / (2 * math.pi * cutoff)
+    tau = 1 / (2 * rate * math.tan(1 / (2 * rate * tau)))
+    k = 2 * tau * rate
+    return np.array([k / (1 + k), -k / (1 + k)], np.float32), np.array([1, (1 - k) / (1 + k)], np.float32)
+
+
+@pytest.mark.parametrize("is_complex,overlap", [(True, 0.0), (True, 0.5), (False, 0.25)])
+def test_welch_spectrum_vs_oracle(is_complex, overlap):
+    """GnuplotSpectrumSink's averaging (gnuplotspectrum.lua:140-193) on the device vs its restatement, ragged chunks"""
+    rng = np.random.default_rng(90)
+    n = 200000
+    x = rand_c(rng, n) if is_complex else rng.standard_normal(n).astype(np.float32)
+    x = x + (np.exp(2j * np.pi * 0.1 * np.arange(n)).astype(np.complex64) if is_complex else np.cos(2 * np.pi * 0.1 * np.arange(n)).astype(np.float32))
+    dev = lr.spectrum_utils.WelchSpectrum(types.ComplexFloat32 if is_complex else types.Float32, 1024, "hamming", 1e6, overlap, 10.0)
+    ora = O.WelchSpectrum(is_complex, 1024, "hamming", 1e6, overlap, 10.0)
+    assert dev.average() is None
+    pos = 0
+    for size in [100, 1024, 5000, 1, 923, 70000, 333, n]:
+        chunk = x[pos:pos + size]
+        pos += len(chunk)
+        dev.process(chunk)
+        ora.process(chunk)
+        if size in (5000, 70000, n):
+            got, want = dev.average(), ora.average()
+            assert dev.frames > 0 and got is not None and want is not None
+            assert np.max(np.abs(got - want)) < 2e-3, (size, float(np.max(np.abs(got - want))))     # dB; f32 sums of ~ -60 dB values
+    assert dev.average() is None
+
+
 def test_golden_binary_blocks():
     for name, cls in (("multiply_spec", lr.MultiplyBlock), ("multiplyconjugate_spec", lr.MultiplyConjugateBlock),
                       ("add_spec", lr.AddBlock), ("subtract_spec", lr.SubtractBlock)):
