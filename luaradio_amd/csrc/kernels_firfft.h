@@ -29,16 +29,8 @@
 #include "common.h"
 #include "kernels_fir.h"
 
-#ifndef LRHIP_FFT_PREFETCH
-#define LRHIP_FFT_PREFETCH 0
-#endif
 // 1: exchange re and im planes one after the other through a half-size per-wave buffer (34 KB of LDS per
 //    workgroup -> 4 workgroups = 16 waves per CU); 0: one ds_*_b64 pass (52 KB -> 12 waves per CU)
-// 1: global loads/stores of the complex path go 16 B per lane through an extra LDS transpose; 0: 8 B per lane directly.
-// Measured equal (247 vs 248 GS/s): the extra LDS round trips cancel what the wider accesses buy, so the simple path is the default.
-#ifndef LRHIP_FFT_VEC
-#define LRHIP_FFT_VEC 0
-#endif
 #ifndef LRHIP_FFT_SPLIT
 #define LRHIP_FFT_SPLIT 0
 #endif
@@ -57,66 +49,108 @@ constexpr int FFT_LDS_TW2 = FFT_LDS_H + 16 * 64;
 constexpr int FFT_LDS_ELEMS = FFT_LDS_TW2 + 64;
 constexpr int FFT_TABLE_ELEMS = 16 * 64 + 16 * 64 + 64;   // tw1 | Hperm | tw2, as uploaded by the host
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+// Complex values live in one 64-bit VGPR pair (re, im) so that the butterflies run on the packed-f32 VALU ops
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two flops per lane-instruction - the plain f32 ops are half rate on CDNA).
+// Swizzles (re <-> im, broadcast) are expressed as shuffles, which hipcc folds into op_sel; the two products that need a
+// one-sided negation (neg_lo / neg_hi) are written as inline VOP3P instructions because the compiler materialises such a
+// negation as a separate v_xor.  LRHIP_FFT_PACKED=0 keeps the scalar formulation for A/B measurements.
+#ifndef LRHIP_FFT_PACKED
+#define LRHIP_FFT_PACKED 1
+#endif
+typedef float cf __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ cf cf_from(float2 a) { return cf{a.x, a.y}; }
+__device__ __forceinline__ float2 cf_to(cf a) { return make_float2(a.x, a.y); }
+
+#if LRHIP_FFT_PACKED
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+// a + j*b, a - j*b: one packed fma with a (-1, 1) / (1, -1) constant pair; exact (the product is +-b)
+__device__ __forceinline__ cf add_j(cf a, cf b) { return __builtin_elementwise_fma(__builtin_shufflevector(b, b, 1, 0), cf{-1.f, 1.f}, a); }
+__device__ __forceinline__ cf sub_j(cf a, cf b) { return __builtin_elementwise_fma(__builtin_shufflevector(b, b, 1, 0), cf{1.f, -1.f}, a); }
+__device__ __forceinline__ cf cmul(cf a, cf w)
 {
-    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+    cf t = __builtin_shufflevector(a, a, 0, 0) * w, r;          // (a.x w.x, a.x w.y)
+    // (-a.y w.y + t.x, a.y w.x + t.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
 }
-// a * conj(b)
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b)
+// a * conj(w)
+__device__ __forceinline__ cf cmulc(cf a, cf w)
 {
-    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+    cf t;                                                       // (a.x w.x, -a.x w.y)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    return __builtin_elementwise_fma(__builtin_shufflevector(a, a, 1, 1), __builtin_shufflevector(w, w, 1, 0), t);
 }
+// a * (WX + j WY) for a compile-time constant: both operand pairs are constants, no negation needed
+__device__ __forceinline__ cf cmul_const(cf a, float wx, float wy)
+{
+    cf t = __builtin_shufflevector(a, a, 0, 0) * cf{wx, wy};
+    return __builtin_elementwise_fma(__builtin_shufflevector(a, a, 1, 1), cf{-wy, wx}, t);
+}
+#else
+__device__ __forceinline__ cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf add_j(cf a, cf b) { return cf{a.x - b.y, a.y + b.x}; }
+__device__ __forceinline__ cf sub_j(cf a, cf b) { return cf{a.x + b.y, a.y - b.x}; }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return cf{fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x)}; }
+__device__ __forceinline__ cf cmulc(cf a, cf b) { return cf{fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y)}; }
+__device__ __forceinline__ cf cmul_const(cf a, float wx, float wy) { return cmul(a, cf{wx, wy}); }
+#endif
 
 // DIR = +1: forward (kernel e^{-j...}), -1: inverse.  In-place 4-point DFT, natural order out.
-template <int DIR>
-__device__ __forceinline__ void radix4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
+// A2J: a2 carries a pending factor W_16^(4*DIR) = -j*DIR (dft16's only trivial twiddle), folded into the first butterfly.
+template <int DIR, bool A2J = false>
+__device__ __forceinline__ void radix4(cf &a0, cf &a1, cf &a2, cf &a3)
 {
-    float2 b0 = cadd(a0, a2), b1 = csub(a0, a2), b2 = cadd(a1, a3), d = csub(a1, a3);
-    float2 b3 = DIR > 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);   // d * (-j) or d * (+j)
+    cf b0, b1;
+    if (!A2J) { b0 = cadd(a0, a2); b1 = csub(a0, a2); }
+    else if (DIR > 0) { b0 = sub_j(a0, a2); b1 = add_j(a0, a2); }
+    else { b0 = add_j(a0, a2); b1 = sub_j(a0, a2); }
+    cf b2 = cadd(a1, a3), d = csub(a1, a3);
     a0 = cadd(b0, b2);
     a2 = csub(b0, b2);
-    a1 = cadd(b1, b3);
-    a3 = csub(b1, b3);
+    a1 = DIR > 0 ? sub_j(b1, d) : add_j(b1, d);     // b1 + d * (-j) (forward) or d * (+j) (inverse)
+    a3 = DIR > 0 ? add_j(b1, d) : sub_j(b1, d);
 }
 
-// multiply by W_16^(DIR*p), p in {1,2,3,4,6,9}
+// multiply by W_16^(DIR*p), p in {1,2,3,6,9}
 template <int DIR, int P>
-__device__ __forceinline__ float2 mul_w16(float2 a)
+__device__ __forceinline__ cf mul_w16(cf a)
 {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
-    if constexpr (P == 1) return DIR > 0 ? cmul(a, make_float2(C1, -S1)) : cmul(a, make_float2(C1, S1));
-    if constexpr (P == 2) return DIR > 0 ? make_float2((a.x + a.y) * R, (a.y - a.x) * R) : make_float2((a.x - a.y) * R, (a.y + a.x) * R);
-    if constexpr (P == 3) return DIR > 0 ? cmul(a, make_float2(S1, -C1)) : cmul(a, make_float2(S1, C1));
-    if constexpr (P == 4) return DIR > 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
-    if constexpr (P == 6) return DIR > 0 ? make_float2((a.y - a.x) * R, -(a.x + a.y) * R) : make_float2(-(a.x + a.y) * R, (a.x - a.y) * R);
-    if constexpr (P == 9) return DIR > 0 ? cmul(a, make_float2(-C1, S1)) : cmul(a, make_float2(-C1, -S1));
+    constexpr float D = DIR > 0 ? -1.f : 1.f;          // sign of the imaginary part
+    if constexpr (P == 1) return cmul_const(a, C1, D * S1);
+    if constexpr (P == 2) return cmul_const(a, R, D * R);
+    if constexpr (P == 3) return cmul_const(a, S1, D * C1);
+    if constexpr (P == 6) return cmul_const(a, -R, D * R);
+    if constexpr (P == 9) return cmul_const(a, -C1, -D * S1);
     return a;
 }
 
 // 16-point DFT of v[0..15] (index n = 4a + b), result in natural order: v[k] = sum_n v[n] W_16^(DIR*n*k)
 template <int DIR>
-__device__ __forceinline__ void dft16(float2 (&v)[16])
+__device__ __forceinline__ void dft16(cf (&v)[16])
 {
     // radix-4 over a for every b: afterwards position 4c+b holds u[b][c]
 #pragma unroll
     for (int b = 0; b < 4; b++) radix4<DIR>(v[b], v[4 + b], v[8 + b], v[12 + b]);
-    // twiddle W_16^(b*c)
+    // twiddle W_16^(b*c); W_16^4 of position 4*2+2 is folded into the radix-4 below
     v[4 * 1 + 1] = mul_w16<DIR, 1>(v[4 * 1 + 1]);
     v[4 * 1 + 2] = mul_w16<DIR, 2>(v[4 * 1 + 2]);
     v[4 * 1 + 3] = mul_w16<DIR, 3>(v[4 * 1 + 3]);
     v[4 * 2 + 1] = mul_w16<DIR, 2>(v[4 * 2 + 1]);
-    v[4 * 2 + 2] = mul_w16<DIR, 4>(v[4 * 2 + 2]);
     v[4 * 2 + 3] = mul_w16<DIR, 6>(v[4 * 2 + 3]);
     v[4 * 3 + 1] = mul_w16<DIR, 3>(v[4 * 3 + 1]);
     v[4 * 3 + 2] = mul_w16<DIR, 6>(v[4 * 3 + 2]);
     v[4 * 3 + 3] = mul_w16<DIR, 9>(v[4 * 3 + 3]);
     // radix-4 over b for every c: position 4c+d holds X[c + 4d]
-#pragma unroll
-    for (int c = 0; c < 4; c++) radix4<DIR>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    radix4<DIR>(v[0], v[1], v[2], v[3]);
+    radix4<DIR>(v[4], v[5], v[6], v[7]);
+    radix4<DIR, true>(v[8], v[9], v[10], v[11]);
+    radix4<DIR>(v[12], v[13], v[14], v[15]);
     // un-permute (compile-time renaming): natural[c + 4d] = v[4c + d]
-    float2 t;
+    cf t;
     t = v[1]; v[1] = v[4]; v[4] = t;
     t = v[2]; v[2] = v[8]; v[8] = t;
     t = v[3]; v[3] = v[12]; v[12] = t;
@@ -127,7 +161,7 @@ __device__ __forceinline__ void dft16(float2 (&v)[16])
 
 // register <-> LDS transpose: lane writes v[k] to element widx(k), then reads element ridx(i) into v[i]
 template <typename WI, typename RI>
-__device__ __forceinline__ void exchange(float2 *ex, float2 (&v)[16], WI widx, RI ridx)
+__device__ __forceinline__ void exchange(cf *ex, cf (&v)[16], WI widx, RI ridx)
 {
 #if LRHIP_FFT_SPLIT
     float *exf = reinterpret_cast<float *>(ex);
@@ -139,7 +173,7 @@ __device__ __forceinline__ void exchange(float2 *ex, float2 (&v)[16], WI widx, R
 #pragma unroll
     for (int k = 0; k < 16; k++) exf[widx(k)] = v[k].y;      // in-order DS queue: the re reads above are already issued
 #pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = make_float2(re[i], exf[ridx(i)]);
+    for (int i = 0; i < 16; i++) v[i] = cf{re[i], exf[ridx(i)]};
 #else
 #pragma unroll
     for (int k = 0; k < 16; k++) ex[widx(k)] = v[k];
@@ -183,9 +217,11 @@ __global__ __launch_bounds__(256, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const 
                                                           double inv_gain, const float2 *__restrict__ disc_prev)
 {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float2 *ex = fl + wave * FFT_EX_ELEMS;
-    const float2 *tw1 = fl + FFT_LDS_TW1, *Hp = fl + FFT_LDS_H, *tw2 = fl + FFT_LDS_TW2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: block addresses and bounds stay on the SALU
+    cf *flc = reinterpret_cast<cf *>(fl);
+    cf *ex = flc + wave * FFT_EX_ELEMS;
+    const cf *tw1 = flc + FFT_LDS_TW1, *Hp = flc + FFT_LDS_H, *tw2 = flc + FFT_LDS_TW2;
 
     for (int i = tid; i < FFT_TABLE_ELEMS; i += 256) fl[FFT_LDS_TW1 + i] = tables[i];
     __syncthreads();
@@ -194,96 +230,48 @@ __global__ __launch_bounds__(256, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const 
     // AND its stored rows start on 512-B boundaries relative to x / y (L = 897 would misalign every row)
     const int V = ((M - 1 + 63) / 64) * 64;
     const int L = FFTN - V;
-    // L is a multiple of 64 samples, so window and output rows keep the 16-B alignment of x and y
-    const bool xy_aligned16 = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && ((V & 1) == 0);
-    (void)xy_aligned16;
     const int sub = lane & 3, k1s = lane >> 2;       // stages 2 and 3: sub = t2 or q, k1s = k1
     constexpr int BPW = S == 2 ? 1 : 2;               // stream blocks per FFT
 
     const long fstep = (long)gridDim.x * 4;
-#if LRHIP_FFT_PREFETCH
-    // register prefetch (S = 2): the next block's 16 loads are issued before this block's arithmetic
-    float2 pre[16];
-    bool have = false;
-    auto interior = [&](long b) { long lo = b * L - V; return b * BPW < nblocks && lo >= 0 && lo + FFTN <= n; };
-    if (S == 2 && interior((long)blockIdx.x * 4 + wave)) {
-        const float2 *src = reinterpret_cast<const float2 *>(x) + (((long)blockIdx.x * 4 + wave) * L - V) + lane;
-#pragma unroll
-        for (int i = 0; i < 16; i++) pre[i] = src[64 * i];
-        have = true;
-    }
-#endif
     for (long fb = (long)blockIdx.x * 4 + wave; fb * BPW < nblocks; fb += fstep) {
-        float2 v[16];
+        cf v[16];
         // ---- load: window position 64*i + lane  (stream = [M-1 history | chunk])
+        // (measured and dropped: register prefetch of the next block, 16-B accesses through an LDS transpose - no gain)
         if (S == 2) {
             const long xlo = fb * L - V;                  // x index of window position 0
             const long p0 = xlo + (M - 1);                // the same in stream coordinates
-#if LRHIP_FFT_PREFETCH
-            if (have) {
-#pragma unroll
-                for (int i = 0; i < 16; i++) v[i] = pre[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    long p = p0 + 64 * i + lane;
-                    v[i] = make_float2(stream_at<2>(hist, x, p, 0, M, n), stream_at<2>(hist, x, p, 1, M, n));
-                }
-            }
-            have = interior(fb + fstep);
-            if (have) {
-                const float2 *src = reinterpret_cast<const float2 *>(x) + ((fb + fstep) * L - V) + lane;
-#pragma unroll
-                for (int i = 0; i < 16; i++) pre[i] = src[64 * i];
-            }
-#else
-#if LRHIP_FFT_VEC
-            if (xlo >= 0 && xlo + FFTN <= n && xy_aligned16) {
-                // 16 B per lane from global (1 KB per wave instruction), transposed to the FFT's lane layout through the
-                // wave's exchange buffer: lane l loads samples 128i + 2l, 128i + 2l + 1 and reads back 64*n1 + l
-                const float4 *src4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(x) + xlo) + lane;
-                float4 ld[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) ld[i] = src4[64 * i];
-#pragma unroll
-                for (int i = 0; i < 8; i++) reinterpret_cast<float4 *>(ex)[64 * i + lane] = ld[i];
-#pragma unroll
-                for (int i = 0; i < 16; i++) v[i] = ex[64 * i + lane];
-            } else
-#endif
             if (xlo >= 0 && xlo + FFTN <= n) {
-                const float2 *src = reinterpret_cast<const float2 *>(x) + xlo + lane;
+                const cf *src = reinterpret_cast<const cf *>(x) + xlo + lane;
 #pragma unroll
                 for (int i = 0; i < 16; i++) v[i] = src[64 * i];
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     long p = p0 + 64 * i + lane;
-                    v[i] = make_float2(stream_at<2>(hist, x, p, 0, M, n), stream_at<2>(hist, x, p, 1, M, n));
+                    v[i] = cf{stream_at<2>(hist, x, p, 0, M, n), stream_at<2>(hist, x, p, 1, M, n)};
                 }
             }
-#endif
         } else {
             const long pa = (fb * 2) * L - V + (M - 1), pb = pa + L;      // stream positions of the two packed blocks
             const long xa = pa - (M - 1), xb = pb - (M - 1);               // their x indices
             if (xa >= PRE && xb + FFTN <= n) {
                 // both windows inside the chunk: coalesced loads, no history
                 if (PRE == 0) {
+                    const float *sa = x + xa + lane, *sb = x + xb + lane;
 #pragma unroll
-                    for (int i = 0; i < 16; i++) v[i] = make_float2(x[xa + 64 * i + lane], x[xb + 64 * i + lane]);
+                    for (int i = 0; i < 16; i++) v[i] = cf{sa[64 * i], sb[64 * i]};
                 } else {
-                    const float2 *c = reinterpret_cast<const float2 *>(x);
+                    const float2 *ca = reinterpret_cast<const float2 *>(x) + xa + lane, *cb = reinterpret_cast<const float2 *>(x) + xb + lane;
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        long ia = xa + 64 * i + lane, ib = xb + 64 * i + lane;
-                        v[i] = make_float2(discriminate(c[ia], c[ia - 1], inv_gain), discriminate(c[ib], c[ib - 1], inv_gain));
-                    }
+                    for (int i = 0; i < 16; i++)
+                        v[i] = cf{discriminate(ca[64 * i], ca[64 * i - 1], inv_gain), discriminate(cb[64 * i], cb[64 * i - 1], inv_gain)};
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; i++)
-                    v[i] = make_float2(fft_real_sample<PRE>(hist, x, pa + 64 * i + lane, M, n, inv_gain, disc_prev),
-                                       fft_real_sample<PRE>(hist, x, pb + 64 * i + lane, M, n, inv_gain, disc_prev));
+                    v[i] = cf{fft_real_sample<PRE>(hist, x, pa + 64 * i + lane, M, n, inv_gain, disc_prev),
+                              fft_real_sample<PRE>(hist, x, pb + 64 * i + lane, M, n, inv_gain, disc_prev)};
             }
         }
 
@@ -327,18 +315,7 @@ __global__ __launch_bounds__(256, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const 
         // firfilter.lua:379 copies output_block[M-1 ..]; we drop up to 63 more so the rows stay aligned)
         if (S == 2) {
             const long o0 = fb * L - V;
-            float2 *dst = reinterpret_cast<float2 *>(y) + o0 + lane;
-#if LRHIP_FFT_VEC
-            if (o0 + FFTN <= n_out && xy_aligned16 && (V & 127) == 0) {
-                // back through the exchange buffer so every lane stores 16 B: rows of 128 samples, the first V/128 dropped
-#pragma unroll
-                for (int i = 0; i < 16; i++) ex[64 * i + lane] = v[i];
-                float4 *dst4 = reinterpret_cast<float4 *>(reinterpret_cast<float2 *>(y) + o0) + lane;
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                    if (128 * i >= V) dst4[64 * i] = reinterpret_cast<const float4 *>(ex)[64 * i + lane];
-            } else
-#endif
+            cf *dst = reinterpret_cast<cf *>(y) + o0 + lane;
             if (o0 + FFTN <= n_out) {
 #pragma unroll
                 for (int i = 0; i < 16; i++)
@@ -352,12 +329,19 @@ __global__ __launch_bounds__(256, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const 
             }
         } else {
             const long oa = (fb * 2) * L - V, ob = oa + L;
+            if (ob + FFTN <= n_out) {
+                float *da = y + oa + lane, *db = y + ob + lane;
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                int nn = 64 * i + lane;
-                if (nn >= V) {
-                    if (oa + nn < n_out) y[oa + nn] = v[i].x;
-                    if (ob + nn < n_out) y[ob + nn] = v[i].y;
+                for (int i = 0; i < 16; i++)
+                    if (64 * i >= V) { da[64 * i] = v[i].x; db[64 * i] = v[i].y; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    int nn = 64 * i + lane;
+                    if (nn >= V) {
+                        if (oa + nn < n_out) y[oa + nn] = v[i].x;
+                        if (ob + nn < n_out) y[ob + nn] = v[i].y;
+                    }
                 }
             }
         }
@@ -385,23 +369,25 @@ __global__ __launch_bounds__(256, 3) void spectrum1024_kernel(const float *__res
                                                                int mode, float out_scale, int shift)
 {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float2 *ex = fl + wave * FFT_EX_ELEMS;
-    const float2 *tw1 = fl + SPEC_LDS_TW1, *tw2 = fl + SPEC_LDS_TW2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    cf *flc = reinterpret_cast<cf *>(fl);
+    cf *ex = flc + wave * FFT_EX_ELEMS;
+    const cf *tw1 = flc + SPEC_LDS_TW1, *tw2 = flc + SPEC_LDS_TW2;
     for (int i = tid; i < SPEC_TABLE_ELEMS; i += 256) fl[SPEC_LDS_TW1 + i] = tables[i];
     __syncthreads();
     const int sub = lane & 3, k1s = lane >> 2;
 
     for (long f = (long)blockIdx.x * 4 + wave; f < nframes; f += (long)gridDim.x * 4) {
-        float2 v[16];
+        cf v[16];
         if (mode <= SPEC_FWD_PSD_LOG) {
             // ---- forward
             if (IN_REAL) {
                 const float *src = x + f * FFTN + lane;
 #pragma unroll
-                for (int i = 0; i < 16; i++) v[i] = make_float2(src[64 * i], 0.f);
+                for (int i = 0; i < 16; i++) v[i] = cf{src[64 * i], 0.f};
             } else {
-                const float2 *src = reinterpret_cast<const float2 *>(x) + f * FFTN + lane;
+                const cf *src = reinterpret_cast<const cf *>(x) + f * FFTN + lane;
 #pragma unroll
                 for (int i = 0; i < 16; i++) v[i] = src[64 * i];
             }
@@ -431,9 +417,9 @@ __global__ __launch_bounds__(256, 3) void spectrum1024_kernel(const float *__res
                 for (int k3 = 0; k3 < 4; k3++) {
                     int k = k1s + 16 * (4 * j + sub) + 256 * k3;
                     int pos = shift ? ((k + FFTN / 2) & (FFTN - 1)) : k;
-                    float2 X = v[4 * j + k3];
+                    cf X = v[4 * j + k3];
                     if (mode == SPEC_FWD_COMPLEX) {
-                        reinterpret_cast<float2 *>(y)[f * FFTN + pos] = make_float2(X.x * out_scale, X.y * out_scale);
+                        reinterpret_cast<cf *>(y)[f * FFTN + pos] = X * cf{out_scale, out_scale};
                     } else {
                         float p = fmaf(X.x, X.x, X.y * X.y) * out_scale;       // spectrum_utils.lua:631-638
                         y[f * FFTN + pos] = mode == SPEC_FWD_PSD_LOG ? 10.0f * log10f(p) : p;
@@ -441,7 +427,7 @@ __global__ __launch_bounds__(256, 3) void spectrum1024_kernel(const float *__res
                 }
         } else {
             // ---- inverse: gather the spectrum in the stage-3 layout, mirror the stages
-            const float2 *src = reinterpret_cast<const float2 *>(x) + f * FFTN;
+            const cf *src = reinterpret_cast<const cf *>(x) + f * FFTN;
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -460,9 +446,9 @@ __global__ __launch_bounds__(256, 3) void spectrum1024_kernel(const float *__res
             for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], tw1[k * 64 + lane]);
             dft16<-1>(v);
             if (mode == SPEC_INV_COMPLEX) {
-                float2 *dst = reinterpret_cast<float2 *>(y) + f * FFTN + lane;
+                cf *dst = reinterpret_cast<cf *>(y) + f * FFTN + lane;
 #pragma unroll
-                for (int i = 0; i < 16; i++) dst[64 * i] = make_float2(v[i].x * out_scale, v[i].y * out_scale);
+                for (int i = 0; i < 16; i++) dst[64 * i] = v[i] * cf{out_scale, out_scale};
             } else {
                 float *dst = y + f * FFTN + lane;
 #pragma unroll
