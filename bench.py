@@ -172,7 +172,7 @@ def main():
         config = {"workload": "configs[2]: examples/rtlsdr_wbfm_mono.lua chain (Tuner -> FrequencyDiscriminator -> Lowpass -> "
                               "FMDeemphasis -> Downsampler) on 2^%d synthetic FM IQ samples @ 1.1025 MS/s, device-resident" % log2n,
                   "samples_per_step_per_gpu": n, "counted": "RF input samples", "parallelism": "independent streams x%d" % world}
-        dominant = "fir_mfma_kernel<S=2,D=5,ROT>"
+        dominant = "fir_mfma_persistent_kernel<2,5,2,true,51>"
     else:
         # fan-out: rank 0 owns the IQ slab; every step it is broadcast over RCCL/xGMI and each rank runs its own
         # Tuner branch (offsets -350 kHz .. +350 kHz step 100 kHz)
@@ -227,6 +227,23 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
 
+    # achievable-bandwidth yardstick on this box: the cheapest streaming kernel of the library (one multiply per scalar,
+    # 8 B in + 8 B out per sample) over the same buffers, HIP-event timed like the workload
+    yard_gbs = None
+    if rank == 0 and args.workload == "fir":
+        mc = lr.MultiplyConstantBlock(1.0)
+        mc.differentiate([types.ComplexFloat32])
+        mc.initialize()
+        mc.process_device(x.data_ptr(), n, y.data_ptr(), n)
+        yt = L.lrhip_timer_create()
+        L.lrhip_timer_start(yt)
+        for _ in range(5):
+            mc.process_device(x.data_ptr(), n, y.data_ptr(), n)
+        L.lrhip_timer_stop(yt)
+        torch.cuda.synchronize()
+        yard_gbs = 16.0 * n * 5 / (L.lrhip_timer_elapsed_ms(yt) / 1e3) / 1e9
+        L.lrhip_timer_destroy(yt)
+
     if rank == 0:
         total = float(out_per_step) * world * args.steps
         launch_s = ev_ms / 1e3 / args.steps          # HIP-event time per step on the launch stream
@@ -252,6 +269,9 @@ def main():
                          "fp32_tflops": round(flops / launch_s / 1e12, 2), "fp32_peak_tflops": FP32_PEAK_TFLOPS,
                          "fp32_frac": round(flops / launch_s / 1e12 / FP32_PEAK_TFLOPS, 4)},
         }
+        if yard_gbs:
+            res["roofline"]["streaming_yardstick"] = {"kernel": "multiply_constant_kernel<1> (8 B in + 8 B out per sample, same buffers)",
+                                                      "GB/s": round(yard_gbs, 1), "frac_of_yardstick": round(achieved / yard_gbs, 4)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "fir":
             res["cpu_baseline"] = cpu_baseline_fir(taps, args.cpu_seconds)
         elif world == 1:

@@ -34,6 +34,15 @@
 #ifndef LRHIP_FFT_SPLIT
 #define LRHIP_FFT_SPLIT 0
 #endif
+// waves per workgroup of fir_fft_kernel: the 17 KB of twiddle / H tables are per workgroup, so larger workgroups fit more
+// waves per CU (4: 3 x 4 = 12 waves, 16: one 1024-thread workgroup = 16 waves)
+#ifndef LRHIP_FFT_WPB
+#define LRHIP_FFT_WPB 4
+#endif
+// 1: the next block's 16 loads are issued into spare registers before this block's arithmetic
+#ifndef LRHIP_FFT_PREFETCH
+#define LRHIP_FFT_PREFETCH 0
+#endif
 
 namespace lrhip {
 
@@ -41,9 +50,10 @@ constexpr int FFTN = 1024;
 constexpr int FFT_E1_ROW = 68;
 constexpr int FFT_E2_ROW = 68;
 constexpr int FFT_EX_ELEMS = LRHIP_FFT_SPLIT ? 16 * FFT_E2_ROW / 2 : 16 * FFT_E2_ROW;   // per-wave exchange buffer (float2 units)
-constexpr int FFT_WAVES_PER_SIMD = LRHIP_FFT_SPLIT ? 4 : 3;
-// LDS map (float2 units): [4 waves x FFT_EX_ELEMS | tw1 16x64 | H 16x64 | tw2 64]
-constexpr int FFT_LDS_TW1 = 4 * FFT_EX_ELEMS;
+constexpr int FFT_WPB = LRHIP_FFT_WPB;
+constexpr int FFT_WAVES_PER_SIMD = FFT_WPB == 16 ? 4 : LRHIP_FFT_SPLIT ? 4 : 3;
+// LDS map (float2 units): [FFT_WPB waves x FFT_EX_ELEMS | tw1 16x64 | H 16x64 | tw2 64]
+constexpr int FFT_LDS_TW1 = FFT_WPB * FFT_EX_ELEMS;
 constexpr int FFT_LDS_H = FFT_LDS_TW1 + 16 * 64;
 constexpr int FFT_LDS_TW2 = FFT_LDS_H + 16 * 64;
 constexpr int FFT_LDS_ELEMS = FFT_LDS_TW2 + 64;
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(256) void fir_fft_pre_history_kernel(const float *_
 }
 
 template <int S, int PRE>
-__global__ __launch_bounds__(256, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const float *__restrict__ hist, const float *__restrict__ x,
+__global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const float *__restrict__ hist, const float *__restrict__ x,
                                                           const float2 *__restrict__ tables, float *__restrict__ y,
                                                           int M, long n, long n_out, long nblocks,
                                                           double inv_gain, const float2 *__restrict__ disc_prev)
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(256, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const 
     cf *ex = flc + wave * FFT_EX_ELEMS;
     const cf *tw1 = flc + FFT_LDS_TW1, *Hp = flc + FFT_LDS_H, *tw2 = flc + FFT_LDS_TW2;
 
-    for (int i = tid; i < FFT_TABLE_ELEMS; i += 256) fl[FFT_LDS_TW1 + i] = tables[i];
+    for (int i = tid; i < FFT_TABLE_ELEMS; i += 64 * FFT_WPB) fl[FFT_LDS_TW1 + i] = tables[i];
     __syncthreads();
 
     // block advance: the overlap is rounded up to a multiple of 64 samples (V >= M-1) so that every block's load window
@@ -233,14 +243,34 @@ __global__ __launch_bounds__(256, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const 
     const int sub = lane & 3, k1s = lane >> 2;       // stages 2 and 3: sub = t2 or q, k1s = k1
     constexpr int BPW = S == 2 ? 1 : 2;               // stream blocks per FFT
 
-    const long fstep = (long)gridDim.x * 4;
-    for (long fb = (long)blockIdx.x * 4 + wave; fb * BPW < nblocks; fb += fstep) {
+    const long fstep = (long)gridDim.x * FFT_WPB;
+#if LRHIP_FFT_PREFETCH
+    cf pre[16];
+    bool have = false;
+    auto prefetch = [&](long b) {
+        long lo = b * L - V;
+        have = S == 2 && b < nblocks && lo >= 0 && lo + FFTN <= n;
+        if (have) {
+            const cf *src = reinterpret_cast<const cf *>(x) + lo + lane;
+#pragma unroll
+            for (int i = 0; i < 16; i++) pre[i] = src[64 * i];
+        }
+    };
+    prefetch((long)blockIdx.x * FFT_WPB + wave);
+#endif
+    for (long fb = (long)blockIdx.x * FFT_WPB + wave; fb * BPW < nblocks; fb += fstep) {
         cf v[16];
         // ---- load: window position 64*i + lane  (stream = [M-1 history | chunk])
-        // (measured and dropped: register prefetch of the next block, 16-B accesses through an LDS transpose - no gain)
+        // (measured and dropped: 16-B accesses through an LDS transpose - no gain)
         if (S == 2) {
             const long xlo = fb * L - V;                  // x index of window position 0
             const long p0 = xlo + (M - 1);                // the same in stream coordinates
+#if LRHIP_FFT_PREFETCH
+            if (have) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[i] = pre[i];
+            } else
+#endif
             if (xlo >= 0 && xlo + FFTN <= n) {
                 const cf *src = reinterpret_cast<const cf *>(x) + xlo + lane;
 #pragma unroll
@@ -277,6 +307,9 @@ __global__ __launch_bounds__(256, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const 
 
         // ---- forward stage 1: radix-16 over n1, twiddle W_1024^(t*k1)
         dft16<1>(v);
+#if LRHIP_FFT_PREFETCH
+        if (S == 2) prefetch(fb + fstep);
+#endif
 #pragma unroll
         for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw1[k * 64 + lane]);
         // E1: write (k1, t), read (k1 = k1s, 4*t1 + t2), t2 = sub

@@ -77,6 +77,9 @@ struct FirStage : lrhip_stage {
     int fft_blocks_per_cu = 0;
     // fused FrequencyDiscriminatorBlock in front (chains): input is ComplexFloat32, the filter runs on arg(c[i] conj c[i-1])/gain
     bool pre_disc = false;
+    // fused FrequencyDiscriminatorBlock behind the filter (chains): ComplexFloat32 in, Float32 out (persistent MFMA kernel epilogue)
+    bool post_disc = false;
+    DeviceBuf edge;
     double disc_gain = 1.0;
     DeviceBuf disc_prev;
     int disc_cur = 0;
@@ -90,7 +93,7 @@ struct FirStage : lrhip_stage {
     int reset() override
     {
         cur = 0; index = 0; count = 0; fill = 0; disc_cur = 0;
-        if (pre_disc && zero_fill(disc_prev, 4 * sizeof(float))) return -1;
+        if ((pre_disc || post_disc) && zero_fill(disc_prev, 4 * sizeof(float))) return -1;
         size_t hb = ((size_t)(M > 1 ? M - 1 : 1) * S + hist_pad) * sizeof(float);
         if (zero_fill(hist[0], hb) || zero_fill(hist[1], hb)) return -1;
         return 0;
@@ -112,12 +115,12 @@ struct FirStage : lrhip_stage {
     }
 
     template <typename K>
-    int prepare_kernel(K kern, size_t lds_bytes, int *blocks_per_cu)
+    int prepare_kernel(K kern, size_t lds_bytes, int *blocks_per_cu, int threads = 256)
     {
         if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         if (blocks_per_cu) {
             int nb = 0;
-            LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds_bytes));
+            LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds_bytes));
             *blocks_per_cu = nb < 1 ? 1 : nb;
         }
         return 0;
@@ -130,7 +133,7 @@ struct FirStage : lrhip_stage {
         constexpr int TILE_OUT = G::tile_out(NACC);
         // alignment slack so that the tile's first staged sample is 16-B aligned in global memory
         if (((uintptr_t)x % (4 * SS)) != 0) {
-            if (rot) return set_error("fir: fused rotator needs a sample-aligned input pointer");
+            if (rot || post_disc) return set_error("fir: fused rotator / discriminator needs a sample-aligned input pointer");
             return launch_direct(x, n, y, n_out);
         }
         long sample_addr = (long)((uintptr_t)x / (4 * SS));
@@ -150,15 +153,31 @@ struct FirStage : lrhip_stage {
                 if (!mfma_blocks_per_cu && prepare_kernel(kern, lds_bytes, &mfma_blocks_per_cu)) return -1;     // queried once per stage
                 long slots = (long)ctx().num_cus * mfma_blocks_per_cu;
                 unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+                if (post_disc && edge.reserve((size_t)ntiles * 2 * sizeof(float2))) return -1;
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, atab, y, M, n, n_out, (long)index, e,
-                                   ntiles, out_aligned, rs, rc);
+                                   ntiles, out_aligned, rs, rc, (float2 *)edge.p, 1.0 / disc_gain);
                 return 0;
             };
             int rc2;
+            if constexpr (SS == 2 && (DD == 1 || DD == 5)) {
+                if (post_disc) {
+                    rc2 = rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS, 1>);
+                    if (rc2) return rc2;
+                    LR_LAUNCH_CHECK();
+                    float2 *dp = (float2 *)disc_prev.p;
+                    hipLaunchKernelGGL(fir_disc_fixup_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, ctx().stream, (const float2 *)edge.p, ntiles,
+                                       TILE_OUT, y, (const float2 *)(dp + disc_cur), dp + (disc_cur ^ 1), 1.0 / disc_gain);
+                    LR_LAUNCH_CHECK();
+                    disc_cur ^= 1;
+                    return 0;
+                }
+            }
+            if (post_disc) return set_error("internal: discriminator epilogue without a persistent kernel variant");
             if constexpr (SS == 2) rc2 = rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS>);
             else rc2 = rot ? set_error("rotator fusion needs complex input") : launch(fir_mfma_persistent_kernel<1, DD, NACC, false, KS>);
             if (rc2) return rc2;
         } else {
+            if (post_disc) return set_error("internal: discriminator epilogue without a persistent kernel variant");
             auto launch = [&](auto kern) -> int {
                 if (prepare_kernel(kern, lds_bytes, nullptr)) return -1;
                 hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds_bytes, ctx().stream, h, x, atab, y, M, n, n_out, (long)index, e,
@@ -221,12 +240,12 @@ struct FirStage : lrhip_stage {
         size_t lds_bytes = (size_t)FFT_LDS_ELEMS * sizeof(float2);
         const float *h = (const float *)hist[cur].p + hist_pad;
         auto go = [&](auto kern) -> int {
-            if (!fft_blocks_per_cu && prepare_kernel(kern, lds_bytes, &fft_blocks_per_cu)) return -1;
+            if (!fft_blocks_per_cu && prepare_kernel(kern, lds_bytes, &fft_blocks_per_cu, 64 * FFT_WPB)) return -1;
             long slots = (long)ctx().num_cus * fft_blocks_per_cu;
-            long want = (nffts + 3) / 4;
+            long want = (nffts + FFT_WPB - 1) / FFT_WPB;
             unsigned grid = (unsigned)(want < slots ? want : slots);
             const float2 *dp = pre_disc ? (const float2 *)disc_prev.p + disc_cur : nullptr;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, (const float2 *)d_fft_tables.p, y, M, n, n_out, nblocks,
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FFT_WPB), lds_bytes, ctx().stream, h, x, (const float2 *)d_fft_tables.p, y, M, n, n_out, nblocks,
                                1.0 / disc_gain, dp);
             return 0;
         };
@@ -269,6 +288,8 @@ struct FirStage : lrhip_stage {
     }
 
     static bool mfma_supported_decim(unsigned d) { return (d >= 1 && d <= 8) || d == 10; }
+    // the discriminator epilogue exists for the persistent instantiations of the complex-stream, real-taps kernel
+    bool can_post_disc() const { return S == 2 && !taps_complex && !fft_arith && !use_fft && ((D == 1 && ksteps == 36) || (D == 5 && ksteps == 51)); }
 
     // filter n inputs (device), emit the retained outputs; advances history / index / count
     long core(const float *x, long n, float *y, unsigned long cap)
@@ -1517,7 +1538,12 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
             continue;
         }
         DownsamplerStage *ds = (fusable_fir && j + 1 < nstages) ? dynamic_cast<DownsamplerStage *>(stages[j + 1]) : nullptr;
-        if (fusable_fir && (rot || ds)) {
+        // ... [discriminator]: runs as the epilogue of the persistent kernel (ComplexFloat32 outputs never reach HBM)
+        static const bool no_disc_fusion = getenv("LRHIP_NO_DISC_FUSION") != nullptr;      // A/B knob
+        unsigned after = j + 1 + (ds ? 1 : 0);
+        FmDiscrimStage *dsc_after = (!no_disc_fusion && fusable_fir && fir->S == 2 && !fir->taps_complex && !fir->fft_arith && after < nstages)
+                                        ? dynamic_cast<FmDiscrimStage *>(stages[after]) : nullptr;
+        if (fusable_fir && (rot || ds || dsc_after)) {
             unsigned D = ds ? (unsigned)ds->factor : 1;
             int ts = fir->taps_complex ? 2 : 1;
             std::vector<float> taps((size_t)fir->M * ts);
@@ -1528,9 +1554,17 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
             if (FirStage::mfma_supported_decim(D) || !rot)
                 fused = fir_build(taps.data(), (unsigned)fir->M, fir->taps_complex, fir->S == 2, D, 0, want_rot, want_rot ? rot->omega : 0.0);
             if (fused && rot && !want_rot) { delete fused; fused = nullptr; }
+            bool with_disc = fused && dsc_after && fused->can_post_disc();
+            if (fused && !rot && !ds && !with_disc) { delete fused; fused = nullptr; }      // nothing was fused
             if (fused) {
+                if (with_disc) {
+                    fused->post_disc = true;
+                    fused->disc_gain = dsc_after->gain;
+                    fused->out_size = 4;                // ComplexFloat32 in, Float32 out
+                    if (fused->reset()) { delete fused; return nullptr; }
+                }
                 c->ops.push_back({fused, true});
-                i = j + (ds ? 2 : 1);
+                i = j + (ds ? 2 : 1) + (with_disc ? 1 : 0);
                 continue;
             }
         }
@@ -1538,7 +1572,7 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
         {
             FmDiscrimStage *dsc = dynamic_cast<FmDiscrimStage *>(stages[i]);
             FirStage *f1 = (dsc && i + 1 < nstages) ? dynamic_cast<FirStage *>(stages[i + 1]) : nullptr;
-            if (f1 && f1->fft_arith && !f1->use_fft && f1->S == 1 && f1->D == 1 && !f1->rot && !f1->pre_disc) {
+            if (!no_disc_fusion && f1 && f1->fft_arith && !f1->use_fft && f1->S == 1 && f1->D == 1 && !f1->rot && !f1->pre_disc) {
                 std::vector<float> taps((size_t)f1->M);
                 for (int t = 0; t < f1->M; t++) taps[t] = f1->taps_rev[f1->M - 1 - t];
                 FirStage *fused = fir_build(taps.data(), (unsigned)f1->M, 0, 0, 1, 2, false, 0.0);

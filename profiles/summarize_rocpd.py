@@ -34,7 +34,7 @@ def main():
             print("%-72s %6s %12s %12s %12s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
             tot = cur.execute("select sum(duration) from kernels").fetchone()[0] or 1
             for k, n, a, lo, hi, s in cur.execute("select name, count(*), avg(duration), min(duration), max(duration), sum(duration) "
-                                                  "from kernels group by name order by sum(duration) desc limit 12"):
+                                                  "from kernels group by name order by sum(duration) desc limit 30"):
                 print("%-72s %6d %12.2f %12.2f %12.2f %6.1f%%" % (short(k), n, a / 1e3, lo / 1e3, hi / 1e3, 100.0 * s / tot))
         print()
 
