@@ -383,11 +383,14 @@ template <int S, int D, int NACC, bool ROT, int KS, int EPI = 0>
 __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persistent_kernel(
     const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_pad, float *__restrict__ y,
     int M, long n, long n_out, long first, int e, long ntiles, int out_aligned,
-    uint64_t rot_step_fx, uint64_t rot_count0, float2 *__restrict__ edge, double inv_gain)
+    uint64_t rot_step_fx, uint64_t rot_count0, float2 *__restrict__ edge, double inv_gain, float *__restrict__ hist_out)
 {
     using G = FirMfmaGeom<S, D>;
     constexpr int TILE_OUT = G::tile_out(NACC);
     constexpr int SPAN = G::span(NACC, KS);
+    // history carry (fir_history_kernel's job, saved launch): the other ping-pong buffer, raw (unrotated) samples
+    if (hist_out && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < (M - 1) * S; i += 256) hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
     constexpr int NF4 = SPAN * S / 4;
     constexpr int UX = (NF4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];

@@ -224,11 +224,14 @@ template <int S, int PRE>
 __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const float *__restrict__ hist, const float *__restrict__ x,
                                                           const float2 *__restrict__ tables, float *__restrict__ y,
                                                           int M, long n, long n_out, long nblocks,
-                                                          double inv_gain, const float2 *__restrict__ disc_prev)
+                                                          double inv_gain, const float2 *__restrict__ disc_prev, float *__restrict__ hist_out)
 {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: block addresses and bounds stay on the SALU
+    // history carry (PRE = 0; saves the fir_history_kernel launch): last M-1 stream samples into the other ping-pong buffer
+    if (PRE == 0 && hist_out && blockIdx.x == 0)
+        for (int i = tid; i < (M - 1) * S; i += 64 * FFT_WPB) hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
     cf *flc = reinterpret_cast<cf *>(fl);
     cf *ex = flc + wave * FFT_EX_ELEMS;
     const cf *tw1 = flc + FFT_LDS_TW1, *Hp = flc + FFT_LDS_H, *tw2 = flc + FFT_LDS_TW2;

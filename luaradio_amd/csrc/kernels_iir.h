@@ -232,6 +232,197 @@ __global__ __launch_bounds__(256) void iir_scan_kernel(const float *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Single-launch variant for filters whose memory is shorter than a tile in Float32 terms (host check: every entry of
+// A^(warm*TILE) is below 1e-46, i.e. underflows to zero - true for every single-pole audio filter of the reference's
+// receivers).  A workgroup emits `run` consecutive tiles, carrying the state from tile to tile in LDS, after running
+// `warm` tiles in front of them from ZERO state with the output discarded: by the time the first emitted tile starts,
+// the zero start has decayed out of the Float32 state.  The workgroups whose warm-up would reach before the chunk start
+// there with the true carried state instead.  One launch, (1 + warm/run) reads + 1 write of the stream, no inter-
+// workgroup dependency.  Same per-sample arithmetic as the three-pass form.
+// ------------------------------------------------------------------------------------------------------------
+template <int S, int P, int NBT>
+__global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict__ x, float *__restrict__ y, long n,
+                                                         const float *__restrict__ xhist, const float *__restrict__ state_in,
+                                                         float *__restrict__ state_out, long dec, long dfirst, int run, int warm, IirCoeffs co,
+                                                         float *__restrict__ xhist_out)
+{
+    constexpr int LC = IIR_LC, TILE = IIR_TILE, PV = NBT - 1;
+    __shared__ float sst[2][S][256][P];
+    __shared__ float carry[S][P];
+    const int tid = threadIdx.x;
+    const int nb = co.nb;
+    // carried feed-forward history (iir_state_kernel's job): the last nb-1 inputs
+    if (blockIdx.x == 0 && tid < (nb - 1) * S) {
+        int r = tid / S, c = tid % S;
+        long g = n - (nb - 1) + r;
+        xhist_out[tid] = g >= 0 ? x[g * S + c] : xhist[(g + (nb - 1)) * S + c];
+    }
+    const long first_tile = (long)blockIdx.x * run;
+    long tb = first_tile - warm;
+    const bool from_true_state = tb <= 0;
+    if (tb < 0) tb = 0;
+    if (tid < S * P) carry[tid / P][tid % P] = from_true_state ? state_in[tid] : 0.f;
+    __syncthreads();
+
+    for (long tt = tb; tt < first_tile + run && tt * TILE < n; tt++) {
+        const bool emit = tt >= first_tile;
+        const long c0 = tt * TILE + (long)tid * LC;
+        // ---- load (as iir_scan_kernel)
+        float xs[S][PV + LC];
+        const bool vec = (c0 + LC <= n) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+        if (vec) {
+            const float4 *src = reinterpret_cast<const float4 *>(x + c0 * S);
+#pragma unroll
+            for (int q = 0; q < LC * S / 4; q++) {
+                float4 v = src[q];
+                if (S == 1) {
+                    xs[0][PV + 4 * q] = v.x; xs[0][PV + 4 * q + 1] = v.y; xs[0][PV + 4 * q + 2] = v.z; xs[0][PV + 4 * q + 3] = v.w;
+                } else {
+                    xs[0][PV + 2 * q] = v.x; xs[S - 1][PV + 2 * q] = v.y; xs[0][PV + 2 * q + 1] = v.z; xs[S - 1][PV + 2 * q + 1] = v.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < LC; i++)
+#pragma unroll
+                for (int c = 0; c < S; c++) xs[c][PV + i] = (c0 + i < n) ? x[(c0 + i) * S + c] : 0.f;
+        }
+#pragma unroll
+        for (int j = 1; j <= PV; j++)
+#pragma unroll
+            for (int c = 0; c < S; c++) {
+                long g = c0 - j;
+                float v = 0.f;
+                if (j < nb && c0 < n) v = g >= 0 ? x[g * S + c] : xhist[(g + (nb - 1)) * S + c];
+                xs[c][PV - j] = v;
+            }
+        float u[S][LC];
+#pragma unroll
+        for (int c = 0; c < S; c++)
+#pragma unroll
+            for (int i = 0; i < LC; i++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < NBT; j++)
+                    if (j < nb) acc = fmaf(co.b[j], xs[c][PV + i - j], acc);
+                u[c][i] = acc;
+            }
+        // ---- zero-state run, scan of the chunk end states seeded with the carried tile start state
+        float st[S][P];
+#pragma unroll
+        for (int c = 0; c < S; c++) {
+#pragma unroll
+            for (int k = 0; k < P; k++) st[c][k] = 0.f;
+#pragma unroll
+            for (int i = 0; i < LC; i++) {
+                float v = u[c][i];
+#pragma unroll
+                for (int k = 0; k < P; k++) v = fmaf(-co.a[k], st[c][k], v);
+#pragma unroll
+                for (int k = P - 1; k > 0; k--) st[c][k] = st[c][k - 1];
+                st[c][0] = v;
+            }
+        }
+        int buf = 0;
+#pragma unroll
+        for (int c = 0; c < S; c++) {
+            if (tid == 0) {
+                float ts[P], tmp[P];
+#pragma unroll
+                for (int k = 0; k < P; k++) ts[k] = carry[c][k];
+                mat_apply<P>(co.Tpow[0], ts, tmp);
+#pragma unroll
+                for (int k = 0; k < P; k++) st[c][k] += tmp[k];
+            }
+#pragma unroll
+            for (int k = 0; k < P; k++) sst[0][c][tid][k] = st[c][k];
+        }
+        __syncthreads();
+        for (int lvl = 0; lvl < 8; lvl++) {
+            int off = 1 << lvl;
+#pragma unroll
+            for (int c = 0; c < S; c++) {
+                float cur[P];
+#pragma unroll
+                for (int k = 0; k < P; k++) cur[k] = sst[buf][c][tid][k];
+                if (tid >= off) {
+                    float prev[P], tmp[P];
+#pragma unroll
+                    for (int k = 0; k < P; k++) prev[k] = sst[buf][c][tid - off][k];
+                    mat_apply<P>(co.Tpow[lvl], prev, tmp);
+#pragma unroll
+                    for (int k = 0; k < P; k++) cur[k] += tmp[k];
+                }
+#pragma unroll
+                for (int k = 0; k < P; k++) sst[buf ^ 1][c][tid][k] = cur[k];
+            }
+            buf ^= 1;
+            __syncthreads();
+        }
+        // ---- true start state of this chunk; the tile end state becomes the next tile's carried state
+#pragma unroll
+        for (int c = 0; c < S; c++)
+#pragma unroll
+            for (int k = 0; k < P; k++) st[c][k] = tid ? sst[buf][c][tid - 1][k] : carry[c][k];
+        __syncthreads();
+        if (tid == 255)
+#pragma unroll
+            for (int c = 0; c < S; c++)
+#pragma unroll
+                for (int k = 0; k < P; k++) carry[c][k] = sst[buf][c][255][k];
+        if (emit) {
+#pragma unroll
+            for (int c = 0; c < S; c++)
+#pragma unroll
+                for (int i = 0; i < LC; i++) {
+                    float v = u[c][i];
+#pragma unroll
+                    for (int k = 0; k < P; k++) v = fmaf(-co.a[k], st[c][k], v);
+#pragma unroll
+                    for (int k = P - 1; k > 0; k--) st[c][k] = st[c][k - 1];
+                    st[c][0] = v;
+                    u[c][i] = v;
+                    long g = c0 + i;
+                    if (g < n && g >= n - P) state_out[c * P + (int)(n - 1 - g)] = v;
+                }
+            if (tt == 0 && tid == 0 && n < P)
+#pragma unroll
+                for (int c = 0; c < S; c++)
+                    for (int k = (int)n; k < P; k++) state_out[c * P + k] = state_in[c * P + k - (int)n];
+            if (dec == 1) {
+                if (vec && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+                    float4 *dst = reinterpret_cast<float4 *>(y + c0 * S);
+#pragma unroll
+                    for (int q = 0; q < LC * S / 4; q++)
+                        dst[q] = S == 1 ? make_float4(u[0][4 * q], u[0][4 * q + 1], u[0][4 * q + 2], u[0][4 * q + 3])
+                                        : make_float4(u[0][2 * q], u[S - 1][2 * q], u[0][2 * q + 1], u[S - 1][2 * q + 1]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < LC; i++)
+#pragma unroll
+                        for (int c = 0; c < S; c++)
+                            if (c0 + i < n) y[(c0 + i) * S + c] = u[c][i];
+                }
+            } else {
+                long k0 = c0 <= dfirst ? 0 : (c0 - dfirst + dec - 1) / dec;
+                long g0 = dfirst + k0 * dec;
+#pragma unroll
+                for (int i = 0; i < LC; i++) {
+                    long g = c0 + i;
+                    if (g == g0 && g < n) {
+#pragma unroll
+                        for (int c = 0; c < S; c++) y[k0 * S + c] = u[c][i];
+                        k0++;
+                        g0 += dec;
+                    }
+                }
+            }
+        }
+        __syncthreads();      // carry is published, sst may be reused
+    }
+}
+
 // pass 2: carry across tiles, s_t = E_{t-1} + A^TILE s_{t-1}, as a 256-thread scan: every thread owns a
 // contiguous segment of `seg` tiles (sequential inside the segment, twice), segment end states are combined with a
 // Kogge-Stone scan using A^(TILE*seg*2^k) (computed on the host per launch in double).

@@ -76,6 +76,7 @@ struct FirStage : lrhip_stage {
     DeviceBuf d_fft_tables;
     int fft_blocks_per_cu = 0;
     // fused FrequencyDiscriminatorBlock in front (chains): input is ComplexFloat32, the filter runs on arg(c[i] conj c[i-1])/gain
+    bool hist_in_kernel = false;          // set by a launch that also wrote the next history buffer
     bool pre_disc = false;
     // fused FrequencyDiscriminatorBlock behind the filter (chains): ComplexFloat32 in, Float32 out (persistent MFMA kernel epilogue)
     bool post_disc = false;
@@ -154,8 +155,10 @@ struct FirStage : lrhip_stage {
                 long slots = (long)ctx().num_cus * mfma_blocks_per_cu;
                 unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
                 if (post_disc && edge.reserve((size_t)ntiles * 2 * sizeof(float2))) return -1;
+                float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, atab, y, M, n, n_out, (long)index, e,
-                                   ntiles, out_aligned, rs, rc, (float2 *)edge.p, 1.0 / disc_gain);
+                                   ntiles, out_aligned, rs, rc, (float2 *)edge.p, 1.0 / disc_gain, ho);
+                hist_in_kernel = ho != nullptr;
                 return 0;
             };
             int rc2;
@@ -245,8 +248,10 @@ struct FirStage : lrhip_stage {
             long want = (nffts + FFT_WPB - 1) / FFT_WPB;
             unsigned grid = (unsigned)(want < slots ? want : slots);
             const float2 *dp = pre_disc ? (const float2 *)disc_prev.p + disc_cur : nullptr;
+            float *ho = (!pre_disc && M > 1) ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FFT_WPB), lds_bytes, ctx().stream, h, x, (const float2 *)d_fft_tables.p, y, M, n, n_out, nblocks,
-                               1.0 / disc_gain, dp);
+                               1.0 / disc_gain, dp, ho);
+            hist_in_kernel = ho != nullptr;
             return 0;
         };
         int rc = S == 2 ? go(fir_fft_kernel<2, 0>) : pre_disc ? go(fir_fft_kernel<1, 1>) : go(fir_fft_kernel<1, 0>);
@@ -295,6 +300,7 @@ struct FirStage : lrhip_stage {
     long core(const float *x, long n, float *y, unsigned long cap)
     {
         if (n <= 0) return 0;
+        hist_in_kernel = false;
         long n_out = (unsigned long)n > index ? (long)((n - index + D - 1) / D) : 0;
         if ((unsigned long)n_out > cap) return set_error("fir: output capacity %lu < %ld", cap, n_out);
         if (n_out > 0) {
@@ -312,6 +318,8 @@ struct FirStage : lrhip_stage {
             LR_LAUNCH_CHECK();
             cur ^= 1;
             disc_cur ^= 1;
+        } else if (hist_in_kernel) {
+            cur ^= 1;
         } else if (M > 1) {
             unsigned grid = grid_for((unsigned long)(M - 1) * S, 256);
             const float *hi = (const float *)hist[cur].p + hist_pad;
@@ -559,6 +567,7 @@ struct IirStage : lrhip_stage {
     IirCoeffs co;
     IirSeqCoeffs seq;
     std::vector<double> Ttile;            // A^TILE in double (row-major PxP) for the per-launch carry powers
+    int warm_tiles = 0;                   // > 0: A^(warm_tiles*TILE) underflows Float32 -> single-launch iir_stream_kernel
     DeviceBuf xhist[2], state[2], tile_end, tile_start, seq_xs, seq_ys;
     int cur = 0;
     unsigned long D = 1, index = 0;       // fused DownsamplerBlock behind the filter (chains)
@@ -578,9 +587,22 @@ struct IirStage : lrhip_stage {
     int run_scan_nb(const float *x, float *y, long n)
     {
         long ntiles = (n + IIR_TILE - 1) / IIR_TILE;
-        if (tile_end.reserve(sizeof(float) * ntiles * SS * PP) || tile_start.reserve(sizeof(float) * ntiles * SS * PP)) return -1;
         const float *xh = (const float *)xhist[cur].p, *st = (const float *)state[cur].p;
         float *st_out = (float *)state[cur ^ 1].p;
+        if (warm_tiles > 0) {
+            // tiles per workgroup: enough workgroups to fill the chip a few times over, at most 8 tiles each
+            long slots = (long)ctx().num_cus * 8;
+            int run = (int)(ntiles / slots);
+            run = run < 1 ? 1 : run > 8 ? 8 : run;
+            if (run < 2 * warm_tiles && ntiles > 4 * warm_tiles) run = 2 * warm_tiles;      // bound the re-read overhead
+            unsigned grid = (unsigned)((ntiles + run - 1) / run);
+            hipLaunchKernelGGL((iir_stream_kernel<SS, PP, NBT>), dim3(grid), dim3(256), 0, ctx().stream, x, y, n, xh, st, st_out, (long)D, (long)index, run,
+                               warm_tiles, co, (float *)xhist[cur ^ 1].p);
+            LR_LAUNCH_CHECK();
+            cur ^= 1;
+            return 0;
+        }
+        if (tile_end.reserve(sizeof(float) * ntiles * SS * PP) || tile_start.reserve(sizeof(float) * ntiles * SS * PP)) return -1;
         if (ntiles > 1) {
             hipLaunchKernelGGL((iir_scan_kernel<SS, PP, false, NBT>), dim3((unsigned)ntiles), dim3(256), 0, ctx().stream, x, (float *)nullptr, n, xh,
                                (const float *)nullptr, (float *)tile_end.p, st, st_out, 1L, 0L, co);
@@ -1248,6 +1270,16 @@ lrhip_stage_t *lrhip_iir_create(const float *b, unsigned nb, const float *a, uns
             for (int i = 0; i < P * P; i++) co.Tpow[k][i] = (float)T[i];
             if (k == 8) q->Ttile = T;
             matmul(T, T, T, P);
+        }
+        // memory shorter than `w` tiles in Float32 terms?  (every entry of A^(w*TILE) underflows)  -> single-launch kernel
+        static const bool force_3pass = getenv("LRHIP_IIR_3PASS") != nullptr;       // A/B knob
+        std::vector<double> W = q->Ttile;
+        for (int w = 1; w <= 4 && !force_3pass && !q->warm_tiles; w *= 2) {
+            double mx = 0.0;
+            bool finite = true;
+            for (double v : W) { finite = finite && std::isfinite(v); mx = std::fabs(v) > mx ? std::fabs(v) : mx; }
+            if (finite && mx < 1e-46) q->warm_tiles = w;
+            matmul(W, W, W, P);
         }
     }
     if (q->reset()) return nullptr;
