@@ -290,34 +290,57 @@ __device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, 
     }
 }
 
-// discriminator epilogue: the tile's ComplexFloat32 outputs, tile-local order, into LDS (same lane pairing as store_tile)
+// discriminator epilogue, in registers: after the re/im exchange a lane owns two consecutive ComplexFloat32 outputs of
+// its wave's WAVE_OUT = NACC*BPA*16 consecutive outputs; the output before the lane's first one lives in another lane
+// (or, for lane 0, in the previous accumulator), one ds_bpermute away.  Only the first output of a WAVE needs another
+// wave's data: each wave records (first, last) in `edge` and fir_disc_fixup_kernel rewrites those samples afterwards.
+// The last valid output of the chunk is published as the carried previous sample.
 template <int D, int NACC>
-__device__ __forceinline__ void stage_tile_outputs(float2 *ldsO, f32x4 (&acc)[1][NACC])
+__device__ __forceinline__ void disc_epilogue(float *__restrict__ y, long tile_k0, long n_out, int out_aligned, f32x4 (&acc)[1][NACC],
+                                              float2 *__restrict__ edge_tile, float2 *__restrict__ prev_out, double inv_gain)
 {
     using G = FirMfmaGeom<2, D>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const bool odd = col & 1;
+    // lane that owns the output just before this lane's first one (lane 0: previous accumulator, handled below)
+    const int src = odd ? lane - 1 : kq ? lane - 15 : col ? col + 47 : 63;
+    const long wave_k0 = tile_k0 + (long)wave * (NACC * G::BPA * 16);
+    float2 carry = make_float2(0.f, 0.f);          // last output of the previous accumulator
 #pragma unroll
     for (int a = 0; a < NACC; a++) {
         const float a0 = acc[0][a][0], a1 = acc[0][a][1], a2 = acc[0][a][2], a3 = acc[0][a][3];
-        float recv0 = __shfl_xor(odd ? a0 : a2, 1);
-        float recv1 = __shfl_xor(odd ? a1 : a3, 1);
-        float4 o = odd ? make_float4(recv0, a2, recv1, a3) : make_float4(a0, recv0, a1, recv1);
-        const int k = 16 * ((wave * NACC + a) * G::BPA + (col >> 1)) + 4 * kq + (odd ? 2 : 0);
-        *reinterpret_cast<float4 *>(ldsO + k) = o;
+        const float recv0 = __shfl_xor(odd ? a0 : a2, 1);
+        const float recv1 = __shfl_xor(odd ? a1 : a3, 1);
+        const float2 o0 = odd ? make_float2(recv0, a2) : make_float2(a0, recv0);
+        const float2 o1 = odd ? make_float2(recv1, a3) : make_float2(a1, recv1);
+        float2 p = make_float2(__shfl(o1.x, src), __shfl(o1.y, src));
+        if (lane == 0) p = carry;
+        carry = make_float2(__shfl(o1.x, 63), __shfl(o1.y, 63));
+        const float2 d = make_float2(discriminate(o0, p, inv_gain), discriminate(o1, o0, inv_gain));
+        const long k = wave_k0 + 16 * (a * G::BPA + (col >> 1)) + 4 * kq + (odd ? 2 : 0);
+        if (out_aligned && k + 1 < n_out) {
+            *reinterpret_cast<float2 *>(y + k) = d;
+        } else {
+            if (k < n_out) y[k] = d.x;
+            if (k + 1 < n_out) y[k + 1] = d.y;
+        }
+        if (k == n_out - 1) *prev_out = o0;
+        if (k + 1 == n_out - 1) *prev_out = o1;
+        if (a == 0 && lane == 0) edge_tile[2 * wave] = o0;
+        if (a == NACC - 1 && lane == 63) edge_tile[2 * wave + 1] = o1;
     }
 }
 
-// second half of the discriminator epilogue: sample t*tile_out needs the last output of tile t-1 (or of the previous chunk)
-__global__ __launch_bounds__(256) void fir_disc_fixup_kernel(const float2 *__restrict__ edge, long ntiles, int tile_out, float *__restrict__ y,
-                                                             const float2 *__restrict__ prev_in, float2 *__restrict__ prev_out, double inv_gain)
+// second half of the discriminator epilogue: the first output of every wave's range (wave_out outputs) needs the last
+// output of the previous wave (or of the previous chunk)
+__global__ __launch_bounds__(256) void fir_disc_fixup_kernel(const float2 *__restrict__ edge, long nwaves, int wave_out, float *__restrict__ y, long n_out,
+                                                             const float2 *__restrict__ prev_in, double inv_gain)
 {
-    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < ntiles) {
-        float2 p = t ? edge[2 * (t - 1) + 1] : *prev_in;
-        y[t * tile_out] = discriminate(edge[2 * t], p, inv_gain);
-        if (t == ntiles - 1) *prev_out = edge[2 * t + 1];
+    long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nwaves && w * wave_out < n_out) {
+        float2 p = w ? edge[2 * (w - 1) + 1] : *prev_in;
+        y[w * wave_out] = discriminate(edge[2 * w], p, inv_gain);
     }
 }
 
@@ -376,14 +399,12 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
 // the current tile's MFMA loop, so HBM latency hides under ~9k cycles of matrix work; they are written to LDS
 // after the loop.  Edge tiles (first tile: history; last tiles: end of chunk) are staged synchronously.
 // EPI = 1 (S = 2, real taps): fused FrequencyDiscriminatorBlock BEHIND the filter (frequencydiscriminator.lua:68-88): the
-// tile's ComplexFloat32 outputs go through LDS instead of global memory, y receives arg(o[k] conj(o[k-1])) / gain as
-// Float32.  The first output of a tile needs the previous tile's last output, which another workgroup owns: every tile
-// records (first, last valid) output in `edge` and fir_disc_fixup_kernel rewrites those ntiles samples afterwards.
+// ComplexFloat32 outputs never leave the registers, y receives arg(o[k] conj(o[k-1])) / gain as Float32 (disc_epilogue).
 template <int S, int D, int NACC, bool ROT, int KS, int EPI = 0>
 __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persistent_kernel(
     const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_pad, float *__restrict__ y,
     int M, long n, long n_out, long first, int e, long ntiles, int out_aligned,
-    uint64_t rot_step_fx, uint64_t rot_count0, float2 *__restrict__ edge, double inv_gain, float *__restrict__ hist_out)
+    uint64_t rot_step_fx, uint64_t rot_count0, float2 *__restrict__ edge, float2 *__restrict__ prev_out, double inv_gain, float *__restrict__ hist_out)
 {
     using G = FirMfmaGeom<S, D>;
     constexpr int TILE_OUT = G::tile_out(NACC);
@@ -445,35 +466,8 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
         if constexpr (EPI == 0) {
             store_tile<S, D, NACC, 1>(y, tile_k0, n_out, out_aligned, acc);
         } else {
-            static_assert(S == 2 && TILE_OUT % 1024 == 0, "discriminator epilogue: complex stream, 4 outputs per thread and pass");
-            __syncthreads();                                  // every wave is done reading its B fragments from ldsX
-            float2 *ldsO = reinterpret_cast<float2 *>(ldsX);   // TILE_OUT complex outputs of this tile
-            stage_tile_outputs<D, NACC>(ldsO, acc);
-            __syncthreads();
-            const long left = n_out - tile_k0;
-            const int nvalid = left < TILE_OUT ? (int)left : TILE_OUT;
-#pragma unroll
-            for (int c = 0; c < TILE_OUT / 1024; c++) {
-                const int k = (c * 256 + tid) * 4;
-                const float4 o01 = *reinterpret_cast<const float4 *>(ldsO + k), o23 = *reinterpret_cast<const float4 *>(ldsO + k + 2);
-                const float2 p = k ? ldsO[k - 1] : make_float2(0.f, 0.f);      // k = 0: rewritten by the fix-up kernel
-                const float2 o0 = make_float2(o01.x, o01.y), o1 = make_float2(o01.z, o01.w), o2 = make_float2(o23.x, o23.y), o3 = make_float2(o23.z, o23.w);
-                const float4 d = make_float4(discriminate(o0, p, inv_gain), discriminate(o1, o0, inv_gain), discriminate(o2, o1, inv_gain),
-                                             discriminate(o3, o2, inv_gain));
-                const long g = tile_k0 + k;
-                if (out_aligned && k + 3 < nvalid) {
-                    *reinterpret_cast<float4 *>(y + g) = d;
-                } else {
-                    if (k < nvalid) y[g] = d.x;
-                    if (k + 1 < nvalid) y[g + 1] = d.y;
-                    if (k + 2 < nvalid) y[g + 2] = d.z;
-                    if (k + 3 < nvalid) y[g + 3] = d.w;
-                }
-            }
-            if (tid == 0) {
-                edge[2 * t] = ldsO[0];
-                edge[2 * t + 1] = ldsO[nvalid - 1];
-            }
+            static_assert(S == 2, "discriminator epilogue: complex stream");
+            disc_epilogue<D, NACC>(y, tile_k0, n_out, out_aligned, acc, edge + 8 * t, prev_out, inv_gain);
         }
         __syncthreads();      // everyone is done reading ldsX before it is overwritten
     }

@@ -154,10 +154,10 @@ struct FirStage : lrhip_stage {
                 if (!mfma_blocks_per_cu && prepare_kernel(kern, lds_bytes, &mfma_blocks_per_cu)) return -1;     // queried once per stage
                 long slots = (long)ctx().num_cus * mfma_blocks_per_cu;
                 unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
-                if (post_disc && edge.reserve((size_t)ntiles * 2 * sizeof(float2))) return -1;
+                if (post_disc && edge.reserve((size_t)ntiles * 8 * sizeof(float2))) return -1;
                 float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, atab, y, M, n, n_out, (long)index, e,
-                                   ntiles, out_aligned, rs, rc, (float2 *)edge.p, 1.0 / disc_gain, ho);
+                                   ntiles, out_aligned, rs, rc, (float2 *)edge.p, post_disc ? (float2 *)disc_prev.p + (disc_cur ^ 1) : nullptr, 1.0 / disc_gain, ho);
                 hist_in_kernel = ho != nullptr;
                 return 0;
             };
@@ -168,8 +168,8 @@ struct FirStage : lrhip_stage {
                     if (rc2) return rc2;
                     LR_LAUNCH_CHECK();
                     float2 *dp = (float2 *)disc_prev.p;
-                    hipLaunchKernelGGL(fir_disc_fixup_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, ctx().stream, (const float2 *)edge.p, ntiles,
-                                       TILE_OUT, y, (const float2 *)(dp + disc_cur), dp + (disc_cur ^ 1), 1.0 / disc_gain);
+                    hipLaunchKernelGGL(fir_disc_fixup_kernel, dim3((unsigned)((4 * ntiles + 255) / 256)), dim3(256), 0, ctx().stream, (const float2 *)edge.p,
+                                       4 * ntiles, TILE_OUT / 4, y, n_out, (const float2 *)(dp + disc_cur), 1.0 / disc_gain);
                     LR_LAUNCH_CHECK();
                     disc_cur ^= 1;
                     return 0;

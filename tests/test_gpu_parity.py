@@ -413,6 +413,59 @@ def test_tuner_fused_rotator_fir_downsampler():
     assert np.array_equal(got, ds.process(lpf.process(rot.process(x))))
 
 
+@pytest.mark.parametrize("decim", [5, 1])
+def test_discriminator_epilogue_equals_unfused_blocks(decim):
+    """[rotator] -> FIR(128 real taps) -> [downsampler] -> discriminator in a chain runs the discriminator as the epilogue of
+    the persistent MFMA kernel (wave-boundary samples fixed up afterwards, previous sample carried across calls): same bits
+    as the separate device blocks, for chunkings that cut inside and across waves (256 outputs) and tiles"""
+    rng = np.random.default_rng(31 + decim)
+    rate = 1102500.0
+    n = 300000 if decim == 5 else 120000
+    x = rand_c(rng, n)
+
+    def blocks():
+        bl = [make(lr.FrequencyTranslatorBlock, [-250e3], x, rate=rate)] if decim == 5 else []
+        bl.append(make(lr.LowpassFilterBlock, [128, 100e3], x, rate=rate))
+        if decim > 1:
+            bl.append(make(lr.DownsamplerBlock, [decim], x, rate=rate))
+        bl.append(make(lr.FrequencyDiscriminatorBlock, [1.25], x, rate=rate))
+        return bl
+
+    chain = lr.Chain(blocks())
+    cuts = [1, 4, 5, 6, 1279, 1280, 1281, 5120, 5121, 70000, 70003, 100000]      # cut positions
+    got = chunked(chain, x, cuts)
+    assert chain.last_launches <= 2              # fused kernel + wave-boundary fix-up
+    ref = blocks()
+    want = x
+    for b in ref:
+        want = b.process(want)
+    assert len(got) == len(want) == (n + decim - 1) // decim
+    assert np.array_equal(got, want)
+    ora = O.FMDiscriminator(1.25).process(O.tuner(-250e3, 200e3, 5, rate, mode=O.MODE_FMA, rot_mode=O.MODE_F64).process(x)) if decim == 5 else None
+    if ora is not None:
+        # the angle of tiny filter outputs is ill-conditioned; compare where the FIR output is not tiny
+        assert np.median(np.abs(got - ora)) < 1e-6
+
+
+def test_iir_single_launch_and_three_pass_paths_vs_oracle():
+    """short-memory filters (A^TILE underflows Float32) take the single-launch kernel, long-memory ones the three-pass scan;
+    both against the f64 recurrence on 1M samples, ragged chunks"""
+    rng = np.random.default_rng(15)
+    n = 1 << 20
+    x = rand_r(rng, n)
+    for cutoff, rate in ((2122.0, 220500.0), (0.5, 48000.0)):      # pole 0.94 (de-emphasis like) and pole 0.99993
+        blk = make(lr.SinglepoleLowpassFilterBlock, [cutoff], x, rate=rate)
+        b, a = O.singlepole_lowpass_taps(cutoff, rate)
+        want = O.IIR(b, a, False, O.MODE_F64).process(x)
+        got = chunked(blk, x, [1, 4095, 4096, 4097, 16384 * 3 + 5, 100000])
+        assert G.max_abs_err(got, want) < 2e-6, cutoff
+    blk = make(lr.SinglepoleHighpassFilterBlock, [100.0], rand_c(rng, 4), rate=48000.0)
+    xc = rand_c(rng, 300000)
+    b, a = _singlepole_highpass_taps(100.0, 48000.0)
+    want = O.IIR(b, a, True, O.MODE_F64).process(xc)
+    assert G.max_abs_err(chunked(blk, xc, [7, 4096, 50000]), want) < 2e-6
+
+
 def test_wbfm_mono_chain_rms_within_1e5():
     """BASELINE.json configs[2] at a size the oracle finishes in seconds: synthetic FM (SURVEY.md 8d C3 recipe),
     chain = examples/rtlsdr_wbfm_mono.lua:12-17,28.  Bar: RMS error <= 1e-5 vs the per-block-pinned oracle."""
