@@ -2,6 +2,7 @@
 // All are streaming kernels: coalesced 8/16-B-per-lane loads, grid-stride, no LDS.
 #pragma once
 #include "common.h"
+#include "pk_math.h"
 
 namespace lrhip {
 
@@ -35,11 +36,49 @@ __device__ __forceinline__ void phasor_from_turns(uint64_t turns_fx, float &c, f
     s = (q & 2) ? -sn : sn;
 }
 
-__device__ __forceinline__ float2 rotate_sample(float2 v, uint64_t turns_fx)
+// The phasor of ABSOLUTE sample index n is defined once, for every kernel that rotates (standalone, fused into the FIR
+// staging, edge tiles), so that fused == unfused and any chunking give the same bits:
+//   even n: the polynomial above;   odd n: phasor(n - 1) * W,  W = phasor of one step (one packed complex multiply).
+// A pair (n, n + 1) with n even therefore costs one polynomial, not two - the rotator is VALU work that the f32 matrix
+// pipe cannot hide.
+__device__ __forceinline__ cf phasor_step(uint64_t step_fx)
 {
     float c, s;
-    phasor_from_turns(turns_fx, c, s);
-    return make_float2(fmaf(v.x, c, -v.y * s), fmaf(v.x, s, v.y * c));
+    phasor_from_turns(step_fx, c, s);
+    return cf{c, s};
+}
+
+__device__ __forceinline__ cf phasor_even(uint64_t step_fx, uint64_t n_even)
+{
+    float c, s;
+    phasor_from_turns(step_fx * n_even, c, s);
+    return cf{c, s};
+}
+
+__device__ __forceinline__ cf phasor_of(uint64_t step_fx, uint64_t n, cf w)
+{
+    cf p = phasor_even(step_fx, n & ~1ull);
+    return (n & 1) ? cmul(p, w) : p;
+}
+
+__device__ __forceinline__ float2 rotate_sample(float2 v, uint64_t step_fx, uint64_t n, cf w)
+{
+    return cf_to(cmul(cf_from(v), phasor_of(step_fx, n, w)));
+}
+
+// two consecutive samples (one 16-B access) whose first has absolute index cnt
+__device__ __forceinline__ float4 rotate_pair(float4 v, uint64_t step_fx, uint64_t cnt, cf w)
+{
+    cf p0, p1;
+    if (!(cnt & 1)) {                 // wave-uniform in every caller (cnt = base + 2 * i)
+        p0 = phasor_even(step_fx, cnt);
+        p1 = cmul(p0, w);
+    } else {
+        p0 = cmul(phasor_even(step_fx, cnt - 1), w);
+        p1 = phasor_even(step_fx, cnt + 1);
+    }
+    cf a = cmul(cf{v.x, v.y}, p0), b = cmul(cf{v.z, v.w}, p1);
+    return make_float4(a.x, a.y, b.x, b.y);
 }
 
 // VEC = 2: two samples (one 16-B access) per lane when both pointers are 16-B aligned; VEC = 1 otherwise.
@@ -48,20 +87,17 @@ __global__ __launch_bounds__(256) void rotator_kernel(const float2 *__restrict__
                                                       unsigned long n, uint64_t step_fx, uint64_t count0)
 {
     unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
+    const cf w = phasor_step(step_fx);
     if (VEC == 2) {
         const float4 *x4 = reinterpret_cast<const float4 *>(x);
         float4 *y4 = reinterpret_cast<float4 *>(y);
         unsigned long n2 = n / 2;
-        for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-            float4 v = x4[i];
-            float2 a = rotate_sample(make_float2(v.x, v.y), step_fx * (count0 + 2 * i));
-            float2 b = rotate_sample(make_float2(v.z, v.w), step_fx * (count0 + 2 * i + 1));
-            y4[i] = make_float4(a.x, a.y, b.x, b.y);
-        }
-        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = rotate_sample(x[n - 1], step_fx * (count0 + n - 1));
+        for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride)
+            y4[i] = rotate_pair(x4[i], step_fx, count0 + 2 * i, w);
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = rotate_sample(x[n - 1], step_fx, count0 + n - 1, w);
     } else {
         for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-            y[i] = rotate_sample(x[i], step_fx * (count0 + i));
+            y[i] = rotate_sample(x[i], step_fx, count0 + i, w);
     }
 }
 

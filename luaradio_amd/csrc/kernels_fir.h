@@ -130,14 +130,7 @@ struct FirMfmaGeom {
 
 // ---- shared device pieces ---------------------------------------------------------------------------------
 
-// fused FrequencyTranslatorBlock: rotate the two ComplexFloat32 samples of a float4 whose first sample has
-// absolute index cnt
-__device__ __forceinline__ float4 rotate_pair(float4 v, uint64_t step_fx, uint64_t cnt)
-{
-    float2 a = rotate_sample(make_float2(v.x, v.y), step_fx * cnt);
-    float2 b = rotate_sample(make_float2(v.z, v.w), step_fx * (cnt + 1));
-    return make_float4(a.x, a.y, b.x, b.y);
-}
+// (fused FrequencyTranslatorBlock: rotate_pair / rotate_sample of kernels_elem.h on the way into LDS)
 
 // one float4 of staged samples (logical float index 4*i4) -> padded LDS rows
 template <int S, int D>
@@ -166,7 +159,7 @@ __device__ __forceinline__ void stage_edge(float *ldsX, const float *__restrict_
         if (ROT) {
             // absolute sample index of stream position p is rot_count0 + p - (M-1); history before the
             // start of the stream is zero, so its phase is irrelevant
-            float2 o = rotate_sample(make_float2(v0, v1), rot_step_fx * (rot_count0 + (uint64_t)(p - (M - 1))));
+            float2 o = rotate_sample(make_float2(v0, v1), rot_step_fx, rot_count0 + (uint64_t)(p - (M - 1)), phasor_step(rot_step_fx));
             v0 = o.x;
             v1 = o.y;
         }
@@ -359,6 +352,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
     float *ldsT = lds;                       // NOUT zero-padded tap arrays
     float *ldsX = lds + NOUT * tlen;         // staged samples (padded rows)
     const int tid = threadIdx.x;
+    const cf rot_w = ROT ? phasor_step(rot_step_fx) : cf{1.f, 0.f};
     const long tile_k0 = (long)blockIdx.x * TILE_OUT;
     const long base = first + tile_k0 * D - e;               // stream position of r = 0
     const int span = G::span(NACC, ksteps);                   // samples to stage
@@ -381,7 +375,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
 #pragma unroll
             for (int u = 0; u < UX; u++) {
                 const int i4 = i0 + u * 256;
-                if (i4 < nf4) lds_put4<S, D>(ldsX, i4, ROT ? rotate_pair(vv[u], rot_step_fx, rot_count0 + (uint64_t)(xlo + 2 * (long)i4)) : vv[u]);
+                if (i4 < nf4) lds_put4<S, D>(ldsX, i4, ROT ? rotate_pair(vv[u], rot_step_fx, rot_count0 + (uint64_t)(xlo + 2 * (long)i4), rot_w) : vv[u]);
             }
         }
     } else {
@@ -419,6 +413,7 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
     float *ldsT = lds;
     float *ldsX = lds + TLEN;
     const int tid = threadIdx.x;
+    const cf rot_w = ROT ? phasor_step(rot_step_fx) : cf{1.f, 0.f};
 
     for (int i = tid; i < TLEN; i += 256) ldsT[i] = taps_pad[i];
 
@@ -444,7 +439,7 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
 #pragma unroll
             for (int u = 0; u < UX; u++) {
                 const int i4 = tid + u * 256;
-                if (i4 < NF4) lds_put4<S, D>(ldsX, i4, ROT ? rotate_pair(pre[u], rot_step_fx, rot_count0 + (uint64_t)(xlo + 2 * (long)i4)) : pre[u]);
+                if (i4 < NF4) lds_put4<S, D>(ldsX, i4, ROT ? rotate_pair(pre[u], rot_step_fx, rot_count0 + (uint64_t)(xlo + 2 * (long)i4), rot_w) : pre[u]);
             }
         } else {
             stage_edge<S, D, ROT>(ldsX, hist, x, first + tile_k0 * D - e, SPAN, M, n, rot_step_fx, rot_count0);
