@@ -103,6 +103,10 @@ lrhip_stage_t *lrhip_multiply_constant_create(float re, float im, int constant_c
 /* UpsamplerBlock (radio/blocks/signal/upsampler.lua:26-53): zero-stuffing by `factor`. elem_size = 8 or 4. */
 lrhip_stage_t *lrhip_upsampler_create(unsigned factor, int elem_size);
 
+/* FrequencyModulatorBlock (radio/blocks/signal/frequencymodulator.lua:24-90; replaces freqmod_create / freqmod_modulate_block
+ * :33-51): Float32 in, ComplexFloat32 out = exp(j * running phase), phase += 2*pi*modulation_index*x[n]. */
+lrhip_stage_t *lrhip_fmmod_create(double modulation_index);
+
 /* One-input element-wise blocks. op: "complexmagnitude", "complexphase", "complextoreal", "complextoimag",
  * "complexconjugate" (ComplexFloat32 in), "realtocomplex", "absolutevalue" (Float32 in), and "addconstant"
  * (radio/blocks/signal/addconstant.lua:26-75: constant (re, im); constant_complex / input_complex as for

@@ -13,7 +13,8 @@ from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock,
                      ComplexBandstopFilterBlock, RootRaisedCosineFilterBlock, MultiplyConstantBlock, UpsamplerBlock, PolyphaseChannelizerBlock, ComplexMagnitudeBlock,
                      ComplexPhaseBlock, ComplexToRealBlock, ComplexToImagBlock, ComplexConjugateBlock, RealToComplexBlock,
                      AbsoluteValueBlock, AddConstantBlock, DelayBlock, HilbertTransformBlock, SinglepoleHighpassFilterBlock,
-                     FMPreemphasisFilterBlock, FloatToComplexBlock, ComplexToFloatBlock)
+                     FMPreemphasisFilterBlock, FloatToComplexBlock, ComplexToFloatBlock, FrequencyModulatorBlock,
+                     PulseMatchedFilterBlock, ManchesterMatchedFilterBlock)
 from .sources import IQFileSource, RealFileSource  # noqa: F401
 from .composites import (Chain, CompositeBlock, DecimatorBlock, InterpolatorBlock, RationalResamplerBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401
                          NBFMDemodulator, AMEnvelopeDemodulator, SSBDemodulator, wbfm_mono_receiver)

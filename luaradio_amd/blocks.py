@@ -500,3 +500,46 @@ class ComplexToFloatBlock(Block):
 
     def process(self, x):
         return self._real.process(x), self._imag.process(x)
+
+
+class FrequencyModulatorBlock(Block):
+    """radio/blocks/signal/frequencymodulator.lua. FrequencyModulatorBlock(modulation_index): Float32 -> ComplexFloat32."""
+    name = "FrequencyModulatorBlock"
+
+    def instantiate(self, modulation_index):
+        assert modulation_index is not None, "Missing argument #1 (modulation_index)"
+        self.modulation_index = modulation_index
+        self.add_type_signature([Input("in", types.Float32)], [Output("out", types.ComplexFloat32)])
+
+    def initialize(self):
+        self._set_stage(_lib.load().lrhip_fmmod_create(float(self.modulation_index)), "Creating lrhip fmmod object")
+
+    def process(self, x):
+        return self._execute(x, np.complex64)
+
+
+class PulseMatchedFilterBlock(FIRFilterBlock):
+    """radio/blocks/signal/pulsematchedfilter.lua:27-47. PulseMatchedFilterBlock(baudrate[, invert=false])."""
+    name = "PulseMatchedFilterBlock"
+    _pattern = (1,)
+
+    def instantiate(self, baudrate, invert=False):
+        assert baudrate is not None, "Missing argument #1 (baudrate)"
+        self.baudrate, self.invert = baudrate, bool(invert)
+        FIRFilterBlock.instantiate(self, types.Float32.vector(32))
+
+    def initialize(self):
+        symbol_period = self.get_rate() / self.baudrate
+        count = int(math.floor(symbol_period))            # Lua: for i = 1, symbol_period
+        sign = -1.0 if self.invert else 1.0
+        taps = []
+        for half in self._pattern:
+            taps.extend([sign * half] * count)
+        self.taps = types.Float32.vector_from_array(taps)
+        FIRFilterBlock.initialize(self)
+
+
+class ManchesterMatchedFilterBlock(PulseMatchedFilterBlock):
+    """radio/blocks/signal/manchestermatchedfilter.lua:27-50: a -1 half symbol followed by a +1 half symbol."""
+    name = "ManchesterMatchedFilterBlock"
+    _pattern = (-1, 1)

@@ -545,6 +545,29 @@ struct FmDiscrimStage : lrhip_stage {
     }
 };
 
+struct FmModStage : lrhip_stage {
+    double k = 0;
+    DeviceBuf phase, tile_sum;     // phase: two uint64 slots, ping-pong
+    int cur = 0;
+    const char *kind() const override { return "fmmod"; }
+    int reset() override { cur = 0; return zero_fill(phase, 2 * sizeof(uint64_t)); }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n > cap) return set_error("fmmod: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        unsigned long ntiles = (n + FMOD_TILE - 1) / FMOD_TILE;
+        if (tile_sum.reserve(ntiles * sizeof(uint64_t))) return -1;
+        uint64_t *ph = (uint64_t *)phase.p, *ts = (uint64_t *)tile_sum.p;
+        hipLaunchKernelGGL(fmod_tile_sum_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx().stream, (const float *)in_dev, n, k, ts);
+        hipLaunchKernelGGL(fmod_tile_scan_kernel, dim3(1), dim3(256), 0, ctx().stream, ts, ntiles, (const uint64_t *)(ph + cur), ph + (cur ^ 1));
+        hipLaunchKernelGGL(fmod_emit_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx().stream, (const float *)in_dev, (float2 *)out_dev, n, k,
+                           (const uint64_t *)ts);
+        LR_LAUNCH_CHECK();
+        cur ^= 1;
+        return (long)n;
+    }
+};
+
 // P x P matrix helpers (double, host) for the transition powers
 static void matmul(const std::vector<double> &A, const std::vector<double> &B, std::vector<double> &C, int P)
 {
@@ -1396,6 +1419,18 @@ lrhip_stage_t *lrhip_upsampler_create(unsigned factor, int elem_size)
     q->factor = factor;
     q->in_size = q->out_size = elem_size;
     return q;
+}
+
+lrhip_stage_t *lrhip_fmmod_create(double modulation_index)
+{
+    if (!std::isfinite(modulation_index)) { set_error("fmmod: modulation index must be finite"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    std::unique_ptr<FmModStage> q(new (std::nothrow) FmModStage());
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->k = modulation_index;
+    q->in_size = 4; q->out_size = 8;
+    if (q->reset()) return nullptr;
+    return q.release();
 }
 
 lrhip_stage_t *lrhip_unary_create(const char *op, float re, float im, int constant_complex, int input_complex)

@@ -643,3 +643,31 @@ long lro_format_convert(const char *format, const unsigned char *raw, long nscal
     }
     return nscalars;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * FrequencyModulatorBlock: radio/blocks/signal/frequencymodulator.lua:71-90 (pure-Lua branch):
+ * phase (a Lua double) = (phase + delta*x) % (2 pi); out = (cosf(phase), sinf(phase)) - the double is narrowed to
+ * float at the cosf/sinf call (ffi.C.cosf takes a float).  Lua's % is a floored modulo.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { double phase, delta; } lro_fmmod;
+
+lro_fmmod *lro_fmmod_create(double modulation_index)
+{
+    lro_fmmod *q = (lro_fmmod *)calloc(1, sizeof(*q));
+    q->delta = 2 * M_PI * modulation_index;      /* :73 */
+    return q;
+}
+void lro_fmmod_destroy(lro_fmmod *q) { free(q); }
+
+long lro_fmmod_process(lro_fmmod *q, const float *x, long n, float *y)
+{
+    const double two_pi = 2 * M_PI;
+    for (long i = 0; i < n; i++) {
+        double p = q->phase + q->delta * (double)x[i];
+        p = p - floor(p / two_pi) * two_pi;          /* Lua: a % b == a - floor(a/b)*b */
+        q->phase = p;
+        y[2 * i] = cosf((float)p);
+        y[2 * i + 1] = sinf((float)p);
+    }
+    return n;
+}

@@ -64,6 +64,11 @@ def lib():
         L.lro_fmdiscrim_process.restype = C.c_long
         L.lro_fmdiscrim_process.argtypes = [vp, fp, C.c_long, fp]
         L.lro_fmdiscrim_destroy.argtypes = [vp]
+        L.lro_fmmod_create.restype = vp
+        L.lro_fmmod_create.argtypes = [C.c_double]
+        L.lro_fmmod_process.restype = C.c_long
+        L.lro_fmmod_process.argtypes = [vp, fp, C.c_long, fp]
+        L.lro_fmmod_destroy.argtypes = [vp]
         L.lro_iir_create.restype = vp
         L.lro_iir_create.argtypes = [fp, C.c_int, fp, C.c_int, C.c_int, C.c_int]
         L.lro_iir_process.restype = C.c_long
@@ -237,6 +242,21 @@ class FMDiscriminator(_Stage):
         assert xc
         y = _out(len(x), False)
         lib().lro_fmdiscrim_process(self.q, _fp(xf), len(x), _fp(y))
+        return y
+
+
+class FMModulator(_Stage):
+    """FrequencyModulatorBlock (frequencymodulator.lua:71-90, pure-Lua branch)."""
+    _destroy = "lro_fmmod_destroy"
+
+    def __init__(self, modulation_index):
+        self.q = lib().lro_fmmod_create(float(modulation_index))
+
+    def process(self, x):
+        xf, xc = _as_f32(x)
+        assert not xc
+        y = _out(len(x), True)
+        lib().lro_fmmod_process(self.q, _fp(xf), len(x), _fp(y.view(np.float32)))
         return y
 
 

@@ -56,6 +56,9 @@ SPECS = [
     "blocks/signal/realtocomplex_spec",
     "blocks/signal/absolutevalue_spec",
     "blocks/signal/delay_spec",
+    "blocks/signal/frequencymodulator_spec",
+    "blocks/signal/pulsematchedfilter_spec",
+    "blocks/signal/manchestermatchedfilter_spec",
     "blocks/signal/singlepolehighpassfilter_spec",
     "blocks/signal/fmpreemphasisfilter_spec",
     "blocks/signal/floattocomplex_spec",

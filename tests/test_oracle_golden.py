@@ -90,6 +90,25 @@ def test_frequencydiscriminator():
         _check(lambda: O.FMDiscriminator(vec["args"][0]), vec, doc["epsilon"])
 
 
+def test_frequencymodulator():
+    doc = G.load("frequencymodulator_spec")
+    assert doc["epsilon"] == 5e-5          # "radio.platform.features.liquid and 5e-3 or 5e-5": the pure-Lua bound
+    for vec in doc["vectors"]:
+        _check(lambda: O.FMModulator(vec["args"][0]), vec, 5e-5)
+
+
+@pytest.mark.parametrize("name,pattern", [("pulsematchedfilter_spec", (1,)), ("manchestermatchedfilter_spec", (-1, 1))])
+def test_matched_filters(name, pattern):
+    """pulsematchedfilter.lua:39-47 / manchestermatchedfilter.lua:39-50: FIRFilterBlock with +-1 taps over the symbol period"""
+    doc = G.load(name)
+    for vec in doc["vectors"]:
+        baudrate, invert = vec["args"]
+        count = int(np.floor(2.0 / baudrate))           # jig rate 2.0
+        sign = -1.0 if invert else 1.0
+        taps = np.concatenate([np.full(count, sign * h, np.float32) for h in pattern])
+        _check(lambda: O.FIR(taps, False), vec, doc["epsilon"])
+
+
 def test_downsampler_bit_exact():
     doc = G.load("downsampler_spec")
     assert len(doc["vectors"]) == 20
