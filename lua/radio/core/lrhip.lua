@@ -70,6 +70,7 @@ void *lrhip_malloc(unsigned long bytes);
 void lrhip_free(void *dev_ptr);
 int lrhip_memcpy_h2d(void *dev_dst, const void *host_src, unsigned long bytes);
 int lrhip_memcpy_d2h(void *host_dst, const void *dev_src, unsigned long bytes);
+int lrhip_memcpy_d2d(void *dev_dst, const void *dev_src, unsigned long bytes);
 void *lrhip_host_alloc(unsigned long bytes);
 void lrhip_host_free(void *host_ptr);
 

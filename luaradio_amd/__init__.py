@@ -16,6 +16,7 @@ from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock,
                      FMPreemphasisFilterBlock, FloatToComplexBlock, ComplexToFloatBlock, FrequencyModulatorBlock,
                      PulseMatchedFilterBlock, ManchesterMatchedFilterBlock)
 from .sources import IQFileSource, RealFileSource  # noqa: F401
+from .graph import DeviceGraph  # noqa: F401
 from .composites import (Chain, CompositeBlock, DecimatorBlock, InterpolatorBlock, RationalResamplerBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401
                          NBFMDemodulator, AMEnvelopeDemodulator, SSBDemodulator, wbfm_mono_receiver)
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     "lrhip_free": (None, [_vp]),
     "lrhip_memcpy_h2d": (C.c_int, [_vp, _vp, _ul]),
     "lrhip_memcpy_d2h": (C.c_int, [_vp, _vp, _ul]),
+    "lrhip_memcpy_d2d": (C.c_int, [_vp, _vp, _ul]),
     "lrhip_host_alloc": (_vp, [_ul]),
     "lrhip_host_free": (None, [_vp]),
     "lrhip_timer_create": (_vp, []),

@@ -494,6 +494,7 @@ class ComplexToFloatBlock(Block):
 
     def initialize(self):
         self._real, self._imag = ComplexToRealBlock(), ComplexToImagBlock()
+        self._sub_blocks = [self._real, self._imag]       # DeviceGraph: one device pass per output
         for b in (self._real, self._imag):
             b.differentiate([types.ComplexFloat32])
             b.initialize()

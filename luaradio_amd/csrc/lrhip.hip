@@ -1840,6 +1840,12 @@ int lrhip_memcpy_d2h(void *dst, const void *src, unsigned long bytes)
     LR_HIP(hipStreamSynchronize(ctx().stream));
     return 0;
 }
+int lrhip_memcpy_d2d(void *dst, const void *src, unsigned long bytes)
+{
+    if (ensure_init()) return -1;
+    if (bytes) LR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx().stream));
+    return 0;
+}
 void *lrhip_host_alloc(unsigned long bytes)
 {
     if (ensure_init()) return nullptr;

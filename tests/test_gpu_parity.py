@@ -900,6 +900,70 @@ def test_reference_top_level_chain_on_device():
         assert G.max_abs_err(got, want) < 1e-6, chunking
 
 
+def test_device_graph_reference_top_level_flow_graph():
+    """the same graph as tests/top_spec.lua:13-54 written with connect() like the reference does, executed as a DAG with
+    every edge in HBM (two sources -> MultiplyConjugate -> Lowpass -> Discriminator -> Decimator): vs top_vectors, eps 1e-6"""
+    v = G.load("top_vectors")["values"]
+    want = np.frombuffer(v["SNK_TEST_VECTOR"], np.float32)
+    s1 = lr.IQFileSource(v["SRC1_TEST_VECTOR"], "f32le", 1000000)
+    s2 = lr.IQFileSource(v["SRC2_TEST_VECTOR"], "f32le", 1000000)
+    s1.initialize()
+    s2.initialize()
+    a, b = s1.read_all(), s2.read_all()
+    for cuts in ([], [1, 7, 100, 101, 400]):
+        g = lr.DeviceGraph()
+        i1, i2 = g.input("a", types.ComplexFloat32, 1e6), g.input("b", types.ComplexFloat32, 1e6)
+        mc = lr.MultiplyConjugateBlock()
+        dec = lr.DecimatorBlock(25, {"num_taps": 16})
+        g.connect(i1, "out", mc, "in1")
+        g.connect(i2, "out", mc, "in2")
+        g.connect(mc, lr.LowpassFilterBlock(16, 100e3), lr.FrequencyDiscriminatorBlock(5.0), dec)
+        g.initialize()
+        parts, pos = [], 0
+        for c in list(cuts) + [len(a)]:
+            out = g.process(a=a[pos:c], b=b[pos:c])
+            assert len(out) == 1
+            parts.append(next(iter(out.values())))
+            pos = c
+        got = np.concatenate(parts)
+        assert len(got) == len(want)
+        assert G.max_abs_err(got, want) < 1e-6
+
+
+def test_device_graph_fan_out_join_and_ragged_inputs():
+    """one source feeding two branches that meet again (x * conj(lowpass(x)) and re/im split -> FloatToComplex), with the
+    two graph inputs arriving in chunks of DIFFERENT length: the join keeps the excess for the next call, like a pipe"""
+    rng = np.random.default_rng(81)
+    n = 50000
+    x, y = rand_c(rng, n), rand_c(rng, n)
+    rate = 48000.0
+    g = lr.DeviceGraph()
+    ix, iy = g.input("x", types.ComplexFloat32, rate), g.input("y", types.ComplexFloat32, rate)
+    lp = lr.LowpassFilterBlock(64, 4e3)
+    mc = lr.MultiplyConjugateBlock()
+    c2f, f2c = lr.ComplexToFloatBlock(), lr.FloatToComplexBlock()
+    add = lr.AddBlock()
+    g.connect(ix, lp)
+    g.connect(ix, "out", mc, "in1")
+    g.connect(lp, "out", mc, "in2")
+    g.connect(iy, c2f)
+    g.connect(c2f, "real", f2c, "imag")          # swap re and im of y
+    g.connect(c2f, "imag", f2c, "real")
+    g.connect(mc, "out", add, "in1")
+    g.connect(f2c, "out", add, "in2")
+    g.initialize()
+    xs = [0, 1000, 1001, 30000, n]
+    ys = [0, 10, 5000, 29000, n]
+    parts = []
+    for k in range(4):
+        parts.append(next(iter(g.process(x=x[xs[k]:xs[k + 1]], y=y[ys[k]:ys[k + 1]]).values())))
+    got = np.concatenate(parts)
+    lpo = O.lowpass(64, 4e3, rate, True, mode=O.MODE_FMA).process(x)
+    want = O.multiply_conjugate(x, lpo) + (y.imag + 1j * y.real).astype(np.complex64)
+    assert len(got) == n
+    assert G.max_abs_err(got, want) < 2e-6
+
+
 def test_chain_ring_pipelined_equals_synchronous():
     """submit()/collect() through the pinned ring gives, chunk for chunk, what lrhip_chain_execute() gives"""
     rng = np.random.default_rng(70)

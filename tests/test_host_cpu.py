@@ -133,3 +133,29 @@ def test_lua_glue_declares_the_same_abi():
     text = open(path).read()
     for name in _header_functions():
         assert name in text, name
+
+
+def test_device_graph_construction_errors_need_no_gpu():
+    """DeviceGraph mirrors CompositeBlock:connect (composite.lua:140-330): bad port names, double connections, missing
+    inputs and feedback loops are rejected before any device object is created"""
+    import pytest
+    import luaradio_amd as lr
+    from luaradio_amd import types
+    g = lr.DeviceGraph()
+    a = g.input("a", types.ComplexFloat32, 1e6)
+    mc = lr.MultiplyConjugateBlock()
+    g.connect(a, "out", mc, "nope")
+    with pytest.raises(KeyError):
+        g.initialize()
+    g = lr.DeviceGraph()
+    a = g.input("a", types.ComplexFloat32, 1e6)
+    mc = lr.MultiplyConjugateBlock()
+    g.connect(a, "out", mc, "in1")
+    with pytest.raises(ValueError, match="unconnected"):
+        g.initialize()
+    g = lr.DeviceGraph()
+    b1, b2 = lr.ComplexConjugateBlock(), lr.ComplexConjugateBlock()
+    g.connect(b1, b2)
+    g.connect(b2, b1)
+    with pytest.raises(ValueError, match="cycle"):
+        g.initialize()
