@@ -337,6 +337,92 @@ __global__ __launch_bounds__(256) void fir_disc_fixup_kernel(const float2 *__res
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Polyphase rational resampler: [MultiplyConstant(c)] -> Upsampler(L) -> FIR(real taps h, M) -> [Downsampler(D)]
+// (radio/composites/interpolator.lua:31-34, rationalresampler.lua:37-44, upsampler.lua:45-53) without the zero-stuffed
+// stream.  Output m sits at upsampled position n = m*D; with p = n mod L, q = n div L
+//     y[m] = sum_{j >= 0, p + jL < M} h[p + jL] * (c * x[q - j])
+// - exactly the nonzero terms of the zero-stuffed direct form, accumulated in the same (ascending time = descending j)
+// order with fmaf, so the result is bit-identical to the unfused chain (a zero sample adds exactly +-0).
+// One output per thread; a workgroup stages the input span of its 256 outputs and the taps in LDS.  q0 / Q0 are absolute
+// sample counts, the history holds the HQ input samples before the chunk.
+// ------------------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void fir_resample_kernel(const float *__restrict__ hist, const float *__restrict__ x,
+                                                           const float *__restrict__ taps, float *__restrict__ y, int M, int L, long D,
+                                                           long n_in, long n_out, uint64_t m0, uint64_t Q0, int HQ, float c, int span_max,
+                                                           float *__restrict__ hist_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int jmax_all = (M - 1) / L;
+    const int TP = (jmax_all + 1) * L;     // taps, zero-padded to a whole number of phases
+    float *ldsT = lds;
+    float *ldsX = lds + ((TP + 3) & ~3);   // staged samples (scaled), S floats each, 16-B aligned
+    const int tid = threadIdx.x;
+    // history carry: last HQ raw input samples of [hist | x]
+    if (hist_out && blockIdx.x == 0)
+        for (int i = tid; i < HQ * S; i += 256) {
+            long g = n_in - HQ + i / S;            // index into x (negative: history)
+            hist_out[i] = g >= 0 ? x[g * S + i % S] : hist[(g + HQ) * S + i % S];
+        }
+    for (int i = tid; i < TP; i += 256) ldsT[i] = i < M ? taps[i] : 0.f;
+    const long mb = (long)blockIdx.x * 256;                   // first output of this workgroup (chunk-relative)
+    // absolute input index range needed: [qlo - jmax_all, qhi]
+    const uint64_t nlo = (m0 + (uint64_t)mb) * (uint64_t)D;
+    const long mlast = mb + 255 < n_out - 1 ? mb + 255 : n_out - 1;
+    const uint64_t nhi = (m0 + (uint64_t)mlast) * (uint64_t)D;
+    const long qbase = (long)(nlo / L) - jmax_all;            // absolute index of ldsX[0] (may be < Q0 - HQ: zeros)
+    const int span = (int)((long)(nhi / L) - qbase + 1);
+    for (int i = tid; i < span && i < span_max; i += 256) {
+        long g = qbase + i - (long)Q0;                        // chunk-relative input index
+#pragma unroll
+        for (int cc = 0; cc < S; cc++) {
+            float v = 0.f;
+            if (g >= 0) { if (g < n_in) v = x[g * S + cc]; }
+            else if (g + HQ >= 0) v = hist[(g + HQ) * S + cc];
+            ldsX[i * S + cc] = v * c;                          // multiplyconstant.lua: Float32 product, rounded once
+        }
+    }
+    __syncthreads();
+    const long m = mb + tid;
+    if (m >= n_out) return;
+    const uint64_t n = (m0 + (uint64_t)m) * (uint64_t)D;
+    const int p = (int)(n % L);
+    const int qi = (int)((long)(n / L) - qbase);              // LDS index of x[q]
+    // uniform trip count: the tap array is zero-padded to (jmax_all + 1) * L entries, and fmaf(x, 0, acc) == acc
+    float re = 0.f, im = 0.f;
+    const float *tp = ldsT + p + jmax_all * L;
+    const float *xp = ldsX + (qi - jmax_all) * S;
+    int j = jmax_all + 1;
+    for (; j >= 4; j -= 4) {
+        float h0 = tp[0], h1 = tp[-L], h2 = tp[-2 * L], h3 = tp[-3 * L];
+        if (S == 2) {
+            float2 x0 = *reinterpret_cast<const float2 *>(xp), x1 = *reinterpret_cast<const float2 *>(xp + 2);
+            float2 x2 = *reinterpret_cast<const float2 *>(xp + 4), x3 = *reinterpret_cast<const float2 *>(xp + 6);
+            re = fmaf(x0.x, h0, re); im = fmaf(x0.y, h0, im);
+            re = fmaf(x1.x, h1, re); im = fmaf(x1.y, h1, im);
+            re = fmaf(x2.x, h2, re); im = fmaf(x2.y, h2, im);
+            re = fmaf(x3.x, h3, re); im = fmaf(x3.y, h3, im);
+        } else {
+            re = fmaf(xp[0], h0, re);
+            re = fmaf(xp[1], h1, re);
+            re = fmaf(xp[2], h2, re);
+            re = fmaf(xp[3], h3, re);
+        }
+        tp -= 4 * L;
+        xp += 4 * S;
+    }
+    for (; j >= 1; j--) {
+        float h0 = tp[0];
+        re = fmaf(xp[0], h0, re);
+        if (S == 2) im = fmaf(xp[1], h0, im);
+        tp -= L;
+        xp += S;
+    }
+    if (S == 2) reinterpret_cast<float2 *>(y)[m] = make_float2(re, im);
+    else y[m] = re;
+}
+
 // ---- generic kernel: run-time number of MFMA steps, one tile per workgroup ----------------------------------------
 // NOUT = 2 (S = 1 geometry over the interleaved float stream, two Toeplitz tables): complex taps.
 template <int S, int D, int NACC, bool ROT, int NOUT>

@@ -995,6 +995,56 @@ struct UpsamplerStage : lrhip_stage {
 };
 
 // =====================================================================================================
+// polyphase rational resampler (chains: [MultiplyConstant] -> Upsampler -> FIR -> [Downsampler])
+// =====================================================================================================
+struct ResampleStage : lrhip_stage {
+    int S = 2, M = 0, L = 1, HQ = 0;
+    unsigned long D = 1;
+    float c = 1.f;
+    DeviceBuf d_taps, hist[2];
+    int cur = 0;
+    uint64_t Q0 = 0, m0 = 0;          // absolute input samples consumed / outputs emitted so far
+    static constexpr int SPAN_MAX = 6144;
+    const char *kind() const override { return "resample"; }
+    unsigned long max_output(unsigned long n) const override { return (n * (unsigned long)L) / D + 2; }
+    static bool fits(int M, int L, unsigned long D) { return L >= 1 && 256 * D / (unsigned long)L + (unsigned long)((M - 1) / L) + 4 <= (unsigned long)SPAN_MAX; }
+    int reset() override
+    {
+        cur = 0; Q0 = 0; m0 = 0;
+        size_t hb = (size_t)(HQ > 0 ? HQ : 1) * S * sizeof(float);
+        return (zero_fill(hist[0], hb) || zero_fill(hist[1], hb)) ? -1 : 0;
+    }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (!n) return 0;
+        // outputs m with m*D inside the upsampled positions [Q0*L, (Q0+n)*L)
+        uint64_t hi = (Q0 + n) * (uint64_t)L;
+        uint64_t m_end = (hi + D - 1) / D;                     // first m with m*D >= hi
+        long n_out = (long)(m_end - m0);
+        if ((unsigned long)n_out > cap) return set_error("resample: output capacity %lu < %ld", cap, n_out);
+        const float *h = (const float *)hist[cur].p;
+        float *ho = (float *)hist[cur ^ 1].p;
+        // per-workgroup input span: 256 outputs advance 256*D/L input samples, plus the (M-1)/L samples of filter memory
+        int span_cap = (int)(256 * D / (unsigned long)L) + (M - 1) / L + 4;
+        size_t lds_bytes = ((size_t)((((M - 1) / L + 1) * L + 3) & ~3) + (size_t)span_cap * S) * sizeof(float);
+        auto go = [&](auto kern) -> int {
+            if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            unsigned grid = n_out > 0 ? (unsigned)((n_out + 255) / 256) : 1;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, (const float *)in_dev, (const float *)d_taps.p, (float *)out_dev, M, L,
+                               (long)D, (long)n, n_out, m0, Q0, HQ, c, span_cap, ho);
+            return 0;
+        };
+        int rc = S == 2 ? go(fir_resample_kernel<2>) : go(fir_resample_kernel<1>);
+        if (rc) return rc;
+        LR_LAUNCH_CHECK();
+        cur ^= 1;
+        Q0 += n;
+        m0 = m_end;
+        return n_out;
+    }
+};
+
+// =====================================================================================================
 // polyphase channelizer as a dense MFMA GEMM
 // =====================================================================================================
 struct ChannelizerStage : lrhip_stage {
@@ -1594,6 +1644,34 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
     if (!c) { set_error("out of memory"); return nullptr; }
     unsigned i = 0;
     while (i < nstages) {
+        // fusion: [multiplyconstant(real)] upsampler fir(real taps, plain) [downsampler]  ->  one polyphase resampling launch
+        {
+            static const bool no_resample_fusion = getenv("LRHIP_NO_RESAMPLE_FUSION") != nullptr;      // A/B knob
+            unsigned k = i;
+            MulConstStage *mc = dynamic_cast<MulConstStage *>(stages[k]);
+            if (mc && mc->mode <= 1) k++; else mc = nullptr;
+            UpsamplerStage *up = k < nstages ? dynamic_cast<UpsamplerStage *>(stages[k]) : nullptr;
+            FirStage *rf = (up && k + 1 < nstages) ? dynamic_cast<FirStage *>(stages[k + 1]) : nullptr;
+            if (!no_resample_fusion && up && rf && !rf->taps_complex && !rf->use_fft && !rf->fft_arith && rf->D == 1 && !rf->rot && !rf->pre_disc) {
+                DownsamplerStage *rd = k + 2 < nstages ? dynamic_cast<DownsamplerStage *>(stages[k + 2]) : nullptr;
+                unsigned long D = rd ? rd->factor : 1;
+                int L = (int)up->factor;
+                if (ResampleStage::fits(rf->M, L, D)) {
+                    std::unique_ptr<ResampleStage> q(new (std::nothrow) ResampleStage());
+                    if (!q) { set_error("out of memory"); return nullptr; }
+                    q->S = rf->S; q->M = rf->M; q->L = L; q->D = D;
+                    q->HQ = (rf->M - 1) / L + 1;
+                    q->c = mc ? mc->cr : 1.f;
+                    q->in_size = q->out_size = rf->S * 4;
+                    std::vector<float> taps((size_t)rf->M);
+                    for (int t = 0; t < rf->M; t++) taps[t] = rf->taps_rev[rf->M - 1 - t];
+                    if (upload(q->d_taps, taps.data(), taps.size() * sizeof(float)) || q->reset()) return nullptr;
+                    c->ops.push_back({q.release(), true});
+                    i = k + 2 + (rd ? 1 : 0);
+                    continue;
+                }
+            }
+        }
         // fusion: [rotator] fir(real taps, plain) [downsampler]  ->  one decimating Toeplitz-MFMA launch
         RotatorStage *rot = dynamic_cast<RotatorStage *>(stages[i]);
         unsigned j = rot ? i + 1 : i;

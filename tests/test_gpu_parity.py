@@ -466,6 +466,32 @@ def test_iir_single_launch_and_three_pass_paths_vs_oracle():
     assert G.max_abs_err(chunked(blk, xc, [7, 4096, 50000]), want) < 2e-6
 
 
+@pytest.mark.parametrize("L,D", [(5, 1), (2, 1), (3, 2), (2, 5), (7, 3), (4, 25), (25, 4)])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_polyphase_resampler_fusion_bit_equal_to_zero_stuffed_chain(L, D, cplx):
+    """[MultiplyConstant] -> Upsampler(L) -> Lowpass -> [Downsampler(D)] in a chain is one polyphase launch that visits only the
+    nonzero terms of the zero-stuffed direct form, in the same order: same bits as the separate device blocks, any chunking"""
+    rng = np.random.default_rng(100 + 10 * L + D)
+    n = 40001
+    x = rand_c(rng, n) if cplx else rand_r(rng, n)
+
+    def blocks():
+        bl = [make(lr.MultiplyConstantBlock, [float(L)], x), make(lr.UpsamplerBlock, [L], x),
+              make(lr.LowpassFilterBlock, [128, min(1 / L, 1 / D), 1.0], x)]
+        if D > 1:
+            bl.append(make(lr.DownsamplerBlock, [D], x))
+        return bl
+
+    chain = lr.Chain(blocks())
+    got = chunked(chain, x, [1, 2, 3, 255, 256, 257, 10000, 10001, 30000])
+    assert chain.last_launches == 1
+    want = x
+    for b in blocks():
+        want = b.process(want)
+    assert len(got) == len(want) == (n * L + D - 1) // D
+    assert np.array_equal(got, want)
+
+
 def test_wbfm_mono_chain_rms_within_1e5():
     """BASELINE.json configs[2] at a size the oracle finishes in seconds: synthetic FM (SURVEY.md 8d C3 recipe),
     chain = examples/rtlsdr_wbfm_mono.lua:12-17,28.  Bar: RMS error <= 1e-5 vs the per-block-pinned oracle."""

@@ -55,7 +55,8 @@ def main():
     def run(name, blk, cplx, alg_bytes_per_sample, flops=0.0):
         x = xc if cplx else xr
         cap = blk.max_output(n)
-        ms = timeit(lambda: blk.process_device(x.data_ptr(), n, out.data_ptr(), cap))
+        dst = out if cap * (2 if cplx else 1) <= out.numel() else torch.empty(cap * 2 + 64, device="cuda")
+        ms = timeit(lambda: blk.process_device(x.data_ptr(), n, dst.data_ptr(), cap))
         gbs = alg_bytes_per_sample * n / ms / 1e6
         rows.append({"block": name, "MS/s": round(n / ms / 1e3, 1), "alg_GB/s": round(gbs, 1), "frac_8TB/s": round(gbs / 8000, 4),
                      "ms": round(ms, 4), "TFLOP/s": round(flops * n / ms / 1e9, 2) if flops else None})
@@ -77,6 +78,8 @@ def main():
     run("FMDeemphasis f32", mk(lr.FMDeemphasisFilterBlock, [75e-6], False, 220500.0), False, 8)
     run("Decimator(5) cf32 (fused FIR+downsample)", mk(lr.DecimatorBlock, [5], True), True, 8 + 8 / 5, 4 * 128 / 5)
     run("Tuner(-250k,200k,5) (fused rot+FIR+downsample)", mk(lr.TunerBlock, [-250e3, 200e3, 5], True), True, 8 + 8 / 5, 4 * 128 / 5 + 6)
+    run("Interpolator(5) cf32 (polyphase, input samples)", mk(lr.InterpolatorBlock, [5], True), True, 8 + 8 * 5, 4 * 128)
+    run("RationalResampler(3, 2) cf32 (polyphase, input samples)", mk(lr.RationalResamplerBlock, [3, 2], True), True, 8 + 8 * 1.5, 4 * 128 * 1.5 / 3)
     rx = lr.wbfm_mono_receiver(1102500.0, -250e3)
     cap = rx.max_output(n)
     ms = timeit(lambda: rx.process_device(xc.data_ptr(), n, out.data_ptr(), cap))
