@@ -74,23 +74,27 @@ __global__ __launch_bounds__(256, 1) void channelizer_kernel(const float *__rest
     constexpr int SLAB_F4 = CHAN_KSLAB * K2 / 4;           // float4 per slab
     constexpr int UW = (SLAB_F4 + 255) / 256;
     const float4 *W4 = reinterpret_cast<const float4 *>(W);
-    auto slab_put = [&](float *dst, const float4 (&reg)[UW]) {
-#pragma unroll
-        for (int u = 0; u < UW; u++) {
-            int i4 = tid + u * 256;
-            if (i4 < SLAB_F4) {
-                int k = (4 * i4) / K2, c = (4 * i4) % K2;
-                *reinterpret_cast<float4 *>(dst + k * WROW + c) = reg[u];
-            }
-        }
-    };
-    float4 wreg[UW];
-#pragma unroll
-    for (int u = 0; u < UW; u++) {
-        int i4 = tid + u * 256;
-        wreg[u] = W4[i4 < SLAB_F4 ? i4 : SLAB_F4 - 1];
+    // The prefetched slab lives in eight NAMED float4 registers: as an array (`float4 wreg[UW]`, however it was indexed) hipcc
+    // kept it in scratch memory and waited for the whole prefetch at the top of every slab - the matrix pipe idled 48 %.
+    static_assert(UW <= 8, "W slab prefetch: at most 8 float4 per thread");
+    float4 w0, w1, w2, w3, w4, w5, w6, w7;
+#define LR_CHAN_FOR8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+#define LR_CHAN_LOAD(U)                                                                          \
+    if (U < UW) {                                                                                \
+        int i4 = tid + U * 256;                                                                  \
+        w##U = W4[wbase + (i4 < SLAB_F4 ? i4 : SLAB_F4 - 1)];                                    \
     }
-    slab_put(ldsW, wreg);
+#define LR_CHAN_PUT(U)                                                                           \
+    if (U < UW) {                                                                                \
+        int i4 = tid + U * 256;                                                                  \
+        if (i4 < SLAB_F4) *reinterpret_cast<float4 *>(wdst + ((4 * i4) / K2) * WROW + (4 * i4) % K2) = w##U; \
+    }
+    {
+        const size_t wbase = 0;
+        float *wdst = ldsW;
+        LR_CHAN_FOR8(LR_CHAN_LOAD)
+        LR_CHAN_FOR8(LR_CHAN_PUT)
+    }
     __syncthreads();
 
     f32x4 acc[CHAN_RT][NCT];
@@ -108,11 +112,8 @@ __global__ __launch_bounds__(256, 1) void channelizer_kernel(const float *__rest
         const bool more = s + 1 < nslabs;
 #endif
         if (more) {
-#pragma unroll
-            for (int u = 0; u < UW; u++) {
-                int i4 = tid + u * 256;
-                wreg[u] = W4[(size_t)(s + 1) * SLAB_F4 + (i4 < SLAB_F4 ? i4 : SLAB_F4 - 1)];
-            }
+            const size_t wbase = (size_t)(s + 1) * SLAB_F4;
+            LR_CHAN_FOR8(LR_CHAN_LOAD)
         }
         // window float j = 64*s + 4*st + kq lives at padded offset j + 2*(j / K2); j / K2 is constant inside a slab
         const float *ap = abase + CHAN_KSLAB * s + 2 * ((CHAN_KSLAB * s) / K2);
@@ -139,7 +140,10 @@ __global__ __launch_bounds__(256, 1) void channelizer_kernel(const float *__rest
                     acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st & 1][r], bv[st & 1][c], acc[r][c], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) slab_put(ldsW + ((s + 1) & 1) * (CHAN_KSLAB * WROW), wreg);
+        if (more) {
+            float *wdst = ldsW + ((s + 1) & 1) * (CHAN_KSLAB * WROW);
+            LR_CHAN_FOR8(LR_CHAN_PUT)
+        }
 #if LRHIP_CHAN_EXP != 1
         __syncthreads();
 #endif
@@ -156,5 +160,9 @@ __global__ __launch_bounds__(256, 1) void channelizer_kernel(const float *__rest
                 if (f < nframes) y[f * K2 + 16 * c + col] = acc[rt][c][r];
             }
 }
+
+#undef LR_CHAN_FOR8
+#undef LR_CHAN_LOAD
+#undef LR_CHAN_PUT
 
 }  // namespace lrhip
