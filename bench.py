@@ -88,6 +88,54 @@ def cpu_baseline_fir(taps, budget_s):
                       "single_core_value = 1 thread (the reference gives a block one core)" % (out["all"][1] >> 22, cores, cands, avail)}
 
 
+def wbfm_chain_report(lr, L, torch, dev, with_cpu):
+    """second half of BASELINE.json's metric (configs[2]) inside the default bench line: the WBFM-mono receiver chain,
+    device-resident, 2^26 synthetic FM IQ samples per step, HIP-event timed; with_cpu also runs the oracle chain (1 core)
+    on the first 2^20 samples for the RMS error and the CPU rate."""
+    import numpy as np
+    fs, n = 1102500.0, 1 << 26
+    t = torch.arange(n, dtype=torch.float64, device=dev) / fs
+    m = 0.5 * torch.sin(2 * np.pi * 1e3 * t) + 0.5 * torch.sin(2 * np.pi * 5e3 * t)
+    ph = 2 * np.pi * 250e3 * t + 2 * np.pi * 75e3 / fs * torch.cumsum(m, 0)
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.stack([torch.cos(ph).float(), torch.sin(ph).float()], 1).reshape(-1)
+    x += 0.01 * (torch.rand(2 * n, dtype=torch.float32, device=dev, generator=g) * 2 - 1)
+    del t, m, ph
+    rx = lr.wbfm_mono_receiver(fs, -250e3)
+    cap = rx.max_output(n)
+    y = torch.empty(cap + 16, dtype=torch.float32, device=dev)
+    steps = 10
+    for _ in range(2):
+        rx.process_device(x.data_ptr(), n, y.data_ptr(), cap)
+    tm = L.lrhip_timer_create()
+    L.lrhip_timer_start(tm)
+    for _ in range(steps):
+        rx.process_device(x.data_ptr(), n, y.data_ptr(), cap)
+    L.lrhip_timer_stop(tm)
+    torch.cuda.synchronize()
+    ms = L.lrhip_timer_elapsed_ms(tm) / steps
+    L.lrhip_timer_destroy(tm)
+    rep = {"workload": "configs[2]: Tuner(-250e3, 200e3, 5) -> FrequencyDiscriminator(1.25) -> Lowpass(128, 15e3) -> FMDeemphasis(75e-6) -> "
+                       "Downsampler(5), 2^26 RF samples per step, device-resident",
+           "value": round(n / ms / 1e3, 1), "unit": "MSamples/s (RF samples in)", "ms_per_step": round(ms, 4), "launches": rx.chain.last_launches,
+           "algorithmic_GB/s": round(8.16 * n / ms / 1e6, 1)}
+    if with_cpu:
+        from oracle import oracle as O
+        k = 1 << 20
+        rx2 = lr.wbfm_mono_receiver(fs, -250e3)
+        xs = x[:2 * k].cpu().numpy().view(np.complex64)
+        got = rx2.process(xs)
+        ch = O.wbfm_mono_chain(fs, -250e3, mode=O.MODE_LUA, rot_mode=O.MODE_F64)
+        t0 = time.perf_counter()
+        want = ch.process(xs)
+        dt = time.perf_counter() - t0
+        err = got.astype(np.float64) - want.astype(np.float64)
+        rep["rms_err_vs_oracle"] = float(np.sqrt(np.mean(err ** 2)))
+        rep["cpu_baseline"] = {"value": round(k / dt / 1e6, 2), "unit": "MSamples/s", "cores": 1, "kind": "port",
+                               "sample": "oracle chain (per-block restatement of the reference's Lua/VOLK arithmetic) on the first 2^20 samples"}
+    return rep
+
+
 def main():
     args = parse()
     import numpy as np
@@ -276,6 +324,10 @@ def main():
             res["cpu_baseline"] = cpu_baseline_fir(taps, args.cpu_seconds)
         elif world == 1:
             res["cpu_baseline"] = None
+        if world == 1 and args.workload == "fir" and log2n >= 26:
+            del x, y
+            torch.cuda.empty_cache()
+            res["wbfm_chain"] = wbfm_chain_report(lr, L, torch, dev, not args.no_cpu_baseline)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
