@@ -492,6 +492,53 @@ def test_polyphase_resampler_fusion_bit_equal_to_zero_stuffed_chain(L, D, cplx):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_randomized_chunkings_fused_chains_equal_unfused_blocks(seed):
+    """stress: random chunk boundaries (including empty and 1-sample chunks) through every fusing chain shape vs the same
+    blocks run one by one; the fused kernels reuse the unfused device functions, so the bits must match"""
+    rng = np.random.default_rng(1000 + seed)
+    rate = 1102500.0
+    n = int(rng.integers(20000, 90000))
+    x = rand_c(rng, n)
+    L, D = int(rng.integers(2, 8)), int(rng.integers(1, 7))
+    dec = int(rng.choice([2, 3, 4, 5, 8, 10]))
+    shapes = {
+        "tuner+disc": lambda: [lr.FrequencyTranslatorBlock(float(rng.uniform(-3e5, 3e5))), lr.LowpassFilterBlock(128, 100e3), lr.DownsamplerBlock(5),
+                               lr.FrequencyDiscriminatorBlock(1.25)],
+        "lowpass+disc": lambda: [lr.LowpassFilterBlock(128, 50e3), lr.FrequencyDiscriminatorBlock(0.8)],
+        "decimator": lambda: [lr.LowpassFilterBlock(128, 0.4 * rate / dec), lr.DownsamplerBlock(dec)],
+        "resampler": lambda: [lr.MultiplyConstantBlock(float(L)), lr.UpsamplerBlock(L), lr.LowpassFilterBlock(96, min(1 / L, 1 / D), 1.0)]
+                             + ([lr.DownsamplerBlock(D)] if D > 1 else []),
+        "disc+fftfir+iir+down": lambda: [lr.FrequencyDiscriminatorBlock(1.25), lr.FIRFilterBlock(O.firwin_lowpass(128, 0.2).astype(np.float32), "fast"),
+                                         lr.FMDeemphasisFilterBlock(75e-6), lr.DownsamplerBlock(5)],
+    }
+    cuts = sorted(set(int(c) for c in rng.integers(0, n, 9)) | {0, 1, n // 2, n // 2 + 1})
+    for name, build in shapes.items():
+        st = rng.bit_generator.state
+
+        def init(blocks):
+            r, t = rate, types.ComplexFloat32
+            for b in blocks:
+                b.rate = r
+                b.differentiate([t])
+                b.initialize()
+                r, t = b.get_rate(), b.get_output_type()
+            return blocks
+
+        fused = lr.Chain(init(build()))
+        rng.bit_generator.state = st              # same random block parameters for the reference run
+        ref = init(build())
+        got = chunked(fused, x, cuts)
+        want = x
+        for b in ref:
+            want = b.process(want)
+        assert len(got) == len(want), name
+        if name == "disc+fftfir+iir+down":
+            assert G.max_abs_err(got, want) < 2e-6, name       # the FFT kernel's blocks fall differently per chunking
+        else:
+            assert np.array_equal(got, want), name
+
+
 def test_wbfm_mono_chain_rms_within_1e5():
     """BASELINE.json configs[2] at a size the oracle finishes in seconds: synthetic FM (SURVEY.md 8d C3 recipe),
     chain = examples/rtlsdr_wbfm_mono.lua:12-17,28.  Bar: RMS error <= 1e-5 vs the per-block-pinned oracle."""
