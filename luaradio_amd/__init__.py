@@ -18,6 +18,6 @@ from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock,
 from .sources import IQFileSource, RealFileSource  # noqa: F401
 from .graph import DeviceGraph  # noqa: F401
 from .composites import (Chain, CompositeBlock, DecimatorBlock, InterpolatorBlock, RationalResamplerBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401
-                         NBFMDemodulator, AMEnvelopeDemodulator, SSBDemodulator, wbfm_mono_receiver)
+                         NBFMDemodulator, AMEnvelopeDemodulator, SSBDemodulator, SSBModulator, wbfm_mono_receiver)
 
 version = "0.1.0"

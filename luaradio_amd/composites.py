@@ -255,6 +255,25 @@ class SSBDemodulator(CompositeBlock):
         self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.Float32)])
 
 
+class SSBModulator(CompositeBlock):
+    """radio/composites/ssbmodulator.lua:25-50. SSBModulator(sideband[, bandwidth=3e3]): Float32 audio -> ComplexFloat32."""
+    name = "SSBModulator"
+
+    def instantiate(self, sideband, bandwidth=None):
+        CompositeBlock.instantiate(self)
+        assert sideband, "Missing argument #1 (sideband)"
+        assert sideband in ("lsb", "usb"), "Sideband should be 'lsb' or 'usb'"
+        bandwidth = bandwidth or 3e3
+        af_filter = B.LowpassFilterBlock(128, bandwidth)
+        hilbert = B.HilbertTransformBlock(129)
+        sb_filter = B.ComplexBandpassFilterBlock(129, [-bandwidth, 0] if sideband == "lsb" else [0, bandwidth])
+        if sideband == "lsb":
+            self.connect(af_filter, hilbert, B.ComplexConjugateBlock(), sb_filter)
+        else:
+            self.connect(af_filter, hilbert, sb_filter)
+        self.add_type_signature([Input("in", types.Float32)], [Output("out", types.ComplexFloat32)])
+
+
 def wbfm_mono_receiver(rate=1102500.0, tune_offset=-250e3):
     """The compute blocks of examples/rtlsdr_wbfm_mono.lua:12-17,28 as one composite:
     Tuner(-250e3, 200e3, 5) -> FrequencyDiscriminator(1.25) -> Lowpass(128, 15e3) -> FMDeemphasis(75e-6) -> Downsampler(5)."""
