@@ -38,46 +38,63 @@ __device__ __forceinline__ void phasor_from_turns(uint64_t turns_fx, float &c, f
 
 // The phasor of ABSOLUTE sample index n is defined once, for every kernel that rotates (standalone, fused into the FIR
 // staging, edge tiles), so that fused == unfused and any chunking give the same bits:
-//   even n: the polynomial above;   odd n: phasor(n - 1) * W,  W = phasor of one step (one packed complex multiply).
-// A pair (n, n + 1) with n even therefore costs one polynomial, not two - the rotator is VALU work that the f32 matrix
-// pipe cannot hide.
-__device__ __forceinline__ cf phasor_step(uint64_t step_fx)
+//     phasor(n) = P(n & ~7) * W[n & 7],   P(m) = polynomial at m * step,   W[k] = polynomial at k * step  (W[0] = 1 exactly)
+// One polynomial serves an aligned block of 8 samples, the other 7 cost one packed complex multiply each - the rotator is
+// VALU work that the f32 matrix pipe cannot hide.
+struct RotTab { cf w[8]; };
+
+__device__ __forceinline__ cf phasor_poly(uint64_t turns_fx)
 {
     float c, s;
-    phasor_from_turns(step_fx, c, s);
+    phasor_from_turns(turns_fx, c, s);
     return cf{c, s};
 }
 
-__device__ __forceinline__ cf phasor_even(uint64_t step_fx, uint64_t n_even)
+__device__ __forceinline__ RotTab rot_tab(uint64_t step_fx)
 {
-    float c, s;
-    phasor_from_turns(step_fx * n_even, c, s);
-    return cf{c, s};
+    RotTab t;
+    t.w[0] = cf{1.f, 0.f};
+#pragma unroll
+    for (int k = 1; k < 8; k++) t.w[k] = phasor_poly(step_fx * (uint64_t)k);
+    return t;
 }
 
-__device__ __forceinline__ cf phasor_of(uint64_t step_fx, uint64_t n, cf w)
+// per-sample paths (edge tiles, unaligned vectors): two polynomials, same bits as the table form
+__device__ __forceinline__ cf phasor_of(uint64_t step_fx, uint64_t n)
 {
-    cf p = phasor_even(step_fx, n & ~1ull);
-    return (n & 1) ? cmul(p, w) : p;
+    const uint64_t k = n & 7;
+    return cmul(phasor_poly(step_fx * (n - k)), k ? phasor_poly(step_fx * k) : cf{1.f, 0.f});
 }
 
-__device__ __forceinline__ float2 rotate_sample(float2 v, uint64_t step_fx, uint64_t n, cf w)
+__device__ __forceinline__ float2 rotate_sample(float2 v, uint64_t step_fx, uint64_t n)
 {
-    return cf_to(cmul(cf_from(v), phasor_of(step_fx, n, w)));
+    return cf_to(cmul(cf_from(v), phasor_of(step_fx, n)));
 }
 
 // two consecutive samples (one 16-B access) whose first has absolute index cnt
-__device__ __forceinline__ float4 rotate_pair(float4 v, uint64_t step_fx, uint64_t cnt, cf w)
+__device__ __forceinline__ float4 rotate_pair(float4 v, uint64_t step_fx, uint64_t cnt, const RotTab &t)
 {
-    cf p0, p1;
-    if (!(cnt & 1)) {                 // wave-uniform in every caller (cnt = base + 2 * i)
-        p0 = phasor_even(step_fx, cnt);
-        p1 = cmul(p0, w);
-    } else {
-        p0 = cmul(phasor_even(step_fx, cnt - 1), w);
-        p1 = phasor_even(step_fx, cnt + 1);
+    if (cnt & 1) {                    // wave-uniform in every caller (cnt = base + 2 * i); rare: odd chunk offsets
+        float2 a = rotate_sample(make_float2(v.x, v.y), step_fx, cnt), b = rotate_sample(make_float2(v.z, v.w), step_fx, cnt + 1);
+        return make_float4(a.x, a.y, b.x, b.y);
     }
-    cf a = cmul(cf{v.x, v.y}, p0), b = cmul(cf{v.z, v.w}, p1);
+    const cf p = phasor_poly(step_fx * (cnt & ~7ull));
+    cf wa, wb;
+    switch ((int)(cnt & 7)) {         // constant register indices in every arm (a dynamic index would put the table in scratch)
+        case 0: wa = t.w[0]; wb = t.w[1]; break;
+        case 2: wa = t.w[2]; wb = t.w[3]; break;
+        case 4: wa = t.w[4]; wb = t.w[5]; break;
+        default: wa = t.w[6]; wb = t.w[7]; break;
+    }
+    cf a = cmul(cf{v.x, v.y}, cmul(p, wa)), b = cmul(cf{v.z, v.w}, cmul(p, wb));
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+
+// the float4 j (0..3) of an ALIGNED block of 8 samples whose phasor base p = P(block start) is already known
+template <int J>
+__device__ __forceinline__ float4 rotate_in_block(float4 v, cf p, const RotTab &t)
+{
+    cf a = cmul(cf{v.x, v.y}, cmul(p, t.w[2 * J])), b = cmul(cf{v.z, v.w}, cmul(p, t.w[2 * J + 1]));
     return make_float4(a.x, a.y, b.x, b.y);
 }
 
@@ -87,17 +104,17 @@ __global__ __launch_bounds__(256) void rotator_kernel(const float2 *__restrict__
                                                       unsigned long n, uint64_t step_fx, uint64_t count0)
 {
     unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
-    const cf w = phasor_step(step_fx);
     if (VEC == 2) {
+        const RotTab tab = rot_tab(step_fx);
         const float4 *x4 = reinterpret_cast<const float4 *>(x);
         float4 *y4 = reinterpret_cast<float4 *>(y);
         unsigned long n2 = n / 2;
         for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride)
-            y4[i] = rotate_pair(x4[i], step_fx, count0 + 2 * i, w);
-        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = rotate_sample(x[n - 1], step_fx, count0 + n - 1, w);
+            y4[i] = rotate_pair(x4[i], step_fx, count0 + 2 * i, tab);
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = rotate_sample(x[n - 1], step_fx, count0 + n - 1);
     } else {
         for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-            y[i] = rotate_sample(x[i], step_fx, count0 + i, w);
+            y[i] = rotate_sample(x[i], step_fx, count0 + i);
     }
 }
 

@@ -159,7 +159,7 @@ __device__ __forceinline__ void stage_edge(float *ldsX, const float *__restrict_
         if (ROT) {
             // absolute sample index of stream position p is rot_count0 + p - (M-1); history before the
             // start of the stream is zero, so its phase is irrelevant
-            float2 o = rotate_sample(make_float2(v0, v1), rot_step_fx, rot_count0 + (uint64_t)(p - (M - 1)), phasor_step(rot_step_fx));
+            float2 o = rotate_sample(make_float2(v0, v1), rot_step_fx, rot_count0 + (uint64_t)(p - (M - 1)));
             v0 = o.x;
             v1 = o.y;
         }
@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
     float *ldsT = lds;                       // NOUT zero-padded tap arrays
     float *ldsX = lds + NOUT * tlen;         // staged samples (padded rows)
     const int tid = threadIdx.x;
-    const cf rot_w = ROT ? phasor_step(rot_step_fx) : cf{1.f, 0.f};
+    RotTab rot_t;
+    if (ROT) rot_t = rot_tab(rot_step_fx);
     const long tile_k0 = (long)blockIdx.x * TILE_OUT;
     const long base = first + tile_k0 * D - e;               // stream position of r = 0
     const int span = G::span(NACC, ksteps);                   // samples to stage
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
 #pragma unroll
             for (int u = 0; u < UX; u++) {
                 const int i4 = i0 + u * 256;
-                if (i4 < nf4) lds_put4<S, D>(ldsX, i4, ROT ? rotate_pair(vv[u], rot_step_fx, rot_count0 + (uint64_t)(xlo + 2 * (long)i4), rot_w) : vv[u]);
+                if (i4 < nf4) lds_put4<S, D>(ldsX, i4, ROT ? rotate_pair(vv[u], rot_step_fx, rot_count0 + (uint64_t)(xlo + 2 * (long)i4), rot_t) : vv[u]);
             }
         }
     } else {
@@ -499,49 +500,73 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
     float *ldsT = lds;
     float *ldsX = lds + TLEN;
     const int tid = threadIdx.x;
-    const cf rot_w = ROT ? phasor_step(rot_step_fx) : cf{1.f, 0.f};
 
     for (int i = tid; i < TLEN; i += 256) ldsT[i] = taps_pad[i];
 
     auto xlo_of = [&](long t) { return first + t * (long)TILE_OUT * D - e - (M - 1); };
     auto interior = [&](long t) { long lo = xlo_of(t); return t < ntiles && lo >= 0 && lo + SPAN <= n; };
 
-    float4 pre[UX];
+    // Thread -> float4 mapping of the staged window (NF4 float4).  Plain: i4 = tid + 256 u.  With the fused rotator a thread
+    // owns whole ALIGNED blocks of 8 samples (4 consecutive float4, block b = tid + 256 v starting at absolute sample index
+    // = 0 mod 8), so one phasor polynomial serves 8 samples; the block grid is shifted by a4 float4 against the window, the
+    // same for every tile because the tile advance TILE_OUT * D is a multiple of 8 samples.
+    static_assert(!ROT || (S == 2 && (TILE_OUT * D) % 8 == 0), "rotator staging: complex stream, tile advance = 0 mod 8 samples");
+    constexpr int NB = ROT ? NF4 / 4 + 2 : 0;                 // blocks that can touch the window
+    constexpr int UB = (NB + 255) / 256;
+    constexpr int NPRE = ROT ? 4 * UB : UX;
+    RotTab rot_t;
+    int a4 = 0;
+    if (ROT) {
+        rot_t = rot_tab(rot_step_fx);
+        a4 = (int)(((rot_count0 + (uint64_t)xlo_of(0)) & 7) >> 1);      // window float4 0 is float4 a4 of its block (even offsets only)
+    }
+    const bool rot_blocks = ROT && (((rot_count0 + (uint64_t)xlo_of(0)) & 1) == 0);
+    auto i4_of = [&](int u) { return ROT ? 4 * (tid + 256 * (u >> 2)) + (u & 3) - a4 : tid + 256 * u; };
+
+    float4 pre[NPRE];
     long t = blockIdx.x;
     bool have = false;
-    if (interior(t)) {
-        const float4 *src = reinterpret_cast<const float4 *>(x + xlo_of(t) * S);
+    auto prefetch = [&](long tt) {
+        have = interior(tt) && (!ROT || rot_blocks);
+        if (have) {
+            const float4 *src = reinterpret_cast<const float4 *>(x + xlo_of(tt) * S);
 #pragma unroll
-        for (int u = 0; u < UX; u++) {
-            int idx = tid + u * 256;
-            pre[u] = src[idx < NF4 ? idx : NF4 - 1];
+            for (int u = 0; u < NPRE; u++) {
+                int idx = i4_of(u);
+                pre[u] = src[idx < 0 ? 0 : idx < NF4 ? idx : NF4 - 1];        // clamped, unconditional: no branch between loads
+            }
         }
-        have = true;
-    }
+    };
+    prefetch(t);
     for (; t < ntiles; t += gridDim.x) {
         const long tile_k0 = t * (long)TILE_OUT;
         if (have) {
             const long xlo = xlo_of(t);
+            if constexpr (ROT) {
 #pragma unroll
-            for (int u = 0; u < UX; u++) {
-                const int i4 = tid + u * 256;
-                if (i4 < NF4) lds_put4<S, D>(ldsX, i4, ROT ? rotate_pair(pre[u], rot_step_fx, rot_count0 + (uint64_t)(xlo + 2 * (long)i4), rot_w) : pre[u]);
+                for (int v = 0; v < UB; v++) {
+                    const int i40 = 4 * (tid + 256 * v) - a4;                 // first float4 of this thread's block
+                    if (i40 + 3 >= 0 && i40 < NF4) {
+                        const cf p = phasor_poly(rot_step_fx * (rot_count0 + (uint64_t)(xlo + 2 * (long)i40)));
+                        if (i40 >= 0) lds_put4<S, D>(ldsX, i40, rotate_in_block<0>(pre[4 * v], p, rot_t));
+                        if (i40 + 1 >= 0 && i40 + 1 < NF4) lds_put4<S, D>(ldsX, i40 + 1, rotate_in_block<1>(pre[4 * v + 1], p, rot_t));
+                        if (i40 + 2 >= 0 && i40 + 2 < NF4) lds_put4<S, D>(ldsX, i40 + 2, rotate_in_block<2>(pre[4 * v + 2], p, rot_t));
+                        if (i40 + 3 < NF4) lds_put4<S, D>(ldsX, i40 + 3, rotate_in_block<3>(pre[4 * v + 3], p, rot_t));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UX; u++) {
+                    const int i4 = tid + u * 256;
+                    if (i4 < NF4) lds_put4<S, D>(ldsX, i4, pre[u]);
+                }
             }
         } else {
             stage_edge<S, D, ROT>(ldsX, hist, x, first + tile_k0 * D - e, SPAN, M, n, rot_step_fx, rot_count0);
         }
         __syncthreads();
         // prefetch the next tile while this one is multiplied
-        const long tn = t + gridDim.x;
-        have = interior(tn);
-        if (have) {
-            const float4 *src = reinterpret_cast<const float4 *>(x + xlo_of(tn) * S);
-#pragma unroll
-            for (int u = 0; u < UX; u++) {
-                int idx = tid + u * 256;
-                pre[u] = src[idx < NF4 ? idx : NF4 - 1];
-            }
-        }
+        prefetch(t + gridDim.x);
         f32x4 acc[1][NACC];
         mfma_tile<S, D, NACC, KS, 1>(ldsT, TLEN, e, ldsX, KS, acc);
         if constexpr (EPI == 0) {
