@@ -18,6 +18,10 @@
 #include "common.h"
 #include "kernels_elem.h"
 
+#ifndef LRHIP_FIR_PIPE
+#define LRHIP_FIR_PIPE 0
+#endif
+
 namespace lrhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -204,7 +208,30 @@ __device__ __forceinline__ void mfma_tile(const float *ldsT, int tlen, int e, co
             for (int o = 0; o < NOUT; o++) acc[o][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[o], bv, acc[o][a], 0, 0, 0);
         }
     };
-    if constexpr (KS > 0) {
+    if constexpr (KS > 0 && LRHIP_FIR_PIPE) {
+        // explicit one-step software pipeline: the fragments of step s+1 are in flight while step s is multiplied.  The
+        // sched_barriers keep hipcc from sinking each ds_read next to its MFMA (where it waits for it at once).
+        float av[2][NOUT], bv[2][NACC];
+        auto fetch = [&](int buf, int s) {
+            const int g = s / G::GROUP, j = s % G::GROUP;
+            const float *ap = aptr + 4 * g * G::GROUP, *bp = bptr + g * (G::ROW + G::PAD);
+#pragma unroll
+            for (int o = 0; o < NOUT; o++) av[buf][o] = ap[o * tlen + 4 * j];
+#pragma unroll
+            for (int a = 0; a < NACC; a++) bv[buf][a] = bp[a * ACC_STRIDE + j * 4 * S];
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            if (s + 1 < KS) fetch((s + 1) & 1, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < NACC; a++)
+#pragma unroll
+                for (int o = 0; o < NOUT; o++) acc[o][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1][o], bv[s & 1][a], acc[o][a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if constexpr (KS > 0) {
 #if LRHIP_FIR_SETPRIO
         __builtin_amdgcn_s_setprio(1);
 #endif
