@@ -543,18 +543,20 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
     constexpr int NPRE = ROT ? 4 * UB : UX;
     RotTab rot_t;
     int a4 = 0;
+    // odd absolute offset (an odd number of samples consumed so far): float4 pairs straddle the blocks; same thread mapping
+    // with a4 = 0 and the general rotate_pair (correct, slower - the reference's own chunk sizes are even)
+    const bool rot_blocks = ROT && (((rot_count0 + (uint64_t)xlo_of(0)) & 1) == 0);
     if (ROT) {
         rot_t = rot_tab(rot_step_fx);
-        a4 = (int)(((rot_count0 + (uint64_t)xlo_of(0)) & 7) >> 1);      // window float4 0 is float4 a4 of its block (even offsets only)
+        if (rot_blocks) a4 = (int)(((rot_count0 + (uint64_t)xlo_of(0)) & 7) >> 1);      // window float4 0 is float4 a4 of its block
     }
-    const bool rot_blocks = ROT && (((rot_count0 + (uint64_t)xlo_of(0)) & 1) == 0);
     auto i4_of = [&](int u) { return ROT ? 4 * (tid + 256 * (u >> 2)) + (u & 3) - a4 : tid + 256 * u; };
 
     float4 pre[NPRE];
     long t = blockIdx.x;
     bool have = false;
     auto prefetch = [&](long tt) {
-        have = interior(tt) && (!ROT || rot_blocks);
+        have = interior(tt);
         if (have) {
             const float4 *src = reinterpret_cast<const float4 *>(x + xlo_of(tt) * S);
 #pragma unroll
@@ -573,7 +575,12 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
 #pragma unroll
                 for (int v = 0; v < UB; v++) {
                     const int i40 = 4 * (tid + 256 * v) - a4;                 // first float4 of this thread's block
-                    if (i40 + 3 >= 0 && i40 < NF4) {
+                    if (!rot_blocks) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (i40 + j < NF4)
+                                lds_put4<S, D>(ldsX, i40 + j, rotate_pair(pre[4 * v + j], rot_step_fx, rot_count0 + (uint64_t)(xlo + 2 * (long)(i40 + j)), rot_t));
+                    } else if (i40 + 3 >= 0 && i40 < NF4) {
                         const cf p = phasor_poly(rot_step_fx * (rot_count0 + (uint64_t)(xlo + 2 * (long)i40)));
                         if (i40 >= 0) lds_put4<S, D>(ldsX, i40, rotate_in_block<0>(pre[4 * v], p, rot_t));
                         if (i40 + 1 >= 0 && i40 + 1 < NF4) lds_put4<S, D>(ldsX, i40 + 1, rotate_in_block<1>(pre[4 * v + 1], p, rot_t));

@@ -539,6 +539,31 @@ def test_randomized_chunkings_fused_chains_equal_unfused_blocks(seed):
             assert np.array_equal(got, want), name
 
 
+@pytest.mark.parametrize("decim", [1, 5])
+def test_rotator_fir_fusion_odd_sample_offsets(decim):
+    """the fused rotator stages aligned blocks of 8 samples; after an odd number of consumed samples the blocks no longer line
+    up with the 16-B loads and the kernel takes its general path - same bits as the separate blocks either way"""
+    rng = np.random.default_rng(33 + decim)
+    rate = 1102500.0
+    n = 150001
+    x = rand_c(rng, n)
+
+    def blocks():
+        bl = [make(lr.FrequencyTranslatorBlock, [123456.0], x, rate=rate), make(lr.LowpassFilterBlock, [128, 100e3], x, rate=rate)]
+        if decim > 1:
+            bl.append(make(lr.DownsamplerBlock, [decim], x, rate=rate))
+        return bl
+
+    chain = lr.Chain(blocks())
+    got = chunked(chain, x, [1, 40001, 40004, 90005, 90007])          # odd, even, odd ... absolute offsets, several tiles each
+    want = x
+    for b in blocks():
+        want = b.process(want)
+    assert np.array_equal(got, want)
+    ora = O.Chain([O.Rotator(2 * np.pi * 123456.0 / rate, O.MODE_F64), O.lowpass(128, 100e3, rate, True, mode=O.MODE_FMA)]).process(x)
+    assert G.max_abs_err(got, ora[::decim]) < 2e-6
+
+
 def test_wbfm_mono_chain_rms_within_1e5():
     """BASELINE.json configs[2] at a size the oracle finishes in seconds: synthetic FM (SURVEY.md 8d C3 recipe),
     chain = examples/rtlsdr_wbfm_mono.lua:12-17,28.  Bar: RMS error <= 1e-5 vs the per-block-pinned oracle."""
