@@ -1141,3 +1141,36 @@ def test_error_paths_report_through_strerror():
     x = np.zeros(10, np.float32)
     rc = L.lrhip_stage_execute(blk.stage_handle(), x.ctypes.data_as(C.c_void_p), 10, out.ctypes.data_as(C.c_void_p), 1)
     assert rc < 0 and b"capacity" in L.lrhip_strerror()
+
+
+def test_create_destroy_many_stages_returns_device_memory():
+    """stages, chains and graphs own device buffers (history, tables, edges, rings); destroying them must give the memory back"""
+    import gc
+    import torch
+    rng = np.random.default_rng(9)
+    x = rand_c(rng, 1 << 18)
+
+    def churn():
+        rx = lr.wbfm_mono_receiver(1102500.0, -250e3)
+        rx.process(x)
+        rx.chain.set_ring(3, 1 << 16)
+        list(rx.chain.stream([x[:1 << 16]] * 4, depth=3))
+        blk = make(lr.FIRFilterBlock, [O.firwin_lowpass(128, 0.2).astype(np.float32), "fast"], x)
+        blk.process(x)
+        w = lr.spectrum_utils.WelchSpectrum(types.ComplexFloat32, 1024, "hamming", 1e6, 0.5)
+        w.process(x)
+        w.average()
+        ch = make(lr.PolyphaseChannelizerBlock, [32], x)
+        ch.process(x[:1 << 16])
+        del rx, blk, w, ch
+        gc.collect()
+
+    churn()
+    lr._lib.load().lrhip_synchronize()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        churn()
+    lr._lib.load().lrhip_synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)
