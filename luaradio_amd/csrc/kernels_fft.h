@@ -11,27 +11,59 @@ namespace lrhip {
 
 enum { FFT_OUT_COMPLEX = 0, FFT_OUT_REAL = 1, FFT_OUT_PSD = 2, FFT_OUT_PSD_LOG = 3 };
 
-// in-LDS autosort radix-2 FFT over `frames` independent frames laid out back to back (N complex each) in
-// buffer a; b is scratch of the same size.  Returns the buffer holding the result.  All 256 threads call it.
-__device__ __forceinline__ float2 *fft_lds(float2 *a, float2 *b, int N, int frames, const float2 *__restrict__ tw,
-                                           bool inverse)
+// in-LDS autosort (Stockham) FFT over `frames` independent frames laid out back to back (N complex each) in buffer a;
+// b is scratch of the same size; tw = W_N^m, m < N/2, in LDS.  Radix-4 passes (half the barriers and LDS round trips of
+// radix-2), one radix-2 pass when log2 N is odd.  Returns the buffer holding the result.  All 256 threads call it.
+__device__ __forceinline__ float2 tw_at(const float2 *tw, int m, int half, bool inverse)
 {
-    const int half = N >> 1;
-    const int total = frames * half;
-    for (int p = 1; p < N; p <<= 1) {
-        const int twstride = half / p;          // W_{2p}^k = W_N^{k*N/(2p)}
+    float2 w = tw[m & (half - 1)];                     // W^(m + N/2) = -W^m
+    if (m & half) w = make_float2(-w.x, -w.y);
+    if (inverse) w.y = -w.y;
+    return w;
+}
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 w) { return make_float2(fmaf(a.x, w.x, -a.y * w.y), fmaf(a.x, w.y, a.y * w.x)); }
+
+__device__ __forceinline__ float2 *fft_lds(float2 *a, float2 *b, int N, int log2n, int frames, const float2 *tw, bool inverse)
+{
+    const int half = N >> 1, quarter = N >> 2;
+    int p = 1, lp = 0;
+    for (; lp + 2 <= log2n; lp += 2, p <<= 2) {
+        const int twstride = quarter >> lp;            // W_{4p}^k = W_N^{k N/(4p)}
+        const int total = frames * quarter;
         for (int w = threadIdx.x; w < total; w += blockDim.x) {
-            int f = w / half, i = w - f * half;
-            int k = i & (p - 1);
-            int j = ((i - k) << 1) + k;
-            float2 wv = tw[k * twstride];
-            if (inverse) wv.y = -wv.y;
-            const float2 *src = a + f * N;
-            float2 *dst = b + f * N;
-            float2 u0 = src[i], x1 = src[i + half];
-            float2 u1 = make_float2(fmaf(x1.x, wv.x, -x1.y * wv.y), fmaf(x1.x, wv.y, x1.y * wv.x));
-            dst[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
-            dst[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+            const int f = w >> (log2n - 2), i = w & (quarter - 1);
+            const int k = i & (p - 1);
+            const int j = ((i - k) << 2) + k;
+            const float2 *src = a + (f << log2n);
+            float2 *dst = b + (f << log2n);
+            float2 x0 = src[i], x1 = src[i + quarter], x2 = src[i + 2 * quarter], x3 = src[i + 3 * quarter];
+            if (p > 1) {
+                x1 = cmulf(x1, tw_at(tw, k * twstride, half, inverse));
+                x2 = cmulf(x2, tw_at(tw, 2 * k * twstride, half, inverse));
+                x3 = cmulf(x3, tw_at(tw, 3 * k * twstride, half, inverse));
+            }
+            const float2 s0 = make_float2(x0.x + x2.x, x0.y + x2.y), d0 = make_float2(x0.x - x2.x, x0.y - x2.y);
+            const float2 s1 = make_float2(x1.x + x3.x, x1.y + x3.y), d1 = make_float2(x1.x - x3.x, x1.y - x3.y);
+            // forward: -j * d1 = (d1.y, -d1.x); inverse: +j * d1
+            const float2 jd = inverse ? make_float2(-d1.y, d1.x) : make_float2(d1.y, -d1.x);
+            dst[j] = make_float2(s0.x + s1.x, s0.y + s1.y);
+            dst[j + p] = make_float2(d0.x + jd.x, d0.y + jd.y);
+            dst[j + 2 * p] = make_float2(s0.x - s1.x, s0.y - s1.y);
+            dst[j + 3 * p] = make_float2(d0.x - jd.x, d0.y - jd.y);
+        }
+        __syncthreads();
+        float2 *t = a; a = b; b = t;
+    }
+    if (lp < log2n) {                                   // last pass radix-2, p = N/2
+        const int total = frames * half;
+        for (int w = threadIdx.x; w < total; w += blockDim.x) {
+            const int f = w >> (log2n - 1), i = w & (half - 1);
+            const float2 *src = a + (f << log2n);
+            float2 *dst = b + (f << log2n);
+            float2 u0 = src[i], u1 = cmulf(src[i + half], tw_at(tw, i, half, inverse));      // k = i, twstride = 1
+            dst[i] = make_float2(u0.x + u1.x, u0.y + u1.y);
+            dst[i + half] = make_float2(u0.x - u1.x, u0.y - u1.y);
         }
         __syncthreads();
         float2 *t = a; a = b; b = t;
@@ -47,21 +79,23 @@ __global__ __launch_bounds__(256) void fft_frames_kernel(const float *__restrict
                                                          float out_scale, int shift)
 {
     extern __shared__ __attribute__((aligned(16))) float2 fbuf[];
-    float2 *a = fbuf, *b = fbuf + (size_t)fpw * N;
+    float2 *a = fbuf, *b = fbuf + (size_t)fpw * N, *twl = fbuf + (size_t)2 * fpw * N;      // [a | b | N/2 twiddles]
+    const int log2n = 31 - __builtin_clz(N);
+    for (int i = threadIdx.x; i < N / 2; i += blockDim.x) twl[i] = tw[i];
     const long f0 = (long)blockIdx.x * fpw;
     int frames = (nframes - f0) < fpw ? (int)(nframes - f0) : fpw;
     const int total = frames * N;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        int s = i % N;
+        int s = i & (N - 1);
         long g = f0 * N + i;
         float2 v = IN_REAL ? make_float2(x[g], 0.f) : reinterpret_cast<const float2 *>(x)[g];
         if (window) { float w = window[s]; v.x *= w; v.y *= w; }
         a[i] = v;
     }
     __syncthreads();
-    float2 *r = fft_lds(a, b, N, frames, tw, inverse != 0);
+    float2 *r = fft_lds(a, b, N, log2n, frames, twl, inverse != 0);
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        int f = i / N, s = i - f * N;
+        int f = i >> log2n, s = i & (N - 1);
         int src = shift ? ((s + N / 2) & (N - 1)) : s;       // fftshift: out[s] = X[(s + N/2) mod N]
         float2 v = r[f * N + src];
         long g = f0 * N + i;

@@ -729,7 +729,7 @@ struct FftStage : lrhip_stage {
             return (long)n;
         }
         unsigned grid = (unsigned)((nframes + fpw - 1) / fpw);
-        size_t lds = (size_t)2 * fpw * N * sizeof(float2);
+        size_t lds = ((size_t)2 * fpw * N + N / 2) * sizeof(float2);
         const float *w = has_window ? (const float *)window.p : nullptr;
         if (in_real) {
             auto kern = fft_frames_kernel<true>;

@@ -697,6 +697,44 @@ def test_psd_many_frames_vs_oracle():
             assert np.max(np.abs(out - want) / np.max(want)) < 1e-5
 
 
+@pytest.mark.parametrize("N", [8, 16, 32, 64, 128, 256, 512, 2048, 4096])
+def test_dft_idft_psd_other_frame_sizes_vs_oracle(N):
+    """power-of-two frame lengths other than 1024 run the LDS radix-4 (+ one radix-2) Stockham kernel: forward / inverse,
+    complex / real side, windowed PSD with and without fftshift, several frames per launch, against the f64-accumulating oracle"""
+    rng = np.random.default_rng(400 + N)
+    frames = 11
+    xc, xr = rand_c(rng, N * frames), rand_r(rng, N * frames)
+    L = lr._lib.load()
+    import ctypes as C
+
+    def run(stage, x, out_dtype):
+        out = np.empty(len(x), out_dtype)
+        n = L.lrhip_stage_execute(stage, x.ctypes.data_as(C.c_void_p), len(x), out.ctypes.data_as(C.c_void_p), len(out))
+        assert n == len(x), L.lrhip_strerror()
+        L.lrhip_stage_destroy(stage)
+        return out
+
+    Xc = run(L.lrhip_dft_create(N, 0, 0), xc, np.complex64)
+    Xr = run(L.lrhip_dft_create(N, 0, 1), xr, np.complex64)
+    for f in range(frames):
+        sl = slice(f * N, (f + 1) * N)
+        want_c, want_r = O.dft(xc[sl]), O.dft(xr[sl])
+        assert G.max_abs_err(Xc[sl], want_c) / np.max(np.abs(want_c)) < 2e-6
+        assert G.max_abs_err(Xr[sl], want_r) / np.max(np.abs(want_r)) < 2e-6
+    assert G.max_abs_err(run(L.lrhip_dft_create(N, 1, 0), Xc, np.complex64), xc) < 2e-6
+    assert G.max_abs_err(run(L.lrhip_dft_create(N, 1, 1), Xr, np.float32), xr) < 2e-6
+    win = np.asarray(lr.window_utils.window(N, "hamming", True), np.float32)
+    scale = 44100.0 * float(np.sum(win.astype(np.float64) ** 2))
+    wp = win.ctypes.data_as(C.POINTER(C.c_float))
+    a = run(L.lrhip_psd_create(N, wp, scale, 0, 1, 0), xc, np.float32)
+    b = run(L.lrhip_psd_create(N, wp, scale, 0, 1, 1), xc, np.float32)
+    for f in range(frames):
+        sl = slice(f * N, (f + 1) * N)
+        assert np.array_equal(np.fft.fftshift(a[sl]), b[sl])
+        want = O.psd(xc[sl], "hamming", 44100.0, False)
+        assert np.max(np.abs(a[sl] - want)) / np.max(want) < 1e-5
+
+
 def test_dft_idft_1024_engine_vs_oracle():
     """N = 1024 frames take the one-wave-per-frame radix-16 engine (forward, inverse, real/complex sides, fftshift)"""
     rng = np.random.default_rng(41)
