@@ -176,14 +176,18 @@ template <int S, int PRE>
 __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const float *__restrict__ hist, const float *__restrict__ x,
                                                           const float2 *__restrict__ tables, float *__restrict__ y,
                                                           int M, long n, long n_out, long nblocks,
-                                                          double inv_gain, const float2 *__restrict__ disc_prev, float *__restrict__ hist_out)
+                                                          double inv_gain, const float2 *__restrict__ disc_prev, float *__restrict__ hist_out,
+                                                          int Mh, long delay, int accumulate)
 {
+    // Long filters are PARTITIONED: this launch applies taps [delay, delay + M) of an Mh-tap filter - the M-tap overlap-save
+    // on the stream delayed by `delay` samples (history = Mh - 1 samples) - and adds to y when accumulate != 0.
+    // A plain filter is the one-partition case Mh = M, delay = 0.
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: block addresses and bounds stay on the SALU
     // history carry (PRE = 0; saves the fir_history_kernel launch): last M-1 stream samples into the other ping-pong buffer
     if (PRE == 0 && hist_out && blockIdx.x == 0)
-        for (int i = tid; i < (M - 1) * S; i += 64 * FFT_WPB) hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
+        for (int i = tid; i < (Mh - 1) * S; i += 64 * FFT_WPB) hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, Mh, n);
     cf *flc = reinterpret_cast<cf *>(fl);
     cf *ex = flc + wave * FFT_EX_ELEMS;
     const cf *tw1 = flc + FFT_LDS_TW1, *Hp = flc + FFT_LDS_H, *tw2 = flc + FFT_LDS_TW2;
@@ -218,8 +222,8 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
         // ---- load: window position 64*i + lane  (stream = [M-1 history | chunk])
         // (measured and dropped: 16-B accesses through an LDS transpose - no gain)
         if (S == 2) {
-            const long xlo = fb * L - V;                  // x index of window position 0
-            const long p0 = xlo + (M - 1);                // the same in stream coordinates
+            const long xlo = fb * L - V - delay;          // x index of window position 0
+            const long p0 = xlo + (Mh - 1);               // the same in stream coordinates
 #if LRHIP_FFT_PREFETCH
             if (have) {
 #pragma unroll
@@ -234,12 +238,12 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     long p = p0 + 64 * i + lane;
-                    v[i] = cf{stream_at<2>(hist, x, p, 0, M, n), stream_at<2>(hist, x, p, 1, M, n)};
+                    v[i] = cf{stream_at<2>(hist, x, p, 0, Mh, n), stream_at<2>(hist, x, p, 1, Mh, n)};
                 }
             }
         } else {
-            const long pa = (fb * 2) * L - V + (M - 1), pb = pa + L;      // stream positions of the two packed blocks
-            const long xa = pa - (M - 1), xb = pb - (M - 1);               // their x indices
+            const long pa = (fb * 2) * L - V - delay + (Mh - 1), pb = pa + L;      // stream positions of the two packed blocks
+            const long xa = pa - (Mh - 1), xb = pb - (Mh - 1);                     // their x indices
             if (xa >= PRE && xb + FFTN <= n) {
                 // both windows inside the chunk: coalesced loads, no history
                 if (PRE == 0) {
@@ -255,8 +259,8 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; i++)
-                    v[i] = cf{fft_real_sample<PRE>(hist, x, pa + 64 * i + lane, M, n, inv_gain, disc_prev),
-                              fft_real_sample<PRE>(hist, x, pb + 64 * i + lane, M, n, inv_gain, disc_prev)};
+                    v[i] = cf{fft_real_sample<PRE>(hist, x, pa + 64 * i + lane, Mh, n, inv_gain, disc_prev),
+                              fft_real_sample<PRE>(hist, x, pb + 64 * i + lane, Mh, n, inv_gain, disc_prev)};
             }
         }
 
@@ -307,12 +311,12 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             if (o0 + FFTN <= n_out) {
 #pragma unroll
                 for (int i = 0; i < 16; i++)
-                    if (64 * i >= V) dst[64 * i] = v[i];            // wave-uniform: whole rows only
+                    if (64 * i >= V) dst[64 * i] = accumulate ? dst[64 * i] + v[i] : v[i];            // wave-uniform: whole rows only
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     int nn = 64 * i + lane;
-                    if (nn >= V && o0 + nn < n_out) dst[64 * i] = v[i];
+                    if (nn >= V && o0 + nn < n_out) dst[64 * i] = accumulate ? dst[64 * i] + v[i] : v[i];
                 }
             }
         } else {
@@ -321,14 +325,17 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
                 float *da = y + oa + lane, *db = y + ob + lane;
 #pragma unroll
                 for (int i = 0; i < 16; i++)
-                    if (64 * i >= V) { da[64 * i] = v[i].x; db[64 * i] = v[i].y; }
+                    if (64 * i >= V) {
+                        da[64 * i] = accumulate ? da[64 * i] + v[i].x : v[i].x;
+                        db[64 * i] = accumulate ? db[64 * i] + v[i].y : v[i].y;
+                    }
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     int nn = 64 * i + lane;
                     if (nn >= V) {
-                        if (oa + nn < n_out) y[oa + nn] = v[i].x;
-                        if (ob + nn < n_out) y[ob + nn] = v[i].y;
+                        if (oa + nn < n_out) y[oa + nn] = accumulate ? y[oa + nn] + v[i].x : v[i].x;
+                        if (ob + nn < n_out) y[ob + nn] = accumulate ? y[ob + nn] + v[i].y : v[i].y;
                     }
                 }
             }

@@ -72,6 +72,7 @@ struct FirStage : lrhip_stage {
     long L = 0, fill = 0;
     DeviceBuf pending, work;
     // overlap-save ARITHMETIC (fused 1024-point FFT kernel); independent of the emission framing
+    static constexpr int FFT_PART = 512;   // taps per overlap-save partition (V = 512, L = 512 of the 1024-point block)
     bool fft_arith = false;
     DeviceBuf d_fft_tables;
     int fft_blocks_per_cu = 0;
@@ -237,26 +238,33 @@ struct FirStage : lrhip_stage {
 
     int launch_fft(const float *x, long n, float *y, long n_out)
     {
-        const long Lf = FFTN - ((M - 1 + 63) / 64) * 64;      // block advance of the fused kernel (overlap rounded to 64)
-        long nblocks = (n_out + Lf - 1) / Lf;
-        long nffts = S == 2 ? nblocks : (nblocks + 1) / 2;
         size_t lds_bytes = (size_t)FFT_LDS_ELEMS * sizeof(float2);
         const float *h = (const float *)hist[cur].p + hist_pad;
-        auto go = [&](auto kern) -> int {
-            if (!fft_blocks_per_cu && prepare_kernel(kern, lds_bytes, &fft_blocks_per_cu, 64 * FFT_WPB)) return -1;
-            long slots = (long)ctx().num_cus * fft_blocks_per_cu;
-            long want = (nffts + FFT_WPB - 1) / FFT_WPB;
-            unsigned grid = (unsigned)(want < slots ? want : slots);      // persistent; a dynamic one-batch-per-workgroup grid measured 3-7 % slower even for 2.4 blocks per wave
-            const float2 *dp = pre_disc ? (const float2 *)disc_prev.p + disc_cur : nullptr;
-            float *ho = (!pre_disc && M > 1) ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FFT_WPB), lds_bytes, ctx().stream, h, x, (const float2 *)d_fft_tables.p, y, M, n, n_out, nblocks,
-                               1.0 / disc_gain, dp, ho);
-            hist_in_kernel = ho != nullptr;
-            return 0;
-        };
-        int rc = S == 2 ? go(fir_fft_kernel<2, 0>) : pre_disc ? go(fir_fft_kernel<1, 1>) : go(fir_fft_kernel<1, 0>);
-        if (rc) return rc;
-        LR_LAUNCH_CHECK();
+        hist_in_kernel = false;
+        // one launch per partition of at most FFT_PART taps (a plain filter has one); partitions after the first accumulate
+        const int nparts = (M + FFT_PART - 1) / FFT_PART;
+        for (int part = 0; part < nparts; part++) {
+            const int Mp = part + 1 < nparts ? FFT_PART : M - part * FFT_PART;
+            const long Lf = FFTN - ((Mp - 1 + 63) / 64) * 64;      // block advance of the fused kernel (overlap rounded to 64)
+            long nblocks = (n_out + Lf - 1) / Lf;
+            long nffts = S == 2 ? nblocks : (nblocks + 1) / 2;
+            const float2 *tables = (const float2 *)d_fft_tables.p + (size_t)part * FFT_TABLE_ELEMS;
+            auto go = [&](auto kern) -> int {
+                if (!fft_blocks_per_cu && prepare_kernel(kern, lds_bytes, &fft_blocks_per_cu, 64 * FFT_WPB)) return -1;
+                long slots = (long)ctx().num_cus * fft_blocks_per_cu;
+                long want = (nffts + FFT_WPB - 1) / FFT_WPB;
+                unsigned grid = (unsigned)(want < slots ? want : slots);      // persistent; a dynamic one-batch-per-workgroup grid measured 3-7 % slower even for 2.4 blocks per wave
+                const float2 *dp = pre_disc ? (const float2 *)disc_prev.p + disc_cur : nullptr;
+                float *ho = (!pre_disc && M > 1 && part == 0) ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FFT_WPB), lds_bytes, ctx().stream, h, x, tables, y, Mp, n, n_out, nblocks,
+                                   1.0 / disc_gain, dp, ho, M, (long)part * FFT_PART, part > 0 ? 1 : 0);
+                if (ho) hist_in_kernel = true;
+                return 0;
+            };
+            int rc = S == 2 ? go(fir_fft_kernel<2, 0>) : pre_disc ? go(fir_fft_kernel<1, 1>) : go(fir_fft_kernel<1, 0>);
+            if (rc) return rc;
+            LR_LAUNCH_CHECK();
+        }
         return 0;
     }
 
@@ -417,44 +425,49 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
         turns -= floorl(turns);
         q->rot_step = (uint64_t)(turns * 18446744073709551616.0L);
     }
-    if (use_fft && decim == 1 && !rot && ntaps >= 32 && ntaps <= 512 && (input_complex || !taps_complex)) {
-        // fused overlap-save kernel tables: tw1[k1][t] | Hperm[4j+k3][lane] | tw2[k2][t2]
+    if (use_fft && decim == 1 && !rot && ntaps >= 32 && ntaps <= 16 * FirStage::FFT_PART && (input_complex || !taps_complex)) {
+        // fused overlap-save kernel tables, one set per partition of <= FFT_PART taps: tw1[k1][t] | Hperm[4j+k3][lane] | tw2[k2][t2]
         const double PI2 = 6.283185307179586476925286766559;
-        std::vector<float> tab((size_t)FFT_TABLE_ELEMS * 2);
-        for (int k1 = 0; k1 < 16; k1++)
-            for (int t = 0; t < 64; t++) {
-                double a = -PI2 * (double)((k1 * t) % FFTN) / FFTN;
-                tab[2 * (k1 * 64 + t)] = (float)std::cos(a);
-                tab[2 * (k1 * 64 + t) + 1] = (float)std::sin(a);
-            }
-        std::vector<double> Hr(FFTN, 0.0), Hi(FFTN, 0.0);
-        for (int k = 0; k < FFTN; k++) {
-            double sr = 0, si = 0;
-            for (unsigned m = 0; m < ntaps; m++) {
-                double a = -PI2 * (double)((k * (long)m) % FFTN) / FFTN, c = std::cos(a), sn = std::sin(a);
-                double hr = taps_complex ? taps[2 * m] : taps[m], hi = taps_complex ? taps[2 * m + 1] : 0.0;
-                sr += hr * c - hi * sn;
-                si += hr * sn + hi * c;
-            }
-            Hr[k] = sr / FFTN;      // the 1/N of the inverse transform (spectrum_utils.lua:335-338) folded in
-            Hi[k] = si / FFTN;
-        }
-        for (int j = 0; j < 4; j++)
-            for (int k3 = 0; k3 < 4; k3++)
-                for (int lane = 0; lane < 64; lane++) {
-                    int qq = lane & 3, k1 = lane >> 2;
-                    int k = k1 + 16 * (4 * j + qq) + 256 * k3;
-                    size_t o = (size_t)16 * 64 + (size_t)(4 * j + k3) * 64 + lane;
-                    tab[2 * o] = (float)Hr[k];
-                    tab[2 * o + 1] = (float)Hi[k];
+        const int nparts = ((int)ntaps + FirStage::FFT_PART - 1) / FirStage::FFT_PART;
+        std::vector<float> tab((size_t)nparts * FFT_TABLE_ELEMS * 2);
+        for (int part = 0; part < nparts; part++) {
+            float *tp = tab.data() + (size_t)part * FFT_TABLE_ELEMS * 2;
+            const unsigned m0 = (unsigned)part * FirStage::FFT_PART, m1 = std::min<unsigned>(ntaps, m0 + FirStage::FFT_PART);
+            for (int k1 = 0; k1 < 16; k1++)
+                for (int t = 0; t < 64; t++) {
+                    double a = -PI2 * (double)((k1 * t) % FFTN) / FFTN;
+                    tp[2 * (k1 * 64 + t)] = (float)std::cos(a);
+                    tp[2 * (k1 * 64 + t) + 1] = (float)std::sin(a);
                 }
-        for (int k2 = 0; k2 < 16; k2++)
-            for (int t2 = 0; t2 < 4; t2++) {
-                double a = -PI2 * (double)((k2 * t2) % 64) / 64.0;
-                size_t o = (size_t)2 * 16 * 64 + k2 * 4 + t2;
-                tab[2 * o] = (float)std::cos(a);
-                tab[2 * o + 1] = (float)std::sin(a);
+            std::vector<double> Hr(FFTN, 0.0), Hi(FFTN, 0.0);
+            for (int k = 0; k < FFTN; k++) {
+                double sr = 0, si = 0;
+                for (unsigned m = m0; m < m1; m++) {
+                    double a = -PI2 * (double)((k * (long)(m - m0)) % FFTN) / FFTN, c = std::cos(a), sn = std::sin(a);
+                    double hr = taps_complex ? taps[2 * m] : taps[m], hi = taps_complex ? taps[2 * m + 1] : 0.0;
+                    sr += hr * c - hi * sn;
+                    si += hr * sn + hi * c;
+                }
+                Hr[k] = sr / FFTN;      // the 1/N of the inverse transform (spectrum_utils.lua:335-338) folded in
+                Hi[k] = si / FFTN;
             }
+            for (int j = 0; j < 4; j++)
+                for (int k3 = 0; k3 < 4; k3++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        int qq = lane & 3, k1 = lane >> 2;
+                        int k = k1 + 16 * (4 * j + qq) + 256 * k3;
+                        size_t o = (size_t)16 * 64 + (size_t)(4 * j + k3) * 64 + lane;
+                        tp[2 * o] = (float)Hr[k];
+                        tp[2 * o + 1] = (float)Hi[k];
+                    }
+            for (int k2 = 0; k2 < 16; k2++)
+                for (int t2 = 0; t2 < 4; t2++) {
+                    double a = -PI2 * (double)((k2 * t2) % 64) / 64.0;
+                    size_t o = (size_t)2 * 16 * 64 + k2 * 4 + t2;
+                    tp[2 * o] = (float)std::cos(a);
+                    tp[2 * o + 1] = (float)std::sin(a);
+                }
+        }
         if (upload(q->d_fft_tables, tab.data(), tab.size() * sizeof(float))) return nullptr;
         q->fft_arith = true;
     }
@@ -1717,7 +1730,7 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
         {
             FmDiscrimStage *dsc = dynamic_cast<FmDiscrimStage *>(stages[i]);
             FirStage *f1 = (dsc && i + 1 < nstages) ? dynamic_cast<FirStage *>(stages[i + 1]) : nullptr;
-            if (!no_disc_fusion && f1 && f1->fft_arith && !f1->use_fft && f1->S == 1 && f1->D == 1 && !f1->rot && !f1->pre_disc) {
+            if (!no_disc_fusion && f1 && f1->fft_arith && f1->M <= FirStage::FFT_PART && !f1->use_fft && f1->S == 1 && f1->D == 1 && !f1->rot && !f1->pre_disc) {
                 std::vector<float> taps((size_t)f1->M);
                 for (int t = 0; t < f1->M; t++) taps[t] = f1->taps_rev[f1->M - 1 - t];
                 FirStage *fused = fir_build(taps.data(), (unsigned)f1->M, 0, 0, 1, 2, false, 0.0);
