@@ -391,7 +391,7 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
     if (upload(q->d_taps, q->taps_rev.data(), q->taps_rev.size() * sizeof(float))) return nullptr;
     if (!taps_complex && FirStage::mfma_supported_decim(decim)) {
         int ks = fir_mfma_ksteps(q->M, (int)decim, q->S);
-        if ((size_t)fir_taps_len((int)decim, ks) * sizeof(float) <= 16 * 1024) {   // tap array must leave LDS room for the tile
+        if ((size_t)fir_taps_len((int)decim, ks) * sizeof(float) <= 24 * 1024) {   // tap array must leave LDS room for the tile
             std::vector<float> tab;
             fir_mfma_build_taps(q->taps_rev.data(), q->M, (int)decim, ks, tab);
             if (upload(q->d_atab, tab.data(), tab.size() * sizeof(float))) return nullptr;
