@@ -15,13 +15,13 @@ class FIRFilterBlock(Block):
 
     use_fft=True is the reference's overlap-save (firfilter.lua:320-398: only whole L = N-M+1 blocks are
     emitted, tail retained); use_fft="fast" runs the same overlap-save arithmetic (fused FFT kernel) but emits one
-    output per input; the default (False) is the direct form on the f32 matrix cores, bit-identical to the fmaf
-    chain in the reference's tap order."""
+    output per input; "auto" picks "fast" from 48 taps up and the direct form below; the default (False) is the direct
+    form on the f32 matrix cores, bit-identical to the fmaf chain in the reference's tap order."""
     name = "FIRFilterBlock"
 
     def instantiate(self, taps, use_fft=None):
         self.taps = as_taps(taps)
-        self.use_fft = 2 if use_fft == "fast" else (1 if use_fft else 0)
+        self.use_fft = 2 if use_fft == "fast" else 3 if use_fft == "auto" else (1 if use_fft else 0)
         self.decimation = 1
         if self.taps.dtype == np.complex64:      # firfilter.lua:68-74
             self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])

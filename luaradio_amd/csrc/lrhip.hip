@@ -375,8 +375,9 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
     if (!taps || ntaps < 1) { set_error("fir: need at least one tap"); return nullptr; }
     if (taps_complex && !input_complex) { set_error("fir: complex taps require ComplexFloat32 input (firfilter.lua:69-74)"); return nullptr; }
     if (decim < 1) { set_error("fir: decimation must be >= 1"); return nullptr; }
+    if (use_fft == 3) use_fft = (decim == 1 && !rot && ntaps >= 48 && ntaps <= 16 * FirStage::FFT_PART && (input_complex || !taps_complex)) ? 2 : 0;
     if (use_fft && decim != 1) { set_error("fir: overlap-save cannot be combined with decimation"); return nullptr; }
-    if (use_fft < 0 || use_fft > 2) { set_error("fir: use_fft must be 0 (direct form), 1 (overlap-save as the reference: block emission) or 2 (overlap-save arithmetic, sample-exact emission)"); return nullptr; }
+    if (use_fft < 0 || use_fft > 2) { set_error("fir: use_fft must be 0 (direct form), 1 (overlap-save as the reference: block emission), 2 (overlap-save arithmetic, sample-exact emission) or 3 (automatic)"); return nullptr; }
     if (ntaps > (1u << 20)) { set_error("fir: too many taps"); return nullptr; }
     if (ensure_init()) return nullptr;
     std::unique_ptr<FirStage> q(new (std::nothrow) FirStage());

@@ -248,6 +248,18 @@ def test_fir_fft_arithmetic_fast_mode(cplx_in, cplx_taps, ntaps):
     assert G.max_abs_err(got2, want) < 1e-6
 
 
+def test_fir_auto_mode_picks_the_faster_arithmetic():
+    rng = np.random.default_rng(8)
+    x = rand_c(rng, 30000)
+    for ntaps, exact in ((16, True), (47, True), (48, False), (300, False), (1000, False)):
+        taps = rand_r(rng, ntaps) / ntaps
+        got = make(lr.FIRFilterBlock, [taps, "auto"], x).process(x)
+        want = O.FIR(taps, True, O.MODE_FMA).process(x)
+        assert len(got) == len(x)
+        assert np.array_equal(got, want) == exact, ntaps       # direct form: bit-exact; FFT form: within 1e-6 but not bit-exact
+        assert G.max_abs_err(got, want) < 1e-6
+
+
 def test_lowpass_128_fft_fast_mode_vs_golden_and_direct():
     doc = G.load("lowpassfilter_spec")
     for vec in doc["vectors"]:
