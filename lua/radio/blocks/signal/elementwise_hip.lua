@@ -121,4 +121,55 @@ function M.patch_hilberttransform(HilbertTransformBlock)
     end
 end
 
+-- Two-input element-wise blocks (multiply.lua, multiplyconjugate.lua, add.lua, subtract.lua, floattocomplex.lua):
+-- M.patch_binary(MultiplyBlock, "multiply")
+function M.patch_binary(Block, op)
+    local function process(self, x, y)
+        local stage = lazy(self, function ()
+            return lrhip.lib.lrhip_binary_create(op, (self:get_input_type() == types.ComplexFloat32) and 1 or 0)
+        end)
+        return lrhip.execute2(stage, x, y, self.out)
+    end
+    Block.process = process
+    Block.process_complex = process
+    Block.process_real = process
+end
+
+-- MultiplyConstantBlock (multiplyconstant.lua:26-75), same constant-type rules as AddConstantBlock
+function M.patch_multiplyconstant(MultiplyConstantBlock)
+    local function process(self, x)
+        local stage = lazy(self, function ()
+            local c = self.constant
+            local cc = ffi.istype(types.ComplexFloat32, c)
+            return lrhip.lib.lrhip_multiply_constant_create(cc and c.real or (type(c) == "number" and c or c.value), cc and c.imag or 0,
+                                                            cc and 1 or 0, (self:get_input_type() == types.ComplexFloat32) and 1 or 0)
+        end)
+        return lrhip.execute(stage, x, self.out)
+    end
+    MultiplyConstantBlock.process_complex_by_complex = process
+    MultiplyConstantBlock.process_complex_by_real = process
+    MultiplyConstantBlock.process_real_by_real = process
+end
+
+-- UpsamplerBlock (upsampler.lua:45-53)
+function M.patch_upsampler(UpsamplerBlock)
+    function UpsamplerBlock:process(x)
+        local stage = lazy(self, function ()
+            return lrhip.lib.lrhip_upsampler_create(self.factor, ffi.sizeof(self:get_input_type()))
+        end)
+        return lrhip.execute(stage, x, self.out)
+    end
+end
+
+-- FrequencyModulatorBlock (frequencymodulator.lua:24-90)
+function M.patch_frequencymodulator(FrequencyModulatorBlock)
+    function FrequencyModulatorBlock:initialize()
+        self.out = types.ComplexFloat32.vector()
+    end
+    function FrequencyModulatorBlock:process(x)
+        local stage = lazy(self, function () return lrhip.lib.lrhip_fmmod_create(self.modulation_index) end)
+        return lrhip.execute(stage, x, self.out)
+    end
+end
+
 return M

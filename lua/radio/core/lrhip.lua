@@ -132,4 +132,16 @@ function M.execute(stage, x, out)
     return out:resize(n)
 end
 
+---
+-- Two-input variant (multiply.lua:43-57 pattern: both inputs have the same length).
+function M.execute2(stage, x, y, out)
+    local lib = M.lib
+    out:resize(x.length)
+    local n = tonumber(lib.lrhip_stage_execute2(stage, x.data, y.data, x.length, out.data, x.length))
+    if n < 0 then
+        error("lrhip_stage_execute2: " .. ffi.string(lib.lrhip_strerror()))
+    end
+    return out:resize(n)
+end
+
 return M
