@@ -191,7 +191,7 @@ def main():
         out_per_step = n
         alg_bytes = 16.0 * n
         flops = 4.0 * 128 * n if fir_mode == "direct" else 125.0 * n
-        dominant = "fir_mfma_persistent_kernel<2,1,8,false,36>" if fir_mode == "direct" else "fir_fft_kernel<2>"
+        dominant = "fir_mfma_persistent_kernel<2,1,8,false,36>" if fir_mode == "direct" else "fir_fft_kernel<2,0>"
         config = {"workload": "configs[1]: 128-tap real-taps FIR (LowpassFilterBlock(128, 15e3) @ 220.5 kHz) on 2^%d synthetic "
                               "ComplexFloat32 IQ per GPU" % log2n,
                   "samples_per_step_per_gpu": n, "taps": 128, "kernel": dominant,
