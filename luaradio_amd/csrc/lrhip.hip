@@ -6,6 +6,9 @@
 #include <memory>
 
 #include "common.h"
+#ifndef LRHIP_FIR_D1_NACC
+#define LRHIP_FIR_D1_NACC 8      /* accumulators per wave of the D = 1 Toeplitz kernel (A/B: 4 with more waves per SIMD) */
+#endif
 #include "kernels_elem.h"
 #include "kernels_fft.h"
 #include "kernels_fir.h"
@@ -287,7 +290,7 @@ struct FirStage : lrhip_stage {
     int dispatch_mfma(const float *x, long n, float *y, long n_out)
     {
         switch (D) {
-            case 1: return launch_mfma<SS, 1, 8>(x, n, y, n_out);
+            case 1: return launch_mfma<SS, 1, LRHIP_FIR_D1_NACC>(x, n, y, n_out);
             case 2: return launch_mfma<SS, 2, 4>(x, n, y, n_out);
             case 3: return launch_mfma<SS, 3, 2>(x, n, y, n_out);
             case 4: return launch_mfma<SS, 4, 2>(x, n, y, n_out);
