@@ -109,6 +109,10 @@ lrhip_stage_t *lrhip_upsampler_create(unsigned factor, int elem_size);
  * :33-51): Float32 in, ComplexFloat32 out = exp(j * running phase), phase += 2*pi*modulation_index*x[n]. */
 lrhip_stage_t *lrhip_fmmod_create(double modulation_index);
 
+/* AGCBlock (radio/blocks/signal/agc.lua:25-96).  power_alpha = 1/(1 + power_tau*rate), gain_alpha = 1/(1 + gain_tau*rate)
+ * (:46-49), target / threshold LINEAR power (10^(dB/10), :53-55).  Both recurrences run as parallel scans in double. */
+lrhip_stage_t *lrhip_agc_create(double power_alpha, double gain_alpha, double target, double threshold, int input_complex);
+
 /* One-input element-wise blocks. op: "complexmagnitude", "complexphase", "complextoreal", "complextoimag",
  * "complexconjugate" (ComplexFloat32 in), "realtocomplex", "absolutevalue" (Float32 in), and "addconstant"
  * (radio/blocks/signal/addconstant.lua:26-75: constant (re, im); constant_complex / input_complex as for

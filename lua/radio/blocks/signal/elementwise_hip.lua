@@ -172,4 +172,17 @@ function M.patch_frequencymodulator(FrequencyModulatorBlock)
     end
 end
 
+-- AGCBlock (agc.lua:45-96): the two recurrences run as prefix scans on the device; alphas as computed in initialize()
+function M.patch_agc(AGCBlock)
+    local function process(self, x)
+        local stage = lazy(self, function ()
+            return lrhip.lib.lrhip_agc_create(self.power_alpha, self.gain_alpha, self.target, self.threshold,
+                                              (self:get_input_type() == types.ComplexFloat32) and 1 or 0)
+        end)
+        return lrhip.execute(stage, x, self.out)
+    end
+    AGCBlock.process_real = process
+    AGCBlock.process_complex = process
+end
+
 return M

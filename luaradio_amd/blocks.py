@@ -544,3 +544,30 @@ class ManchesterMatchedFilterBlock(PulseMatchedFilterBlock):
     """radio/blocks/signal/manchestermatchedfilter.lua:27-50: a -1 half symbol followed by a +1 half symbol."""
     name = "ManchesterMatchedFilterBlock"
     _pattern = (-1, 1)
+
+
+class AGCBlock(Block):
+    """radio/blocks/signal/agc.lua:25-96. AGCBlock(mode[, target=-35[, threshold=-75[, {gain_tau=, power_tau=}]]])."""
+    name = "AGCBlock"
+
+    def instantiate(self, mode, target=None, threshold=None, options=None):
+        assert mode, 'Missing argument #1 (mode), can be "fast", "slow", or "custom"'
+        assert mode in ("fast", "slow", "custom"), 'Invalid mode "%s"' % mode
+        options = options or {}
+        self.mode = mode
+        self.target = -35 if target is None else target
+        self.threshold = -75 if threshold is None else threshold
+        self.gain_tau = {"fast": 0.1, "slow": 3.0}.get(mode, options.get("gain_tau"))
+        self.power_tau = options.get("power_tau") or 1.0
+        assert self.gain_tau, 'Missing gain_tau parameter for "custom" mode'
+        self.add_type_signature([Input("in", types.Float32)], [Output("out", types.Float32)])
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+
+    def initialize(self):
+        rate = self.get_rate()
+        self._set_stage(_lib.load().lrhip_agc_create(1 / (1 + self.power_tau * rate), 1 / (1 + self.gain_tau * rate), 10 ** (self.target / 10),
+                                                     10 ** (self.threshold / 10), int(self.get_input_type() is types.ComplexFloat32)),
+                        "Creating lrhip agc object")
+
+    def process(self, x):
+        return self._execute(x, self.get_output_type().dtype)

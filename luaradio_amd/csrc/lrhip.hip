@@ -15,6 +15,7 @@
 #include "kernels_firfft.h"
 #include "kernels_channelizer.h"
 #include "kernels_iir.h"
+#include "kernels_agc.h"
 
 using namespace lrhip;
 
@@ -701,6 +702,43 @@ struct IirStage : lrhip_stage {
         if (rc) return rc;
         if (D > 1) index = index + n_out * D - n;       // downsampler.lua:53
         return (long)n_out;
+    }
+};
+
+// =====================================================================================================
+// AGCBlock
+// =====================================================================================================
+struct AgcStage : lrhip_stage {
+    AgcParams p;
+    int S = 1;
+    DeviceBuf state, mapsP, mapsG, startP, startG;     // state: two (P, G) double pairs, ping-pong
+    int cur = 0;
+    const char *kind() const override { return "agc"; }
+    int reset() override { cur = 0; return zero_fill(state, 4 * sizeof(double)); }
+    template <int SS>
+    int go(const float *x, float *y, unsigned long n)
+    {
+        unsigned long nt = (n + AGC_TILE - 1) / AGC_TILE;
+        if (mapsP.reserve(nt * 2 * sizeof(double)) || mapsG.reserve(nt * 2 * sizeof(double)) || startP.reserve(nt * sizeof(double)) ||
+            startG.reserve(nt * sizeof(double))) return -1;
+        double *st = (double *)state.p + 2 * cur, *st_out = (double *)state.p + 2 * (cur ^ 1);
+        double *mp = (double *)mapsP.p, *mg = (double *)mapsG.p, *sp = (double *)startP.p, *sg = (double *)startG.p;
+        dim3 g((unsigned)nt), b(256);
+        hipLaunchKernelGGL((agc_pass_kernel<SS, 0>), g, b, 0, ctx().stream, x, y, n, p, mp, mg, (const double *)sp, (const double *)sg, st_out);
+        hipLaunchKernelGGL(agc_carry_kernel, dim3(1), b, 0, ctx().stream, (const double *)mp, nt, (const double *)st, sp);
+        hipLaunchKernelGGL((agc_pass_kernel<SS, 1>), g, b, 0, ctx().stream, x, y, n, p, mp, mg, (const double *)sp, (const double *)sg, st_out);
+        hipLaunchKernelGGL(agc_carry_kernel, dim3(1), b, 0, ctx().stream, (const double *)mg, nt, (const double *)(st + 1), sg);
+        hipLaunchKernelGGL((agc_pass_kernel<SS, 2>), g, b, 0, ctx().stream, x, y, n, p, mp, mg, (const double *)sp, (const double *)sg, st_out);
+        LR_LAUNCH_CHECK();
+        cur ^= 1;
+        return 0;
+    }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n > cap) return set_error("agc: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        int rc = S == 2 ? go<2>((const float *)in_dev, (float *)out_dev, n) : go<1>((const float *)in_dev, (float *)out_dev, n);
+        return rc ? rc : (long)n;
     }
 };
 
@@ -1486,6 +1524,20 @@ lrhip_stage_t *lrhip_upsampler_create(unsigned factor, int elem_size)
     q->factor = factor;
     q->in_size = q->out_size = elem_size;
     return q;
+}
+
+lrhip_stage_t *lrhip_agc_create(double power_alpha, double gain_alpha, double target, double threshold, int input_complex)
+{
+    if (!(power_alpha > 0.0 && power_alpha <= 1.0) || !(gain_alpha > 0.0 && gain_alpha <= 1.0)) { set_error("agc: alphas must be in (0, 1]"); return nullptr; }
+    if (!(target > 0.0) || !(threshold >= 0.0)) { set_error("agc: target and threshold are linear powers (> 0)"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    std::unique_ptr<AgcStage> q(new (std::nothrow) AgcStage());
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->p = AgcParams{power_alpha, gain_alpha, target, threshold};
+    q->S = input_complex ? 2 : 1;
+    q->in_size = q->out_size = 4 * q->S;
+    if (q->reset()) return nullptr;
+    return q.release();
 }
 
 lrhip_stage_t *lrhip_fmmod_create(double modulation_index)

@@ -671,3 +671,34 @@ long lro_fmmod_process(lro_fmmod *q, const float *x, long n, float *y)
     }
     return n;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * AGCBlock: radio/blocks/signal/agc.lua:45-96.  average_power and gain are Lua numbers (double); the input sample is
+ * Float32; out = sqrt(gain) * x narrowed to Float32 on store.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { double pa, ga, target, thr, power, gain; int cplx; } lro_agc;
+
+lro_agc *lro_agc_create(double power_alpha, double gain_alpha, double target_lin, double threshold_lin, int input_complex)
+{
+    lro_agc *q = (lro_agc *)calloc(1, sizeof(*q));
+    q->pa = power_alpha; q->ga = gain_alpha; q->target = target_lin; q->thr = threshold_lin; q->cplx = input_complex;
+    return q;
+}
+void lro_agc_destroy(lro_agc *q) { free(q); }
+
+long lro_agc_process(lro_agc *q, const float *x, long n, float *y)
+{
+    int S = q->cplx ? 2 : 1;
+    for (long i = 0; i < n; i++) {
+        double e = S == 1 ? (double)x[i] * (double)x[i] : (double)x[2 * i] * (double)x[2 * i] + (double)x[2 * i + 1] * (double)x[2 * i + 1];
+        q->power = (1 - q->pa) * q->power + q->pa * e;                                   /* :50 / :70 */
+        if (q->power >= q->thr) {
+            q->gain = (1 - q->ga) * q->gain + q->ga * (q->target * (1 / q->power));      /* :54 */
+            double g = sqrt(q->gain);
+            for (int c = 0; c < S; c++) y[S * i + c] = (float)(g * (double)x[S * i + c]);
+        } else {
+            for (int c = 0; c < S; c++) y[S * i + c] = x[S * i + c];
+        }
+    }
+    return n;
+}

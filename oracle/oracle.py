@@ -64,6 +64,11 @@ def lib():
         L.lro_fmdiscrim_process.restype = C.c_long
         L.lro_fmdiscrim_process.argtypes = [vp, fp, C.c_long, fp]
         L.lro_fmdiscrim_destroy.argtypes = [vp]
+        L.lro_agc_create.restype = vp
+        L.lro_agc_create.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
+        L.lro_agc_process.restype = C.c_long
+        L.lro_agc_process.argtypes = [vp, fp, C.c_long, fp]
+        L.lro_agc_destroy.argtypes = [vp]
         L.lro_fmmod_create.restype = vp
         L.lro_fmmod_create.argtypes = [C.c_double]
         L.lro_fmmod_process.restype = C.c_long
@@ -242,6 +247,24 @@ class FMDiscriminator(_Stage):
         assert xc
         y = _out(len(x), False)
         lib().lro_fmdiscrim_process(self.q, _fp(xf), len(x), _fp(y))
+        return y
+
+
+class AGC(_Stage):
+    """AGCBlock (agc.lua:25-96): AGC(mode, target_dB, threshold_dB, rate[, gain_tau, power_tau])."""
+    _destroy = "lro_agc_destroy"
+
+    def __init__(self, mode, target, threshold, rate, input_complex, gain_tau=None, power_tau=1.0):
+        gain_tau = {"fast": 0.1, "slow": 3.0}.get(mode, gain_tau)
+        self.input_complex = bool(input_complex)
+        self.q = lib().lro_agc_create(1 / (1 + power_tau * rate), 1 / (1 + gain_tau * rate), 10 ** (target / 10), 10 ** (threshold / 10),
+                                      int(input_complex))
+
+    def process(self, x):
+        xf, xc = _as_f32(x)
+        assert xc == self.input_complex
+        y = _out(len(x), xc)
+        lib().lro_agc_process(self.q, _fp(xf), len(x), _fp(y.view(np.float32)))
         return y
 
 

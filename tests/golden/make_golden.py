@@ -56,6 +56,7 @@ SPECS = [
     "blocks/signal/realtocomplex_spec",
     "blocks/signal/absolutevalue_spec",
     "blocks/signal/delay_spec",
+    "blocks/signal/agc_spec",
     "blocks/signal/frequencymodulator_spec",
     "blocks/signal/pulsematchedfilter_spec",
     "blocks/signal/manchestermatchedfilter_spec",

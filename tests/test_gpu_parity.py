@@ -1006,6 +1006,32 @@ def test_welch_spectrum_vs_oracle(is_complex, overlap):
     assert dev.average() is None
 
 
+def test_golden_agc():
+    doc = G.load("agc_spec")
+    for vec in doc["vectors"]:
+        _golden_both_modes(lr.AGCBlock, vec, doc["epsilon"])
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_agc_parallel_scans_vs_sequential_oracle(cplx):
+    """agc.lua:45-96 reads like a feedback loop; it runs as two chained prefix scans over affine maps (power estimator with
+    ~10^5-sample memory, gain filter frozen below the threshold).  Against the sequential double-precision oracle on a signal
+    whose level moves across the threshold, ragged chunks"""
+    rng = np.random.default_rng(55 + cplx)
+    rate, n = 48000.0, 600000
+    level = 10 ** (np.repeat(rng.uniform(-90, -20, n // 20000), 20000) / 20)          # steps between -90 and -20 dBFS
+    x = (rand_c(rng, n) if cplx else rand_r(rng, n)) * level.astype(np.float32)
+    for mode, opts in (("fast", None), ("slow", None), ("custom", {"gain_tau": 0.01, "power_tau": 0.05})):
+        blk = make(lr.AGCBlock, [mode, -35, -60, opts], x, rate=rate)
+        got = chunked(blk, x, [1, 2047, 2048, 2049, 100000, 100003, 350000])
+        ora = O.AGC(mode, -35, -60, rate, cplx, **({"gain_tau": opts["gain_tau"], "power_tau": opts["power_tau"]} if opts else {}))
+        want = ora.process(x)
+        assert len(got) == n
+        scale = np.maximum(np.abs(want), 1e-6)
+        assert np.max(np.abs(got - want) / scale) < 2e-5, mode
+        assert not np.array_equal(got, x)             # the gain really engaged somewhere
+
+
 def test_golden_frequencymodulator_and_matched_filters():
     doc = G.load("frequencymodulator_spec")
     for vec in doc["vectors"]:

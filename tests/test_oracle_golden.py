@@ -90,6 +90,14 @@ def test_frequencydiscriminator():
         _check(lambda: O.FMDiscriminator(vec["args"][0]), vec, doc["epsilon"])
 
 
+def test_agc():
+    doc = G.load("agc_spec")
+    assert len(doc["vectors"]) == 6
+    for vec in doc["vectors"]:
+        x = vec["inputs"][0]
+        _check(lambda: O.AGC(vec["args"][0], vec["args"][1], vec["args"][2], 2.0, np.iscomplexobj(x)), vec, doc["epsilon"])
+
+
 def test_frequencymodulator():
     doc = G.load("frequencymodulator_spec")
     assert doc["epsilon"] == 5e-5          # "radio.platform.features.liquid and 5e-3 or 5e-5": the pure-Lua bound

@@ -91,6 +91,7 @@ def main():
     run("Downsampler (M = 5), Real input", 253.07, mk(lr.DownsamplerBlock, [5], False), False)
     run("Frequency Translator", 396.69, mk(lr.FrequencyTranslatorBlock, [0.2], True), True)
     run("Hilbert Transform (65 taps)", None, mk(lr.HilbertTransformBlock, [65], False), False)
+    run("AGC (fast), Complex input", None, mk(lr.AGCBlock, ["fast"], True, 1e6), True)
     run("Frequency Discriminator", 111.61, mk(lr.FrequencyDiscriminatorBlock, [1.25], True), True)
     for r in rows:
         print(json.dumps(r))
