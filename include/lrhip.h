@@ -113,6 +113,10 @@ lrhip_stage_t *lrhip_fmmod_create(double modulation_index);
  * (:46-49), target / threshold LINEAR power (10^(dB/10), :53-55).  Both recurrences run as parallel scans in double. */
 lrhip_stage_t *lrhip_agc_create(double power_alpha, double gain_alpha, double target, double threshold, int input_complex);
 
+/* PowerSquelchBlock (radio/blocks/signal/powersquelch.lua:26-80): alpha = 1/(1 + tau*rate), threshold LINEAR power; samples
+ * pass while the running average power is at or above the threshold, else zeros. */
+lrhip_stage_t *lrhip_powersquelch_create(double alpha, double threshold, int input_complex);
+
 /* One-input element-wise blocks. op: "complexmagnitude", "complexphase", "complextoreal", "complextoimag",
  * "complexconjugate" (ComplexFloat32 in), "realtocomplex", "absolutevalue" (Float32 in), and "addconstant"
  * (radio/blocks/signal/addconstant.lua:26-75: constant (re, im); constant_complex / input_complex as for

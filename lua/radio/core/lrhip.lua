@@ -42,6 +42,7 @@ lrhip_stage_t *lrhip_channelizer_create(const float *taps, unsigned ntaps, unsig
 lrhip_stage_t *lrhip_welch_create(unsigned n, const float *window, double scale, int logarithmic, int input_complex, unsigned overlap);
 long lrhip_welch_read(lrhip_stage_t *q, float *avg_host, int reset);
 lrhip_stage_t *lrhip_fmmod_create(double modulation_index);
+lrhip_stage_t *lrhip_powersquelch_create(double alpha, double threshold, int input_complex);
 lrhip_stage_t *lrhip_agc_create(double power_alpha, double gain_alpha, double target, double threshold, int input_complex);
 lrhip_stage_t *lrhip_unary_create(const char *op, float re, float im, int constant_complex, int input_complex);
 lrhip_stage_t *lrhip_delay_create(unsigned num_samples, int elem_size);

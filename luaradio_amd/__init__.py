@@ -14,7 +14,7 @@ from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock,
                      ComplexPhaseBlock, ComplexToRealBlock, ComplexToImagBlock, ComplexConjugateBlock, RealToComplexBlock,
                      AbsoluteValueBlock, AddConstantBlock, DelayBlock, HilbertTransformBlock, SinglepoleHighpassFilterBlock,
                      FMPreemphasisFilterBlock, FloatToComplexBlock, ComplexToFloatBlock, FrequencyModulatorBlock,
-                     PulseMatchedFilterBlock, ManchesterMatchedFilterBlock, AGCBlock)
+                     PulseMatchedFilterBlock, ManchesterMatchedFilterBlock, AGCBlock, PowerSquelchBlock)
 from .sources import IQFileSource, RealFileSource  # noqa: F401
 from .graph import DeviceGraph  # noqa: F401
 from .composites import (Chain, CompositeBlock, DecimatorBlock, InterpolatorBlock, RationalResamplerBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401

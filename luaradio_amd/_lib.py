@@ -42,6 +42,7 @@ SIGNATURES = {
     "lrhip_welch_create": (_vp, [C.c_uint, _fp, C.c_double, C.c_int, C.c_int, C.c_uint]),
     "lrhip_welch_read": (C.c_long, [_vp, _fp, C.c_int]),
     "lrhip_fmmod_create": (_vp, [C.c_double]),
+    "lrhip_powersquelch_create": (_vp, [C.c_double, C.c_double, C.c_int]),
     "lrhip_agc_create": (_vp, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
     "lrhip_unary_create": (_vp, [C.c_char_p, C.c_float, C.c_float, C.c_int, C.c_int]),
     "lrhip_delay_create": (_vp, [C.c_uint, C.c_int]),

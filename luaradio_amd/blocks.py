@@ -571,3 +571,23 @@ class AGCBlock(Block):
 
     def process(self, x):
         return self._execute(x, self.get_output_type().dtype)
+
+
+class PowerSquelchBlock(Block):
+    """radio/blocks/signal/powersquelch.lua:26-80. PowerSquelchBlock(threshold_dBFS[, tau=0.001])."""
+    name = "PowerSquelchBlock"
+
+    def instantiate(self, threshold, tau=None):
+        assert threshold is not None, "Missing argument #1 (threshold)"
+        self.threshold = threshold
+        self.tau = 0.001        # powersquelch.lua:28: `self.tau = tau or 0.001` reads an undefined global, so it is always 0.001
+        self.add_type_signature([Input("in", types.Float32)], [Output("out", types.Float32)])
+        self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
+
+    def initialize(self):
+        self._set_stage(_lib.load().lrhip_powersquelch_create(1 / (1 + self.tau * self.get_rate()), 10 ** (self.threshold / 10),
+                                                              int(self.get_input_type() is types.ComplexFloat32)),
+                        "Creating lrhip powersquelch object")
+
+    def process(self, x):
+        return self._execute(x, self.get_output_type().dtype)

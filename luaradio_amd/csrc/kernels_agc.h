@@ -12,6 +12,7 @@
 //   pass 0: tile maps of P           -> carry kernel -> P at every tile start
 //   pass 1: true P, tile maps of G   -> carry kernel -> G at every tile start
 //   pass 2: true P, true G, output, final (P, G) for the next call.
+// PowerSquelchBlock is the first scan alone followed by the gate (pass 3).
 // Traffic: 3 reads + 1 write of the stream.
 #pragma once
 #include "common.h"
@@ -79,6 +80,18 @@ __global__ __launch_bounds__(256) void agc_pass_kernel(const float *__restrict__
         return;
     }
     double P = fma(Ap, startP[blockIdx.x], Bp);          // P just before this thread's chunk
+    if (PASS == 3) {
+        // PowerSquelchBlock (radio/blocks/signal/powersquelch.lua:45-80): the same power estimator, the sample passes or is zeroed
+#pragma unroll
+        for (int i = 0; i < AGC_LC; i++)
+            if (c0 + i < n) {
+                P = cp * P + p.ap * e[i];
+#pragma unroll
+                for (int c = 0; c < S; c++) y[(c0 + i) * S + c] = P >= p.thr ? xv[i][c] : 0.f;
+                if (c0 + i == n - 1) { state_out[0] = P; state_out[1] = 0.0; }
+            }
+        return;
+    }
     // ---- G: per-sample maps from the true P
     double Pn[AGC_LC], Ag = 1.0, Bg = 0.0;
 #pragma unroll

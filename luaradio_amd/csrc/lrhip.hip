@@ -711,6 +711,7 @@ struct IirStage : lrhip_stage {
 struct AgcStage : lrhip_stage {
     AgcParams p;
     int S = 1;
+    bool squelch = false;                              // PowerSquelchBlock: power scan + gate only
     DeviceBuf state, mapsP, mapsG, startP, startG;     // state: two (P, G) double pairs, ping-pong
     int cur = 0;
     const char *kind() const override { return "agc"; }
@@ -726,6 +727,12 @@ struct AgcStage : lrhip_stage {
         dim3 g((unsigned)nt), b(256);
         hipLaunchKernelGGL((agc_pass_kernel<SS, 0>), g, b, 0, ctx().stream, x, y, n, p, mp, mg, (const double *)sp, (const double *)sg, st_out);
         hipLaunchKernelGGL(agc_carry_kernel, dim3(1), b, 0, ctx().stream, (const double *)mp, nt, (const double *)st, sp);
+        if (squelch) {
+            hipLaunchKernelGGL((agc_pass_kernel<SS, 3>), g, b, 0, ctx().stream, x, y, n, p, mp, mg, (const double *)sp, (const double *)sg, st_out);
+            LR_LAUNCH_CHECK();
+            cur ^= 1;
+            return 0;
+        }
         hipLaunchKernelGGL((agc_pass_kernel<SS, 1>), g, b, 0, ctx().stream, x, y, n, p, mp, mg, (const double *)sp, (const double *)sg, st_out);
         hipLaunchKernelGGL(agc_carry_kernel, dim3(1), b, 0, ctx().stream, (const double *)mg, nt, (const double *)(st + 1), sg);
         hipLaunchKernelGGL((agc_pass_kernel<SS, 2>), g, b, 0, ctx().stream, x, y, n, p, mp, mg, (const double *)sp, (const double *)sg, st_out);
@@ -1538,6 +1545,14 @@ lrhip_stage_t *lrhip_agc_create(double power_alpha, double gain_alpha, double ta
     q->in_size = q->out_size = 4 * q->S;
     if (q->reset()) return nullptr;
     return q.release();
+}
+
+lrhip_stage_t *lrhip_powersquelch_create(double alpha, double threshold, int input_complex)
+{
+    if (!(alpha > 0.0 && alpha <= 1.0)) { set_error("powersquelch: alpha must be in (0, 1]"); return nullptr; }
+    AgcStage *q = (AgcStage *)lrhip_agc_create(alpha, 1.0, 1.0, threshold, input_complex);
+    if (q) q->squelch = true;
+    return q;
 }
 
 lrhip_stage_t *lrhip_fmmod_create(double modulation_index)

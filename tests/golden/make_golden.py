@@ -57,6 +57,7 @@ SPECS = [
     "blocks/signal/absolutevalue_spec",
     "blocks/signal/delay_spec",
     "blocks/signal/agc_spec",
+    "blocks/signal/powersquelch_spec",
     "blocks/signal/frequencymodulator_spec",
     "blocks/signal/pulsematchedfilter_spec",
     "blocks/signal/manchestermatchedfilter_spec",

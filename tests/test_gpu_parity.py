@@ -1006,6 +1006,25 @@ def test_welch_spectrum_vs_oracle(is_complex, overlap):
     assert dev.average() is None
 
 
+def test_golden_powersquelch_and_large():
+    doc = G.load("powersquelch_spec")
+    for vec in doc["vectors"]:
+        _golden_both_modes(lr.PowerSquelchBlock, vec, doc["epsilon"], exact=True)
+    rng = np.random.default_rng(66)
+    n, rate = 300000, 48000.0
+    level = 10 ** (np.repeat(rng.uniform(-80, -20, n // 10000), 10000) / 20)
+    x = rand_c(rng, n) * level.astype(np.float32)
+    got = chunked(make(lr.PowerSquelchBlock, [-45], x, rate=rate), x, [1, 2049, 150000])
+    alpha, p, want = 1 / (1 + 0.001 * rate), 0.0, np.empty_like(x)
+    e = x.real.astype(np.float64) ** 2 + x.imag.astype(np.float64) ** 2
+    thr = 10 ** (-45 / 10)
+    for i in range(n):
+        p = (1 - alpha) * p + alpha * e[i]
+        want[i] = x[i] if p >= thr else 0
+    mism = np.nonzero(got != want)[0]
+    assert len(mism) <= 2 and 0 < np.count_nonzero(want) < n          # a threshold crossing may land one sample apart (scan vs sequential rounding)
+
+
 def test_golden_agc():
     doc = G.load("agc_spec")
     for vec in doc["vectors"]:

@@ -98,6 +98,20 @@ def test_agc():
         _check(lambda: O.AGC(vec["args"][0], vec["args"][1], vec["args"][2], 2.0, np.iscomplexobj(x)), vec, doc["epsilon"])
 
 
+def test_powersquelch():
+    """powersquelch.lua:45-80 restated with numpy (the power estimator of the AGC + a gate); tau is always 0.001 there"""
+    doc = G.load("powersquelch_spec")
+    for vec in doc["vectors"]:
+        x, want = vec["inputs"][0], vec["outputs"][0]
+        alpha, thr, p = 1 / (1 + 0.001 * 2.0), 10 ** (vec["args"][0] / 10), 0.0
+        e = np.abs(x.astype(np.complex128)) ** 2
+        got = np.empty_like(x)
+        for i in range(len(x)):
+            p = (1 - alpha) * p + alpha * e[i]
+            got[i] = x[i] if p >= thr else 0
+        assert G.max_abs_err(got, want) < doc["epsilon"], vec["desc"]
+
+
 def test_frequencymodulator():
     doc = G.load("frequencymodulator_spec")
     assert doc["epsilon"] == 5e-5          # "radio.platform.features.liquid and 5e-3 or 5e-5": the pure-Lua bound
