@@ -365,6 +365,105 @@ __global__ __launch_bounds__(256) void fir_disc_fixup_kernel(const float2 *__res
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Decimating FIR for the decimations the Toeplitz kernel has no instantiation for (9, 25, 50, ...: the reference's own
+// examples tune with TunerBlock(offset, bw, 50)), real taps, optional fused rotator.  One output per thread as an fmaf
+// chain in the reference's tap order (bit-identical to the direct form), but from a tile staged ONCE in LDS - rotated once
+// per sample, block-of-8 phasors - instead of 128 cached global reads per output.  OW outputs per tile (host: as many as
+// DECIM_SPAN_MAX staged samples allow, at most 256), persistent over tiles.  LDS index = p + (p >> 5): the pad keeps the
+// thread stride of D samples off the bank period for even D.  HBM bound: S*4 B in, S*4/D B out per input sample.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int DECIM_SPAN_MAX = 6144;
+
+__device__ __forceinline__ int decim_phys(int p) { return p + (p >> 5); }
+
+template <int S, bool ROT>
+__global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_rev,
+                                                            float *__restrict__ y, int M, long n, long n_out, long first, long D, int OW, long ntiles,
+                                                            uint64_t rot_step_fx, uint64_t rot_count0, float *__restrict__ hist_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ldsT = lds;                              // M reversed taps
+    float *ldsX = lds + ((M + 3) & ~3);             // staged samples, S floats each, padded index
+    const int tid = threadIdx.x;
+    if (hist_out && blockIdx.x == 0)
+        for (int i = tid; i < (M - 1) * S; i += 256) hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
+    for (int i = tid; i < M; i += 256) ldsT[i] = taps_rev[i];
+    RotTab rt;
+    if (ROT) rt = rot_tab(rot_step_fx);
+    const int span = (int)((OW - 1) * D) + M;
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long k0 = t * OW;                     // first output of the tile
+        const long q0 = first + k0 * D;             // stream position of staged sample 0 (stream = [M-1 history | chunk])
+        const long g0 = q0 - (M - 1);               // the same as an index into x (negative: history)
+        const bool interior = g0 >= 0 && g0 + span <= n;
+        if (ROT) {
+            // aligned blocks of 8 absolute samples: block b covers window positions 8b - a .. 8b - a + 7
+            const int a = (int)((rot_count0 + (uint64_t)g0) & 7);
+            const int nblk = (span + a + 7) >> 3;
+            for (int b = tid; b < nblk; b += 256) {
+                const int w0 = 8 * b - a;
+                const cf pb = phasor_poly(rot_step_fx * (rot_count0 + (uint64_t)(g0 + w0)));
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int w = w0 + j;
+                    if (w >= 0 && w < span) {
+                        const cf v = interior ? reinterpret_cast<const cf *>(x)[g0 + w]
+                                              : cf{stream_at<2>(hist, x, q0 + w, 0, M, n), stream_at<2>(hist, x, q0 + w, 1, M, n)};
+                        const cf r = cmul(v, cmul(pb, rt.w[j]));
+                        *reinterpret_cast<float2 *>(ldsX + 2 * decim_phys(w)) = make_float2(r.x, r.y);
+                    }
+                }
+            }
+        } else {
+            if (interior) {
+                for (int w = tid; w < span; w += 256) {
+                    if (S == 2) *reinterpret_cast<float2 *>(ldsX + 2 * decim_phys(w)) = reinterpret_cast<const float2 *>(x)[g0 + w];
+                    else ldsX[decim_phys(w)] = x[g0 + w];
+                }
+            } else {
+                for (int w = tid; w < span; w += 256) {
+#pragma unroll
+                    for (int c = 0; c < S; c++) ldsX[S * decim_phys(w) + c] = stream_at<S>(hist, x, q0 + w, c, M, n);
+                }
+            }
+        }
+        __syncthreads();
+        const long k = k0 + tid;
+        if (tid < OW && k < n_out) {
+            int p = tid * (int)D;
+            float re = 0.f, im = 0.f;
+            int tt = 0;
+            for (; tt + 4 <= M; tt += 4) {
+                const float h0 = ldsT[tt], h1 = ldsT[tt + 1], h2 = ldsT[tt + 2], h3 = ldsT[tt + 3];
+                const int i0 = decim_phys(p + tt), i1 = decim_phys(p + tt + 1), i2 = decim_phys(p + tt + 2), i3 = decim_phys(p + tt + 3);
+                if (S == 2) {
+                    const float2 x0 = *reinterpret_cast<const float2 *>(ldsX + 2 * i0), x1 = *reinterpret_cast<const float2 *>(ldsX + 2 * i1);
+                    const float2 x2 = *reinterpret_cast<const float2 *>(ldsX + 2 * i2), x3 = *reinterpret_cast<const float2 *>(ldsX + 2 * i3);
+                    re = fmaf(x0.x, h0, re); im = fmaf(x0.y, h0, im);
+                    re = fmaf(x1.x, h1, re); im = fmaf(x1.y, h1, im);
+                    re = fmaf(x2.x, h2, re); im = fmaf(x2.y, h2, im);
+                    re = fmaf(x3.x, h3, re); im = fmaf(x3.y, h3, im);
+                } else {
+                    re = fmaf(ldsX[i0], h0, re);
+                    re = fmaf(ldsX[i1], h1, re);
+                    re = fmaf(ldsX[i2], h2, re);
+                    re = fmaf(ldsX[i3], h3, re);
+                }
+            }
+            for (; tt < M; tt++) {
+                const float h0 = ldsT[tt];
+                const int i0 = decim_phys(p + tt);
+                re = fmaf(ldsX[S * i0], h0, re);
+                if (S == 2) im = fmaf(ldsX[2 * i0 + 1], h0, im);
+            }
+            if (S == 2) reinterpret_cast<float2 *>(y)[k] = make_float2(re, im);
+            else y[k] = re;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Polyphase rational resampler: [MultiplyConstant(c)] -> Upsampler(L) -> FIR(real taps h, M) -> [Downsampler(D)]
 // (radio/composites/interpolator.lua:31-34, rationalresampler.lua:37-44, upsampler.lua:45-53) without the zero-stuffed
 // stream.  Output m sits at upsampled position n = m*D; with p = n mod L, q = n div L

@@ -272,6 +272,34 @@ struct FirStage : lrhip_stage {
         return 0;
     }
 
+    // decimations without a Toeplitz instantiation (and taps too long for its LDS table): LDS-staged one-output-per-thread kernel
+    bool decim_lds_ok() const { return !taps_complex && !fft_arith && !use_fft && M + 255 <= DECIM_SPAN_MAX; }
+    int decim_blocks_per_cu = 0;
+    int launch_decim_lds(const float *x, long n, float *y, long n_out)
+    {
+        long ow = (DECIM_SPAN_MAX - M) / (long)D + 1;
+        int OW = (int)(ow > 256 ? 256 : ow < 1 ? 1 : ow);
+        long ntiles = (n_out + OW - 1) / OW;
+        long span = (long)(OW - 1) * D + M;
+        size_t lds_bytes = ((size_t)((M + 3) & ~3) + (size_t)S * (span + (span >> 5) + 2)) * sizeof(float);
+        const float *h = (const float *)hist[cur].p + hist_pad;
+        float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
+        auto go = [&](auto kern) -> int {
+            if (!decim_blocks_per_cu && prepare_kernel(kern, lds_bytes, &decim_blocks_per_cu)) return -1;
+            long slots = (long)ctx().num_cus * decim_blocks_per_cu;
+            unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, (const float *)d_taps.p, y, M, n, n_out, (long)index, (long)D, OW,
+                               ntiles, rot ? rot_step : (uint64_t)0, rot ? count : (uint64_t)0, ho);
+            hist_in_kernel = ho != nullptr;
+            return 0;
+        };
+        int rc = S == 2 ? (rot ? go(fir_decim_lds_kernel<2, true>) : go(fir_decim_lds_kernel<2, false>))
+                        : (rot ? set_error("rotator fusion needs complex input") : go(fir_decim_lds_kernel<1, false>));
+        if (rc) return rc;
+        LR_LAUNCH_CHECK();
+        return 0;
+    }
+
     int launch_direct(const float *x, long n, float *y, long n_out)
     {
         if (rot) return set_error("internal: direct FIR kernel has no fused rotator");
@@ -300,7 +328,7 @@ struct FirStage : lrhip_stage {
             case 7: return launch_mfma<SS, 7, 1>(x, n, y, n_out);
             case 8: return launch_mfma<SS, 8, 1>(x, n, y, n_out);
             case 10: return launch_mfma<SS, 10, 1>(x, n, y, n_out);
-            default: return launch_direct(x, n, y, n_out);
+            default: return decim_lds_ok() ? launch_decim_lds(x, n, y, n_out) : launch_direct(x, n, y, n_out);
         }
     }
 
@@ -317,7 +345,7 @@ struct FirStage : lrhip_stage {
         if ((unsigned long)n_out > cap) return set_error("fir: output capacity %lu < %ld", cap, n_out);
         if (n_out > 0) {
             int rc = fft_arith ? launch_fft(x, n, y, n_out)
-                     : !ksteps ? launch_direct(x, n, y, n_out)
+                     : !ksteps ? (decim_lds_ok() ? launch_decim_lds(x, n, y, n_out) : launch_direct(x, n, y, n_out))
                      : taps_complex ? dispatch_mfma_cc(x, n, y, n_out)
                      : S == 1 ? dispatch_mfma<1>(x, n, y, n_out) : dispatch_mfma<2>(x, n, y, n_out);
             if (rc) return rc;
@@ -425,7 +453,10 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
         }
     }
     if (rot) {
-        if (!q->ksteps) { set_error("fir: rotator fusion unavailable for this tap count / decimation"); return nullptr; }
+        if (!q->ksteps && !(input_complex && !taps_complex && (int)ntaps + 255 <= DECIM_SPAN_MAX)) {
+            set_error("fir: rotator fusion unavailable for this tap count / decimation");
+            return nullptr;
+        }
         long double turns = (long double)omega / (2.0L * 3.14159265358979323846264338327950288L);
         turns -= floorl(turns);
         q->rot_step = (uint64_t)(turns * 18446744073709551616.0L);
@@ -1780,7 +1811,7 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
                 for (int cc = 0; cc < ts; cc++) taps[(size_t)t * ts + cc] = fir->taps_rev[(size_t)(fir->M - 1 - t) * ts + cc];
             bool want_rot = rot && fir->S == 2;
             FirStage *fused = nullptr;
-            if (FirStage::mfma_supported_decim(D) || !rot)
+            if (FirStage::mfma_supported_decim(D) || !rot || (fir->S == 2 && !fir->taps_complex && fir->M + 255 <= DECIM_SPAN_MAX))
                 fused = fir_build(taps.data(), (unsigned)fir->M, fir->taps_complex, fir->S == 2, D, 0, want_rot, want_rot ? rot->omega : 0.0);
             if (fused && rot && !want_rot) { delete fused; fused = nullptr; }
             bool with_disc = fused && dsc_after && fused->can_post_disc();
