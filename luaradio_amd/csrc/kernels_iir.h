@@ -14,7 +14,7 @@
 //           its chunk from its TRUE start state and writes y.  Inside a chunk the arithmetic is the plain
 //           sequential f32 recurrence.
 // Traffic: 2 reads + 1 write of the stream (12 B per Float32 sample against an 8 B algorithmic minimum).
-// Orders above 4 use the sequential kernel (one thread per component) - correct, not fast.
+// Orders 1-8 take the scan paths; above that the sequential kernel (one thread per component) - correct, not fast.
 #pragma once
 #include "common.h"
 
@@ -23,26 +23,66 @@ namespace lrhip {
 constexpr int IIR_LC = 16;                    // samples per thread chunk
 constexpr int IIR_TILE = 256 * IIR_LC;        // samples per workgroup tile
 constexpr int IIR_MAX_NB = 16;
-constexpr int IIR_MAX_P = 4;                  // scan path; above this -> sequential kernel
+constexpr int IIR_MAX_P = 8;                  // scan path; above this -> sequential kernel
 constexpr int IIR_SEQ_MAX = 32;
 
+// The transition powers A^(LC*2^k), k = 0..8 (k = 8 is the whole-tile transition), row-major PxP each, live in device
+// memory (`tpow`, 9*P*P floats; uniform addresses -> scalar loads): by value they would not fit the kernel-argument limit.
 struct IirCoeffs {
     int nb, P;
     float b[IIR_MAX_NB];                 // b[j]/a0
     float a[IIR_MAX_P];                  // a[i+1]/a0
-    float Tpow[9][IIR_MAX_P * IIR_MAX_P];  // A^(LC*2^k), k = 0..8 (k = 8 is the whole-tile transition), row-major PxP
 };
 
 // state convention: st[i] = y[n-1-i] (st[0] newest).  One homogeneous step: y = -sum a[i] st[i].
-template <int P>
-__device__ __forceinline__ void mat_apply(const float *T, const float *v, float *out)
+// The scan over chunk / tile states (S_c = z_c + A^k S_{c-1}) runs in Float32 up to order 4 and in double above: the powers
+// of a companion matrix of order 5-8 have large, cancelling entries, and Float32 there loses up to 50x against the plain
+// sequential Float32 recurrence (measured on four pole pairs at radius 0.9995).  The per-sample recurrence stays Float32.
+template <int P> struct IirScanT { using T = float; };
+template <> struct IirScanT<5> { using T = double; };
+template <> struct IirScanT<6> { using T = double; };
+template <> struct IirScanT<7> { using T = double; };
+template <> struct IirScanT<8> { using T = double; };
+
+template <int P, typename T>
+__device__ __forceinline__ void mat_apply(const T *M, const T *v, T *out)
 {
 #pragma unroll
     for (int r = 0; r < P; r++) {
-        float acc = 0.f;
+        T acc = 0;
 #pragma unroll
-        for (int c = 0; c < P; c++) acc = fmaf(T[r * P + c], v[c], acc);
+        for (int c = 0; c < P; c++) acc = fma(M[r * P + c], v[c], acc);
         out[r] = acc;
+    }
+}
+
+// inclusive Kogge-Stone scan over the 256 chunk states already in sst (and synchronised): S_c = z_c + A^(LC) S_{c-1}
+template <int S, int P, typename T>
+__device__ __forceinline__ void iir_block_scan(T (*sst)[256][P], const T *__restrict__ tpow)
+{
+    const int tid = threadIdx.x;
+    for (int lvl = 0; lvl < 8; lvl++) {
+        const int off = 1 << lvl;
+        T nv[S][P];
+#pragma unroll
+        for (int c = 0; c < S; c++) {
+#pragma unroll
+            for (int k = 0; k < P; k++) nv[c][k] = sst[c][tid][k];
+            if (tid >= off) {
+                T prev[P], tmp[P];
+#pragma unroll
+                for (int k = 0; k < P; k++) prev[k] = sst[c][tid - off][k];
+                mat_apply<P, T>(tpow + lvl * P * P, prev, tmp);
+#pragma unroll
+                for (int k = 0; k < P; k++) nv[c][k] += tmp[k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < S; c++)
+#pragma unroll
+            for (int k = 0; k < P; k++) sst[c][tid][k] = nv[c][k];
+        __syncthreads();
     }
 }
 
@@ -56,13 +96,14 @@ __device__ __forceinline__ void mat_apply(const float *T, const float *v, float 
 template <int S, int P, bool FINAL, int NBT>
 __global__ __launch_bounds__(256) void iir_scan_kernel(const float *__restrict__ x, float *__restrict__ y, long n,
                                                        const float *__restrict__ xhist,      // nb-1 samples before x[0]
-                                                       const float *__restrict__ tile_start, // FINAL: [tile][S][P]
-                                                       float *__restrict__ tile_end,         // !FINAL: [tile][S][P]
+                                                       const typename IirScanT<P>::T *__restrict__ tile_start, // FINAL: [tile][S][P]
+                                                       typename IirScanT<P>::T *__restrict__ tile_end,         // !FINAL: [tile][S][P]
                                                        const float *__restrict__ state_in, float *__restrict__ state_out,
-                                                       long dec, long dfirst, IirCoeffs co)
+                                                       long dec, long dfirst, IirCoeffs co, const typename IirScanT<P>::T *__restrict__ tpow)
 {
+    using ST = typename IirScanT<P>::T;
     constexpr int LC = IIR_LC, TILE = IIR_TILE, PV = NBT - 1;
-    __shared__ float sst[2][S][256][P];      // chunk end states (double-buffered scan)
+    __shared__ ST sst[S][256][P];            // chunk end states
 
     const int tid = threadIdx.x;
     const long t0 = (long)blockIdx.x * TILE;
@@ -130,49 +171,31 @@ __global__ __launch_bounds__(256) void iir_scan_kernel(const float *__restrict__
     }
 
     // ---- inclusive Kogge-Stone scan of chunk end states: S_c = z_c + A^LC S_{c-1}  (S_{-1} = tile start state)
-    int buf = 0;
 #pragma unroll
     for (int c = 0; c < S; c++) {
+        ST z[P];
+#pragma unroll
+        for (int k = 0; k < P; k++) z[k] = (ST)st[c][k];
         if (FINAL && tid == 0) {
-            float ts[P], tmp[P];
+            ST ts[P], tmp[P];
 #pragma unroll
             for (int k = 0; k < P; k++) ts[k] = tile_start[((long)blockIdx.x * S + c) * P + k];
-            mat_apply<P>(co.Tpow[0], ts, tmp);
+            mat_apply<P, ST>(tpow, ts, tmp);
 #pragma unroll
-            for (int k = 0; k < P; k++) st[c][k] += tmp[k];
+            for (int k = 0; k < P; k++) z[k] += tmp[k];
         }
 #pragma unroll
-        for (int k = 0; k < P; k++) sst[0][c][tid][k] = st[c][k];
+        for (int k = 0; k < P; k++) sst[c][tid][k] = z[k];
     }
     __syncthreads();
-    for (int lvl = 0; lvl < 8; lvl++) {
-        int off = 1 << lvl;
-#pragma unroll
-        for (int c = 0; c < S; c++) {
-            float cur[P];
-#pragma unroll
-            for (int k = 0; k < P; k++) cur[k] = sst[buf][c][tid][k];
-            if (tid >= off) {
-                float prev[P], tmp[P];
-#pragma unroll
-                for (int k = 0; k < P; k++) prev[k] = sst[buf][c][tid - off][k];
-                mat_apply<P>(co.Tpow[lvl], prev, tmp);
-#pragma unroll
-                for (int k = 0; k < P; k++) cur[k] += tmp[k];
-            }
-#pragma unroll
-            for (int k = 0; k < P; k++) sst[buf ^ 1][c][tid][k] = cur[k];
-        }
-        buf ^= 1;
-        __syncthreads();
-    }
+    iir_block_scan<S, P, ST>(sst, tpow);
 
     if (!FINAL) {
         if (tid == 255)
 #pragma unroll
             for (int c = 0; c < S; c++)
 #pragma unroll
-                for (int k = 0; k < P; k++) tile_end[((long)blockIdx.x * S + c) * P + k] = sst[buf][c][255][k];
+                for (int k = 0; k < P; k++) tile_end[((long)blockIdx.x * S + c) * P + k] = sst[c][255][k];
         return;
     }
 
@@ -181,7 +204,7 @@ __global__ __launch_bounds__(256) void iir_scan_kernel(const float *__restrict__
     for (int c = 0; c < S; c++) {
 #pragma unroll
         for (int k = 0; k < P; k++)
-            st[c][k] = tid ? sst[buf][c][tid - 1][k] : tile_start[((long)blockIdx.x * S + c) * P + k];
+            st[c][k] = (float)(tid ? sst[c][tid - 1][k] : tile_start[((long)blockIdx.x * S + c) * P + k]);
 #pragma unroll
         for (int i = 0; i < LC; i++) {
             float v = u[c][i];
@@ -245,11 +268,12 @@ template <int S, int P, int NBT>
 __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict__ x, float *__restrict__ y, long n,
                                                          const float *__restrict__ xhist, const float *__restrict__ state_in,
                                                          float *__restrict__ state_out, long dec, long dfirst, int run, int warm, IirCoeffs co,
-                                                         float *__restrict__ xhist_out)
+                                                         float *__restrict__ xhist_out, const typename IirScanT<P>::T *__restrict__ tpow)
 {
+    using ST = typename IirScanT<P>::T;
     constexpr int LC = IIR_LC, TILE = IIR_TILE, PV = NBT - 1;
-    __shared__ float sst[2][S][256][P];
-    __shared__ float carry[S][P];
+    __shared__ ST sst[S][256][P];
+    __shared__ ST carry[S][P];
     const int tid = threadIdx.x;
     const int nb = co.nb;
     // carried feed-forward history (iir_state_kernel's job): the last nb-1 inputs
@@ -262,7 +286,7 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
     long tb = first_tile - warm;
     const bool from_true_state = tb <= 0;
     if (tb < 0) tb = 0;
-    if (tid < S * P) carry[tid / P][tid % P] = from_true_state ? state_in[tid] : 0.f;
+    if (tid < S * P) carry[tid / P][tid % P] = from_true_state ? (ST)state_in[tid] : (ST)0;
     __syncthreads();
 
     for (long tt = tb; tt < first_tile + run && tt * TILE < n; tt++) {
@@ -324,53 +348,35 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
                 st[c][0] = v;
             }
         }
-        int buf = 0;
 #pragma unroll
         for (int c = 0; c < S; c++) {
+            ST z[P];
+#pragma unroll
+            for (int k = 0; k < P; k++) z[k] = (ST)st[c][k];
             if (tid == 0) {
-                float ts[P], tmp[P];
+                ST ts[P], tmp[P];
 #pragma unroll
                 for (int k = 0; k < P; k++) ts[k] = carry[c][k];
-                mat_apply<P>(co.Tpow[0], ts, tmp);
+                mat_apply<P, ST>(tpow, ts, tmp);
 #pragma unroll
-                for (int k = 0; k < P; k++) st[c][k] += tmp[k];
+                for (int k = 0; k < P; k++) z[k] += tmp[k];
             }
 #pragma unroll
-            for (int k = 0; k < P; k++) sst[0][c][tid][k] = st[c][k];
+            for (int k = 0; k < P; k++) sst[c][tid][k] = z[k];
         }
         __syncthreads();
-        for (int lvl = 0; lvl < 8; lvl++) {
-            int off = 1 << lvl;
-#pragma unroll
-            for (int c = 0; c < S; c++) {
-                float cur[P];
-#pragma unroll
-                for (int k = 0; k < P; k++) cur[k] = sst[buf][c][tid][k];
-                if (tid >= off) {
-                    float prev[P], tmp[P];
-#pragma unroll
-                    for (int k = 0; k < P; k++) prev[k] = sst[buf][c][tid - off][k];
-                    mat_apply<P>(co.Tpow[lvl], prev, tmp);
-#pragma unroll
-                    for (int k = 0; k < P; k++) cur[k] += tmp[k];
-                }
-#pragma unroll
-                for (int k = 0; k < P; k++) sst[buf ^ 1][c][tid][k] = cur[k];
-            }
-            buf ^= 1;
-            __syncthreads();
-        }
+        iir_block_scan<S, P, ST>(sst, tpow);
         // ---- true start state of this chunk; the tile end state becomes the next tile's carried state
 #pragma unroll
         for (int c = 0; c < S; c++)
 #pragma unroll
-            for (int k = 0; k < P; k++) st[c][k] = tid ? sst[buf][c][tid - 1][k] : carry[c][k];
+            for (int k = 0; k < P; k++) st[c][k] = (float)(tid ? sst[c][tid - 1][k] : carry[c][k]);
         __syncthreads();
         if (tid == 255)
 #pragma unroll
             for (int c = 0; c < S; c++)
 #pragma unroll
-                for (int k = 0; k < P; k++) carry[c][k] = sst[buf][c][255][k];
+                for (int k = 0; k < P; k++) carry[c][k] = sst[c][255][k];
         if (emit) {
 #pragma unroll
             for (int c = 0; c < S; c++)
@@ -425,70 +431,76 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
 
 // pass 2: carry across tiles, s_t = E_{t-1} + A^TILE s_{t-1}, as a 256-thread scan: every thread owns a
 // contiguous segment of `seg` tiles (sequential inside the segment, twice), segment end states are combined with a
-// Kogge-Stone scan using A^(TILE*seg*2^k) (computed on the host per launch in double).
-struct IirCarryPowers {
-    float Tseg[8][IIR_MAX_P * IIR_MAX_P];
-};
-template <int S, int P>
-__global__ __launch_bounds__(256) void iir_carry_kernel(const float *__restrict__ tile_end, float *__restrict__ tile_start, long ntiles,
-                                                        long seg, const float *__restrict__ state_in, IirCoeffs co, IirCarryPowers pw)
+// Kogge-Stone scan using tseg[k] = A^(TILE*seg*2^k), which iir_tseg_kernel computes in double from A^TILE per launch.
+template <int P, typename T>
+__global__ void iir_tseg_kernel(const double *__restrict__ ttile, long seg, T *__restrict__ tseg)
 {
-    __shared__ float sst[2][S][256][P];
+    if (threadIdx.x || blockIdx.x) return;
+    double R[P * P], B[P * P], Tm[P * P];
+    for (int i = 0; i < P * P; i++) { B[i] = ttile[i]; R[i] = (i / P == i % P) ? 1.0 : 0.0; }
+    auto mul = [&](const double *X, const double *Y, double *Z) {          // Z = X * Y (Z may alias neither)
+        for (int r = 0; r < P; r++)
+            for (int c = 0; c < P; c++) {
+                double acc = 0;
+                for (int k = 0; k < P; k++) acc += X[r * P + k] * Y[k * P + c];
+                Z[r * P + c] = acc;
+            }
+    };
+    for (long e = seg; e > 0; e >>= 1) {                                   // R = ttile^seg by repeated squaring
+        if (e & 1) { mul(R, B, Tm); for (int i = 0; i < P * P; i++) R[i] = Tm[i]; }
+        mul(B, B, Tm);
+        for (int i = 0; i < P * P; i++) B[i] = Tm[i];
+    }
+    for (int k = 0; k < 8; k++) {
+        for (int i = 0; i < P * P; i++) tseg[k * P * P + i] = (T)R[i];
+        mul(R, R, Tm);
+        for (int i = 0; i < P * P; i++) R[i] = Tm[i];
+    }
+}
+
+template <int S, int P>
+__global__ __launch_bounds__(256) void iir_carry_kernel(const typename IirScanT<P>::T *__restrict__ tile_end, typename IirScanT<P>::T *__restrict__ tile_start,
+                                                        long ntiles, long seg, const float *__restrict__ state_in,
+                                                        const typename IirScanT<P>::T *__restrict__ tseg, const typename IirScanT<P>::T *__restrict__ tpow)
+{
+    using ST = typename IirScanT<P>::T;
+    __shared__ ST sst[S][256][P];
     const int tid = threadIdx.x;
     const long t0 = (long)tid * seg, t1 = (t0 + seg < ntiles) ? t0 + seg : ntiles;
-    float z[S][P], tmp[P];
+    const ST *ttile = tpow + 8 * P * P;
+    ST tmp[P];
 #pragma unroll
     for (int c = 0; c < S; c++) {
+        ST z[P];
 #pragma unroll
-        for (int k = 0; k < P; k++) z[c][k] = 0.f;
+        for (int k = 0; k < P; k++) z[k] = 0;
         for (long t = t0; t < t1; t++) {
-            mat_apply<P>(co.Tpow[8], z[c], tmp);
+            mat_apply<P, ST>(ttile, z, tmp);
 #pragma unroll
-            for (int k = 0; k < P; k++) z[c][k] = tile_end[(t * S + c) * P + k] + tmp[k];
+            for (int k = 0; k < P; k++) z[k] = tile_end[(t * S + c) * P + k] + tmp[k];
         }
         if (tid == 0) {      // fold the carried state into segment 0: S_0 = z_0 + A^(TILE*seg) * carried
-            float ci[P];
+            ST ci[P];
 #pragma unroll
-            for (int k = 0; k < P; k++) ci[k] = state_in[c * P + k];
-            mat_apply<P>(pw.Tseg[0], ci, tmp);
+            for (int k = 0; k < P; k++) ci[k] = (ST)state_in[c * P + k];
+            mat_apply<P, ST>(tseg, ci, tmp);
 #pragma unroll
-            for (int k = 0; k < P; k++) z[c][k] += tmp[k];
+            for (int k = 0; k < P; k++) z[k] += tmp[k];
         }
 #pragma unroll
-        for (int k = 0; k < P; k++) sst[0][c][tid][k] = z[c][k];
+        for (int k = 0; k < P; k++) sst[c][tid][k] = z[k];
     }
     __syncthreads();
-    int buf = 0;
-    for (int lvl = 0; lvl < 8; lvl++) {
-        int off = 1 << lvl;
-#pragma unroll
-        for (int c = 0; c < S; c++) {
-            float cur[P];
-#pragma unroll
-            for (int k = 0; k < P; k++) cur[k] = sst[buf][c][tid][k];
-            if (tid >= off) {
-                float prev[P];
-#pragma unroll
-                for (int k = 0; k < P; k++) prev[k] = sst[buf][c][tid - off][k];
-                mat_apply<P>(pw.Tseg[lvl], prev, tmp);
-#pragma unroll
-                for (int k = 0; k < P; k++) cur[k] += tmp[k];
-            }
-#pragma unroll
-            for (int k = 0; k < P; k++) sst[buf ^ 1][c][tid][k] = cur[k];
-        }
-        buf ^= 1;
-        __syncthreads();
-    }
+    iir_block_scan<S, P, ST>(sst, tseg);
 #pragma unroll
     for (int c = 0; c < S; c++) {
-        float s[P];
+        ST s[P];
 #pragma unroll
-        for (int k = 0; k < P; k++) s[k] = tid ? sst[buf][c][tid - 1][k] : state_in[c * P + k];
+        for (int k = 0; k < P; k++) s[k] = tid ? sst[c][tid - 1][k] : (ST)state_in[c * P + k];
         for (long t = t0; t < t1; t++) {
 #pragma unroll
             for (int k = 0; k < P; k++) tile_start[(t * S + c) * P + k] = s[k];
-            mat_apply<P>(co.Tpow[8], s, tmp);
+            mat_apply<P, ST>(ttile, s, tmp);
 #pragma unroll
             for (int k = 0; k < P; k++) s[k] = tile_end[(t * S + c) * P + k] + tmp[k];
         }

@@ -637,6 +637,7 @@ struct IirStage : lrhip_stage {
     int S = 1, nb = 0, na = 0, P = 0;
     bool scan = false;
     IirCoeffs co;
+    DeviceBuf d_tpow, d_ttile, d_tseg;    // A^(LC*2^k), k = 0..8 (9 PxP matrices, float up to order 4, double above); A^TILE in double; per-launch carry powers
     IirSeqCoeffs seq;
     std::vector<double> Ttile;            // A^TILE in double (row-major PxP) for the per-launch carry powers
     int warm_tiles = 0;                   // > 0: A^(warm_tiles*TILE) underflows Float32 -> single-launch iir_stream_kernel
@@ -658,9 +659,11 @@ struct IirStage : lrhip_stage {
     template <int SS, int PP, int NBT>
     int run_scan_nb(const float *x, float *y, long n)
     {
+        using ST = typename IirScanT<PP>::T;
         long ntiles = (n + IIR_TILE - 1) / IIR_TILE;
         const float *xh = (const float *)xhist[cur].p, *st = (const float *)state[cur].p;
         float *st_out = (float *)state[cur ^ 1].p;
+        const ST *tp = (const ST *)d_tpow.p;
         if (warm_tiles > 0) {
             // tiles per workgroup: enough workgroups to fill the chip a few times over, at most 8 tiles each
             long slots = (long)ctx().num_cus * 8;
@@ -669,37 +672,26 @@ struct IirStage : lrhip_stage {
             if (run < 2 * warm_tiles && ntiles > 4 * warm_tiles) run = 2 * warm_tiles;      // bound the re-read overhead
             unsigned grid = (unsigned)((ntiles + run - 1) / run);
             hipLaunchKernelGGL((iir_stream_kernel<SS, PP, NBT>), dim3(grid), dim3(256), 0, ctx().stream, x, y, n, xh, st, st_out, (long)D, (long)index, run,
-                               warm_tiles, co, (float *)xhist[cur ^ 1].p);
+                               warm_tiles, co, (float *)xhist[cur ^ 1].p, tp);
             LR_LAUNCH_CHECK();
             cur ^= 1;
             return 0;
         }
-        if (tile_end.reserve(sizeof(float) * ntiles * SS * PP) || tile_start.reserve(sizeof(float) * ntiles * SS * PP)) return -1;
+        if (tile_end.reserve(sizeof(ST) * ntiles * SS * PP) || tile_start.reserve(sizeof(ST) * ntiles * SS * PP) ||
+            d_tseg.reserve(sizeof(ST) * 8 * PP * PP)) return -1;
         if (ntiles > 1) {
             hipLaunchKernelGGL((iir_scan_kernel<SS, PP, false, NBT>), dim3((unsigned)ntiles), dim3(256), 0, ctx().stream, x, (float *)nullptr, n, xh,
-                               (const float *)nullptr, (float *)tile_end.p, st, st_out, 1L, 0L, co);
+                               (const ST *)nullptr, (ST *)tile_end.p, st, st_out, 1L, 0L, co, tp);
             LR_LAUNCH_CHECK();
         }
-        // carry scan: 256 segments of `seg` tiles; powers A^(TILE*seg*2^k) in double on the host
+        // carry scan: 256 segments of `seg` tiles; the powers A^(TILE*seg*2^k) are computed on the device in double
         long nt = ntiles > 1 ? ntiles : 1, seg = (nt + 255) / 256;
-        IirCarryPowers pw;
-        {
-            std::vector<double> T = Ttile, R((size_t)PP * PP, 0.0);
-            for (int i = 0; i < PP; i++) R[i * PP + i] = 1.0;
-            for (long e = seg; e > 0; e >>= 1) {          // R = Ttile^seg by repeated squaring
-                if (e & 1) matmul(R, T, R, PP);
-                matmul(T, T, T, PP);
-            }
-            for (int k = 0; k < 8; k++) {
-                for (int i = 0; i < PP * PP; i++) pw.Tseg[k][i] = (float)R[i];
-                matmul(R, R, R, PP);
-            }
-        }
-        hipLaunchKernelGGL((iir_carry_kernel<SS, PP>), dim3(1), dim3(256), 0, ctx().stream, (const float *)tile_end.p, (float *)tile_start.p,
-                           nt, seg, st, co, pw);
+        hipLaunchKernelGGL((iir_tseg_kernel<PP, ST>), dim3(1), dim3(1), 0, ctx().stream, (const double *)d_ttile.p, seg, (ST *)d_tseg.p);
+        hipLaunchKernelGGL((iir_carry_kernel<SS, PP>), dim3(1), dim3(256), 0, ctx().stream, (const ST *)tile_end.p, (ST *)tile_start.p,
+                           nt, seg, st, (const ST *)d_tseg.p, tp);
         LR_LAUNCH_CHECK();
         hipLaunchKernelGGL((iir_scan_kernel<SS, PP, true, NBT>), dim3((unsigned)ntiles), dim3(256), 0, ctx().stream, x, y, n, xh,
-                           (const float *)tile_start.p, (float *)nullptr, st, st_out, (long)D, (long)index, co);
+                           (const ST *)tile_start.p, (ST *)nullptr, st, st_out, (long)D, (long)index, co, tp);
         LR_LAUNCH_CHECK();
         if (nb > 1) {
             hipLaunchKernelGGL(iir_state_kernel<SS>, dim3(1), dim3(64), 0, ctx().stream, x, n, nb, xh, (float *)xhist[cur ^ 1].p);
@@ -723,8 +715,10 @@ struct IirStage : lrhip_stage {
         int rc = 0;
         if (scan) {
             // with a single tile the carry kernel just seeds tile_start[0] from the carried state
-            if (S == 1) rc = P == 1 ? run_scan<1, 1>(x, y, (long)n) : P == 2 ? run_scan<1, 2>(x, y, (long)n) : P == 3 ? run_scan<1, 3>(x, y, (long)n) : run_scan<1, 4>(x, y, (long)n);
-            else rc = P == 1 ? run_scan<2, 1>(x, y, (long)n) : P == 2 ? run_scan<2, 2>(x, y, (long)n) : P == 3 ? run_scan<2, 3>(x, y, (long)n) : run_scan<2, 4>(x, y, (long)n);
+#define LR_IIR_P(SS, PP) case PP: rc = run_scan<SS, PP>(x, y, (long)n); break
+            if (S == 1) switch (P) { LR_IIR_P(1, 1); LR_IIR_P(1, 2); LR_IIR_P(1, 3); LR_IIR_P(1, 4); LR_IIR_P(1, 5); LR_IIR_P(1, 6); LR_IIR_P(1, 7); default: rc = run_scan<1, 8>(x, y, (long)n); }
+            else switch (P) { LR_IIR_P(2, 1); LR_IIR_P(2, 2); LR_IIR_P(2, 3); LR_IIR_P(2, 4); LR_IIR_P(2, 5); LR_IIR_P(2, 6); LR_IIR_P(2, 7); default: rc = run_scan<2, 8>(x, y, (long)n); }
+#undef LR_IIR_P
         } else {
             if (S == 1) hipLaunchKernelGGL(iir_seq_kernel<1>, dim3(1), dim3(64), 0, ctx().stream, x, y, (long)n, seq, (float *)seq_xs.p, (float *)seq_ys.p);
             else hipLaunchKernelGGL(iir_seq_kernel<2>, dim3(1), dim3(64), 0, ctx().stream, x, y, (long)n, seq, (float *)seq_xs.p, (float *)seq_ys.p);
@@ -1432,11 +1426,15 @@ lrhip_stage_t *lrhip_iir_create(const float *b, unsigned nb, const float *a, uns
         for (int r = 1; r < P; r++) A[r * P + r - 1] = 1.0;
         T = A;
         for (int s = 1; s < IIR_LC; s <<= 1) matmul(T, T, T, P);      // A^LC (LC is a power of two)
+        std::vector<float> tpow((size_t)9 * P * P);
+        std::vector<double> tpow64((size_t)9 * P * P);
         for (int k = 0; k <= 8; k++) {
-            for (int i = 0; i < P * P; i++) co.Tpow[k][i] = (float)T[i];
+            for (int i = 0; i < P * P; i++) { tpow[(size_t)k * P * P + i] = (float)T[i]; tpow64[(size_t)k * P * P + i] = T[i]; }
             if (k == 8) q->Ttile = T;
             matmul(T, T, T, P);
         }
+        if (P > 4 ? upload(q->d_tpow, tpow64.data(), tpow64.size() * sizeof(double)) : upload(q->d_tpow, tpow.data(), tpow.size() * sizeof(float))) return nullptr;
+        if (upload(q->d_ttile, q->Ttile.data(), q->Ttile.size() * sizeof(double))) return nullptr;
         // memory shorter than `w` tiles in Float32 terms?  (every entry of A^(w*TILE) underflows)  -> single-launch kernel
         static const bool force_3pass = getenv("LRHIP_IIR_3PASS") != nullptr;       // A/B knob
         std::vector<double> W = q->Ttile;

@@ -460,6 +460,29 @@ def test_discriminator_epilogue_equals_unfused_blocks(decim):
         assert np.median(np.abs(got - ora)) < 1e-6
 
 
+@pytest.mark.parametrize("order", [5, 6, 7, 8])
+def test_iir_orders_five_to_eight_scan_paths(order):
+    """orders up to 8 run the scan kernels (the transition powers live in device memory); short-memory poles take the
+    single-launch kernel, poles at radius 0.9995 the three-pass one.  A direct-form Float32 IIR of this order is itself only
+    1e-5..1e-3 accurate (the reference's own sequential Float32 recurrence against the f64 one), so the bar is that yardstick:
+    the scan may not be more than 10x worse than the sequential Float32 form"""
+    rng = np.random.default_rng(500 + order)
+    n = 300000
+    x = rand_r(rng, n)
+    for radius in (0.85, 0.9995):
+        ang = np.linspace(0.15, 1.2, order // 2)
+        poles = list(radius * np.exp(1j * ang)) + list(radius * np.exp(-1j * ang)) + ([0.5] if order % 2 else [])
+        a32 = np.real(np.poly(poles)).astype(np.float32)
+        b32 = (np.real(np.poly([-1.0] * 3)) * 0.01).astype(np.float32)
+        blk = make(lr.IIRFilterBlock, [b32, a32], x)
+        want = O.IIR(b32, a32, False, O.MODE_F64).process(x)
+        yard = G.max_abs_err(O.IIR(b32, a32, False, O.MODE_LUA).process(x), want)
+        got = chunked(blk, x, [3, 4096, 4097, 150000])
+        scale = max(1.0, float(np.max(np.abs(want))))
+        err = G.max_abs_err(got, want)
+        assert err <= 10 * yard + 2e-6 * scale, (order, radius, err, yard, scale)
+
+
 def test_iir_single_launch_and_three_pass_paths_vs_oracle():
     """short-memory filters (A^TILE underflows Float32) take the single-launch kernel, long-memory ones the three-pass scan;
     both against the f64 recurrence on 1M samples, ragged chunks"""
