@@ -376,18 +376,19 @@ constexpr int DECIM_SPAN_MAX = 6144;
 
 __device__ __forceinline__ int decim_phys(int p) { return p + (p >> 5); }
 
-template <int S, bool ROT>
+template <int S, bool ROT, bool CT = false>      // CT: ComplexFloat32 taps (S = 2), taps_rev as {re, im} pairs
 __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_rev,
                                                             float *__restrict__ y, int M, long n, long n_out, long first, long D, int OW, long ntiles,
                                                             uint64_t rot_step_fx, uint64_t rot_count0, float *__restrict__ hist_out)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TS = CT ? 2 : 1;
     float *ldsT = lds;                              // M reversed taps
-    float *ldsX = lds + ((M + 3) & ~3);             // staged samples, S floats each, padded index
+    float *ldsX = lds + ((TS * M + 3) & ~3);        // staged samples, S floats each, padded index
     const int tid = threadIdx.x;
     if (hist_out && blockIdx.x == 0)
         for (int i = tid; i < (M - 1) * S; i += 256) hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
-    for (int i = tid; i < M; i += 256) ldsT[i] = taps_rev[i];
+    for (int i = tid; i < TS * M; i += 256) ldsT[i] = taps_rev[i];
     RotTab rt;
     if (ROT) rt = rot_tab(rot_step_fx);
     const int span = (int)((OW - 1) * D) + M;
@@ -433,6 +434,17 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
             int p = tid * (int)D;
             float re = 0.f, im = 0.f;
             int tt = 0;
+            if constexpr (CT) {
+                // complex taps: the operation order of fir_direct_kernel<2> (re += xr hr; re += xi (-hi); im += xr hi; im += xi hr)
+                for (; tt < M; tt++) {
+                    const float2 h = *reinterpret_cast<const float2 *>(ldsT + 2 * tt);
+                    const float2 xv = *reinterpret_cast<const float2 *>(ldsX + 2 * decim_phys(p + tt));
+                    re = fmaf(xv.x, h.x, re);
+                    re = fmaf(xv.y, -h.y, re);
+                    im = fmaf(xv.x, h.y, im);
+                    im = fmaf(xv.y, h.x, im);
+                }
+            }
             for (; tt + 4 <= M; tt += 4) {
                 const float h0 = ldsT[tt], h1 = ldsT[tt + 1], h2 = ldsT[tt + 2], h3 = ldsT[tt + 3];
                 const int i0 = decim_phys(p + tt), i1 = decim_phys(p + tt + 1), i2 = decim_phys(p + tt + 2), i3 = decim_phys(p + tt + 3);

@@ -236,7 +236,7 @@ struct FirStage : lrhip_stage {
             case 3: return launch_mfma_cc<6, 1>(x, n, y, n_out);
             case 4: return launch_mfma_cc<8, 1>(x, n, y, n_out);
             case 5: return launch_mfma_cc<10, 1>(x, n, y, n_out);
-            default: return launch_direct(x, n, y, n_out);
+            default: return decim_lds_ok() ? launch_decim_lds(x, n, y, n_out) : launch_direct(x, n, y, n_out);
         }
     }
 
@@ -273,7 +273,7 @@ struct FirStage : lrhip_stage {
     }
 
     // decimations without a Toeplitz instantiation (and taps too long for its LDS table): LDS-staged one-output-per-thread kernel
-    bool decim_lds_ok() const { return !taps_complex && !fft_arith && !use_fft && M + 255 <= DECIM_SPAN_MAX; }
+    bool decim_lds_ok() const { return !fft_arith && !use_fft && M + 255 <= DECIM_SPAN_MAX && !(taps_complex && rot); }
     int decim_blocks_per_cu = 0;
     int launch_decim_lds(const float *x, long n, float *y, long n_out)
     {
@@ -281,7 +281,7 @@ struct FirStage : lrhip_stage {
         int OW = (int)(ow > 256 ? 256 : ow < 1 ? 1 : ow);
         long ntiles = (n_out + OW - 1) / OW;
         long span = (long)(OW - 1) * D + M;
-        size_t lds_bytes = ((size_t)((M + 3) & ~3) + (size_t)S * (span + (span >> 5) + 2)) * sizeof(float);
+        size_t lds_bytes = ((size_t)(((taps_complex ? 2 : 1) * M + 3) & ~3) + (size_t)S * (span + (span >> 5) + 2)) * sizeof(float);
         const float *h = (const float *)hist[cur].p + hist_pad;
         float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
         auto go = [&](auto kern) -> int {
@@ -293,7 +293,8 @@ struct FirStage : lrhip_stage {
             hist_in_kernel = ho != nullptr;
             return 0;
         };
-        int rc = S == 2 ? (rot ? go(fir_decim_lds_kernel<2, true>) : go(fir_decim_lds_kernel<2, false>))
+        int rc = taps_complex ? go(fir_decim_lds_kernel<2, false, true>)
+                 : S == 2 ? (rot ? go(fir_decim_lds_kernel<2, true>) : go(fir_decim_lds_kernel<2, false>))
                         : (rot ? set_error("rotator fusion needs complex input") : go(fir_decim_lds_kernel<1, false>));
         if (rc) return rc;
         LR_LAUNCH_CHECK();
@@ -390,7 +391,7 @@ struct FirStage : lrhip_stage {
             return 0;
         }
         if ((unsigned long)emit > cap) return set_error("fir(fft framing): output capacity %lu < %ld", cap, emit);
-        if (work.reserve((size_t)total * ss)) return -1;
+        if (work.reserve((size_t)((long)n_in + L) * ss)) return -1;      // the largest total this chunk size can see: no regrowth as `fill` moves
         if (fill) LR_HIP(hipMemcpyAsync(work.p, pending.p, fill * ss, hipMemcpyDeviceToDevice, ctx().stream));
         LR_HIP(hipMemcpyAsync((char *)work.p + fill * ss, x, n_in * ss, hipMemcpyDeviceToDevice, ctx().stream));
         long rc = core((const float *)work.p, emit, y, cap);

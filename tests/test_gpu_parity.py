@@ -409,6 +409,20 @@ def test_decimator_fused_bit_exact_vs_unfused_oracle(factor, cplx):
     assert dec.chain.last_launches <= 2          # decimating FIR (+ history carry): the downsampler is fused away
 
 
+@pytest.mark.parametrize("decim", [2, 5, 6, 10, 25])
+def test_complex_taps_decimating_chain_bit_exact(decim):
+    """ComplexFloat32 taps followed by a downsampler: Toeplitz MFMA path up to 5, the LDS-staged kernel above; both give the
+    fmaf chain of the direct form in the reference's operation order"""
+    rng = np.random.default_rng(90 + decim)
+    x = rand_c(rng, 70001)
+    taps = (rand_c(rng, 129) / 129).astype(np.complex64)
+    chain = lr.Chain([make(lr.FIRFilterBlock, [taps], x), make(lr.DownsamplerBlock, [decim], x)])
+    got = chunked(chain, x, [1, 2, 4097, 30000])
+    want = O.FIR(taps, True, O.MODE_FMA).process(x)[::decim]
+    assert len(got) == len(want)
+    assert np.array_equal(got, want)
+
+
 def test_tuner_fused_rotator_fir_downsampler():
     rng = np.random.default_rng(30)
     x = rand_c(rng, 120000)
