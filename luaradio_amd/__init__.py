@@ -18,6 +18,7 @@ from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock,
 from .sources import IQFileSource, RealFileSource  # noqa: F401
 from .graph import DeviceGraph  # noqa: F401
 from .composites import (Chain, CompositeBlock, DecimatorBlock, InterpolatorBlock, RationalResamplerBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401
-                         NBFMDemodulator, AMEnvelopeDemodulator, SSBDemodulator, SSBModulator, wbfm_mono_receiver)
+                         NBFMDemodulator, AMEnvelopeDemodulator, SSBDemodulator, SSBModulator, wbfm_mono_receiver, am_envelope_receiver,
+                         ssb_receiver, nbfm_receiver)
 
 version = "0.1.0"

@@ -286,3 +286,35 @@ def wbfm_mono_receiver(rate=1102500.0, tune_offset=-250e3):
     top.differentiate([types.ComplexFloat32])
     top.initialize()
     return top
+
+
+def _receiver(blocks, rate, in_type=types.ComplexFloat32):
+    top = CompositeBlock()
+    top.connect(*blocks)
+    top.rate = rate
+    top.differentiate([in_type])
+    top.initialize()
+    return top
+
+
+def am_envelope_receiver(rate=1102500.0, tune_offset=-100e3, bandwidth=5e3):
+    """The compute blocks of examples/rtlsdr_am_envelope.lua:11-20,28 as one device chain:
+    Tuner(offset, 2*bw, 50) -> ComplexMagnitude -> SinglepoleHighpass(100) -> Lowpass(128, bw) -> AGC('slow')."""
+    return _receiver([TunerBlock(tune_offset, 2 * bandwidth, 50), B.ComplexMagnitudeBlock(), B.SinglepoleHighpassFilterBlock(100),
+                      B.LowpassFilterBlock(128, bandwidth), B.AGCBlock("slow")], rate)
+
+
+def ssb_receiver(sideband="usb", rate=1102500.0, tune_offset=-100e3, bandwidth=3e3):
+    """The compute blocks of examples/rtlsdr_ssb.lua:13-24,34 as one device chain:
+    Tuner(offset, 2*bw, 50) -> ComplexBandpass(129, {0, +-bw}) -> ComplexToReal -> Lowpass(128, bw) -> AGC('fast')."""
+    assert sideband in ("lsb", "usb"), "Sideband should be 'lsb' or 'usb'."
+    return _receiver([TunerBlock(tune_offset, 2 * bandwidth, 50),
+                      B.ComplexBandpassFilterBlock(129, [0, -bandwidth] if sideband == "lsb" else [0, bandwidth]), B.ComplexToRealBlock(),
+                      B.LowpassFilterBlock(128, bandwidth), B.AGCBlock("fast")], rate)
+
+
+def nbfm_receiver(rate=1102500.0, tune_offset=-100e3, deviation=5e3, bandwidth=4e3):
+    """The compute blocks of examples/rtlsdr_nbfm.lua as one device chain:
+    Tuner(offset, 2*(deviation + bw), 50) -> FrequencyDiscriminator(deviation/bw) -> Lowpass(128, bw)."""
+    return _receiver([TunerBlock(tune_offset, 2 * (deviation + bandwidth), 50), B.FrequencyDiscriminatorBlock(deviation / bandwidth),
+                      B.LowpassFilterBlock(128, bandwidth)], rate)

@@ -1003,6 +1003,48 @@ def test_ssb_modulator_then_demodulator_round_trip(sideband):
     assert np.sqrt(np.mean((a - g * b) ** 2)) < 0.02 * np.sqrt(np.mean(a ** 2))
 
 
+@pytest.mark.parametrize("which", ["am", "ssb", "nbfm"])
+def test_example_receivers_vs_oracle_chain(which):
+    """the compute blocks of examples/rtlsdr_am_envelope.lua, rtlsdr_ssb.lua and rtlsdr_nbfm.lua (Tuner with decimation 50, then the
+    demodulator, audio filter and AGC) as device chains, against the same blocks chained in the oracle; 2^20 RF samples at
+    1.1025 MS/s, ragged chunks; RMS error <= 1e-5 of the output RMS"""
+    fs, n = 1102500.0, 1 << 20
+    rng = np.random.default_rng(120)
+    t = np.arange(n) / fs
+    audio = 0.5 * np.sin(2 * np.pi * 800 * t) + 0.3 * np.sin(2 * np.pi * 1900 * t)
+    carrier = np.exp(2j * np.pi * 100e3 * t)
+    noise = 0.003 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    fa = fs / 50
+    if which == "am":
+        x = 0.05 * (1 + 0.7 * audio) * carrier + noise
+        rx = lr.am_envelope_receiver(fs, -100e3)
+        hb, ha = _singlepole_highpass_taps(100, fa)
+        stages = [O.tuner(-100e3, 10e3, 50, fs, mode=O.MODE_FMA, rot_mode=O.MODE_F64),
+                  _OracleFn(lambda v: np.abs(v.astype(np.complex128)).astype(np.float32)), O.IIR(hb, ha, False),
+                  O.lowpass(128, 5e3, fa, False, mode=O.MODE_FMA), O.AGC("slow", -35, -75, fa, False)]
+    elif which == "ssb":
+        x = 0.05 * (audio + 0j) * carrier * np.exp(2j * np.pi * 50 * t) + noise
+        rx = lr.ssb_receiver("usb", fs, -100e3)
+        taps = types.ComplexFloat32.vector_from_array(lr.filter_utils.firwin_complex_bandpass(129, [0, 3e3 / (fa / 2)]))
+        stages = [O.tuner(-100e3, 6e3, 50, fs, mode=O.MODE_FMA, rot_mode=O.MODE_F64), O.FIR(taps, True, O.MODE_FMA),
+                  _OracleFn(lambda v: np.ascontiguousarray(v.real)), O.lowpass(128, 3e3, fa, False, mode=O.MODE_FMA), O.AGC("fast", -35, -75, fa, False)]
+    else:
+        x = 0.05 * np.exp(2j * np.pi * 5e3 * np.cumsum(audio) / fs) * carrier + noise
+        rx = lr.nbfm_receiver(fs, -100e3)
+        stages = [O.tuner(-100e3, 18e3, 50, fs, mode=O.MODE_FMA, rot_mode=O.MODE_F64), O.FMDiscriminator(5e3 / 4e3),
+                  O.lowpass(128, 4e3, fa, False, mode=O.MODE_FMA)]
+    x = x.astype(np.complex64)
+    got = chunked(rx, x, [8192, 8193, 500001])
+    want = x
+    for st in stages:
+        want = st.process(want)
+    assert len(got) == len(want) == (n + 49) // 50
+    rms = float(np.sqrt(np.mean(want.astype(np.float64) ** 2)))
+    err = float(np.sqrt(np.mean((got.astype(np.float64) - want) ** 2)))
+    assert rms > 1e-3 and err <= 1e-5 * max(rms, 1.0), (which, err, rms)
+    assert rx.chain.last_launches <= 6
+
+
 class _OracleFn:
     def __init__(self, fn):
         self.fn = fn
