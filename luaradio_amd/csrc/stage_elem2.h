@@ -1,0 +1,144 @@
+// stage_elem2.h - file sample formats, two-input blocks, MultiplyConstant, Upsampler
+// (part of liblrhip.so; included by lrhip.hip in this order, one translation unit)
+#pragma once
+
+// =====================================================================================================
+// IQFileSource / RealFileSource format conversion
+// =====================================================================================================
+struct FormatStage : lrhip_stage {
+    int fmt = 0;          // index into kFormats
+    int scalars = 1;      // raw scalars per sample (2 for I/Q)
+    const char *kind() const override { return "format"; }
+    int reset() override { return 0; }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override;
+};
+
+struct FormatDesc {
+    const char *name;
+    int bytes;        // per scalar
+    int cls;          // 0 u8, 1 s8, 2 u16, 3 s16, 4 u32, 5 s32, 6 f32, 7 f64
+    bool swap;        // file byte order differs from the (little-endian) device
+    double offset, scale;
+};
+// radio/utilities/format_utils.lua:82-97
+static const FormatDesc kFormats[] = {
+    {"u8", 1, 0, false, 127.5, 127.5},           {"s8", 1, 1, false, 0.0, 127.5},
+    {"u16le", 2, 2, false, 32767.5, 32767.5},    {"u16be", 2, 2, true, 32767.5, 32767.5},
+    {"s16le", 2, 3, false, 0.0, 32767.5},        {"s16be", 2, 3, true, 0.0, 32767.5},
+    {"u32le", 4, 4, false, 2147483647.5, 2147483647.5}, {"u32be", 4, 4, true, 2147483647.5, 2147483647.5},
+    {"s32le", 4, 5, false, 0.0, 2147483647.5},   {"s32be", 4, 5, true, 0.0, 2147483647.5},
+    {"f32le", 4, 6, false, 0.0, 1.0},            {"f32be", 4, 6, true, 0.0, 1.0},
+    {"f64le", 8, 7, false, 0.0, 1.0},            {"f64be", 8, 7, true, 0.0, 1.0},
+};
+
+long FormatStage::run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap)
+{
+    if (n > cap) return set_error("format: output capacity %lu < %lu", cap, n);
+    if (!n) return 0;
+    const FormatDesc &f = kFormats[fmt];
+    unsigned long ns = n * scalars;
+    unsigned grid = grid_for(ns, 256, ctx().num_cus * 16);
+    float *out = (float *)out_dev;
+#define LR_FMT(RAW, VAL)                                                                                                   \
+    do {                                                                                                                   \
+        if (f.swap) hipLaunchKernelGGL((format_convert_kernel<RAW, VAL, true>), dim3(grid), dim3(256), 0, ctx().stream, (const RAW *)in_dev, out, ns, f.offset, f.scale); \
+        else hipLaunchKernelGGL((format_convert_kernel<RAW, VAL, false>), dim3(grid), dim3(256), 0, ctx().stream, (const RAW *)in_dev, out, ns, f.offset, f.scale);      \
+    } while (0)
+    switch (f.cls) {
+        case 0: LR_FMT(uint8_t, uint8_t); break;
+        case 1: LR_FMT(uint8_t, int8_t); break;
+        case 2: LR_FMT(uint16_t, uint16_t); break;
+        case 3: LR_FMT(uint16_t, int16_t); break;
+        case 4: LR_FMT(uint32_t, uint32_t); break;
+        case 5: LR_FMT(uint32_t, int32_t); break;
+        case 6: LR_FMT(uint32_t, float); break;
+        default: LR_FMT(uint64_t, double); break;
+    }
+#undef LR_FMT
+    LR_LAUNCH_CHECK();
+    return (long)n;
+}
+
+// =====================================================================================================
+// MultiplyBlock / MultiplyConjugateBlock / AddBlock / SubtractBlock
+// =====================================================================================================
+struct BinaryStage : lrhip_stage {
+    int op = BIN_MULTIPLY;
+    PinnedBuf h_in2;
+    DeviceBuf d_in2;
+    const char *kind() const override { return "binary"; }
+    int reset() override { return 0; }
+    long run(const void *, unsigned long, void *, unsigned long) override { return set_error("binary stage needs two inputs: use lrhip_stage_execute2"); }
+    long run2(const void *a, const void *b, unsigned long n, void *y, unsigned long cap) override
+    {
+        if (n > cap) return set_error("binary: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+        if (op == BIN_F2C) {
+            hipLaunchKernelGGL(float_to_complex_kernel, dim3(grid), dim3(256), 0, ctx().stream, (const float *)a, (const float *)b, (float2 *)y, n);
+            LR_LAUNCH_CHECK();
+            return (long)n;
+        }
+#define LR_BIN(K, OP, T) hipLaunchKernelGGL((K<OP>), dim3(grid), dim3(256), 0, ctx().stream, (const T *)a, (const T *)b, (T *)y, n)
+        if (in_size == 8) {
+            switch (op) {
+                case BIN_MULTIPLY: LR_BIN(binary_complex_kernel, BIN_MULTIPLY, float2); break;
+                case BIN_MULTIPLY_CONJ: LR_BIN(binary_complex_kernel, BIN_MULTIPLY_CONJ, float2); break;
+                case BIN_ADD: LR_BIN(binary_complex_kernel, BIN_ADD, float2); break;
+                default: LR_BIN(binary_complex_kernel, BIN_SUBTRACT, float2); break;
+            }
+        } else {
+            switch (op) {
+                case BIN_MULTIPLY: LR_BIN(binary_real_kernel, BIN_MULTIPLY, float); break;
+                case BIN_ADD: LR_BIN(binary_real_kernel, BIN_ADD, float); break;
+                default: LR_BIN(binary_real_kernel, BIN_SUBTRACT, float); break;
+            }
+        }
+#undef LR_BIN
+        LR_LAUNCH_CHECK();
+        return (long)n;
+    }
+};
+
+// =====================================================================================================
+// MultiplyConstantBlock, UpsamplerBlock
+// =====================================================================================================
+struct MulConstStage : lrhip_stage {
+    float cr = 1.f, ci = 0.f;
+    int mode = 0;
+    const char *kind() const override { return "multiplyconstant"; }
+    int reset() override { return 0; }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n > cap) return set_error("multiplyconstant: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+        const float *x = (const float *)in_dev;
+        float *y = (float *)out_dev;
+        if (mode == 0) hipLaunchKernelGGL(multiply_constant_kernel<0>, dim3(grid), dim3(256), 0, ctx().stream, x, y, n, cr, ci);
+        else if (mode == 1) hipLaunchKernelGGL(multiply_constant_kernel<1>, dim3(grid), dim3(256), 0, ctx().stream, x, y, n, cr, ci);
+        else hipLaunchKernelGGL(multiply_constant_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, x, y, n, cr, ci);
+        LR_LAUNCH_CHECK();
+        return (long)n;
+    }
+};
+
+struct UpsamplerStage : lrhip_stage {
+    unsigned long factor = 1;
+    const char *kind() const override { return "upsampler"; }
+    int reset() override { return 0; }
+    unsigned long max_output(unsigned long n) const override { return n * factor; }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        unsigned long n_out = n * factor;                 // upsampler.lua:46
+        if (n_out > cap) return set_error("upsampler: output capacity %lu < %lu", cap, n_out);
+        if (!n_out) return 0;
+        unsigned grid = grid_for(n_out, 256, ctx().num_cus * 16);
+        if (in_size == 8)
+            hipLaunchKernelGGL(upsample_kernel<float2>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n_out, factor);
+        else
+            hipLaunchKernelGGL(upsample_kernel<float>, dim3(grid), dim3(256), 0, ctx().stream, (const float *)in_dev, (float *)out_dev, n_out, factor);
+        LR_LAUNCH_CHECK();
+        return (long)n_out;
+    }
+};

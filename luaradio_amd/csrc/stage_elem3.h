@@ -1,0 +1,79 @@
+// stage_elem3.h - one-input element-wise blocks, Delay, HilbertTransform
+// (part of liblrhip.so; included by lrhip.hip in this order, one translation unit)
+#pragma once
+
+// =====================================================================================================
+// one-input element-wise blocks, DelayBlock, HilbertTransformBlock
+// =====================================================================================================
+struct UnaryStage : lrhip_stage {
+    int op = 0;
+    float cr = 0.f, ci = 0.f;
+    const char *kind() const override { return "unary"; }
+    int reset() override { return 0; }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n > cap) return set_error("unary: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+        const float *x = (const float *)in_dev;
+        float *y = (float *)out_dev;
+#define LR_UN(OP) case OP: hipLaunchKernelGGL(unary_kernel<OP>, dim3(grid), dim3(256), 0, ctx().stream, x, y, n, cr, ci); break
+        switch (op) {
+            LR_UN(UN_CMAG); LR_UN(UN_CPHASE); LR_UN(UN_CREAL); LR_UN(UN_CIMAG); LR_UN(UN_CCONJ); LR_UN(UN_R2C); LR_UN(UN_ABS);
+            LR_UN(UN_ADDC_REAL); LR_UN(UN_ADDC_CPLX_BY_REAL); LR_UN(UN_ADDC_CPLX);
+            default: return set_error("unary: bad op");
+        }
+#undef LR_UN
+        LR_LAUNCH_CHECK();
+        return (long)n;
+    }
+};
+
+struct DelayStage : lrhip_stage {
+    unsigned long D = 1;
+    DeviceBuf state[2];
+    int cur = 0;
+    const char *kind() const override { return "delay"; }
+    int reset() override
+    {
+        cur = 0;
+        return (zero_fill(state[0], D * in_size) || zero_fill(state[1], D * in_size)) ? -1 : 0;
+    }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n > cap) return set_error("delay: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        unsigned grid = grid_for(n + D, 256, ctx().num_cus * 16);
+        if (in_size == 8)
+            hipLaunchKernelGGL(delay_kernel<float2>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)state[cur].p, (const float2 *)in_dev,
+                               (float2 *)out_dev, (float2 *)state[cur ^ 1].p, n, D);
+        else
+            hipLaunchKernelGGL(delay_kernel<float>, dim3(grid), dim3(256), 0, ctx().stream, (const float *)state[cur].p, (const float *)in_dev,
+                               (float *)out_dev, (float *)state[cur ^ 1].p, n, D);
+        LR_LAUNCH_CHECK();
+        cur ^= 1;
+        return (long)n;
+    }
+};
+
+struct HilbertStage : lrhip_stage {
+    std::unique_ptr<FirStage> fir;     // real taps, Float32 stream: the imaginary part
+    DeviceBuf tmp;
+    const char *kind() const override { return "hilbert"; }
+    int reset() override { return fir->reset(); }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (n > cap) return set_error("hilbert: output capacity %lu < %lu", cap, n);
+        if (!n) return 0;
+        if (tmp.reserve(n * sizeof(float))) return -1;
+        long got = fir->core((const float *)in_dev, (long)n, (float *)tmp.p, n);
+        if (got < 0) return got;
+        // core() has swapped the ping-pong history: the history that was current for this chunk is the other one
+        const float *old_hist = (const float *)fir->hist[fir->cur ^ 1].p;
+        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+        hipLaunchKernelGGL(hilbert_combine_kernel, dim3(grid), dim3(256), 0, ctx().stream, old_hist, (const float *)in_dev, (const float *)tmp.p,
+                           (float2 *)out_dev, n, fir->M);
+        LR_LAUNCH_CHECK();
+        return (long)n;
+    }
+};

@@ -1,0 +1,465 @@
+// stage_fir.h - FIRFilterBlock stage: direct Toeplitz-MFMA / overlap-save FFT / decimating kernels, fused rotator, downsampler, discriminator; fir_build()
+// (part of liblrhip.so; included by lrhip.hip in this order, one translation unit)
+#pragma once
+
+// =====================================================================================================
+// FIRFilterBlock (+ fused FrequencyTranslatorBlock in front, + fused DownsamplerBlock behind)
+// =====================================================================================================
+struct FirStage : lrhip_stage {
+    int M = 0, S = 2, taps_complex = 0;
+    unsigned D = 1;
+    bool use_fft = false;
+    std::vector<float> taps_rev;          // host copy, reversed (firfilter.lua:234-238)
+    DeviceBuf d_taps, d_atab;
+    int ksteps = 0;                       // 0 => MFMA path unavailable for this (M, D)
+    int mfma_blocks_per_cu = 0;           // resident workgroups of the persistent kernel (occupancy query, cached)
+    int hist_pad = 0;                     // leading pad floats in the history buffers (1 for complex taps, see launch_mfma_cc)
+    DeviceBuf hist[2];
+    int cur = 0;
+    unsigned long index = 0;              // carried downsampler index (downsampler.lua:53)
+    bool rot = false;                     // fused rotator in front
+    uint64_t rot_step = 0, count = 0;     // absolute index of the next input sample
+    // overlap-save emission framing (firfilter.lua:451-485)
+    long L = 0, fill = 0;
+    DeviceBuf pending, work;
+    // overlap-save ARITHMETIC (fused 1024-point FFT kernel); independent of the emission framing
+    static constexpr int FFT_PART = 512;   // taps per overlap-save partition (V = 512, L = 512 of the 1024-point block)
+    bool fft_arith = false;
+    DeviceBuf d_fft_tables;
+    int fft_blocks_per_cu = 0;
+    // fused FrequencyDiscriminatorBlock in front (chains): input is ComplexFloat32, the filter runs on arg(c[i] conj c[i-1])/gain
+    bool hist_in_kernel = false;          // set by a launch that also wrote the next history buffer
+    bool pre_disc = false;
+    // fused FrequencyDiscriminatorBlock behind the filter (chains): ComplexFloat32 in, Float32 out (persistent MFMA kernel epilogue)
+    bool post_disc = false;
+    DeviceBuf edge;
+    double disc_gain = 1.0;
+    DeviceBuf disc_prev;
+    int disc_cur = 0;
+
+    const char *kind() const override { return "fir"; }
+    unsigned long max_output(unsigned long n) const override
+    {
+        if (use_fft) return (unsigned long)(((fill + (long)n) / L) * L);
+        return D == 1 ? n : n / D + 1;
+    }
+    int reset() override
+    {
+        cur = 0; index = 0; count = 0; fill = 0; disc_cur = 0;
+        if ((pre_disc || post_disc) && zero_fill(disc_prev, 4 * sizeof(float))) return -1;
+        size_t hb = ((size_t)(M > 1 ? M - 1 : 1) * S + hist_pad) * sizeof(float);
+        if (zero_fill(hist[0], hb) || zero_fill(hist[1], hb)) return -1;
+        return 0;
+    }
+
+    template <int SS, int DD, int NACC>
+    int launch_mfma(const float *x, long n, float *y, long n_out)
+    {
+        // the shapes that matter most get the persistent, fully unrolled instantiation:
+        // M = 128 at D = 1 (36 MFMA steps, the headline) and M = 128 at D = 5 (60 steps, the WBFM tuner)
+        if constexpr (DD == 1) {
+            if (ksteps == 36) return launch_mfma_ks<SS, DD, NACC, 36>(x, n, y, n_out);     // M = 128, cf32
+            if (ksteps == 37) return launch_mfma_ks<SS, DD, NACC, 37>(x, n, y, n_out);     // M = 128, f32 (slack up to 3 samples)
+        }
+        if constexpr (DD == 5) {
+            if (ksteps == 51) return launch_mfma_ks<SS, DD, NACC, 51>(x, n, y, n_out);     // M = 128 at D = 5 (Tuner / Decimator(5))
+        }
+        return launch_mfma_ks<SS, DD, NACC, 0>(x, n, y, n_out);
+    }
+
+    template <typename K>
+    int prepare_kernel(K kern, size_t lds_bytes, int *blocks_per_cu, int threads = 256)
+    {
+        if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (blocks_per_cu) {
+            int nb = 0;
+            LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds_bytes));
+            *blocks_per_cu = nb < 1 ? 1 : nb;
+        }
+        return 0;
+    }
+
+    template <int SS, int DD, int NACC, int KS>
+    int launch_mfma_ks(const float *x, long n, float *y, long n_out)
+    {
+        using G = FirMfmaGeom<SS, DD>;
+        constexpr int TILE_OUT = G::tile_out(NACC);
+        // alignment slack so that the tile's first staged sample is 16-B aligned in global memory
+        if (((uintptr_t)x % (4 * SS)) != 0) {
+            if (rot || post_disc) return set_error("fir: fused rotator / discriminator needs a sample-aligned input pointer");
+            return launch_direct(x, n, y, n_out);
+        }
+        long sample_addr = (long)((uintptr_t)x / (4 * SS));
+        int q = 4 / SS;
+        long v = sample_addr + (long)index - (M - 1);
+        int e = (int)(((v % q) + q) % q);
+        int span = G::span(NACC, ksteps);
+        size_t lds_floats = (size_t)fir_taps_len(DD, ksteps) + (size_t)G::phys(SS * span) + G::PAD + 8;
+        size_t lds_bytes = lds_floats * sizeof(float);
+        long ntiles = (n_out + TILE_OUT - 1) / TILE_OUT;
+        const float *atab = (const float *)d_atab.p;          // zero-padded reversed taps
+        const float *h = (const float *)hist[cur].p + hist_pad;
+        int out_aligned = ((uintptr_t)y % 16) == 0;
+        uint64_t rs = rot ? rot_step : 0, rc = rot ? count : 0;
+        if constexpr (KS > 0) {
+            auto launch = [&](auto kern) -> int {
+                if (!mfma_blocks_per_cu && prepare_kernel(kern, lds_bytes, &mfma_blocks_per_cu)) return -1;     // queried once per stage
+                long slots = (long)ctx().num_cus * mfma_blocks_per_cu;
+                unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+                if (post_disc && edge.reserve((size_t)ntiles * 8 * sizeof(float2))) return -1;
+                float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, atab, y, M, n, n_out, (long)index, e,
+                                   ntiles, out_aligned, rs, rc, (float2 *)edge.p, post_disc ? (float2 *)disc_prev.p + (disc_cur ^ 1) : nullptr, 1.0 / disc_gain, ho);
+                hist_in_kernel = ho != nullptr;
+                return 0;
+            };
+            int rc2;
+            if constexpr (SS == 2 && (DD == 1 || DD == 5)) {
+                if (post_disc) {
+                    rc2 = rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS, 1>);
+                    if (rc2) return rc2;
+                    LR_LAUNCH_CHECK();
+                    float2 *dp = (float2 *)disc_prev.p;
+                    hipLaunchKernelGGL(fir_disc_fixup_kernel, dim3((unsigned)((4 * ntiles + 255) / 256)), dim3(256), 0, ctx().stream, (const float2 *)edge.p,
+                                       4 * ntiles, TILE_OUT / 4, y, n_out, (const float2 *)(dp + disc_cur), 1.0 / disc_gain);
+                    LR_LAUNCH_CHECK();
+                    disc_cur ^= 1;
+                    return 0;
+                }
+            }
+            if (post_disc) return set_error("internal: discriminator epilogue without a persistent kernel variant");
+            if constexpr (SS == 2) rc2 = rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS>);
+            else rc2 = rot ? set_error("rotator fusion needs complex input") : launch(fir_mfma_persistent_kernel<1, DD, NACC, false, KS>);
+            if (rc2) return rc2;
+        } else {
+            if (post_disc) return set_error("internal: discriminator epilogue without a persistent kernel variant");
+            auto launch = [&](auto kern) -> int {
+                if (prepare_kernel(kern, lds_bytes, nullptr)) return -1;
+                hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds_bytes, ctx().stream, h, x, atab, y, M, n, n_out, (long)index, e,
+                                   ksteps, out_aligned, rs, rc);
+                return 0;
+            };
+            int rc2;
+            if constexpr (SS == 2) rc2 = rot ? launch(fir_mfma_kernel<2, DD, NACC, true, 1>) : launch(fir_mfma_kernel<2, DD, NACC, false, 1>);
+            else rc2 = rot ? set_error("rotator fusion needs complex input") : launch(fir_mfma_kernel<1, DD, NACC, false, 1>);
+            if (rc2) return rc2;
+        }
+        LR_LAUNCH_CHECK();
+        return 0;
+    }
+
+    // complex taps: two real Toeplitz filters (re / im) of 2M taps over the interleaved float stream, decimation 2D,
+    // sharing every B fragment.  Stream position of output k in float units is 2*q_k + 1 once the float stream is
+    // given one leading pad float (so the history is the 2M-1 floats the S = 1 kernel expects).
+    template <int DD2, int NACC>
+    int launch_mfma_cc(const float *x, long n, float *y, long n_out)
+    {
+        using G = FirMfmaGeom<1, DD2>;
+        constexpr int TILE_OUT = G::tile_out(NACC);
+        if (((uintptr_t)x % 8) != 0) return launch_direct(x, n, y, n_out);
+        const int M2 = 2 * M;
+        const long first2 = 2 * (long)index + 1, n2 = 2 * n;
+        long v = (long)((uintptr_t)x / 4) + first2 - (M2 - 1);
+        int e = (int)(((v % 4) + 4) % 4);
+        int span = G::span(NACC, ksteps);
+        size_t lds_bytes = ((size_t)2 * fir_taps_len(DD2, ksteps) + (size_t)G::phys(span) + G::PAD + 8) * sizeof(float);
+        long ntiles = (n_out + TILE_OUT - 1) / TILE_OUT;
+        const float *atab = (const float *)d_atab.p;          // [re taps | im taps], each zero-padded
+        const float *h = (const float *)hist[cur].p;          // includes the pad float
+        int out_aligned = ((uintptr_t)y % 16) == 0;
+        auto kern = fir_mfma_kernel<1, DD2, NACC, false, 2>;
+        if (prepare_kernel(kern, lds_bytes, nullptr)) return -1;
+        hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds_bytes, ctx().stream, h, x, atab, y, M2, n2, n_out, first2, e,
+                           ksteps, out_aligned, (uint64_t)0, (uint64_t)0);
+        LR_LAUNCH_CHECK();
+        return 0;
+    }
+
+    int dispatch_mfma_cc(const float *x, long n, float *y, long n_out)
+    {
+        switch (D) {
+            case 1: return launch_mfma_cc<2, 4>(x, n, y, n_out);
+            case 2: return launch_mfma_cc<4, 2>(x, n, y, n_out);
+            case 3: return launch_mfma_cc<6, 1>(x, n, y, n_out);
+            case 4: return launch_mfma_cc<8, 1>(x, n, y, n_out);
+            case 5: return launch_mfma_cc<10, 1>(x, n, y, n_out);
+            default: return decim_lds_ok() ? launch_decim_lds(x, n, y, n_out) : launch_direct(x, n, y, n_out);
+        }
+    }
+
+    int launch_fft(const float *x, long n, float *y, long n_out)
+    {
+        size_t lds_bytes = (size_t)FFT_LDS_ELEMS * sizeof(float2);
+        const float *h = (const float *)hist[cur].p + hist_pad;
+        hist_in_kernel = false;
+        // one launch per partition of at most FFT_PART taps (a plain filter has one); partitions after the first accumulate
+        const int nparts = (M + FFT_PART - 1) / FFT_PART;
+        for (int part = 0; part < nparts; part++) {
+            const int Mp = part + 1 < nparts ? FFT_PART : M - part * FFT_PART;
+            const long Lf = FFTN - ((Mp - 1 + 63) / 64) * 64;      // block advance of the fused kernel (overlap rounded to 64)
+            long nblocks = (n_out + Lf - 1) / Lf;
+            long nffts = S == 2 ? nblocks : (nblocks + 1) / 2;
+            const float2 *tables = (const float2 *)d_fft_tables.p + (size_t)part * FFT_TABLE_ELEMS;
+            auto go = [&](auto kern) -> int {
+                if (!fft_blocks_per_cu && prepare_kernel(kern, lds_bytes, &fft_blocks_per_cu, 64 * FFT_WPB)) return -1;
+                long slots = (long)ctx().num_cus * fft_blocks_per_cu;
+                long want = (nffts + FFT_WPB - 1) / FFT_WPB;
+                unsigned grid = (unsigned)(want < slots ? want : slots);      // persistent; a dynamic one-batch-per-workgroup grid measured 3-7 % slower even for 2.4 blocks per wave
+                const float2 *dp = pre_disc ? (const float2 *)disc_prev.p + disc_cur : nullptr;
+                float *ho = (!pre_disc && M > 1 && part == 0) ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FFT_WPB), lds_bytes, ctx().stream, h, x, tables, y, Mp, n, n_out, nblocks,
+                                   1.0 / disc_gain, dp, ho, M, (long)part * FFT_PART, part > 0 ? 1 : 0);
+                if (ho) hist_in_kernel = true;
+                return 0;
+            };
+            int rc = S == 2 ? go(fir_fft_kernel<2, 0>) : pre_disc ? go(fir_fft_kernel<1, 1>) : go(fir_fft_kernel<1, 0>);
+            if (rc) return rc;
+            LR_LAUNCH_CHECK();
+        }
+        return 0;
+    }
+
+    // decimations without a Toeplitz instantiation (and taps too long for its LDS table): LDS-staged one-output-per-thread kernel
+    bool decim_lds_ok() const { return !fft_arith && !use_fft && M + 255 <= DECIM_SPAN_MAX && !(taps_complex && rot); }
+    int decim_blocks_per_cu = 0;
+    int launch_decim_lds(const float *x, long n, float *y, long n_out)
+    {
+        long ow = (DECIM_SPAN_MAX - M) / (long)D + 1;
+        int OW = (int)(ow > 256 ? 256 : ow < 1 ? 1 : ow);
+        long ntiles = (n_out + OW - 1) / OW;
+        long span = (long)(OW - 1) * D + M;
+        size_t lds_bytes = ((size_t)(((taps_complex ? 2 : 1) * M + 3) & ~3) + (size_t)S * (span + (span >> 5) + 2)) * sizeof(float);
+        const float *h = (const float *)hist[cur].p + hist_pad;
+        float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
+        auto go = [&](auto kern) -> int {
+            if (!decim_blocks_per_cu && prepare_kernel(kern, lds_bytes, &decim_blocks_per_cu)) return -1;
+            long slots = (long)ctx().num_cus * decim_blocks_per_cu;
+            unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, (const float *)d_taps.p, y, M, n, n_out, (long)index, (long)D, OW,
+                               ntiles, rot ? rot_step : (uint64_t)0, rot ? count : (uint64_t)0, ho);
+            hist_in_kernel = ho != nullptr;
+            return 0;
+        };
+        int rc = taps_complex ? go(fir_decim_lds_kernel<2, false, true>)
+                 : S == 2 ? (rot ? go(fir_decim_lds_kernel<2, true>) : go(fir_decim_lds_kernel<2, false>))
+                        : (rot ? set_error("rotator fusion needs complex input") : go(fir_decim_lds_kernel<1, false>));
+        if (rc) return rc;
+        LR_LAUNCH_CHECK();
+        return 0;
+    }
+
+    int launch_direct(const float *x, long n, float *y, long n_out)
+    {
+        if (rot) return set_error("internal: direct FIR kernel has no fused rotator");
+        unsigned grid = grid_for((unsigned long)n_out, 256);
+        const float *h = (const float *)hist[cur].p + hist_pad, *t = (const float *)d_taps.p;
+        if (S == 1)
+            hipLaunchKernelGGL(fir_direct_kernel<0>, dim3(grid), dim3(256), 0, ctx().stream, h, x, t, y, M, n, n_out, (long)index, (long)D);
+        else if (!taps_complex)
+            hipLaunchKernelGGL(fir_direct_kernel<1>, dim3(grid), dim3(256), 0, ctx().stream, h, x, t, y, M, n, n_out, (long)index, (long)D);
+        else
+            hipLaunchKernelGGL(fir_direct_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, h, x, t, y, M, n, n_out, (long)index, (long)D);
+        LR_LAUNCH_CHECK();
+        return 0;
+    }
+
+    template <int SS>
+    int dispatch_mfma(const float *x, long n, float *y, long n_out)
+    {
+        switch (D) {
+            case 1: return launch_mfma<SS, 1, LRHIP_FIR_D1_NACC>(x, n, y, n_out);
+            case 2: return launch_mfma<SS, 2, 4>(x, n, y, n_out);
+            case 3: return launch_mfma<SS, 3, 2>(x, n, y, n_out);
+            case 4: return launch_mfma<SS, 4, 2>(x, n, y, n_out);
+            case 5: return launch_mfma<SS, 5, 2>(x, n, y, n_out);
+            case 6: return launch_mfma<SS, 6, 1>(x, n, y, n_out);
+            case 7: return launch_mfma<SS, 7, 1>(x, n, y, n_out);
+            case 8: return launch_mfma<SS, 8, 1>(x, n, y, n_out);
+            case 10: return launch_mfma<SS, 10, 1>(x, n, y, n_out);
+            default: return decim_lds_ok() ? launch_decim_lds(x, n, y, n_out) : launch_direct(x, n, y, n_out);
+        }
+    }
+
+    static bool mfma_supported_decim(unsigned d) { return (d >= 1 && d <= 8) || d == 10; }
+    // the discriminator epilogue exists for the persistent instantiations of the complex-stream, real-taps kernel
+    bool can_post_disc() const { return S == 2 && !taps_complex && !fft_arith && !use_fft && ((D == 1 && ksteps == 36) || (D == 5 && ksteps == 51)); }
+
+    // filter n inputs (device), emit the retained outputs; advances history / index / count
+    long core(const float *x, long n, float *y, unsigned long cap)
+    {
+        if (n <= 0) return 0;
+        hist_in_kernel = false;
+        long n_out = (unsigned long)n > index ? (long)((n - index + D - 1) / D) : 0;
+        if ((unsigned long)n_out > cap) return set_error("fir: output capacity %lu < %ld", cap, n_out);
+        if (n_out > 0) {
+            int rc = fft_arith ? launch_fft(x, n, y, n_out)
+                     : !ksteps ? (decim_lds_ok() ? launch_decim_lds(x, n, y, n_out) : launch_direct(x, n, y, n_out))
+                     : taps_complex ? dispatch_mfma_cc(x, n, y, n_out)
+                     : S == 1 ? dispatch_mfma<1>(x, n, y, n_out) : dispatch_mfma<2>(x, n, y, n_out);
+            if (rc) return rc;
+        }
+        if (pre_disc) {
+            unsigned grid = grid_for((unsigned long)(M > 1 ? M - 1 : 1), 256);
+            float2 *dp = (float2 *)disc_prev.p;
+            hipLaunchKernelGGL(fir_fft_pre_history_kernel, dim3(grid), dim3(256), 0, ctx().stream, (const float *)hist[cur].p, x, (float *)hist[cur ^ 1].p, M, n,
+                               1.0 / disc_gain, (const float2 *)(dp + disc_cur), dp + (disc_cur ^ 1));
+            LR_LAUNCH_CHECK();
+            cur ^= 1;
+            disc_cur ^= 1;
+        } else if (hist_in_kernel) {
+            cur ^= 1;
+        } else if (M > 1) {
+            unsigned grid = grid_for((unsigned long)(M - 1) * S, 256);
+            const float *hi = (const float *)hist[cur].p + hist_pad;
+            float *ho = (float *)hist[cur ^ 1].p + hist_pad;
+            if (S == 1)
+                hipLaunchKernelGGL(fir_history_kernel<1>, dim3(grid), dim3(256), 0, ctx().stream, hi, x, ho, M, n);
+            else
+                hipLaunchKernelGGL(fir_history_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, hi, x, ho, M, n);
+            LR_LAUNCH_CHECK();
+            cur ^= 1;
+        }
+        index = index + (unsigned long)n_out * D - (unsigned long)n;
+        count += (uint64_t)n;
+        return n_out;
+    }
+
+    long run(const void *in_dev, unsigned long n_in, void *out_dev, unsigned long cap) override
+    {
+        const float *x = (const float *)in_dev;
+        float *y = (float *)out_dev;
+        if (!use_fft) return core(x, (long)n_in, y, cap);
+        // overlap-save framing: emit only whole L-blocks, keep the tail pending (firfilter.lua:451-485)
+        long total = fill + (long)n_in, emit = (total / L) * L;
+        size_t ss = (size_t)S * sizeof(float);
+        if (emit == 0) {
+            if (n_in) LR_HIP(hipMemcpyAsync((char *)pending.p + fill * ss, x, n_in * ss, hipMemcpyDeviceToDevice, ctx().stream));
+            fill = total;
+            return 0;
+        }
+        if ((unsigned long)emit > cap) return set_error("fir(fft framing): output capacity %lu < %ld", cap, emit);
+        if (work.reserve((size_t)((long)n_in + L) * ss)) return -1;      // the largest total this chunk size can see: no regrowth as `fill` moves
+        if (fill) LR_HIP(hipMemcpyAsync(work.p, pending.p, fill * ss, hipMemcpyDeviceToDevice, ctx().stream));
+        LR_HIP(hipMemcpyAsync((char *)work.p + fill * ss, x, n_in * ss, hipMemcpyDeviceToDevice, ctx().stream));
+        long rc = core((const float *)work.p, emit, y, cap);
+        if (rc < 0) return rc;
+        fill = total - emit;
+        if (fill) LR_HIP(hipMemcpyAsync(pending.p, (char *)work.p + emit * ss, fill * ss, hipMemcpyDeviceToDevice, ctx().stream));
+        return emit;
+    }
+};
+
+static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, int input_complex, unsigned decim,
+                           int use_fft, bool rot, double omega)
+{
+    if (!taps || ntaps < 1) { set_error("fir: need at least one tap"); return nullptr; }
+    if (taps_complex && !input_complex) { set_error("fir: complex taps require ComplexFloat32 input (firfilter.lua:69-74)"); return nullptr; }
+    if (decim < 1) { set_error("fir: decimation must be >= 1"); return nullptr; }
+    if (use_fft == 3) use_fft = (decim == 1 && !rot && ntaps >= 48 && ntaps <= 16 * FirStage::FFT_PART && (input_complex || !taps_complex)) ? 2 : 0;
+    if (use_fft && decim != 1) { set_error("fir: overlap-save cannot be combined with decimation"); return nullptr; }
+    if (use_fft < 0 || use_fft > 2) { set_error("fir: use_fft must be 0 (direct form), 1 (overlap-save as the reference: block emission), 2 (overlap-save arithmetic, sample-exact emission) or 3 (automatic)"); return nullptr; }
+    if (ntaps > (1u << 20)) { set_error("fir: too many taps"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    std::unique_ptr<FirStage> q(new (std::nothrow) FirStage());
+    if (!q) { set_error("out of memory"); return nullptr; }
+    q->M = (int)ntaps; q->S = input_complex ? 2 : 1; q->taps_complex = taps_complex; q->D = decim;
+    q->use_fft = use_fft == 1; q->rot = rot;     // 1: reference emission framing; 2: FFT arithmetic, sample-exact emission
+    q->in_size = q->out_size = 4 * q->S;
+    int ts = taps_complex ? 2 : 1;
+    q->taps_rev.resize((size_t)ntaps * ts);
+    for (unsigned i = 0; i < ntaps; i++)
+        for (int c = 0; c < ts; c++) q->taps_rev[(size_t)i * ts + c] = taps[(size_t)(ntaps - 1 - i) * ts + c];
+    if (upload(q->d_taps, q->taps_rev.data(), q->taps_rev.size() * sizeof(float))) return nullptr;
+    if (!taps_complex && FirStage::mfma_supported_decim(decim)) {
+        int ks = fir_mfma_ksteps(q->M, (int)decim, q->S);
+        if ((size_t)fir_taps_len((int)decim, ks) * sizeof(float) <= 24 * 1024) {   // tap array must leave LDS room for the tile
+            std::vector<float> tab;
+            fir_mfma_build_taps(q->taps_rev.data(), q->M, (int)decim, ks, tab);
+            if (upload(q->d_atab, tab.data(), tab.size() * sizeof(float))) return nullptr;
+            q->ksteps = ks;
+        }
+    }
+    if (taps_complex && decim <= 5) {
+        // taps'_re = interleave(hr_rev, -hi_rev), taps'_im = interleave(hi_rev, hr_rev) over the float stream
+        int M2 = 2 * q->M, D2 = 2 * (int)decim;
+        int ks = fir_mfma_ksteps(M2, D2, 1, 2);          // 8-B aligned complex input => float slack e in {0, 2}
+        if ((size_t)2 * fir_taps_len(D2, ks) * sizeof(float) <= 32 * 1024) {
+            std::vector<float> tre((size_t)M2), tim((size_t)M2), tab;
+            for (int j = 0; j < q->M; j++) {
+                float hr = q->taps_rev[2 * j], hi = q->taps_rev[2 * j + 1];
+                tre[2 * j] = hr; tre[2 * j + 1] = -hi;
+                tim[2 * j] = hi; tim[2 * j + 1] = hr;
+            }
+            std::vector<float> are, aim;
+            fir_mfma_build_taps(tre.data(), M2, D2, ks, are);
+            fir_mfma_build_taps(tim.data(), M2, D2, ks, aim);
+            tab = are;
+            tab.insert(tab.end(), aim.begin(), aim.end());
+            if (upload(q->d_atab, tab.data(), tab.size() * sizeof(float))) return nullptr;
+            q->ksteps = ks;
+            q->hist_pad = 1;
+        }
+    }
+    if (rot) {
+        if (!q->ksteps && !(input_complex && !taps_complex && (int)ntaps + 255 <= DECIM_SPAN_MAX)) {
+            set_error("fir: rotator fusion unavailable for this tap count / decimation");
+            return nullptr;
+        }
+        long double turns = (long double)omega / (2.0L * 3.14159265358979323846264338327950288L);
+        turns -= floorl(turns);
+        q->rot_step = (uint64_t)(turns * 18446744073709551616.0L);
+    }
+    if (use_fft && decim == 1 && !rot && ntaps >= 32 && ntaps <= 16 * FirStage::FFT_PART && (input_complex || !taps_complex)) {
+        // fused overlap-save kernel tables, one set per partition of <= FFT_PART taps: tw1[k1][t] | Hperm[4j+k3][lane] | tw2[k2][t2]
+        const double PI2 = 6.283185307179586476925286766559;
+        const int nparts = ((int)ntaps + FirStage::FFT_PART - 1) / FirStage::FFT_PART;
+        std::vector<float> tab((size_t)nparts * FFT_TABLE_ELEMS * 2);
+        for (int part = 0; part < nparts; part++) {
+            float *tp = tab.data() + (size_t)part * FFT_TABLE_ELEMS * 2;
+            const unsigned m0 = (unsigned)part * FirStage::FFT_PART, m1 = std::min<unsigned>(ntaps, m0 + FirStage::FFT_PART);
+            for (int k1 = 0; k1 < 16; k1++)
+                for (int t = 0; t < 64; t++) {
+                    double a = -PI2 * (double)((k1 * t) % FFTN) / FFTN;
+                    tp[2 * (k1 * 64 + t)] = (float)std::cos(a);
+                    tp[2 * (k1 * 64 + t) + 1] = (float)std::sin(a);
+                }
+            std::vector<double> Hr(FFTN, 0.0), Hi(FFTN, 0.0);
+            for (int k = 0; k < FFTN; k++) {
+                double sr = 0, si = 0;
+                for (unsigned m = m0; m < m1; m++) {
+                    double a = -PI2 * (double)((k * (long)(m - m0)) % FFTN) / FFTN, c = std::cos(a), sn = std::sin(a);
+                    double hr = taps_complex ? taps[2 * m] : taps[m], hi = taps_complex ? taps[2 * m + 1] : 0.0;
+                    sr += hr * c - hi * sn;
+                    si += hr * sn + hi * c;
+                }
+                Hr[k] = sr / FFTN;      // the 1/N of the inverse transform (spectrum_utils.lua:335-338) folded in
+                Hi[k] = si / FFTN;
+            }
+            for (int j = 0; j < 4; j++)
+                for (int k3 = 0; k3 < 4; k3++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        int qq = lane & 3, k1 = lane >> 2;
+                        int k = k1 + 16 * (4 * j + qq) + 256 * k3;
+                        size_t o = (size_t)16 * 64 + (size_t)(4 * j + k3) * 64 + lane;
+                        tp[2 * o] = (float)Hr[k];
+                        tp[2 * o + 1] = (float)Hi[k];
+                    }
+            for (int k2 = 0; k2 < 16; k2++)
+                for (int t2 = 0; t2 < 4; t2++) {
+                    double a = -PI2 * (double)((k2 * t2) % 64) / 64.0;
+                    size_t o = (size_t)2 * 16 * 64 + k2 * 4 + t2;
+                    tp[2 * o] = (float)std::cos(a);
+                    tp[2 * o + 1] = (float)std::sin(a);
+                }
+        }
+        if (upload(q->d_fft_tables, tab.data(), tab.size() * sizeof(float))) return nullptr;
+        q->fft_arith = true;
+    }
+    if (q->use_fft) {
+        long N = 1L << (long)std::floor(std::log(8.0 * ntaps) / std::log(2.0));   // firfilter.lua:329
+        q->L = N - (long)ntaps + 1;
+        if (q->pending.reserve((size_t)q->L * q->S * sizeof(float))) return nullptr;
+    }
+    if (q->reset()) return nullptr;
+    return q.release();
+}

@@ -1,0 +1,104 @@
+// stage_resample.h - polyphase rational resampler and the MFMA channelizer
+// (part of liblrhip.so; included by lrhip.hip in this order, one translation unit)
+#pragma once
+
+// =====================================================================================================
+// polyphase rational resampler (chains: [MultiplyConstant] -> Upsampler -> FIR -> [Downsampler])
+// =====================================================================================================
+struct ResampleStage : lrhip_stage {
+    int S = 2, M = 0, L = 1, HQ = 0;
+    unsigned long D = 1;
+    float c = 1.f;
+    DeviceBuf d_taps, hist[2];
+    int cur = 0;
+    uint64_t Q0 = 0, m0 = 0;          // absolute input samples consumed / outputs emitted so far
+    static constexpr int SPAN_MAX = 6144;
+    const char *kind() const override { return "resample"; }
+    unsigned long max_output(unsigned long n) const override { return (n * (unsigned long)L) / D + 2; }
+    static bool fits(int M, int L, unsigned long D) { return L >= 1 && 256 * D / (unsigned long)L + (unsigned long)((M - 1) / L) + 4 <= (unsigned long)SPAN_MAX; }
+    int reset() override
+    {
+        cur = 0; Q0 = 0; m0 = 0;
+        size_t hb = (size_t)(HQ > 0 ? HQ : 1) * S * sizeof(float);
+        return (zero_fill(hist[0], hb) || zero_fill(hist[1], hb)) ? -1 : 0;
+    }
+    long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
+    {
+        if (!n) return 0;
+        // outputs m with m*D inside the upsampled positions [Q0*L, (Q0+n)*L)
+        uint64_t hi = (Q0 + n) * (uint64_t)L;
+        uint64_t m_end = (hi + D - 1) / D;                     // first m with m*D >= hi
+        long n_out = (long)(m_end - m0);
+        if ((unsigned long)n_out > cap) return set_error("resample: output capacity %lu < %ld", cap, n_out);
+        const float *h = (const float *)hist[cur].p;
+        float *ho = (float *)hist[cur ^ 1].p;
+        // per-workgroup input span: 256 outputs advance 256*D/L input samples, plus the (M-1)/L samples of filter memory
+        int span_cap = (int)(256 * D / (unsigned long)L) + (M - 1) / L + 4;
+        size_t lds_bytes = ((size_t)((((M - 1) / L + 1) * L + 3) & ~3) + (size_t)span_cap * S) * sizeof(float);
+        auto go = [&](auto kern) -> int {
+            if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            unsigned grid = n_out > 0 ? (unsigned)((n_out + 255) / 256) : 1;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, (const float *)in_dev, (const float *)d_taps.p, (float *)out_dev, M, L,
+                               (long)D, (long)n, n_out, m0, Q0, HQ, c, span_cap, ho);
+            return 0;
+        };
+        int rc = S == 2 ? go(fir_resample_kernel<2>) : go(fir_resample_kernel<1>);
+        if (rc) return rc;
+        LR_LAUNCH_CHECK();
+        cur ^= 1;
+        Q0 += n;
+        m0 = m_end;
+        return n_out;
+    }
+};
+
+// =====================================================================================================
+// polyphase channelizer as a dense MFMA GEMM
+// =====================================================================================================
+struct ChannelizerStage : lrhip_stage {
+    int M = 0, K = 0;
+    DeviceBuf W, hist[2];
+    int cur = 0;
+    unsigned long index = 0;
+    const char *kind() const override { return "channelizer"; }
+    unsigned long max_output(unsigned long n) const override { return (n / K + 1) * K; }
+    int reset() override
+    {
+        cur = 0; index = 0;
+        size_t hb = (size_t)(M - 1) * 2 * sizeof(float);
+        return (zero_fill(hist[0], hb) || zero_fill(hist[1], hb)) ? -1 : 0;
+    }
+    template <int NCT>
+    int launch(const float *x, long n, float *y, long nframes)
+    {
+        constexpr int K2 = 16 * NCT;
+        int nflt = 2 * ((CHAN_MT - 1) * K + M);
+        size_t dsize = (size_t)((nflt + 2 * (nflt / K2) + 2 + 3) / 4) * 4;
+        size_t lds_bytes = (dsize + (size_t)2 * CHAN_KSLAB * (K2 + 16)) * sizeof(float);
+        auto kern = channelizer_kernel<NCT>;
+        if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        unsigned grid = (unsigned)((nframes + CHAN_MT - 1) / CHAN_MT);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p, x, (const float *)W.p, y, M, n,
+                           nframes, (long)index);
+        LR_LAUNCH_CHECK();
+        return 0;
+    }
+    long run(const void *in_dev, unsigned long n_in, void *out_dev, unsigned long cap) override
+    {
+        long n = (long)n_in;
+        if (n <= 0) return 0;
+        long nframes = n_in > index ? (long)((n_in - index + K - 1) / K) : 0;
+        if ((unsigned long)(nframes * K) > cap) return set_error("channelizer: output capacity %lu < %ld", cap, nframes * K);
+        const float *x = (const float *)in_dev;
+        if (nframes > 0) {
+            int rc = K == 32 ? launch<4>(x, n, (float *)out_dev, nframes) : launch<8>(x, n, (float *)out_dev, nframes);
+            if (rc) return rc;
+        }
+        unsigned grid = grid_for((unsigned long)(M - 1) * 2, 256);
+        hipLaunchKernelGGL(fir_history_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, (const float *)hist[cur].p, x, (float *)hist[cur ^ 1].p, M, n);
+        LR_LAUNCH_CHECK();
+        cur ^= 1;
+        index = index + (unsigned long)nframes * K - n_in;
+        return nframes * K;
+    }
+};
