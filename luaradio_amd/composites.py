@@ -24,7 +24,9 @@ class Chain:
         L = _lib.load()
         arr = (C.c_void_p * len(self.blocks))(*[b.stage_handle() for b in self.blocks])
         self._chain = _lib.check_ptr(L.lrhip_chain_create(arr, len(self.blocks)), "Creating lrhip chain object")
-        self.in_type = self.blocks[0].get_input_type()
+        # a chain may start with a file source's format stage: its input is then RAW file records (uint8, record_size bytes each)
+        self.in_record = getattr(self.blocks[0], "record_size", None)
+        self.in_type = None if self.in_record else self.blocks[0].get_input_type()
         self.out_type = self.blocks[-1].get_output_type()
 
     def __del__(self):
@@ -38,14 +40,23 @@ class Chain:
     def max_output(self, n_in):
         return _lib.load().lrhip_chain_max_output(self._chain, n_in)
 
-    def process(self, x):
-        L = _lib.load()
+    def _count(self, x):
+        """input vector -> (contiguous array, number of input samples)"""
         x = np.ascontiguousarray(x)
+        if self.in_record:
+            if x.dtype != np.uint8 or len(x) % self.in_record:
+                raise TypeError("chain expects raw file records (uint8, %d bytes each)" % self.in_record)
+            return x, len(x) // self.in_record
         if x.dtype != self.in_type.dtype:
             raise TypeError("chain expects %s input, got %s" % (self.in_type, x.dtype))
-        cap = L.lrhip_chain_max_output(self._chain, len(x))
+        return x, len(x)
+
+    def process(self, x):
+        L = _lib.load()
+        x, count = self._count(x)
+        cap = L.lrhip_chain_max_output(self._chain, count)
         out = np.empty(cap, dtype=self.out_type.dtype)
-        n = L.lrhip_chain_execute(self._chain, x.ctypes.data_as(C.c_void_p), len(x), out.ctypes.data_as(C.c_void_p), cap)
+        n = L.lrhip_chain_execute(self._chain, x.ctypes.data_as(C.c_void_p), count, out.ctypes.data_as(C.c_void_p), cap)
         _lib.check(n, "chain:process")
         return out[:n]
 
@@ -63,10 +74,8 @@ class Chain:
         self._ring_out = np.empty(max_chunk + 64, dtype=self.out_type.dtype)
 
     def submit(self, x):
-        x = np.ascontiguousarray(x)
-        if x.dtype != self.in_type.dtype:
-            raise TypeError("chain expects %s input, got %s" % (self.in_type, x.dtype))
-        return _lib.check(_lib.load().lrhip_chain_submit(self._chain, x.ctypes.data_as(C.c_void_p), len(x)), "chain:submit")
+        x, count = self._count(x)
+        return _lib.check(_lib.load().lrhip_chain_submit(self._chain, x.ctypes.data_as(C.c_void_p), count), "chain:submit")
 
     def collect(self):
         n = _lib.load().lrhip_chain_collect(self._chain, self._ring_out.ctypes.data_as(C.c_void_p), len(self._ring_out))

@@ -5,6 +5,8 @@ plus randomized chunkings, large sizes and size-independent properties.
 Tolerances: FIR (real taps) bit-exact vs the oracle's fmaf-chain mode and < 1e-6 vs golden / f64;
 rotator 1e-5 vs golden (reference epsilon) and 1e-6 vs closed form; discriminator 1e-6; downsampler
 bit-exact; IIR 1e-6; DFT 1e-5; PSD 1e-5 (lin) / 3 dB (log, reference epsilon)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1349,3 +1351,26 @@ def test_create_destroy_many_stages_returns_device_memory():
     lr._lib.load().lrhip_synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, (free0, free1)
+
+
+def test_example_iqfile_wbfm_mono_end_to_end(tmp_path):
+    """examples/iqfile_wbfm_mono.py: a u8 IQ recording goes to the device as raw bytes (format conversion is the first stage of
+    the chain), through the pinned ring, and comes back as audio; equals the same blocks fed with host-converted samples"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("iqfile_wbfm_mono", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                     "examples", "iqfile_wbfm_mono.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    raw = ex.synth_capture(1102500.0, -250e3, 0.3)
+    path = tmp_path / "capture.u8"
+    path.write_bytes(raw)
+    src, chain, out_rate = ex.build_chain(str(path), "u8", 1102500.0, -250e3)
+    audio = ex.demodulate(src, chain, 1 << 16)
+    assert abs(out_rate - 44100.0) < 1e-6 and len(audio) == (len(raw) // 2 + 24) // 25
+    ref = lr.wbfm_mono_receiver(1102500.0, -250e3)
+    host = lr.IQFileSource(raw, "u8", 1102500.0)
+    host.initialize()
+    want = ref.process(host.read_all())
+    assert G.max_abs_err(audio, want) < 1e-6
+    ex.write_wav(str(tmp_path / "out.wav"), audio, out_rate)
+    assert (tmp_path / "out.wav").stat().st_size == 44 + 2 * len(audio)
