@@ -91,6 +91,10 @@ lrhip_stage_t *lrhip_dft_create(unsigned n, int inverse, int real_side);
  * Input samples are the RAW file records (lrhip_stage_input_size() bytes each), so the bytes read from the file
  * are handed over unchanged and converted on the device. */
 lrhip_stage_t *lrhip_format_convert_create(const char *format, int complex_out);
+/* The sink direction (radio/blocks/sinks/iqfile.lua:68-85, realfile.lua): ComplexFloat32 / Float32 samples -> raw file records
+ * raw = x*scale + offset stored into the format's type (C conversion, i.e. truncation for the integer formats), byte-swapped
+ * for the big-endian formats.  Output samples are lrhip_stage_output_size() bytes each. */
+lrhip_stage_t *lrhip_format_pack_create(const char *format, int complex_in);
 
 /* Two-input element-wise blocks: op = "multiply" (radio/blocks/signal/multiply.lua:43-76), "multiplyconjugate"
  * (multiplyconjugate.lua:41-59, complex only), "add" (add.lua), "subtract" (subtract.lua), "floattocomplex" (floattocomplex.lua: two Float32 inputs ->

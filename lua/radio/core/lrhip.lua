@@ -35,6 +35,7 @@ lrhip_stage_t *lrhip_iir_create(const float *b, unsigned nb, const float *a, uns
 lrhip_stage_t *lrhip_psd_create(unsigned n, const float *window, double scale, int logarithmic, int input_complex, int fftshift);
 lrhip_stage_t *lrhip_dft_create(unsigned n, int inverse, int real_side);
 lrhip_stage_t *lrhip_format_convert_create(const char *format, int complex_out);
+lrhip_stage_t *lrhip_format_pack_create(const char *format, int complex_in);
 lrhip_stage_t *lrhip_binary_create(const char *op, int input_complex);
 lrhip_stage_t *lrhip_multiply_constant_create(float re, float im, int constant_complex, int input_complex);
 lrhip_stage_t *lrhip_upsampler_create(unsigned factor, int elem_size);

@@ -15,7 +15,7 @@ from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock,
                      AbsoluteValueBlock, AddConstantBlock, DelayBlock, HilbertTransformBlock, SinglepoleHighpassFilterBlock,
                      FMPreemphasisFilterBlock, FloatToComplexBlock, ComplexToFloatBlock, FrequencyModulatorBlock,
                      PulseMatchedFilterBlock, ManchesterMatchedFilterBlock, AGCBlock, PowerSquelchBlock)
-from .sources import IQFileSource, RealFileSource  # noqa: F401
+from .sources import IQFileSource, RealFileSource, IQFileSink, RealFileSink  # noqa: F401
 from .graph import DeviceGraph  # noqa: F401
 from .composites import (Chain, CompositeBlock, DecimatorBlock, InterpolatorBlock, RationalResamplerBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401
                          NBFMDemodulator, AMEnvelopeDemodulator, SSBDemodulator, SSBModulator, wbfm_mono_receiver, am_envelope_receiver,

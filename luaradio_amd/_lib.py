@@ -35,6 +35,7 @@ SIGNATURES = {
     "lrhip_psd_create": (_vp, [C.c_uint, _fp, C.c_double, C.c_int, C.c_int, C.c_int]),
     "lrhip_dft_create": (_vp, [C.c_uint, C.c_int, C.c_int]),
     "lrhip_format_convert_create": (_vp, [C.c_char_p, C.c_int]),
+    "lrhip_format_pack_create": (_vp, [C.c_char_p, C.c_int]),
     "lrhip_binary_create": (_vp, [C.c_char_p, C.c_int]),
     "lrhip_multiply_constant_create": (_vp, [C.c_float, C.c_float, C.c_int, C.c_int]),
     "lrhip_upsampler_create": (_vp, [C.c_uint, C.c_int]),

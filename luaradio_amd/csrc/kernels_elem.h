@@ -220,6 +220,23 @@ __global__ __launch_bounds__(256) void format_convert_kernel(const RAW *__restri
 }
 
 
+// IQFileSink / RealFileSink direction (radio/blocks/sinks/iqfile.lua:68-85, realfile.lua): raw.value = x*scale + offset
+// evaluated in double and stored into the raw type by the C conversion LuaJIT applies to a cdata assignment
+// (truncation toward zero for the integer formats), then the byte swap.
+template <typename RAW, typename VAL, bool SWAP>
+__global__ __launch_bounds__(256) void format_pack_kernel(const float *__restrict__ in, RAW *__restrict__ out, unsigned long n,
+                                                          double offset, double scale)
+{
+    unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        VAL v = (VAL)((double)in[i] * scale + offset);
+        RAW r;
+        __builtin_memcpy(&r, &v, sizeof(r));
+        if (SWAP) r = byteswap_raw(r);
+        out[i] = r;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Two-input element-wise blocks: MultiplyBlock (radio/blocks/signal/multiply.lua:43-76), MultiplyConjugateBlock
 // (multiplyconjugate.lua:41-59), AddBlock (add.lua), SubtractBlock (subtract.lua).  Complex products follow the

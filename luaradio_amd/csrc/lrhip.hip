@@ -253,6 +253,15 @@ lrhip_stage_t *lrhip_format_convert_create(const char *format, int complex_out)
     return q;
 }
 
+lrhip_stage_t *lrhip_format_pack_create(const char *format, int complex_in)
+{
+    FormatStage *q = (FormatStage *)lrhip_format_convert_create(format, complex_in);
+    if (!q) return nullptr;
+    q->pack = true;
+    std::swap(q->in_size, q->out_size);
+    return q;
+}
+
 lrhip_stage_t *lrhip_multiply_constant_create(float re, float im, int constant_complex, int input_complex)
 {
     if (constant_complex && !input_complex) { set_error("multiplyconstant: a complex constant takes ComplexFloat32 input only (multiplyconstant.lua:42-44)"); return nullptr; }

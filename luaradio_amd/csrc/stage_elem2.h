@@ -8,6 +8,7 @@
 struct FormatStage : lrhip_stage {
     int fmt = 0;          // index into kFormats
     int scalars = 1;      // raw scalars per sample (2 for I/Q)
+    bool pack = false;    // sink direction: Float32 / ComplexFloat32 -> raw records
     const char *kind() const override { return "format"; }
     int reset() override { return 0; }
     long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override;
@@ -39,6 +40,26 @@ long FormatStage::run(const void *in_dev, unsigned long n, void *out_dev, unsign
     unsigned long ns = n * scalars;
     unsigned grid = grid_for(ns, 256, ctx().num_cus * 16);
     float *out = (float *)out_dev;
+    if (pack) {
+#define LR_PACK(RAW, VAL)                                                                                                  \
+    do {                                                                                                                   \
+        if (f.swap) hipLaunchKernelGGL((format_pack_kernel<RAW, VAL, true>), dim3(grid), dim3(256), 0, ctx().stream, (const float *)in_dev, (RAW *)out_dev, ns, f.offset, f.scale); \
+        else hipLaunchKernelGGL((format_pack_kernel<RAW, VAL, false>), dim3(grid), dim3(256), 0, ctx().stream, (const float *)in_dev, (RAW *)out_dev, ns, f.offset, f.scale);      \
+    } while (0)
+        switch (f.cls) {
+            case 0: LR_PACK(uint8_t, uint8_t); break;
+            case 1: LR_PACK(uint8_t, int8_t); break;
+            case 2: LR_PACK(uint16_t, uint16_t); break;
+            case 3: LR_PACK(uint16_t, int16_t); break;
+            case 4: LR_PACK(uint32_t, uint32_t); break;
+            case 5: LR_PACK(uint32_t, int32_t); break;
+            case 6: LR_PACK(uint32_t, float); break;
+            default: LR_PACK(uint64_t, double); break;
+        }
+#undef LR_PACK
+        LR_LAUNCH_CHECK();
+        return (long)n;
+    }
 #define LR_FMT(RAW, VAL)                                                                                                   \
     do {                                                                                                                   \
         if (f.swap) hipLaunchKernelGGL((format_convert_kernel<RAW, VAL, true>), dim3(grid), dim3(256), 0, ctx().stream, (const RAW *)in_dev, out, ns, f.offset, f.scale); \

@@ -10,7 +10,7 @@ import io
 import numpy as np
 
 from . import _lib, types
-from .block import Block, Output
+from .block import Block, Input, Output
 
 # radio/utilities/format_utils.lua:82-97 (bytes per raw scalar)
 FORMAT_BYTES = {"u8": 1, "s8": 1, "u16le": 2, "u16be": 2, "s16le": 2, "s16be": 2, "u32le": 4, "u32be": 4,
@@ -87,4 +87,47 @@ class IQFileSource(_FileSource):
 class RealFileSource(_FileSource):
     """radio/blocks/sources/realfile.lua. RealFileSource(file, format, rate[, repeat_on_eof])."""
     name = "RealFileSource"
+    _complex = False
+
+
+class _FileSink(Block):
+    """radio/blocks/sinks/iqfile.lua / realfile.lua: samples -> raw records on the device, written by the host."""
+    _complex = True
+
+    def instantiate(self, file, format):
+        assert file is not None, "Missing argument #1 (file)"
+        assert format, "Missing argument #2 (format)"
+        if format not in FORMAT_BYTES:
+            raise AssertionError('Unsupported format ("%s")' % format)
+        self.file, self.format = file, format
+        self.record_size = FORMAT_BYTES[format] * (2 if self._complex else 1)
+        self.add_type_signature([Input("in", types.ComplexFloat32 if self._complex else types.Float32)], [])
+
+    def initialize(self):
+        self._fh = open(self.file, "wb") if isinstance(self.file, str) else self.file
+        self._set_stage(_lib.load().lrhip_format_pack_create(self.format.encode(), int(self._complex)), "Creating lrhip format object")
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, dtype=self.get_input_type().dtype)
+        out = np.empty(len(x) * self.record_size, np.uint8)
+        n = _lib.load().lrhip_stage_execute(self._stage, x.ctypes.data_as(C.c_void_p), len(x), out.ctypes.data_as(C.c_void_p), len(x))
+        _lib.check(n, "%s:process" % self.name)
+        self._fh.write(out.tobytes())
+
+    def cleanup(self):
+        if isinstance(self.file, str):
+            self._fh.close()
+        else:
+            self._fh.flush()
+
+
+class IQFileSink(_FileSink):
+    """radio/blocks/sinks/iqfile.lua. IQFileSink(file, format)."""
+    name = "IQFileSink"
+    _complex = True
+
+
+class RealFileSink(_FileSink):
+    """radio/blocks/sinks/realfile.lua. RealFileSink(file, format)."""
+    name = "RealFileSink"
     _complex = False
