@@ -40,16 +40,23 @@ def build_chain(path_or_bytes, fmt, rate, offset):
 
 
 def demodulate(src, chain, chunk_records=1 << 20):
-    chain.set_ring(3, chunk_records)
-
-    def records():
-        while True:
-            raw = src._fh.read(chunk_records * src.record_size)
-            if len(raw) < src.record_size:
-                return
-            yield np.frombuffer(raw, np.uint8, (len(raw) // src.record_size) * src.record_size)
-
-    return np.concatenate(list(chain.stream(records(), depth=3)))
+    """file -> pinned ring slot (readinto, no staging copy) -> device -> audio"""
+    if getattr(chain, "_ring_chunk", 0) != chunk_records:
+        chain.set_ring(3, chunk_records)       # pinned host + device slots, allocated once
+    parts = []
+    while True:
+        view = chain.ring_input()
+        if view is None:                       # ring full: take the oldest chunk out first
+            parts.append(chain.collect())
+            continue
+        got = src._fh.readinto(view)
+        records = (got or 0) // src.record_size
+        if records == 0:
+            break
+        chain.submit(view[:records * src.record_size])
+    while chain.in_flight:
+        parts.append(chain.collect())
+    return np.concatenate(parts)
 
 
 def write_wav(path, audio, rate):

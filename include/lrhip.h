@@ -198,6 +198,10 @@ long lrhip_chain_execute_device(lrhip_chain_t *c, const void *in_dev, unsigned l
  * (pipe.lua:495-533, :252-262) becomes for a device chain. */
 int  lrhip_chain_set_ring(lrhip_chain_t *c, unsigned depth, unsigned long max_chunk);
 long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_in);
+/* Zero-copy input: the pinned host buffer of the slot the NEXT lrhip_chain_submit() will use (max_chunk input samples), or
+ * NULL when the ring is full.  A source can read()/recv() straight into it and pass the same pointer to
+ * lrhip_chain_submit(), which then skips its staging copy. */
+void *lrhip_chain_ring_input(lrhip_chain_t *c);
 long lrhip_chain_collect(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
 /* Chunks submitted and not yet collected. */
 int  lrhip_chain_in_flight(const lrhip_chain_t *c);

@@ -66,6 +66,7 @@ long lrhip_chain_execute_device(lrhip_chain_t *c, const void *in_dev, unsigned l
 int lrhip_chain_last_launches(const lrhip_chain_t *c);
 int lrhip_chain_set_ring(lrhip_chain_t *c, unsigned depth, unsigned long max_chunk);
 long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_in);
+void *lrhip_chain_ring_input(lrhip_chain_t *c);
 long lrhip_chain_collect(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
 int lrhip_chain_in_flight(const lrhip_chain_t *c);
 

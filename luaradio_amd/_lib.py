@@ -65,6 +65,7 @@ SIGNATURES = {
     "lrhip_chain_last_launches": (C.c_int, [_vp]),
     "lrhip_chain_set_ring": (C.c_int, [_vp, C.c_uint, _ul]),
     "lrhip_chain_submit": (C.c_long, [_vp, _vp, _ul]),
+    "lrhip_chain_ring_input": (_vp, [_vp]),
     "lrhip_chain_collect": (C.c_long, [_vp, _vp, _ul]),
     "lrhip_chain_in_flight": (C.c_int, [_vp]),
     "lrhip_malloc": (_vp, [_ul]),

@@ -71,11 +71,23 @@ class Chain:
     # ---- pipelined host path (ring of pinned + device slots; H2D / kernels / D2H of neighbouring chunks overlap)
     def set_ring(self, depth, max_chunk):
         _lib.check(_lib.load().lrhip_chain_set_ring(self._chain, depth, max_chunk), "chain:set_ring")
+        self._ring_chunk = int(max_chunk)
         self._ring_out = np.empty(max_chunk + 64, dtype=self.out_type.dtype)
 
     def submit(self, x):
         x, count = self._count(x)
         return _lib.check(_lib.load().lrhip_chain_submit(self._chain, x.ctypes.data_as(C.c_void_p), count), "chain:submit")
+
+    def ring_input(self):
+        """numpy view (uint8 for raw-record chains, else the input dtype) of the pinned buffer the next submit() will use:
+        fill it in place (file.readinto(view), socket.recv_into(view)) and submit(view[:n]) - no staging copy.  None when the
+        ring is full."""
+        p = _lib.load().lrhip_chain_ring_input(self._chain)
+        if not p:
+            return None
+        dt = np.dtype(np.uint8) if self.in_record else self.in_type.dtype
+        nbytes = self._ring_chunk * (self.in_record or dt.itemsize)
+        return np.frombuffer((C.c_uint8 * nbytes).from_address(p), dtype=dt)
 
     def collect(self):
         n = _lib.load().lrhip_chain_collect(self._chain, self._ring_out.ctypes.data_as(C.c_void_p), len(self._ring_out))

@@ -689,14 +689,14 @@ long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_i
     if (!c) return set_error("null chain");
     if (c->ring.empty()) return set_error("chain has no ring: call lrhip_chain_set_ring first");
     if (n_in > c->ring_chunk) return set_error("chunk of %lu samples exceeds the ring's max_chunk %lu", n_in, c->ring_chunk);
-    if (n_in && !in_host) return set_error("null input buffer");
     if (c->inflight == c->ring.size()) return set_error("ring full: collect a chunk first (%u in flight)", c->inflight);
     lrhip_chain::Slot &sl = *c->ring[c->head];
+    if (n_in && !in_host) return set_error("null input buffer");
     int in_size = c->ops.front().stage->in_size, out_size = c->ops.back().stage->out_size;
     size_t bytes = (size_t)n_in * in_size;
     // the slot was collected (ev_out waited) before it can be reused, so its buffers are free on host and device
     if (bytes) {
-        memcpy(sl.h_in.p, in_host, bytes);
+        if (in_host != sl.h_in.p) memcpy(sl.h_in.p, in_host, bytes);      // lrhip_chain_ring_input(): the caller filled the slot itself
         LR_HIP(hipMemcpyAsync(sl.d_in.p, sl.h_in.p, bytes, hipMemcpyHostToDevice, c->s_in));
     }
     LR_HIP(hipEventRecord(sl.ev_in, c->s_in));
@@ -713,6 +713,14 @@ long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_i
     c->head = (c->head + 1) % c->ring.size();
     c->inflight++;
     return n_out;
+}
+
+void *lrhip_chain_ring_input(lrhip_chain_t *c)
+{
+    if (!c) { set_error("null chain"); return nullptr; }
+    if (c->ring.empty()) { set_error("chain has no ring: call lrhip_chain_set_ring first"); return nullptr; }
+    if (c->inflight == c->ring.size()) { set_error("ring full: collect a chunk first (%u in flight)", c->inflight); return nullptr; }
+    return c->ring[c->head]->h_in.p;
 }
 
 long lrhip_chain_collect(lrhip_chain_t *c, void *out_host, unsigned long out_capacity)
