@@ -181,6 +181,8 @@ long lrhip_stage_execute2_device(lrhip_stage_t *q, const void *in1_dev, const vo
  * adjacent stages where a fused kernel exists (rotator -> FIR -> downsampler, FIR -> downsampler). */
 lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages);
 void lrhip_chain_destroy(lrhip_chain_t *c);
+/* Back to the initial state (zero history, phase, indices) for every stage of the chain, including the fused ones it built. */
+int   lrhip_chain_reset(lrhip_chain_t *c);
 unsigned long lrhip_chain_max_output(const lrhip_chain_t *c, unsigned long n_in);
 long lrhip_chain_execute(lrhip_chain_t *c, const void *in_host, unsigned long n_in,
                          void *out_host, unsigned long out_capacity);

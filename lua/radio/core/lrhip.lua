@@ -60,6 +60,7 @@ long lrhip_stage_execute2_device(lrhip_stage_t *q, const void *in1_dev, const vo
 
 lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages);
 void lrhip_chain_destroy(lrhip_chain_t *c);
+int lrhip_chain_reset(lrhip_chain_t *c);
 unsigned long lrhip_chain_max_output(const lrhip_chain_t *c, unsigned long n_in);
 long lrhip_chain_execute(lrhip_chain_t *c, const void *in_host, unsigned long n_in, void *out_host, unsigned long out_capacity);
 long lrhip_chain_execute_device(lrhip_chain_t *c, const void *in_dev, unsigned long n_in, void *out_dev, unsigned long out_capacity);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "lrhip_stage_execute_device": (C.c_long, [_vp, _vp, _ul, _vp, _ul]),
     "lrhip_chain_create": (_vp, [C.POINTER(_vp), C.c_uint]),
     "lrhip_chain_destroy": (None, [_vp]),
+    "lrhip_chain_reset": (C.c_int, [_vp]),
     "lrhip_chain_max_output": (_ul, [_vp, _ul]),
     "lrhip_chain_execute": (C.c_long, [_vp, _vp, _ul, _vp, _ul]),
     "lrhip_chain_execute_device": (C.c_long, [_vp, _vp, _ul, _vp, _ul]),

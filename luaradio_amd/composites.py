@@ -40,6 +40,9 @@ class Chain:
     def max_output(self, n_in):
         return _lib.load().lrhip_chain_max_output(self._chain, n_in)
 
+    def reset(self):
+        _lib.check(_lib.load().lrhip_chain_reset(self._chain), "chain:reset")
+
     def _count(self, x):
         """input vector -> (contiguous array, number of input samples)"""
         x = np.ascontiguousarray(x)
@@ -157,6 +160,9 @@ class CompositeBlock(Block):
 
     def max_output(self, n_in):
         return self._chain.max_output(n_in)
+
+    def reset(self):
+        self._chain.reset()
 
     @property
     def chain(self):

@@ -597,6 +597,16 @@ void lrhip_chain_destroy(lrhip_chain_t *c)
     delete c;
 }
 
+int lrhip_chain_reset(lrhip_chain_t *c)
+{
+    if (!c) return set_error("null chain");
+    if (c->inflight) return set_error("chain reset: %u chunks still in flight", c->inflight);
+    if (ctx().ready) LR_HIP(hipStreamSynchronize(ctx().stream));
+    for (auto &o : c->ops)
+        if (o.stage->reset()) return -1;
+    return 0;
+}
+
 unsigned long lrhip_chain_max_output(const lrhip_chain_t *c, unsigned long n_in)
 {
     if (!c) return 0;

@@ -1405,3 +1405,19 @@ def test_file_sinks_round_trip_and_truncation(cplx):
     snk.process(x)
     flat = x.view(np.float32) if cplx else x
     assert np.array_equal(np.frombuffer(buf.getvalue(), "<i2"), np.trunc(flat.astype(np.float64) * 32767.5).astype(np.int16))
+
+
+def test_chain_reset_restores_the_initial_state():
+    """lrhip_chain_reset(): every stage of the chain, including the fused copies the chain built itself, starts over"""
+    rng = np.random.default_rng(17)
+    x = rand_c(rng, 200000)
+    for rx in (lr.wbfm_mono_receiver(1102500.0, -250e3), lr.am_envelope_receiver(), lr.InterpolatorBlock(3)):
+        if isinstance(rx, lr.InterpolatorBlock):
+            rx.rate = 1e6
+            rx.differentiate([types.ComplexFloat32])
+            rx.initialize()
+        first = rx.process(x)
+        again = rx.process(x)
+        assert not np.array_equal(first, again)            # state (history, phase, AGC level ...) was carried
+        rx.reset()
+        assert np.array_equal(rx.process(x), first)
