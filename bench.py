@@ -16,8 +16,10 @@ N > 1: one process per GPU (torchrun), each rank filters its own independent str
 
 value = MSamples/s with inputs already in HBM.  roofline.achieved = algorithmic bytes (16 B/sample, SURVEY.md
 section 8d) per launch / average launch duration measured with HIP events on the launch stream inside the timed region.
-cpu_baseline = the CPU restatement (oracle, VOLK-style SIMD dot products) timed on this box's host cores on a
-bounded sample of the same workload (rank 0, N = 1 only).
+cpu_baseline = the reference's two CPU forms of the block (oracle/lr_cpu_baseline.c: FFT overlap-save = its default, and one
+SIMD dot product per output) timed on this box's host cores on a bounded sample of the same workload, 5 trials, mean and
+sigma (rank 0, N = 1 only).  verified / max_err = the output of the last timed step checked against the oracle on slabs.
+At N = 1 the line also carries wbfm_chain (configs[2]), channelizer (configs[4]) and fanout (configs[3], degenerate) legs.
 """
 import argparse
 import json
@@ -47,13 +49,36 @@ def parse():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs of the multi-rank plumbing)")
     ap.add_argument("--same-device", action="store_true", help="dry run: every rank uses cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed FIR output")
+    ap.add_argument("--headline-only", action="store_true", help="fir workload: skip the wbfm_chain / channelizer / fanout legs of the line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (seconds of CPU work)")
     return ap.parse_args()
 
 
+def _trials(fn, samples_per_call, seconds_per_trial, ntrials=5):
+    """the reference suite's protocol (benchmarks/luaradio_benchmark.lua:10-13, :722-738): several trials, mean and sigma of
+    samples/s; a trial repeats fn() until seconds_per_trial has elapsed"""
+    import statistics
+    fn()                                    # warm-up (page faults, OpenMP team start)
+    rates = []
+    for _ in range(ntrials):
+        done, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            done += samples_per_call
+            dt = time.perf_counter() - t0
+            if dt >= seconds_per_trial:
+                break
+        rates.append(done / dt / 1e6)
+    return {"mean": round(statistics.mean(rates), 2), "sigma": round(statistics.pstdev(rates), 2), "trials": ntrials}
+
+
 def cpu_baseline_fir(taps, budget_s):
-    """Oracle FIR (VOLK-style SIMD dot products) on a bounded sample of the same workload: 2^22-sample slabs of
-    the same U(-1,1) IQ, repeated until ~budget_s of wall time; all host cores via OpenMP, and single core."""
+    """The reference's two CPU forms of this block (oracle/lr_cpu_baseline.c), timed on this box's host cores on a bounded
+    sample of the same workload (2^22-sample slabs of the same U(-1,1) IQ): (1) one SIMD dot product per output
+    (firfilter.lua:129-145), (2) FFT overlap-save, the reference's default whenever FFTW is present (firfilter.lua:57,
+    :320-398).  Each with one thread (the reference gives a block one core) and with the fastest OpenMP thread count;
+    5 trials each, mean and sigma (luaradio_benchmark.lua:10-13)."""
     import numpy as np
     from oracle import oracle as O
     try:
@@ -64,28 +89,54 @@ def cpu_baseline_fir(taps, budget_s):
     rng = np.random.default_rng(2)
     x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
     y = np.empty(n, np.complex64)
+    forms = {"dot_product": O.baseline_fir_dot, "overlap_save": O.baseline_fir_overlap_save}
+    per_trial = budget_s / 24.0             # 4 timed legs x 5 trials (+ probes)
+    out = {}
+    for name, fn in forms.items():
+        # pick the thread count that is actually fastest on this box (cgroup quotas make "all logical CPUs" a bad guess)
+        cands = sorted({c for c in (2, 4, 8, 16, 32, 64, 128, avail) if c <= avail})
+        probe = {}
+        for c in cands:
+            fn(taps, x[:1 << 18], c, out=y[:1 << 18])
+            t0 = time.perf_counter()
+            fn(taps, x, c, out=y)
+            probe[c] = n / (time.perf_counter() - t0)
+        cores = max(probe, key=probe.get)
+        out[name] = {"single_core": _trials(lambda: fn(taps, x, 1, out=y), n, per_trial),
+                     "all_cores": dict(_trials(lambda: fn(taps, x, cores, out=y), n, per_trial), threads=cores)}
+    prod = out["overlap_save"]
+    return {"value": prod["all_cores"]["mean"], "sigma": prod["all_cores"]["sigma"], "unit": "MSamples/s", "cores": prod["all_cores"]["threads"],
+            "kind": "port", "single_core_value": prod["single_core"]["mean"], "forms": out, "logical_cpus": avail,
+            "sample": "oracle/lr_cpu_baseline.c on 2^22-sample slabs of the same U(-1,1) ComplexFloat32 IQ, 128 real taps; value = the reference's "
+                      "production form (FFT overlap-save, firfilter.lua:320-398; self-contained Float32 Stockham FFT, not FFTW) on the fastest "
+                      "OpenMP thread count; forms.dot_product = one SIMD dot product per output (firfilter.lua:129-145); single_core = 1 thread "
+                      "(the reference gives a block one core); 5 trials each, mean and sigma (luaradio_benchmark.lua:10-13)"}
 
-    def rate(nt, seconds):
-        f = O.FIR(taps, True)
-        f.process_simd(x[:1 << 16], nt, out=y[:1 << 16])     # warm-up
-        done, t0 = 0, time.perf_counter()
-        while True:
-            f.process_simd(x, nt, out=y)
-            done += n
-            dt = time.perf_counter() - t0
-            if dt >= seconds:
-                return done / dt / 1e6, done
 
-    # pick the thread count that is actually fastest on this box (cgroup quotas make "all logical CPUs" a bad guess)
-    cands = sorted({c for c in (2, 4, 8, 16, 32, 64, 128, avail) if c <= avail})
-    probe = {c: rate(c, 0.25)[0] for c in cands}
-    cores = max(probe, key=probe.get)
-    out = {"single": rate(1, budget_s * 0.35), "all": rate(cores, budget_s * 0.4)}
-    return {"value": round(out["all"][0], 2), "unit": "MSamples/s", "cores": cores, "kind": "port",
-            "single_core_value": round(out["single"][0], 2),
-            "sample": "oracle/lr_oracle.c lro_fir_process_simd (VOLK-style SIMD dot product per output, the form of "
-                      "firfilter.lua:139-142), 128 real taps on %d x 2^22-sample slabs of the same U(-1,1) IQ, OpenMP %d threads (best of %s; %d logical CPUs available); "
-                      "single_core_value = 1 thread (the reference gives a block one core)" % (out["all"][1] >> 22, cores, cands, avail)}
+def verify_fir_output(torch, x, y, n, taps, fir_mode):
+    """Check the output of the LAST timed step against the oracle on slabs of 2^18 samples at spread offsets (first, middle, last,
+    three more).  Every step filters the same vector with the history carried from the previous step, so the samples before
+    x[0] are the tail of x.  fft mode: <= 1e-6 of the f64 oracle; direct mode: bit-exact against the fmaf-chain oracle."""
+    import numpy as np
+    from oracle import oracle as O
+    M, ln = len(taps), 1 << 18
+    offs = sorted({0, n // 2 - ln // 2, n - ln, (n // 7) & ~1, (3 * n // 5) | 1, (n // 2) - 64})
+    worst, exact = 0.0, True
+    for o in offs:
+        o = max(0, min(o, n - ln))
+        if o >= M - 1:
+            xs = x[2 * (o - (M - 1)):2 * (o + ln)].cpu().numpy().view(np.complex64)
+        else:
+            xs = torch.cat([x[2 * (n - (M - 1) + o):], x[:2 * (o + ln)]]).cpu().numpy().view(np.complex64)
+        got = y[2 * o:2 * (o + ln)].cpu().numpy().view(np.complex64)
+        ref = O.FIR(taps, True, mode=O.MODE_F64).process(xs)[M - 1:]
+        worst = max(worst, float(np.max(np.abs(got - ref))))
+        if fir_mode == "direct":
+            exact = exact and bool(np.array_equal(got, O.FIR(taps, True, mode=O.MODE_FMA).process(xs)[M - 1:]))
+    ok = worst <= 1e-6 and (exact or fir_mode != "direct")
+    return {"verified": bool(ok), "max_err": worst, "bit_exact_vs_fmaf_oracle": exact if fir_mode == "direct" else None,
+            "verify": "output of the last timed step vs oracle (f64 mode%s) on %d slabs of 2^18 samples at offsets %s" %
+                      (", and bit-compared with the fmaf-chain mode" if fir_mode == "direct" else "", len(offs), offs)}
 
 
 def wbfm_chain_report(lr, L, torch, dev, with_cpu):
@@ -119,21 +170,129 @@ def wbfm_chain_report(lr, L, torch, dev, with_cpu):
                        "Downsampler(5), 2^26 RF samples per step, device-resident",
            "value": round(n / ms / 1e3, 1), "unit": "MSamples/s (RF samples in)", "ms_per_step": round(ms, 4), "launches": rx.chain.last_launches,
            "algorithmic_GB/s": round(8.16 * n / ms / 1e6, 1)}
+    rep["roofline_frac"] = round(8.16 * n / ms / 1e6 / HBM_PEAK_GBS, 4)
     if with_cpu:
-        from oracle import oracle as O
-        k = 1 << 20
-        rx2 = lr.wbfm_mono_receiver(fs, -250e3)
-        xs = x[:2 * k].cpu().numpy().view(np.complex64)
-        got = rx2.process(xs)
-        ch = O.wbfm_mono_chain(fs, -250e3, mode=O.MODE_LUA, rot_mode=O.MODE_F64)
+        rep.update(verify_wbfm_chain(lr, torch, x, n, fs, -250e3))
+    return rep
+
+
+def verify_wbfm_chain(lr, torch, x, n, fs, offset, nslabs=8, slab_rf=262150, warm_rf=100000):
+    """The device chain's audio for the WHOLE 2^26-sample vector against the oracle chain (composition of the pinned per-block
+    restatements) on `nslabs` slabs spread from the first to the last sample.  A slab away from the start runs the oracle
+    from zero state `warm_rf` RF samples early (a multiple of 25 = both decimations; the de-emphasis pole 0.941^4000 and the
+    FIR transients are long gone) and compares the following slab_rf / 25 audio samples.  Also times the oracle (1 core)."""
+    import numpy as np
+    from oracle import oracle as O
+    rx = lr.wbfm_mono_receiver(fs, offset)
+    cap = rx.max_output(n)
+    y = torch.empty(cap + 16, dtype=torch.float32, device=x.device)
+    got_n = rx.process_device(x.data_ptr(), n, y.data_ptr(), cap)
+    torch.cuda.synchronize()
+    starts = [0] + [int((n - slab_rf) * k / (nslabs - 1)) // 25 * 25 for k in range(1, nslabs)]
+    se, cnt, worst, cpu_s, cpu_n = 0.0, 0, 0.0, 0.0, 0
+    for s0 in starts:
+        lo = max(0, s0 - warm_rf)
+        xs = x[2 * lo:2 * (s0 + slab_rf)].cpu().numpy().view(np.complex64)
+        ch = O.wbfm_mono_chain(fs, offset, mode=O.MODE_LUA, rot_mode=O.MODE_F64)
         t0 = time.perf_counter()
         want = ch.process(xs)
-        dt = time.perf_counter() - t0
-        err = got.astype(np.float64) - want.astype(np.float64)
-        rep["rms_err_vs_oracle"] = float(np.sqrt(np.mean(err ** 2)))
-        rep["cpu_baseline"] = {"value": round(k / dt / 1e6, 2), "unit": "MSamples/s", "cores": 1, "kind": "port",
-                               "sample": "oracle chain (per-block restatement of the reference's Lua/VOLK arithmetic) on the first 2^20 samples"}
+        cpu_s += time.perf_counter() - t0
+        cpu_n += len(xs)
+        want = want[(s0 - lo) // 25:]
+        a0 = s0 // 25
+        got = y[a0:a0 + len(want)].cpu().numpy()
+        m = min(len(got), len(want))
+        err = got[:m].astype(np.float64) - want[:m].astype(np.float64)
+        se += float(np.sum(err ** 2))
+        cnt += m
+        worst = max(worst, float(np.max(np.abs(err))))
+    rms = (se / max(cnt, 1)) ** 0.5
+    return {"rms_err_vs_oracle": rms, "max_err_vs_oracle": worst, "verified": bool(rms <= 1e-5 and got_n > 0),
+            "verify": "device audio of the full 2^26-sample vector vs the oracle chain on %d slabs of %d RF samples from the first to the last "
+                      "sample (%d audio samples compared), bar: RMS <= 1e-5" % (len(starts), slab_rf, cnt),
+            "cpu_baseline": {"value": round(cpu_n / cpu_s / 1e6, 2), "unit": "MSamples/s", "cores": 1, "kind": "port",
+                             "sample": "oracle chain (per-block restatement of the reference's Lua arithmetic) on the %d verification slabs, %d RF samples" % (len(starts), cpu_n)}}
+
+
+def channelizer_report(lr, L, torch, dev, with_cpu):
+    """BASELINE.json configs[4]: 64-channel critically sampled filterbank, 1024-tap prototype, as one dense GEMM on the f32 matrix
+    cores, 2^24 ComplexFloat32 samples per step.  Reports TFLOP/s against the 157.3 TFLOP/s f32 MFMA peak (the matrix-pipe busy
+    fraction from counters is in profiles/), and the error against K oracle chains Translator -> FIR -> Downsampler."""
+    import numpy as np
+    from luaradio_amd import types
+    n, K, M = 1 << 24, 64, 1024
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand(2 * n, dtype=torch.float32, device=dev, generator=g) * 2 - 1
+    ch = lr.PolyphaseChannelizerBlock(K)
+    ch.rate = 1102500.0
+    ch.differentiate([types.ComplexFloat32])
+    ch.initialize()
+    cap = ch.max_output(n)
+    y = torch.empty(2 * cap + 64, dtype=torch.float32, device=dev)
+    ch.process_device(x.data_ptr(), n, y.data_ptr(), cap)
+    steps = 5
+    tm = L.lrhip_timer_create()
+    L.lrhip_timer_start(tm)
+    for _ in range(steps):
+        ch.process_device(x.data_ptr(), n, y.data_ptr(), cap)
+    L.lrhip_timer_stop(tm)
+    torch.cuda.synchronize()
+    ms = L.lrhip_timer_elapsed_ms(tm) / steps
+    L.lrhip_timer_destroy(tm)
+    tf = 8.0 * M * n / ms / 1e9
+    rep = {"workload": "configs[4]: %d-channel polyphase filterbank, %d-tap prototype, dense batched GEMM [T x 2M].[2M x 2K] on v_mfma_f32_16x16x4_f32, "
+                       "2^24 ComplexFloat32 samples per step" % (K, M),
+           "value": round(n / ms / 1e3, 1), "unit": "MSamples/s (input)", "ms_per_step": round(ms, 4), "dtype": "f32",
+           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP32_PEAK_TFLOPS, 4),
+                        "flops_per_sample": 8 * M, "mfma_busy_counter": "profiles/ (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES)"}}
+    if with_cpu:
+        from oracle import oracle as O
+        ns = K * 96
+        ch2 = lr.PolyphaseChannelizerBlock(K)
+        ch2.rate = 1102500.0
+        ch2.differentiate([types.ComplexFloat32])
+        ch2.initialize()
+        xs = x[:2 * ns].cpu().numpy().view(np.complex64)
+        got = ch2.process(xs)
+        taps = ch2.taps
+        se, cnt, worst = 0.0, 0, 0.0
+        for c in range(0, K, 7):
+            want = O.Chain([O.Rotator(-2 * np.pi * c / K, O.MODE_F64), O.FIR(taps, True, O.MODE_F64), O.Downsampler(K, True)]).process(xs)
+            e = np.abs(got[:, c].astype(np.complex128) - want.astype(np.complex128))
+            se += float(np.sum(e ** 2)); cnt += len(e); worst = max(worst, float(e.max()))
+        rep.update({"rms_err_vs_oracle_chains": (se / cnt) ** 0.5, "max_err_vs_oracle_chains": worst, "verified": bool(worst < 2e-6),
+                    "verify": "first %d samples, channels 0,7,..,63 vs oracle chains FrequencyTranslator(-c/K) -> FIRFilter(h) -> Downsampler(K) in f64 "
+                              "(no reference block exists: parity unpinned, SURVEY.md 8c-ii)" % ns})
     return rep
+
+
+def fanout_report(lr, L, torch, dev):
+    """BASELINE.json configs[3] degenerate at N = 1: the per-GPU branch of the fan-out (one Tuner(offset_0, 100e3, 5) on the slab the
+    source GPU would broadcast), 2^26 samples per step; the broadcast itself only exists for N > 1 (bench.py --workload fanout)."""
+    from luaradio_amd import fanout, types
+    n, fs = 1 << 26, 1102500.0
+    g = torch.Generator(device=dev).manual_seed(4)
+    x = torch.rand(2 * n, dtype=torch.float32, device=dev, generator=g) * 2 - 1
+    tun = lr.TunerBlock(fanout.branch_offsets(8)[0], 100e3, 5)
+    tun.rate = fs
+    tun.differentiate([types.ComplexFloat32])
+    tun.initialize()
+    fo = fanout.FanOut(None, 0, 1, 1, {0: fanout.DeviceBranch(tun, n)}, src=0)
+    fo.push(x)
+    steps = 10
+    tm = L.lrhip_timer_create()
+    L.lrhip_timer_start(tm)
+    for _ in range(steps):
+        fo.push(x)
+    L.lrhip_timer_stop(tm)
+    torch.cuda.synchronize()
+    ms = L.lrhip_timer_elapsed_ms(tm) / steps
+    L.lrhip_timer_destroy(tm)
+    return {"workload": "configs[3] at N = 1: one fan-out branch Tuner(-350e3, 100e3, 5) on a 2^26-sample slab (no broadcast with one GPU)",
+            "value": round(n / ms / 1e3, 1), "unit": "MSamples/s (branch input)", "ms_per_step": round(ms, 4),
+            "algorithmic_GB/s": round(9.6 * n / ms / 1e6, 1), "roofline_frac": round(9.6 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
+            "xgmi_link_bound_MSps": 19125.0,
+            "note": "for N > 1 every receiving GPU is bounded by one xGMI link: 153 GB/s / 8 B = 19.1 GS/s of ComplexFloat32, far below this branch rate"}
 
 
 def main():
@@ -318,16 +477,22 @@ def main():
                          "fp32_frac": round(flops / launch_s / 1e12 / FP32_PEAK_TFLOPS, 4)},
         }
         if yard_gbs:
-            res["roofline"]["streaming_yardstick"] = {"kernel": "multiply_constant_kernel<1> (8 B in + 8 B out per sample, same buffers)",
+            res["roofline"]["streaming_yardstick"] = {"kernel": "multiply_constant_vec4_kernel<0> (MultiplyConstantBlock: 16 B per lane, one item per thread; 8 B in + 8 B out per sample, same buffers)",
                                                       "GB/s": round(yard_gbs, 1), "frac_of_yardstick": round(achieved / yard_gbs, 4)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "fir":
             res["cpu_baseline"] = cpu_baseline_fir(taps, args.cpu_seconds)
         elif world == 1:
             res["cpu_baseline"] = None
-        if world == 1 and args.workload == "fir" and log2n >= 26:
+        if world == 1 and args.workload == "fir" and not args.no_verify:
+            res.update(verify_fir_output(torch, x, y, n, taps, fir_mode))
+        if world == 1 and args.workload == "fir" and log2n >= 26 and not args.headline_only:
             del x, y
             torch.cuda.empty_cache()
             res["wbfm_chain"] = wbfm_chain_report(lr, L, torch, dev, not args.no_cpu_baseline)
+            torch.cuda.empty_cache()
+            res["channelizer"] = channelizer_report(lr, L, torch, dev, not args.no_cpu_baseline)
+            torch.cuda.empty_cache()
+            res["fanout"] = fanout_report(lr, L, torch, dev)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

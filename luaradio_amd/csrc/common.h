@@ -129,11 +129,17 @@ struct PinnedBuf {
     ~PinnedBuf() { release(); }
 };
 
+// Streaming kernels are launched ONE-SHOT: a workgroup per 256 work items, every thread one item (the grid-stride loops in
+// the kernels then run once and only guard grids clipped at 2^31-1).  Measured on MI355X (tools/mb_stream.hip, 2 GiB in +
+// 2 GiB out): one item per thread 6.2-6.4 TB/s; a persistent grid of 2048-16384 workgroups striding through the same
+// buffers 4.4-5.4 TB/s - the dispatcher hands out workgroups in address order, so the set of DRAM pages in flight stays
+// compact, while persistent waves drift apart.
 inline unsigned grid_for(unsigned long work_items, unsigned per_block, unsigned max_blocks = 0)
 {
     unsigned long g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
     if (max_blocks && g > max_blocks) g = max_blocks;
+    if (g > 0x7fffffffUL) g = 0x7fffffffUL;
     return (unsigned)g;
 }
 

@@ -173,6 +173,27 @@ __global__ __launch_bounds__(256) void fmdiscrim_kernel(const float2 *__restrict
     }
 }
 
+// 16 B in / 8 B out per lane, one item per thread (one-shot grid, common.h grid_for): samples 2i and 2i+1; the sample before
+// them is one more 8-B load from the lines the neighbouring lane fetches anyway.  Needs 16-B aligned x and 8-B aligned y.
+__global__ __launch_bounds__(256) void fmdiscrim_vec2_kernel(const float2 *__restrict__ x, float *__restrict__ y,
+                                                             unsigned long n, double inv_gain,
+                                                             const float2 *__restrict__ prev_in, float2 *__restrict__ prev_out)
+{
+    const unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x, n2 = n / 2;
+    if (i < n2) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        const float2 a = make_float2(v.x, v.y), b = make_float2(v.z, v.w);
+        const float2 p = i ? x[2 * i - 1] : *prev_in;
+        reinterpret_cast<float2 *>(y)[i] = make_float2(discriminate(a, p, inv_gain), discriminate(b, a, inv_gain));
+        if (2 * i + 2 == n) *prev_out = b;
+    }
+    if ((n & 1) && i == n2) {        // odd tail sample
+        const float2 a = x[n - 1], p = n > 1 ? x[n - 2] : *prev_in;
+        y[n - 1] = discriminate(a, p, inv_gain);
+        *prev_out = a;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // DownsamplerBlock  (reference: radio/blocks/signal/downsampler.lua:45-56):  y[m] = x[index + m*factor].
 // Bit-exact copies.  Traffic: E/factor out + between E/factor and E in (sector granularity).
@@ -262,6 +283,26 @@ __global__ __launch_bounds__(256) void binary_complex_kernel(const float2 *__res
     }
 }
 
+// 16 B per lane (two ComplexFloat32 or four Float32 per thread); `nf` = number of floats, pointers 16-B aligned.
+// CPLX_MUL: 0 = element-wise on floats (add / subtract of either type, real multiply), 1 = complex multiply, 2 = multiply by conjugate.
+template <int OP, int CPLX_MUL>
+__global__ __launch_bounds__(256) void binary_vec4_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ y, unsigned long nf)
+{
+    const unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x, n4 = nf / 4;
+    if (i < n4) {
+        const float4 p = reinterpret_cast<const float4 *>(a)[i], q = reinterpret_cast<const float4 *>(b)[i];
+        float4 o;
+        if (CPLX_MUL) {
+            const double s = CPLX_MUL == 2 ? -1.0 : 1.0;
+            const double ar0 = p.x, ai0 = p.y, br0 = q.x, bi0 = s * (double)q.y, ar1 = p.z, ai1 = p.w, br1 = q.z, bi1 = s * (double)q.w;
+            o = make_float4((float)(ar0 * br0 - ai0 * bi0), (float)(ar0 * bi0 + ai0 * br0), (float)(ar1 * br1 - ai1 * bi1), (float)(ar1 * bi1 + ai1 * br1));
+        } else if (OP == BIN_ADD) o = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+        else if (OP == BIN_SUBTRACT) o = make_float4(p.x - q.x, p.y - q.y, p.z - q.z, p.w - q.w);
+        else o = make_float4(p.x * q.x, p.y * q.y, p.z * q.z, p.w * q.w);
+        reinterpret_cast<float4 *>(y)[i] = o;
+    }
+}
+
 template <int OP>
 __global__ __launch_bounds__(256) void binary_real_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                           float *__restrict__ y, unsigned long n)
@@ -297,6 +338,24 @@ __global__ __launch_bounds__(256) void multiply_constant_kernel(const float *__r
             }
             reinterpret_cast<float2 *>(y)[i] = o;
         }
+    }
+}
+
+// 16 B per lane, one item per thread.  MODE 0 / 1 are the same operation on the float stream (x * cr per scalar); MODE 2 =
+// two ComplexFloat32 times the complex constant.  `nf` = number of floats (the caller handles nf % 4 with the scalar kernel).
+template <int MODE>
+__global__ __launch_bounds__(256) void multiply_constant_vec4_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned long nf, float cr, float ci)
+{
+    const unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nf / 4) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        float4 o;
+        if (MODE != 2) o = make_float4(v.x * cr, v.y * cr, v.z * cr, v.w * cr);
+        else {
+            const double c = cr, d = ci, ar = v.x, ai = v.y, br = v.z, bi = v.w;
+            o = make_float4((float)(ar * c - ai * d), (float)(ar * d + ai * c), (float)(br * c - bi * d), (float)(br * d + bi * c));
+        }
+        reinterpret_cast<float4 *>(y)[i] = o;
     }
 }
 

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
                                                           const float2 *__restrict__ tables, float *__restrict__ y,
                                                           int M, long n, long n_out, long nblocks,
                                                           double inv_gain, const float2 *__restrict__ disc_prev, float *__restrict__ hist_out,
-                                                          int Mh, long delay, int accumulate)
+                                                          int Mh, long delay, int accumulate, int rounds)
 {
     // Long filters are PARTITIONED: this launch applies taps [delay, delay + M) of an Mh-tap filter - the M-tap overlap-save
     // on the stream delayed by `delay` samples (history = Mh - 1 samples) - and adds to y when accumulate != 0.
@@ -202,7 +202,13 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
     const int sub = lane & 3, k1s = lane >> 2;       // stages 2 and 3: sub = t2 or q, k1s = k1
     constexpr int BPW = S == 2 ? 1 : 2;               // stream blocks per FFT
 
-    const long fstep = (long)gridDim.x * FFT_WPB;
+    // Block order.  rounds == 0: persistent, workgroup g walks batches g, g + gridDim.x, ...  rounds > 0: one-shot, workgroup g
+    // owns the `rounds` consecutive batches starting at g * rounds (a batch = FFT_WPB transforms, one per wave) and the
+    // dispatcher hands workgroups out in address order - the shape that reaches 6.3 TB/s in tools/mb_stream.hip where the
+    // persistent stride reaches 4.4-5.4.
+    const long fstep = rounds > 0 ? FFT_WPB : (long)gridDim.x * FFT_WPB;
+    const long ffirst = (rounds > 0 ? (long)blockIdx.x * rounds : (long)blockIdx.x) * FFT_WPB + wave;
+    const long fend = rounds > 0 ? ((long)blockIdx.x + 1) * rounds * FFT_WPB : (nblocks + 1);
 #if LRHIP_FFT_PREFETCH
     cf pre[16];
     bool have = false;
@@ -215,9 +221,9 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             for (int i = 0; i < 16; i++) pre[i] = src[64 * i];
         }
     };
-    prefetch((long)blockIdx.x * FFT_WPB + wave);
+    prefetch(ffirst);
 #endif
-    for (long fb = (long)blockIdx.x * FFT_WPB + wave; fb * BPW < nblocks; fb += fstep) {
+    for (long fb = ffirst; fb * BPW < nblocks && fb < fend; fb += fstep) {
         cf v[16];
         // ---- load: window position 64*i + lane  (stream = [M-1 history | chunk])
         // (measured and dropped: 16-B accesses through an LDS transpose - no gain)

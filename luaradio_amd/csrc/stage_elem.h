@@ -21,7 +21,7 @@ struct RotatorStage : lrhip_stage {
     {
         if (n > cap) return set_error("rotator: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
-        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+        unsigned grid = grid_for(n, 256);
         if ((((uintptr_t)in_dev | (uintptr_t)out_dev) & 15) == 0)
             hipLaunchKernelGGL(rotator_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n, step, count);
         else
@@ -45,7 +45,7 @@ struct DownsamplerStage : lrhip_stage {
         unsigned long n_out = n > index ? (n - index + factor - 1) / factor : 0;   // downsampler.lua:46
         if (n_out > cap) return set_error("downsampler: output capacity %lu < %lu", cap, n_out);
         if (n_out) {
-            unsigned grid = grid_for(n_out, 256, ctx().num_cus * 16);
+            unsigned grid = grid_for(n_out, 256);
             if (in_size == 8)
                 hipLaunchKernelGGL(downsample_kernel<float2>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n_out, index, factor);
             else
@@ -70,10 +70,13 @@ struct FmDiscrimStage : lrhip_stage {
     {
         if (n > cap) return set_error("fmdiscrim: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
-        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
         float2 *p = (float2 *)prev.p;
-        hipLaunchKernelGGL(fmdiscrim_kernel, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float *)out_dev, n, 1.0 / gain,
-                           (const float2 *)(p + cur), p + (cur ^ 1));
+        if ((((uintptr_t)in_dev & 15) | ((uintptr_t)out_dev & 7)) == 0)
+            hipLaunchKernelGGL(fmdiscrim_vec2_kernel, dim3(grid_for(n / 2 + 1, 256)), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float *)out_dev, n, 1.0 / gain,
+                               (const float2 *)(p + cur), p + (cur ^ 1));
+        else
+            hipLaunchKernelGGL(fmdiscrim_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float *)out_dev, n, 1.0 / gain,
+                               (const float2 *)(p + cur), p + (cur ^ 1));
         LR_LAUNCH_CHECK();
         cur ^= 1;
         return (long)n;

@@ -38,7 +38,7 @@ long FormatStage::run(const void *in_dev, unsigned long n, void *out_dev, unsign
     if (!n) return 0;
     const FormatDesc &f = kFormats[fmt];
     unsigned long ns = n * scalars;
-    unsigned grid = grid_for(ns, 256, ctx().num_cus * 16);
+    unsigned grid = grid_for(ns, 256);
     float *out = (float *)out_dev;
     if (pack) {
 #define LR_PACK(RAW, VAL)                                                                                                  \
@@ -94,12 +94,36 @@ struct BinaryStage : lrhip_stage {
     {
         if (n > cap) return set_error("binary: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
-        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
         if (op == BIN_F2C) {
-            hipLaunchKernelGGL(float_to_complex_kernel, dim3(grid), dim3(256), 0, ctx().stream, (const float *)a, (const float *)b, (float2 *)y, n);
+            hipLaunchKernelGGL(float_to_complex_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx().stream, (const float *)a, (const float *)b, (float2 *)y, n);
             LR_LAUNCH_CHECK();
             return (long)n;
         }
+        // 16 B per lane when the three vectors allow it (the odd tail, at most 3 floats, goes through the scalar kernels below)
+        const unsigned long nf = n * (in_size / 4), nf4 = nf & ~3ul;
+        if (nf4 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15) == 0) {
+            unsigned g4 = grid_for(nf4 / 4, 256);
+#define LR_BIN4(OP, CM) hipLaunchKernelGGL((binary_vec4_kernel<OP, CM>), dim3(g4), dim3(256), 0, ctx().stream, (const float *)a, (const float *)b, (float *)y, nf4)
+            if (op == BIN_ADD) LR_BIN4(BIN_ADD, 0);
+            else if (op == BIN_SUBTRACT) LR_BIN4(BIN_SUBTRACT, 0);
+            else if (in_size == 4) LR_BIN4(BIN_MULTIPLY, 0);
+            else if (op == BIN_MULTIPLY) LR_BIN4(BIN_MULTIPLY, 1);
+            else LR_BIN4(BIN_MULTIPLY_CONJ, 2);
+#undef LR_BIN4
+            LR_LAUNCH_CHECK();
+            const unsigned long done = nf4 / (in_size / 4);        // samples covered
+            if (done == n) return (long)n;
+            a = (const char *)a + done * in_size; b = (const char *)b + done * in_size; y = (char *)y + done * in_size;
+            const unsigned long rest = n - done;
+            long r = run2_scalar(a, b, rest, y);
+            return r < 0 ? r : (long)n;
+        }
+        long r = run2_scalar(a, b, n, y);
+        return r < 0 ? r : (long)n;
+    }
+    long run2_scalar(const void *a, const void *b, unsigned long n, void *y)
+    {
+        unsigned grid = grid_for(n, 256);
 #define LR_BIN(K, OP, T) hipLaunchKernelGGL((K<OP>), dim3(grid), dim3(256), 0, ctx().stream, (const T *)a, (const T *)b, (T *)y, n)
         if (in_size == 8) {
             switch (op) {
@@ -133,9 +157,24 @@ struct MulConstStage : lrhip_stage {
     {
         if (n > cap) return set_error("multiplyconstant: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
-        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
         const float *x = (const float *)in_dev;
         float *y = (float *)out_dev;
+        const unsigned long nf = n * (in_size / 4), nf4 = nf & ~3ul;
+        if (nf4 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+            unsigned g4 = grid_for(nf4 / 4, 256);
+            if (mode != 2) hipLaunchKernelGGL(multiply_constant_vec4_kernel<0>, dim3(g4), dim3(256), 0, ctx().stream, x, y, nf4, cr, ci);
+            else hipLaunchKernelGGL(multiply_constant_vec4_kernel<2>, dim3(g4), dim3(256), 0, ctx().stream, x, y, nf4, cr, ci);
+            LR_LAUNCH_CHECK();
+            const unsigned long done = nf4 / (in_size / 4);
+            if (done == n) return (long)n;
+            long r = run_scalar(x + nf4, y + nf4, n - done);      // the odd tail (< 4 floats)
+            return r < 0 ? r : (long)n;
+        }
+        return run_scalar(x, y, n);
+    }
+    long run_scalar(const float *x, float *y, unsigned long n)
+    {
+        unsigned grid = grid_for(n, 256);
         if (mode == 0) hipLaunchKernelGGL(multiply_constant_kernel<0>, dim3(grid), dim3(256), 0, ctx().stream, x, y, n, cr, ci);
         else if (mode == 1) hipLaunchKernelGGL(multiply_constant_kernel<1>, dim3(grid), dim3(256), 0, ctx().stream, x, y, n, cr, ci);
         else hipLaunchKernelGGL(multiply_constant_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, x, y, n, cr, ci);
@@ -154,7 +193,7 @@ struct UpsamplerStage : lrhip_stage {
         unsigned long n_out = n * factor;                 // upsampler.lua:46
         if (n_out > cap) return set_error("upsampler: output capacity %lu < %lu", cap, n_out);
         if (!n_out) return 0;
-        unsigned grid = grid_for(n_out, 256, ctx().num_cus * 16);
+        unsigned grid = grid_for(n_out, 256);
         if (in_size == 8)
             hipLaunchKernelGGL(upsample_kernel<float2>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n_out, factor);
         else

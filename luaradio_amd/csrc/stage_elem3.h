@@ -14,7 +14,7 @@ struct UnaryStage : lrhip_stage {
     {
         if (n > cap) return set_error("unary: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
-        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+        unsigned grid = grid_for(n, 256);
         const float *x = (const float *)in_dev;
         float *y = (float *)out_dev;
 #define LR_UN(OP) case OP: hipLaunchKernelGGL(unary_kernel<OP>, dim3(grid), dim3(256), 0, ctx().stream, x, y, n, cr, ci); break
@@ -43,7 +43,7 @@ struct DelayStage : lrhip_stage {
     {
         if (n > cap) return set_error("delay: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
-        unsigned grid = grid_for(n + D, 256, ctx().num_cus * 16);
+        unsigned grid = grid_for(n + D, 256);
         if (in_size == 8)
             hipLaunchKernelGGL(delay_kernel<float2>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)state[cur].p, (const float2 *)in_dev,
                                (float2 *)out_dev, (float2 *)state[cur ^ 1].p, n, D);
@@ -70,7 +70,7 @@ struct HilbertStage : lrhip_stage {
         if (got < 0) return got;
         // core() has swapped the ping-pong history: the history that was current for this chunk is the other one
         const float *old_hist = (const float *)fir->hist[fir->cur ^ 1].p;
-        unsigned grid = grid_for(n, 256, ctx().num_cus * 16);
+        unsigned grid = grid_for(n, 256);
         hipLaunchKernelGGL(hilbert_combine_kernel, dim3(grid), dim3(256), 0, ctx().stream, old_hist, (const float *)in_dev, (const float *)tmp.p,
                            (float2 *)out_dev, n, fir->M);
         LR_LAUNCH_CHECK();

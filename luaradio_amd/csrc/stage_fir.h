@@ -204,11 +204,16 @@ struct FirStage : lrhip_stage {
                 if (!fft_blocks_per_cu && prepare_kernel(kern, lds_bytes, &fft_blocks_per_cu, 64 * FFT_WPB)) return -1;
                 long slots = (long)ctx().num_cus * fft_blocks_per_cu;
                 long want = (nffts + FFT_WPB - 1) / FFT_WPB;
-                unsigned grid = (unsigned)(want < slots ? want : slots);      // persistent; a dynamic one-batch-per-workgroup grid measured 3-7 % slower even for 2.4 blocks per wave
+                const int rounds_env = getenv("LRHIP_FFT_ROUNDS") ? atoi(getenv("LRHIP_FFT_ROUNDS")) : -1;      // A/B knob
+                // one-shot order with 8 batches per workgroup once the launch exceeds the resident slots: 316 GS/s against 263-314
+                // (run-to-run spread) for the persistent stride on 2^28 samples, same box, alternating
+                int rounds = rounds_env >= 0 ? rounds_env : 8;
+                if (want <= slots) rounds = 0;
+                unsigned grid = rounds > 0 ? (unsigned)((want + rounds - 1) / rounds) : (unsigned)(want < slots ? want : slots);
                 const float2 *dp = pre_disc ? (const float2 *)disc_prev.p + disc_cur : nullptr;
                 float *ho = (!pre_disc && M > 1 && part == 0) ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FFT_WPB), lds_bytes, ctx().stream, h, x, tables, y, Mp, n, n_out, nblocks,
-                                   1.0 / disc_gain, dp, ho, M, (long)part * FFT_PART, part > 0 ? 1 : 0);
+                                   1.0 / disc_gain, dp, ho, M, (long)part * FFT_PART, part > 0 ? 1 : 0, rounds);
                 if (ho) hist_in_kernel = true;
                 return 0;
             };

@@ -133,7 +133,7 @@ struct WelchStage : lrhip_stage {
             if (P == 0 && hop == N) frames_in = x;             // contiguous frames: no gather
             else {
                 if (frames.reserve(nf * N * sizeof(T))) return -1;
-                hipLaunchKernelGGL(welch_gather_kernel<T>, dim3(grid_for(nf * N, 256, ctx().num_cus * 16)), dim3(256), 0, ctx().stream, pend, P, x,
+                hipLaunchKernelGGL(welch_gather_kernel<T>, dim3(grid_for(nf * N, 256)), dim3(256), 0, ctx().stream, pend, P, x,
                                    (T *)frames.p, nf, N, hop);
                 LR_LAUNCH_CHECK();
                 frames_in = frames.p;

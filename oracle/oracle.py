@@ -16,8 +16,8 @@ MODE_LUA, MODE_FMA, MODE_F64, MODE_SIMD = 0, 1, 2, 3
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "lr_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("lr_oracle.c", "lr_cpu_baseline.c", "Makefile")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -43,6 +43,10 @@ def lib():
         L.lro_fir_destroy.argtypes = [vp]
         L.lro_fir_process_simd.restype = C.c_long
         L.lro_fir_process_simd.argtypes = [vp, fp, C.c_long, fp, C.c_int]
+        L.lrb_fir_dot.restype = C.c_long
+        L.lrb_fir_dot.argtypes = [fp, C.c_int, C.c_int, fp, C.c_long, fp, C.c_int]
+        L.lrb_fir_overlap_save.restype = C.c_long
+        L.lrb_fir_overlap_save.argtypes = [fp, C.c_int, C.c_int, C.c_int, fp, C.c_long, fp, C.c_int]
         L.lro_firfft_create.restype = vp
         L.lro_firfft_create.argtypes = [fp, C.c_int, C.c_int, C.c_int]
         L.lro_firfft_process.restype = C.c_long
@@ -180,6 +184,28 @@ def _fir_process_simd(self, x, nthreads=1, out=None):
 
 
 FIR.process_simd = _fir_process_simd
+
+
+def baseline_fir_dot(taps, x, nthreads=1, out=None):
+    """Timed CPU form (1): one SIMD dot product per output (firfilter.lua:129-145), zero history.  lr_cpu_baseline.c"""
+    t, tc = _as_f32(np.asarray(taps))
+    assert not tc
+    xf, xc = _as_f32(x)
+    y = out if out is not None else _out(len(x), xc)
+    n = lib().lrb_fir_dot(_fp(t), t.size, int(xc), _fp(xf), len(x), _fp(y.view(np.float32)), int(nthreads))
+    assert n == len(x)
+    return y
+
+
+def baseline_fir_overlap_save(taps, x, nthreads=1, out=None):
+    """Timed CPU form (2): FFT overlap-save, the reference's default (firfilter.lua:57, :320-398), Float32 Stockham FFT,
+    zero history, every output emitted.  lr_cpu_baseline.c"""
+    t, tc = _as_f32(np.asarray(taps))
+    xf, xc = _as_f32(x)
+    y = out if out is not None else _out(len(x), xc)
+    n = lib().lrb_fir_overlap_save(_fp(t), t.size // (2 if tc else 1), int(tc), int(xc), _fp(xf), len(x), _fp(y.view(np.float32)), int(nthreads))
+    assert n == len(x)
+    return y
 
 
 class FIRFFT(_Stage):
