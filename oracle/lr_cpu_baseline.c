@@ -30,9 +30,14 @@
 long lrb_fir_dot(const float *taps, int M, int input_complex, const float *x, long n, float *y, int nthreads)
 {
     const int es = input_complex ? 2 : 1;
-    float *state = (float *)calloc((size_t)(M - 1 + n) * es + 16, sizeof(float));
+    /* the state vector [M-1 zeros | chunk] of firfilter.lua:131-137, kept between calls (the Lua block keeps its Vector too) */
+    static float *state = NULL;
+    static size_t state_cap = 0;
+    const size_t need = (size_t)(M - 1 + n) * es + 16;
+    if (need > state_cap) { free(state); state = (float *)malloc(need * sizeof(float)); state_cap = state ? need : 0; }
     float *hd = (float *)malloc(sizeof(float) * es * M);
-    if (!state || !hd) { free(state); free(hd); return -1; }
+    if (!state || !hd) { free(hd); return -1; }
+    memset(state, 0, sizeof(float) * es * (M - 1));
     memcpy(state + (size_t)es * (M - 1), x, sizeof(float) * es * n);
     for (int j = 0; j < M; j++) for (int c = 0; c < es; c++) hd[j * es + c] = taps[M - 1 - j];
     const int len = M * es;
@@ -48,7 +53,7 @@ long lrb_fir_dot(const float *taps, int M, int input_complex, const float *x, lo
         for (int l = 0; l < 16; l += 2) { e += acc[l]; o += acc[l + 1]; }
         if (es == 2) { y[2 * i] = e; y[2 * i + 1] = o; } else y[i] = e + o;
     }
-    free(state); free(hd);
+    free(hd);
     return n;
 }
 

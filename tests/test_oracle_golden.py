@@ -271,3 +271,26 @@ def test_file_source_formats():
             got = O.format_convert(fmt, raw, cplx)
             want = vec["outputs"][0]
             assert len(got) == len(want) and G.max_abs_err(got, want) < doc["epsilon"], vec["desc"]
+
+
+def test_timed_cpu_baseline_forms_match_golden_and_f64():
+    """bench.py's cpu_baseline legs (oracle/lr_cpu_baseline.c: SIMD dot product per output, and the reference's default FFT
+    overlap-save form on a Float32 Stockham FFT) are held to the 128-tap golden vectors and to the f64 restatement"""
+    doc = G.load("lowpassfilter_spec")
+    for vec in doc["vectors"][:3] + doc["vectors"][6:9]:        # the default-nyquist, default-window vectors (as the test above)
+        x, want = vec["inputs"][0], vec["outputs"][0]
+        taps = O.firwin_lowpass(vec["args"][0], vec["args"][1] / (RATE / 2)).astype(np.float32)
+        for fn in (O.baseline_fir_dot, O.baseline_fir_overlap_save):
+            assert G.max_abs_err(fn(taps, x), want) < doc["epsilon"], vec["desc"]
+    rng = np.random.default_rng(11)
+    for M, cplx in ((128, True), (128, False), (33, True), (200, False), (513, True)):
+        n = 30000
+        x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64) if cplx else rng.uniform(-1, 1, n).astype(np.float32)
+        taps = O.firwin_lowpass(M, 0.21).astype(np.float32)
+        ref = O.FIR(taps, cplx, O.MODE_F64).process(x)
+        assert G.max_abs_err(O.baseline_fir_dot(taps, x), ref) < 1e-6
+        assert G.max_abs_err(O.baseline_fir_overlap_save(taps, x), ref) < 1e-6
+        assert np.array_equal(O.baseline_fir_overlap_save(taps, x, 3), O.baseline_fir_overlap_save(taps, x))
+    ct = (O.firwin_lowpass(64, 0.3) * (1 + 0.5j)).astype(np.complex64)
+    x = (rng.uniform(-1, 1, 9000) + 1j * rng.uniform(-1, 1, 9000)).astype(np.complex64)
+    assert G.max_abs_err(O.baseline_fir_overlap_save(ct, x), O.FIR(ct, True, O.MODE_F64).process(x)) < 1e-6
