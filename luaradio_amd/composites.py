@@ -169,6 +169,14 @@ class CompositeBlock(Block):
         return self._chain
 
 
+def _fft_option(options):
+    """options["use_fft"] of the decimating composites: False / None = direct form (bit-identical to the fmaf chain), "fast" /
+    "auto" = overlap-save arithmetic (the reference's own default FIR form, firfilter.lua:57); fused with the downsampler it
+    becomes the polyphase FFT kernel (kernels_firdecfft.h)."""
+    v = options.get("use_fft")
+    return 2 if v in ("fast", True) else 3 if v == "auto" else 0
+
+
 class DecimatorBlock(CompositeBlock):
     """radio/composites/decimator.lua:28-42. DecimatorBlock(decimation[, {num_taps=, window=}])."""
     name = "DecimatorBlock"
@@ -178,6 +186,7 @@ class DecimatorBlock(CompositeBlock):
         assert decimation, "Missing argument #1 (decimation)"
         options = options or {}
         filt = B.LowpassFilterBlock(options.get("num_taps") or 128, 1 / decimation, 1.0, options.get("window"))
+        filt.use_fft = _fft_option(options)
         downsampler = B.DownsamplerBlock(decimation)
         self.connect(filt, downsampler)
         self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
@@ -227,6 +236,7 @@ class TunerBlock(CompositeBlock):
         options = options or {}
         translator = B.FrequencyTranslatorBlock(offset)
         filt = B.LowpassFilterBlock(options.get("num_taps") or 128, bandwidth / 2, None, options.get("window"))
+        filt.use_fft = _fft_option(options)
         downsampler = B.DownsamplerBlock(decimation)
         self.connect(translator, filt, downsampler)
         self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])
@@ -301,13 +311,13 @@ class SSBModulator(CompositeBlock):
         self.add_type_signature([Input("in", types.Float32)], [Output("out", types.ComplexFloat32)])
 
 
-def wbfm_mono_receiver(rate=1102500.0, tune_offset=-250e3):
+def wbfm_mono_receiver(rate=1102500.0, tune_offset=-250e3, use_fft="fast"):
     """The compute blocks of examples/rtlsdr_wbfm_mono.lua:12-17,28 as one composite:
     Tuner(-250e3, 200e3, 5) -> FrequencyDiscriminator(1.25) -> Lowpass(128, 15e3) -> FMDeemphasis(75e-6) -> Downsampler(5)."""
     top = CompositeBlock()
     af_filter = B.LowpassFilterBlock(128, 15e3)
     af_filter.use_fft = 2        # overlap-save arithmetic, one output per input (the reference's default FIR form is FFT too)
-    top.connect(TunerBlock(tune_offset, 200e3, 5), B.FrequencyDiscriminatorBlock(1.25), af_filter,
+    top.connect(TunerBlock(tune_offset, 200e3, 5, {"use_fft": use_fft}), B.FrequencyDiscriminatorBlock(1.25), af_filter,
                 B.FMDeemphasisFilterBlock(75e-6), B.DownsamplerBlock(5))
     top.rate = rate
     top.differentiate([types.ComplexFloat32])

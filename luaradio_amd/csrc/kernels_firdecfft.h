@@ -1,0 +1,310 @@
+// kernels_firdecfft.h - decimating FIR (Decimator / Tuner: [FrequencyTranslator ->] FIRFilter -> Downsampler, optionally
+// -> FrequencyDiscriminator) by POLYPHASE FFT overlap-save, one fused kernel.
+//
+// Reference semantics (radio/composites/tuner.lua:32-48, decimator.lua:28-42, radio/blocks/signal/firfilter.lua:230-305,
+// downsampler.lua:45-56, frequencytranslator.lua:93-110): with the chunk x[0..n), the carried downsampler index `first`
+// and c0 = absolute index of x[0], output k sits at input index n_k = first + k*D and is
+//     y[k] = sum_i h[i] * x[n_k - i] * e^{j w (c0 + n_k - i)}  =  e^{j w (c0 + n_k)} * z[k],
+//     z[k] = sum_i g[i] x[n_k - i],    g[i] = h[i] e^{-j w i}            (w = 0: plain Decimator, g = h)
+// The reference computes every full-rate output and throws D-1 of D away; the direct-form kernel here (kernels_fir.h)
+// computes only the kept ones but pays 15*D + M Toeplitz columns for M useful ones on the f32 matrix pipe, plus a rotator
+// per INPUT sample on the VALU that shares that pipe.  This kernel uses the reference's own production algorithm (FFT
+// overlap-save, firfilter.lua:320-398) in its polyphase form instead:
+//     i = D q + r:   z[k] = sum_r (g_r * u_r)[k],   u_r[m] = x[first + D m - r],   g_r[q] = g[D q + r]
+// D branch convolutions at the LOW rate, each done as a 256-point FFT overlap-save (branch filters have ceil(M/D) <= 32
+// taps -> overlap V = 32, 224 new outputs per block) and summed in the frequency domain:
+//     Z = sum_r FFT256(u_r) . G_r ;   z = IFFT256(Z)            -> D forward FFTs + 1 inverse per 224 outputs
+// about 62 flop per input sample at D = 5 against 163 issued by the Toeplitz form, the rotation moves from every input sample
+// to the OUTPUT (1/D of the rate) - and disappears altogether behind a discriminator: arg(y[k] conj(y[k-1])) =
+// arg(z[k] conj(z[k-1]) e^{j w D}), one constant.  Not bit-identical to the fmaf-chain direct form: Float32 FFT arithmetic,
+// <= 1e-6 of the f64 oracle for |x| <= 1 (same bar as the overlap-save kernel of kernels_firfft.h; tuner_spec holds 1e-5).
+//
+// Geometry.  A 256-point FFT = 16 lanes x 16 registers (dft16 in registers, twiddle, 16x16 transpose through LDS, dft16),
+// so a wave runs FOUR transforms at a time, one per row of 16 lanes.  D = 4A + C phases:
+//   * per block, A batches: rows 0..3 transform phases 4t..4t+3 of THIS block (staged once, coalesced, in LDS); the products
+//     with G are summed over t in registers and then across the four rows with v_permlane32_swap / v_permlane16_swap
+//     (gfx950), which leaves 8 floats per lane;
+//   * the C left-over phases of four consecutive blocks (a "quad") wait in registers and are transformed together, row b =
+//     block b, after a 4x4 register/row transpose with the same swap instructions (which also brings every block's partial
+//     sum to its row);
+//   * one inverse batch per quad, row b = block b; outputs land as z[16 i + u] in register i of lane u: consecutive lanes =
+//     consecutive outputs.
+// No cross-wave exchange at all: the discriminator's previous output z[k-1] of a block's first output is position V-1 of the
+// same transform (valid, because V - 1 >= ceil(M/D) - 1), so neither edge buffer nor fix-up launch exists.
+// LDS: per wave 256*D complex staging (reused as the transpose buffer), per workgroup twiddles 16x16, G D x 256, output
+// phasors 256 (D = 5: 54 KB -> 2 workgroups = 8 waves per CU).
+#pragma once
+#include "common.h"
+#include "kernels_fir.h"
+#include "kernels_firfft.h"
+#include "pk_math.h"
+
+namespace lrhip {
+
+constexpr int DF_N = 256;                 // transform length (decimated samples per block window)
+constexpr int DF_V = 32;                  // overlap in decimated samples
+constexpr int DF_LO = DF_N - DF_V;        // new outputs per block
+constexpr int DF_ROW = 17;                // padded row of the 16x16 transpose (complex elements)
+constexpr int DF_GRP = 16 * DF_ROW;       // transpose area per 16-lane row
+
+// per-wave LDS: the staged window, and the transpose area - aliased onto the window when every staged sample is read before the
+// first transpose (one full batch per block at most: D < 8), behind it otherwise
+__host__ __device__ constexpr int df_ex_offset(int D) { return D / 4 >= 2 ? DF_N * D : 0; }
+__host__ __device__ constexpr int df_stage_elems(int D) { return D / 4 >= 2 ? DF_N * D + 4 * DF_GRP : (DF_N * D > 4 * DF_GRP ? DF_N * D : 4 * DF_GRP); }
+// table layout (complex elements): twA[16][16] | G full batches [A][16 k2][64 lanes] | G left-over [C][16 k2][16 k1] | rot[256]
+__host__ __device__ constexpr int df_table_elems(int D) { return 256 + (D / 4) * 1024 + (D % 4) * 256 + 256; }
+__host__ __device__ constexpr int df_lds_elems(int D) { return 4 * df_stage_elems(D) + df_table_elems(D); }
+
+__device__ __forceinline__ void swap32(float &a, float &b)      // a = [a.lo32 | b.lo32], b = [a.hi32 | b.hi32]
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r.x);
+    b = __uint_as_float(r.y);
+}
+__device__ __forceinline__ void swap16(float &a, float &b)      // a = [a.r0 b.r0 a.r2 b.r2], b = [a.r1 b.r1 a.r3 b.r3]  (rows of 16 lanes)
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r.x);
+    b = __uint_as_float(r.y);
+}
+// four registers (one per block), four rows each  ->  row b of p_s = row s of the old p_b   (4 x 4 transpose register <-> row)
+__device__ __forceinline__ void transpose_rows(float &p0, float &p1, float &p2, float &p3)
+{
+    swap32(p0, p2);      // p0 = [p0.r0 p0.r1 p2.r0 p2.r1], p2 = [p0.r2 p0.r3 p2.r2 p2.r3]
+    swap32(p1, p3);
+    swap16(p0, p1);      // p0 = [p0.r0 p1.r0 p2.r0 p3.r0], p1 = [p0.r1 p1.r1 p2.r1 p3.r1]
+    swap16(p2, p3);      // p2 = rows 2, p3 = rows 3
+}
+
+// 16 x 16 transpose inside every row of 16 lanes: lane a register b -> lane b register a
+__device__ __forceinline__ void df_transpose(cf *ex, cf (&v)[16], int g, int u)
+{
+    cf *base = ex + g * DF_GRP;
+#pragma unroll
+    for (int k = 0; k < 16; k++) base[u * DF_ROW + k] = v[k];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = base[k * DF_ROW + u];
+}
+
+// forward: lane u holds in[16 i + u] in register i  ->  lane k1 holds X[k1 + 16 k2] in register k2
+__device__ __forceinline__ void df_fft_fwd(cf *ex, const cf *twA, cf (&v)[16], int g, int u)
+{
+    dft16<1>(v);
+#pragma unroll
+    for (int k = 1; k < 16; k++) v[k] = cmul(v[k], twA[k * 16 + u]);
+    df_transpose(ex, v, g, u);
+    dft16<1>(v);
+}
+// inverse (no 1/N): lane k1 holds Z[k1 + 16 k2] in register k2  ->  lane u holds z[16 i + u] in register i
+__device__ __forceinline__ void df_fft_inv(cf *ex, const cf *twA, cf (&v)[16], int g, int u)
+{
+    dft16<-1>(v);
+#pragma unroll
+    for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], twA[k * 16 + u]);
+    df_transpose(ex, v, g, u);
+    dft16<-1>(v);
+}
+
+// previous element along a row of 16 lanes: lane u gets `cur` of lane u-1, lane 0 gets `before` of lane 15
+__device__ __forceinline__ float row_prev(float cur, float before)
+{
+    const int wrapped = __builtin_amdgcn_update_dpp(0, __float_as_int(before), 0x121 /* row_ror:1 */, 0xf, 0xf, false);
+    return __int_as_float(__builtin_amdgcn_update_dpp(wrapped, __float_as_int(cur), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+}
+
+// discriminator on UNROTATED filter outputs: arg(a conj(b) cD) / gain, cD = e^{j w D}.  Zero products take the reference's
+// sign-of-zero path (frequencydiscriminator.lua:74 with complexfloat32.lua:79-81) on the rotated samples.
+__device__ __forceinline__ float df_discriminate(float2 a, float2 b, float2 cD, double inv_gain, uint64_t step_fx, uint64_t n_abs, unsigned D)
+{
+    const float tr = fmaf(a.x, b.x, a.y * b.y), ti = fmaf(a.y, b.x, -a.x * b.y);
+    if (tr == 0.f && ti == 0.f) {
+        const float2 ar = step_fx ? rotate_sample(a, step_fx, n_abs) : a;
+        const float2 br = (step_fx && (b.x != 0.f || b.y != 0.f)) ? rotate_sample(b, step_fx, n_abs - D) : b;
+        return discriminate(ar, br, inv_gain);
+    }
+    return fast_atan2f(fmaf(tr, cD.y, ti * cD.x), fmaf(tr, cD.x, -ti * cD.y)) * (float)inv_gain;
+}
+
+struct DfParams {
+    int M;
+    long n, n_out, first;          // chunk length, outputs, carried downsampler index
+    long nblocks;
+    int rounds;                    // quads per wave (one-shot order)
+    uint64_t rot_step_fx, rot_count0;   // rot_step_fx = 0: no rotation
+    float2 cD;                     // e^{j w D}
+    double inv_gain;
+};
+
+// EPI 0: ComplexFloat32 out (rotated when p.rot_step_fx != 0).  EPI 1: Float32 out = discriminator of the rotated outputs.
+template <int D, int EPI>
+__global__ __launch_bounds__(256, 2) void fir_decfft_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float2 *__restrict__ tables,
+                                                            float *__restrict__ y, DfParams p, const float2 *__restrict__ disc_prev_in,
+                                                            float2 *__restrict__ disc_prev_out, float *__restrict__ hist_out)
+{
+    constexpr int A = D / 4, C = D % 4, NL = 4 * D;            // NL: 8-byte loads per lane per block (256 D samples / 64 lanes)
+    constexpr int STG = df_stage_elems(D);
+    extern __shared__ __attribute__((aligned(16))) float2 fl[];
+    cf *flc = reinterpret_cast<cf *>(fl);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, u = lane & 15;
+    cf *stg = flc + wave * STG;
+    cf *ex = stg + df_ex_offset(D);
+    const cf *twA = flc + 4 * STG, *Gf = twA + 256, *Gl = Gf + A * 1024, *rotT = Gl + C * 256;
+    const int M = p.M;
+
+    for (int i = tid; i < df_table_elems(D); i += 256) fl[4 * STG + i] = tables[i];
+    // history carry: last M-1 raw input samples into the other ping-pong buffer
+    if (hist_out && blockIdx.x == 0)
+        for (int i = tid; i < (M - 1) * 2; i += 256) hist_out[i] = stream_at<2>(hist, x, p.n + i / 2, i % 2, M, p.n);
+    __syncthreads();
+
+    const long nquads = (p.nblocks + 3) / 4;
+    const float2 *xc = reinterpret_cast<const float2 *>(x);
+    for (int r = 0; r < p.rounds; r++) {
+        const long quad = ((long)blockIdx.x * p.rounds + r) * 4 + wave;
+        if (quad >= nquads) break;
+        float T[4][8];                   // per block: partial sums over the full batches, 8 floats per lane after the row reduction
+        cf left[C > 0 ? C : 1][4][4];    // left-over phases: [c][block][cc] = sample mm = 16 (4 g + cc) + u of phase 4A + c
+#pragma unroll
+        for (int bq = 0; bq < 4; bq++) {
+            const long b = quad * 4 + bq;
+            // ---- stage the block's 256 D input samples: window position j <-> x index xs + j
+            const long xs = p.first + (long)D * (b * DF_LO - DF_V) - (D - 1);
+            if (b < p.nblocks) {
+                cf ld[NL];
+                if (xs >= 0 && xs + DF_N * D <= p.n) {
+#pragma unroll
+                    for (int c = 0; c < NL; c++) ld[c] = cf_from(xc[xs + 64 * c + lane]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NL; c++) {
+                        const long ps = xs + 64 * c + lane + (M - 1);        // stream position ([M-1 history | chunk]); before the history: 0
+                        ld[c] = cf{stream_at<2>(hist, x, ps, 0, M, p.n), stream_at<2>(hist, x, ps, 1, M, p.n)};
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NL; c++) stg[64 * c + lane] = ld[c];
+            }
+            // ---- full batches: row g transforms phase 4t + g (window position j = D mm + phase)
+            cf acc[16];
+#pragma unroll
+            for (int t = 0; t < A; t++) {
+                cf v[16];
+                if (b < p.nblocks) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) v[i] = stg[D * (16 * i + u) + 4 * t + g];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) v[i] = cf{0.f, 0.f};
+                }
+                if (t == A - 1 && C > 0 && b < p.nblocks) {
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+#pragma unroll
+                        for (int cc = 0; cc < 4; cc++) left[c][bq][cc] = stg[D * (16 * (4 * g + cc) + u) + 4 * A + c];
+                }
+                df_fft_fwd(ex, twA, v, g, u);
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const cf pr = cmul(v[k], Gf[t * 1024 + k * 64 + lane]);
+                    acc[k] = t == 0 ? pr : acc[k] + pr;
+                }
+            }
+            if (A == 0) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[k] = cf{0.f, 0.f};
+                if (b < p.nblocks) {
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+#pragma unroll
+                        for (int cc = 0; cc < 4; cc++) left[c][bq][cc] = stg[D * (16 * (4 * g + cc) + u) + c];
+                }
+            }
+            if (C > 0 && !(b < p.nblocks)) {
+#pragma unroll
+                for (int c = 0; c < C; c++)
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) left[c][bq][cc] = cf{0.f, 0.f};
+            }
+            // ---- sum the four rows (phases): 32 floats -> 8 per lane; row g ends up with (Re Z[2t], Re Z[2t+1], Im Z[2t], Im Z[2t+1])[g]
+#pragma unroll
+            for (int t2 = 0; t2 < 8; t2++) {
+                float s0, s1;
+                {
+                    float a = acc[2 * t2].x, c = acc[2 * t2].y;
+                    swap32(a, c);
+                    s0 = a + c;
+                }
+                {
+                    float a = acc[2 * t2 + 1].x, c = acc[2 * t2 + 1].y;
+                    swap32(a, c);
+                    s1 = a + c;
+                }
+                swap16(s0, s1);
+                T[bq][t2] = s0 + s1;
+            }
+        }
+        // ---- bring block b's sums to row b
+        cf z[16];
+#pragma unroll
+        for (int t2 = 0; t2 < 8; t2++) {
+            transpose_rows(T[0][t2], T[1][t2], T[2][t2], T[3][t2]);
+            z[2 * t2] = cf{T[0][t2], T[2][t2]};
+            z[2 * t2 + 1] = cf{T[1][t2], T[3][t2]};
+        }
+        // ---- left-over phases of the four blocks, row b = block b
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            cf v[16];
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                float r0 = left[c][0][cc].x, r1 = left[c][1][cc].x, r2 = left[c][2][cc].x, r3 = left[c][3][cc].x;
+                float i0 = left[c][0][cc].y, i1 = left[c][1][cc].y, i2 = left[c][2][cc].y, i3 = left[c][3][cc].y;
+                transpose_rows(r0, r1, r2, r3);
+                transpose_rows(i0, i1, i2, i3);
+                v[cc] = cf{r0, i0};           // register i = 4 s + cc <- old row s
+                v[4 + cc] = cf{r1, i1};
+                v[8 + cc] = cf{r2, i2};
+                v[12 + cc] = cf{r3, i3};
+            }
+            df_fft_fwd(ex, twA, v, g, u);
+#pragma unroll
+            for (int k = 0; k < 16; k++) z[k] = z[k] + cmul(v[k], Gl[c * 256 + k * 16 + u]);
+        }
+        // ---- inverse: row g = block quad*4 + g; z[i] = output window position w = 16 i + u
+        df_fft_inv(ex, twA, z, g, u);
+        const long b = quad * 4 + g;
+        const long k0 = b * DF_LO - DF_V;            // output index of window position 0
+        if (b < p.nblocks) {
+            if (EPI == 0) {
+                cf base = cf{1.f, 0.f};
+                if (p.rot_step_fx) base = phasor_poly(p.rot_step_fx * (p.rot_count0 + (uint64_t)(p.first + (long)D * k0)));
+                float2 *yo = reinterpret_cast<float2 *>(y);
+#pragma unroll
+                for (int i = DF_V / 16; i < 16; i++) {
+                    const long k = k0 + 16 * i + u;
+                    cf o = z[i];
+                    if (p.rot_step_fx) o = cmul(o, cmul(base, rotT[16 * i + u]));
+                    if (k < p.n_out) yo[k] = cf_to(o);
+                }
+            } else {
+#pragma unroll
+                for (int i = DF_V / 16; i < 16; i++) {
+                    const long k = k0 + 16 * i + u;
+                    float2 prev = make_float2(row_prev(z[i].x, z[i - 1].x), row_prev(z[i].y, z[i - 1].y));
+                    if (k == 0) prev = *disc_prev_in;
+                    const float2 cur = cf_to(z[i]);
+                    if (k < p.n_out) {
+                        y[k] = df_discriminate(cur, prev, p.cD, p.inv_gain, p.rot_step_fx, p.rot_count0 + (uint64_t)(p.first + (long)D * k), D);
+                        if (k == p.n_out - 1) *disc_prev_out = cur;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace lrhip

@@ -13,6 +13,7 @@
 #include "kernels_fft.h"
 #include "kernels_fir.h"
 #include "kernels_firfft.h"
+#include "kernels_firdecfft.h"
 #include "kernels_channelizer.h"
 #include "kernels_iir.h"
 #include "kernels_agc.h"
@@ -523,7 +524,9 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
         // ... [discriminator]: runs as the epilogue of the persistent kernel (ComplexFloat32 outputs never reach HBM)
         static const bool no_disc_fusion = getenv("LRHIP_NO_DISC_FUSION") != nullptr;      // A/B knob
         unsigned after = j + 1 + (ds ? 1 : 0);
-        FmDiscrimStage *dsc_after = (!no_disc_fusion && fusable_fir && fir->S == 2 && !fir->taps_complex && !fir->fft_arith && after < nstages)
+        // a filter that asked for overlap-save arithmetic keeps it when fused with a downsampler (polyphase FFT form, kernels_firdecfft.h)
+        const bool want_fft = fusable_fir && fir->fft_arith && ds && FirStage::decfft_supported((unsigned)ds->factor, fir->M, fir->S);
+        FmDiscrimStage *dsc_after = (!no_disc_fusion && fusable_fir && fir->S == 2 && !fir->taps_complex && (!fir->fft_arith || want_fft) && after < nstages)
                                         ? dynamic_cast<FmDiscrimStage *>(stages[after]) : nullptr;
         if (fusable_fir && (rot || ds || dsc_after)) {
             unsigned D = ds ? (unsigned)ds->factor : 1;
@@ -533,8 +536,8 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
                 for (int cc = 0; cc < ts; cc++) taps[(size_t)t * ts + cc] = fir->taps_rev[(size_t)(fir->M - 1 - t) * ts + cc];
             bool want_rot = rot && fir->S == 2;
             FirStage *fused = nullptr;
-            if (FirStage::mfma_supported_decim(D) || !rot || (fir->S == 2 && !fir->taps_complex && fir->M + 255 <= DECIM_SPAN_MAX))
-                fused = fir_build(taps.data(), (unsigned)fir->M, fir->taps_complex, fir->S == 2, D, 0, want_rot, want_rot ? rot->omega : 0.0);
+            if (want_fft || FirStage::mfma_supported_decim(D) || !rot || (fir->S == 2 && !fir->taps_complex && fir->M + 255 <= DECIM_SPAN_MAX))
+                fused = fir_build(taps.data(), (unsigned)fir->M, fir->taps_complex, fir->S == 2, D, want_fft ? 2 : 0, want_rot, want_rot ? rot->omega : 0.0);
             if (fused && rot && !want_rot) { delete fused; fused = nullptr; }
             bool with_disc = fused && dsc_after && fused->can_post_disc();
             if (fused && !rot && !ds && !with_disc) { delete fused; fused = nullptr; }      // nothing was fused

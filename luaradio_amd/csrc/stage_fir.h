@@ -27,6 +27,12 @@ struct FirStage : lrhip_stage {
     bool fft_arith = false;
     DeviceBuf d_fft_tables;
     int fft_blocks_per_cu = 0;
+    // decimating polyphase-FFT form (kernels_firdecfft.h): ComplexFloat32 stream, D >= 2, ceil(M / D) <= 32
+    bool decfft = false;
+    DeviceBuf d_dec_tables;
+    int dec_blocks_per_cu = 0;
+    double rot_omega = 0.0;
+    static bool decfft_supported(unsigned d, int m, int s) { return s == 2 && (d == 2 || d == 4 || d == 5 || d == 8 || d == 10) && (m + (int)d - 1) / (int)d <= DF_V && m >= 8; }
     // fused FrequencyDiscriminatorBlock in front (chains): input is ComplexFloat32, the filter runs on arg(c[i] conj c[i-1])/gain
     bool hist_in_kernel = false;          // set by a launch that also wrote the next history buffer
     bool pre_disc = false;
@@ -253,6 +259,50 @@ struct FirStage : lrhip_stage {
         return 0;
     }
 
+    template <int DD>
+    int launch_decfft_d(const float *x, long n, float *y, long n_out)
+    {
+        const size_t lds_bytes = (size_t)df_lds_elems(DD) * sizeof(float2);
+        DfParams pr;
+        pr.M = M; pr.n = n; pr.n_out = n_out; pr.first = (long)index;
+        pr.nblocks = (n_out + DF_LO - 1) / DF_LO;
+        pr.rot_step_fx = rot ? rot_step : 0; pr.rot_count0 = rot ? count : 0;
+        const double wD = rot ? rot_omega * (double)DD : 0.0;
+        pr.cD = make_float2((float)std::cos(wD), (float)std::sin(wD));
+        pr.inv_gain = 1.0 / disc_gain;
+        const float *h = (const float *)hist[cur].p + hist_pad;
+        float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
+        auto go = [&](auto kern) -> int {
+            if (!dec_blocks_per_cu && prepare_kernel(kern, lds_bytes, &dec_blocks_per_cu)) return -1;
+            const long nquads = (pr.nblocks + 3) / 4, slots = (long)ctx().num_cus * dec_blocks_per_cu;
+            const int rounds_env = getenv("LRHIP_DECFFT_ROUNDS") ? atoi(getenv("LRHIP_DECFFT_ROUNDS")) : 0;      // A/B knob
+            // one-shot order (common.h grid_for); more quads per wave only once the launch is several times the resident slots
+            int rounds = rounds_env > 0 ? rounds_env : (nquads > 16 * slots ? 2 : 1);
+            pr.rounds = rounds;
+            const long wgs = (nquads + 4L * rounds - 1) / (4L * rounds);
+            float2 *dp = (float2 *)disc_prev.p;
+            hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds_bytes, ctx().stream, h, x, (const float2 *)d_dec_tables.p, y, pr,
+                               post_disc ? (const float2 *)(dp + disc_cur) : nullptr, post_disc ? dp + (disc_cur ^ 1) : nullptr, ho);
+            hist_in_kernel = ho != nullptr;
+            return 0;
+        };
+        int rc = post_disc ? go(fir_decfft_kernel<DD, 1>) : go(fir_decfft_kernel<DD, 0>);
+        if (rc) return rc;
+        LR_LAUNCH_CHECK();
+        if (post_disc) disc_cur ^= 1;
+        return 0;
+    }
+    int launch_decfft(const float *x, long n, float *y, long n_out)
+    {
+        switch (D) {
+            case 2: return launch_decfft_d<2>(x, n, y, n_out);
+            case 4: return launch_decfft_d<4>(x, n, y, n_out);
+            case 5: return launch_decfft_d<5>(x, n, y, n_out);
+            case 8: return launch_decfft_d<8>(x, n, y, n_out);
+            default: return launch_decfft_d<10>(x, n, y, n_out);
+        }
+    }
+
     int launch_direct(const float *x, long n, float *y, long n_out)
     {
         if (rot) return set_error("internal: direct FIR kernel has no fused rotator");
@@ -287,7 +337,7 @@ struct FirStage : lrhip_stage {
 
     static bool mfma_supported_decim(unsigned d) { return (d >= 1 && d <= 8) || d == 10; }
     // the discriminator epilogue exists for the persistent instantiations of the complex-stream, real-taps kernel
-    bool can_post_disc() const { return S == 2 && !taps_complex && !fft_arith && !use_fft && ((D == 1 && ksteps == 36) || (D == 5 && ksteps == 51)); }
+    bool can_post_disc() const { return decfft || (S == 2 && !taps_complex && !fft_arith && !use_fft && ((D == 1 && ksteps == 36) || (D == 5 && ksteps == 51))); }
 
     // filter n inputs (device), emit the retained outputs; advances history / index / count
     long core(const float *x, long n, float *y, unsigned long cap)
@@ -297,7 +347,8 @@ struct FirStage : lrhip_stage {
         long n_out = (unsigned long)n > index ? (long)((n - index + D - 1) / D) : 0;
         if ((unsigned long)n_out > cap) return set_error("fir: output capacity %lu < %ld", cap, n_out);
         if (n_out > 0) {
-            int rc = fft_arith ? launch_fft(x, n, y, n_out)
+            int rc = (decfft && ((uintptr_t)x & 7) == 0) ? launch_decfft(x, n, y, n_out)
+                     : fft_arith ? launch_fft(x, n, y, n_out)
                      : !ksteps ? (decim_lds_ok() ? launch_decim_lds(x, n, y, n_out) : launch_direct(x, n, y, n_out))
                      : taps_complex ? dispatch_mfma_cc(x, n, y, n_out)
                      : S == 1 ? dispatch_mfma<1>(x, n, y, n_out) : dispatch_mfma<2>(x, n, y, n_out);
@@ -354,14 +405,79 @@ struct FirStage : lrhip_stage {
     }
 };
 
+// Tables of fir_decfft_kernel (layout: df_table_elems): 256-point twiddles, the D polyphase branch responses G_rho (1/256 of the
+// inverse transform folded in) in the lane order of the forward batches, and the output phasors e^{j w D k}.  All in double.
+// Window position j = D mm + rho of a block is input x[first + D m - r] with r = D - 1 - rho, so branch rho uses g_r[q] = g[D q + r],
+// g[i] = h[i] e^{-j w i}.
+static void decfft_build_tables(const float *taps, int M, int taps_complex, int D, double omega, std::vector<float> &out)
+{
+    const double PI2 = 6.283185307179586476925286766559;
+    const int A = D / 4, C = D % 4;
+    out.assign((size_t)df_table_elems(D) * 2, 0.f);
+    float *tw = out.data(), *Gf = tw + 2 * 256, *Gl = Gf + 2 * (size_t)A * 1024, *rt = Gl + 2 * (size_t)C * 256;
+    for (int k1 = 0; k1 < 16; k1++)
+        for (int u = 0; u < 16; u++) {
+            double a = -PI2 * (double)(k1 * u) / DF_N;
+            tw[2 * (k1 * 16 + u)] = (float)std::cos(a);
+            tw[2 * (k1 * 16 + u) + 1] = (float)std::sin(a);
+        }
+    long double turns = (long double)omega / (2.0L * 3.14159265358979323846264338327950288L);
+    turns -= floorl(turns);
+    std::vector<double> gr((size_t)M), gi((size_t)M);
+    for (int i = 0; i < M; i++) {
+        long double f = turns * (long double)i;
+        f -= floorl(f);
+        double a = -PI2 * (double)f, c = std::cos(a), sn = std::sin(a);
+        double hr = taps_complex ? taps[2 * i] : taps[i], hi = taps_complex ? taps[2 * i + 1] : 0.0;
+        gr[i] = hr * c - hi * sn;
+        gi[i] = hr * sn + hi * c;
+    }
+    std::vector<double> Gr(DF_N), Gi(DF_N);
+    for (int rho = 0; rho < D; rho++) {
+        const int r = D - 1 - rho;
+        for (int k = 0; k < DF_N; k++) {
+            double sr = 0, si = 0;
+            for (int qq = 0; D * qq + r < M; qq++) {
+                double a = -PI2 * (double)((qq * k) % DF_N) / DF_N, c = std::cos(a), sn = std::sin(a);
+                sr += gr[D * qq + r] * c - gi[D * qq + r] * sn;
+                si += gr[D * qq + r] * sn + gi[D * qq + r] * c;
+            }
+            Gr[k] = sr / DF_N;
+            Gi[k] = si / DF_N;
+        }
+        for (int k2 = 0; k2 < 16; k2++)
+            for (int k1 = 0; k1 < 16; k1++) {
+                const int k = k1 + 16 * k2;
+                float *dst = rho < 4 * A ? Gf + 2 * ((size_t)(rho / 4) * 1024 + k2 * 64 + 16 * (rho % 4) + k1)
+                                         : Gl + 2 * ((size_t)(rho - 4 * A) * 256 + k2 * 16 + k1);
+                dst[0] = (float)Gr[k];
+                dst[1] = (float)Gi[k];
+            }
+    }
+    for (int w = 0; w < DF_N; w++) {
+        long double f = turns * (long double)D * (long double)w;
+        f -= floorl(f);
+        double a = PI2 * (double)f;
+        rt[2 * w] = (float)std::cos(a);
+        rt[2 * w + 1] = (float)std::sin(a);
+    }
+}
+
 static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, int input_complex, unsigned decim,
                            int use_fft, bool rot, double omega)
 {
     if (!taps || ntaps < 1) { set_error("fir: need at least one tap"); return nullptr; }
     if (taps_complex && !input_complex) { set_error("fir: complex taps require ComplexFloat32 input (firfilter.lua:69-74)"); return nullptr; }
     if (decim < 1) { set_error("fir: decimation must be >= 1"); return nullptr; }
+    // decimating filters: overlap-save arithmetic exists in the polyphase form (kernels_firdecfft.h) for the complex stream
+    bool want_decfft = false;
+    if (decim > 1 && (use_fft == 2 || use_fft == 3)) {
+        want_decfft = FirStage::decfft_supported(decim, (int)ntaps, input_complex ? 2 : 1) && (use_fft == 2 || ntaps >= 32);
+        if (!want_decfft && use_fft == 2) { set_error("fir: no overlap-save form for %u taps at decimation %u on this input type", ntaps, decim); return nullptr; }
+        use_fft = 0;
+    }
     if (use_fft == 3) use_fft = (decim == 1 && !rot && ntaps >= 48 && ntaps <= 16 * FirStage::FFT_PART && (input_complex || !taps_complex)) ? 2 : 0;
-    if (use_fft && decim != 1) { set_error("fir: overlap-save cannot be combined with decimation"); return nullptr; }
+    if (use_fft && decim != 1) { set_error("fir: the reference's block-emission framing (use_fft = 1) cannot be combined with decimation"); return nullptr; }
     if (use_fft < 0 || use_fft > 2) { set_error("fir: use_fft must be 0 (direct form), 1 (overlap-save as the reference: block emission), 2 (overlap-save arithmetic, sample-exact emission) or 3 (automatic)"); return nullptr; }
     if (ntaps > (1u << 20)) { set_error("fir: too many taps"); return nullptr; }
     if (ensure_init()) return nullptr;
@@ -405,8 +521,15 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
             q->hist_pad = 1;
         }
     }
+    if (want_decfft) {
+        std::vector<float> tab;
+        decfft_build_tables(taps, (int)ntaps, taps_complex, (int)decim, rot ? omega : 0.0, tab);
+        if (upload(q->d_dec_tables, tab.data(), tab.size() * sizeof(float))) return nullptr;
+        q->decfft = true;
+        q->rot_omega = rot ? omega : 0.0;
+    }
     if (rot) {
-        if (!q->ksteps && !(input_complex && !taps_complex && (int)ntaps + 255 <= DECIM_SPAN_MAX)) {
+        if (!q->decfft && !q->ksteps && !(input_complex && !taps_complex && (int)ntaps + 255 <= DECIM_SPAN_MAX)) {
             set_error("fir: rotator fusion unavailable for this tap count / decimation");
             return nullptr;
         }

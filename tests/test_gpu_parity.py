@@ -476,6 +476,88 @@ def test_discriminator_epilogue_equals_unfused_blocks(decim):
         assert np.median(np.abs(got - ora)) < 1e-6
 
 
+# ---- decimating filters in overlap-save form: the polyphase FFT kernel (kernels_firdecfft.h), the reference's own default
+# arithmetic (firfilter.lua:57, :320-398) - Float32 FFT, so the bar is the f64 oracle to 1e-6, not the fmaf chain bit for bit
+@pytest.mark.parametrize("factor", [2, 4, 5, 8, 10])
+@pytest.mark.parametrize("ntaps", [128, 33])
+def test_decimator_polyphase_fft_vs_f64_oracle(factor, ntaps):
+    rng = np.random.default_rng(700 + factor + ntaps)
+    n = 60000 + factor
+    x = rand_c(rng, n)
+    dec = make(lr.DecimatorBlock, [factor, {"num_taps": ntaps, "use_fft": "fast"}], x)
+    want = O.decimator(factor, RATE, True, num_taps=ntaps, mode=O.MODE_F64).process(x)
+    whole = dec.process(x)
+    if (ntaps + factor - 1) // factor <= 32:       # branch filters of at most 32 taps have the polyphase FFT form; else: direct form
+        assert dec.chain.last_launches == 1        # one kernel: filter, downsampler and the history carry
+    assert len(whole) == len(want) and G.max_abs_err(whole, want) < 1e-6
+    dec.reset()
+    got = chunked(dec, x, [1, 2, 3, 7, 1000, 1001, 1121, 2241, 30000, 30001])       # block (224 D) and quad boundaries, odd offsets
+    assert len(got) == len(want) and G.max_abs_err(got, want) < 1e-6
+    # chunking moves block boundaries, not values beyond Float32 FFT rounding
+    assert G.max_abs_err(got, whole) < 5e-7
+
+
+def test_decimator_polyphase_fft_golden_and_one_sample_chunks():
+    """the reference's decimator_spec vectors (factors 2 and 4 have a polyphase FFT instantiation) in both jig modes"""
+    doc = G.load("decimator_spec")
+    for vec in doc["vectors"]:
+        if vec["args"][0] in (2, 4) and np.iscomplexobj(vec["inputs"][0]):
+            v = dict(vec, args=[vec["args"][0], {"use_fft": "fast"}])
+            _golden_both_modes(lr.DecimatorBlock, v, doc["epsilon"])
+
+
+@pytest.mark.parametrize("ntaps", [128, 160, 64])
+def test_tuner_polyphase_fft(ntaps):
+    """Tuner = rotator -> lowpass -> downsampler with the rotation folded into the taps (g = h e^{-jwi}) and applied once per
+    OUTPUT: against the oracle (closed-form rotator, f64 FIR) to 1e-6, whole and ragged; the reference's tuner_spec at its 1e-5"""
+    rng = np.random.default_rng(730 + ntaps)
+    rate = 1102500.0
+    x = rand_c(rng, 150003)
+    tun = make(lr.TunerBlock, [-250e3, 200e3, 5, {"num_taps": ntaps, "use_fft": "fast"}], x, rate=rate)
+    want = O.tuner(-250e3, 200e3, 5, rate, num_taps=ntaps, mode=O.MODE_F64, rot_mode=O.MODE_F64).process(x)
+    whole = tun.process(x)
+    assert tun.chain.last_launches == 1
+    assert len(whole) == len(want) and G.max_abs_err(whole, want) < 1e-6
+    tun.reset()
+    got = chunked(tun, x, [1, 5, 6, 4097, 65536, 65537, 100000])
+    assert len(got) == len(want) and G.max_abs_err(got, want) < 1e-6
+    if ntaps == 128:
+        doc = G.load("tuner_spec")
+        for vec in doc["vectors"]:
+            _golden_both_modes(lr.TunerBlock, dict(vec, args=list(vec["args"]) + [{"use_fft": "fast"}]), doc["epsilon"])
+
+
+@pytest.mark.parametrize("rotate", [True, False])
+def test_discriminator_behind_polyphase_fft_filter(rotate):
+    """[rotator] -> FIR (overlap-save) -> downsampler -> discriminator as ONE launch: the discriminator works on the unrotated
+    filter outputs times the constant e^{jwD}.  Against the oracle chain and against the separate device blocks, where the angle is
+    well conditioned (|filter output| not tiny); first sample (zero previous sample) follows the reference's sign-of-zero rule."""
+    rng = np.random.default_rng(760 + rotate)
+    rate, n = 1102500.0, 200001
+    t = np.arange(n) / rate
+    x = (np.exp(1j * (2 * np.pi * (250e3 if rotate else 20e3) * t + 3.0 * np.sin(2 * np.pi * 3e3 * t))) + 0.01 * rand_c(rng, n)).astype(np.complex64)
+
+    def blocks():
+        bl = [make(lr.FrequencyTranslatorBlock, [-250e3], x, rate=rate)] if rotate else []
+        f = lr.LowpassFilterBlock(128, 100e3)
+        f.use_fft = 2
+        f.rate = rate
+        f.differentiate([types.ComplexFloat32])
+        f.initialize()
+        return bl + [f, make(lr.DownsamplerBlock, [5], x, rate=rate), make(lr.FrequencyDiscriminatorBlock, [1.25], x, rate=rate)]
+
+    chain = lr.Chain(blocks())
+    whole = chain.process(x)
+    assert chain.last_launches == 1
+    chain.reset()
+    got = chunked(chain, x, [1, 4, 5, 6, 1119, 1120, 1121, 4480, 4481, 70000, 70003])
+    ora = O.Chain(([O.Rotator(2 * np.pi * (-250e3 / rate), O.MODE_F64)] if rotate else []) +
+                  [O.lowpass(128, 100e3, rate, True, mode=O.MODE_F64), O.Downsampler(5, True), O.FMDiscriminator(1.25)]).process(x)
+    assert len(got) == len(whole) == len(ora) == (n + 4) // 5
+    assert G.max_abs_err(whole[30:], ora[30:]) < 1e-6 and G.max_abs_err(got[30:], ora[30:]) < 1e-6     # past the filter's start-up (tiny outputs)
+    assert got[0] == ora[0] or abs(float(got[0]) - float(ora[0])) < 1e-6          # sign-of-zero case of the very first sample
+
+
 @pytest.mark.parametrize("order", [5, 6, 7, 8])
 def test_iir_orders_five_to_eight_scan_paths(order):
     """orders up to 8 run the scan kernels (the transition powers live in device memory); short-memory poles take the
