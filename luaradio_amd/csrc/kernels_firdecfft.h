@@ -21,7 +21,11 @@
 //
 // Geometry.  A 256-point FFT = 16 lanes x 16 registers (dft16 in registers, twiddle, 16x16 transpose through LDS, dft16),
 // so a wave runs FOUR transforms at a time, one per row of 16 lanes.  D = 4A + C phases:
-//   * per block, A batches: rows 0..3 transform phases 4t..4t+3 of THIS block (staged once, coalesced, in LDS); the products
+//   * per block, A batches: rows 0..3 transform phases 4t..4t+3 of THIS block.  The block's 256 D samples are loaded
+//     coalesced (8 B per lane, natural order), staged in LDS and read back in polyphase order, window position
+//     D (16 i + u) + 4t + g into register i of lane (row g, u).  (Measured and dropped: loading in polyphase order straight
+//     from global memory - every wave-load then covers one contiguous 128 D byte span, but 64 separate 8-byte pieces of it,
+//     and the address pipeline, not HBM, became the limit: 0.18 ms against 0.15 ms for 2^26 samples.)  The products
 //     with G are summed over t in registers and then across the four rows with v_permlane32_swap / v_permlane16_swap
 //     (gfx950), which leaves 8 floats per lane;
 //   * the C left-over phases of four consecutive blocks (a "quad") wait in registers and are transformed together, row b =
@@ -31,8 +35,10 @@
 //     consecutive outputs.
 // No cross-wave exchange at all: the discriminator's previous output z[k-1] of a block's first output is position V-1 of the
 // same transform (valid, because V - 1 >= ceil(M/D) - 1), so neither edge buffer nor fix-up launch exists.
-// LDS: per wave 256*D complex staging (reused as the transpose buffer), per workgroup twiddles 16x16, G D x 256, output
-// phasors 256 (D = 5: 54 KB -> 2 workgroups = 8 waves per CU).
+// The next block's samples are requested before the current block's arithmetic (register prefetch); the 15 stage twiddles
+// W_256^(u k) depend on the lane only and stay in registers; the G rows are read from LDS one dft16 ahead of their use.
+// LDS: per wave the staged window (256 D complex; the 4 x 16 x 17 transpose area is laid over it when a block has one full
+// batch), per workgroup G (D x 256) and the 256 output phasors (D = 5: 52 KB -> 2 workgroups = 8 waves per CU).
 #pragma once
 #include "common.h"
 #include "kernels_fir.h"
@@ -46,14 +52,16 @@ constexpr int DF_V = 32;                  // overlap in decimated samples
 constexpr int DF_LO = DF_N - DF_V;        // new outputs per block
 constexpr int DF_ROW = 17;                // padded row of the 16x16 transpose (complex elements)
 constexpr int DF_GRP = 16 * DF_ROW;       // transpose area per 16-lane row
-
-// per-wave LDS: the staged window, and the transpose area - aliased onto the window when every staged sample is read before the
-// first transpose (one full batch per block at most: D < 8), behind it otherwise
+constexpr int DF_EX = 4 * DF_GRP;         // transpose area per wave
+// per-wave LDS (complex elements): the staged window, and the transpose area - aliased onto the window when every staged sample
+// is read before the first transpose (at most one full batch per block: D < 8), behind it otherwise
 __host__ __device__ constexpr int df_ex_offset(int D) { return D / 4 >= 2 ? DF_N * D : 0; }
-__host__ __device__ constexpr int df_stage_elems(int D) { return D / 4 >= 2 ? DF_N * D + 4 * DF_GRP : (DF_N * D > 4 * DF_GRP ? DF_N * D : 4 * DF_GRP); }
+__host__ __device__ constexpr int df_wave_elems(int D) { return D / 4 >= 2 ? DF_N * D + DF_EX : (DF_N * D > DF_EX ? DF_N * D : DF_EX); }
+
 // table layout (complex elements): twA[16][16] | G full batches [A][16 k2][64 lanes] | G left-over [C][16 k2][16 k1] | rot[256]
 __host__ __device__ constexpr int df_table_elems(int D) { return 256 + (D / 4) * 1024 + (D % 4) * 256 + 256; }
-__host__ __device__ constexpr int df_lds_elems(int D) { return 4 * df_stage_elems(D) + df_table_elems(D); }
+// LDS (complex elements): 4 waves x per-wave area | the tables without twA
+__host__ __device__ constexpr int df_lds_elems(int D) { return 4 * df_wave_elems(D) + df_table_elems(D) - 256; }
 
 __device__ __forceinline__ void swap32(float &a, float &b)      // a = [a.lo32 | b.lo32], b = [a.hi32 | b.hi32]
 {
@@ -88,21 +96,21 @@ __device__ __forceinline__ void df_transpose(cf *ex, cf (&v)[16], int g, int u)
     for (int k = 0; k < 16; k++) v[k] = base[k * DF_ROW + u];
 }
 
-// forward: lane u holds in[16 i + u] in register i  ->  lane k1 holds X[k1 + 16 k2] in register k2
-__device__ __forceinline__ void df_fft_fwd(cf *ex, const cf *twA, cf (&v)[16], int g, int u)
+// forward: lane u holds in[16 i + u] in register i  ->  lane k1 holds X[k1 + 16 k2] in register k2.  tw[k] = W_256^(u k).
+__device__ __forceinline__ void df_fft_fwd(cf *ex, const cf (&tw)[16], cf (&v)[16], int g, int u)
 {
     dft16<1>(v);
 #pragma unroll
-    for (int k = 1; k < 16; k++) v[k] = cmul(v[k], twA[k * 16 + u]);
+    for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw[k]);
     df_transpose(ex, v, g, u);
     dft16<1>(v);
 }
 // inverse (no 1/N): lane k1 holds Z[k1 + 16 k2] in register k2  ->  lane u holds z[16 i + u] in register i
-__device__ __forceinline__ void df_fft_inv(cf *ex, const cf *twA, cf (&v)[16], int g, int u)
+__device__ __forceinline__ void df_fft_inv(cf *ex, const cf (&tw)[16], cf (&v)[16], int g, int u)
 {
     dft16<-1>(v);
 #pragma unroll
-    for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], twA[k * 16 + u]);
+    for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], tw[k]);
     df_transpose(ex, v, g, u);
     dft16<-1>(v);
 }
@@ -115,16 +123,28 @@ __device__ __forceinline__ float row_prev(float cur, float before)
 }
 
 // discriminator on UNROTATED filter outputs: arg(a conj(b) cD) / gain, cD = e^{j w D}.  Zero products take the reference's
-// sign-of-zero path (frequencydiscriminator.lua:74 with complexfloat32.lua:79-81) on the rotated samples.
+// sign-of-zero path (frequencydiscriminator.lua:74 with complexfloat32.lua:79-81) on the rotated samples - out of line, it
+// only runs for the very first output of a stream (zero previous sample) or an exactly silent input.
+__device__ __noinline__ float df_discriminate_zero(float2 a, float2 b, double inv_gain, uint64_t step_fx, uint64_t n_abs, unsigned D)
+{
+    const float2 ar = step_fx ? rotate_sample(a, step_fx, n_abs) : a;
+    const float2 br = (step_fx && (b.x != 0.f || b.y != 0.f)) ? rotate_sample(b, step_fx, n_abs - D) : b;
+    return discriminate(ar, br, inv_gain);
+}
 __device__ __forceinline__ float df_discriminate(float2 a, float2 b, float2 cD, double inv_gain, uint64_t step_fx, uint64_t n_abs, unsigned D)
 {
     const float tr = fmaf(a.x, b.x, a.y * b.y), ti = fmaf(a.y, b.x, -a.x * b.y);
-    if (tr == 0.f && ti == 0.f) {
-        const float2 ar = step_fx ? rotate_sample(a, step_fx, n_abs) : a;
-        const float2 br = (step_fx && (b.x != 0.f || b.y != 0.f)) ? rotate_sample(b, step_fx, n_abs - D) : b;
-        return discriminate(ar, br, inv_gain);
-    }
+    if (__builtin_expect(tr == 0.f && ti == 0.f, 0)) return df_discriminate_zero(a, b, inv_gain, step_fx, n_abs, D);
     return fast_atan2f(fmaf(tr, cD.y, ti * cD.x), fmaf(tr, cD.x, -ti * cD.y)) * (float)inv_gain;
+}
+
+// one sample of the stream [.. zeros | M-1 history | chunk | zeros ..] by its x index, branch-free (edge blocks only)
+__device__ __forceinline__ cf df_sample_edge(const float2 *__restrict__ hc, const float2 *__restrict__ xc, long xi, int M, long n)
+{
+    const bool inx = xi >= 0 && xi < n, inh = xi < 0 && xi >= -(long)(M - 1);
+    const float2 *src = inx ? xc + xi : hc + (inh ? xi + (M - 1) : 0);
+    const float2 v = *src;
+    return (inx || inh) ? cf{v.x, v.y} : cf{0.f, 0.f};
 }
 
 struct DfParams {
@@ -135,6 +155,7 @@ struct DfParams {
     uint64_t rot_step_fx, rot_count0;   // rot_step_fx = 0: no rotation
     float2 cD;                     // e^{j w D}
     double inv_gain;
+    int dbg;                       // ablation bits for tools/ab_decfft.py (0 in production): 1 no global loads, 2 no staging, 4 no forward batches, 8 no inverse, 16 no epilogue arithmetic, 32 no stores
 };
 
 // EPI 0: ComplexFloat32 out (rotated when p.rot_step_fx != 0).  EPI 1: Float32 out = discriminator of the rotated outputs.
@@ -143,117 +164,139 @@ __global__ __launch_bounds__(256, 2) void fir_decfft_kernel(const float *__restr
                                                             float *__restrict__ y, DfParams p, const float2 *__restrict__ disc_prev_in,
                                                             float2 *__restrict__ disc_prev_out, float *__restrict__ hist_out)
 {
-    constexpr int A = D / 4, C = D % 4, NL = 4 * D;            // NL: 8-byte loads per lane per block (256 D samples / 64 lanes)
-    constexpr int STG = df_stage_elems(D);
+    constexpr int A = D / 4, C = D % 4;
+    constexpr int NV = A > 0 ? A : 1, NC = C > 0 ? C : 1;
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     cf *flc = reinterpret_cast<cf *>(fl);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, u = lane & 15;
-    cf *stg = flc + wave * STG;
-    cf *ex = stg + df_ex_offset(D);
-    const cf *twA = flc + 4 * STG, *Gf = twA + 256, *Gl = Gf + A * 1024, *rotT = Gl + C * 256;
+    constexpr int WV = df_wave_elems(D);
+    cf *stg = flc + wave * WV, *ex = stg + df_ex_offset(D);
+    const cf *Gf = flc + 4 * WV, *Gl = Gf + A * 1024, *rotT = Gl + C * 256;
     const int M = p.M;
 
-    for (int i = tid; i < df_table_elems(D); i += 256) fl[4 * STG + i] = tables[i];
+    for (int i = tid; i < df_table_elems(D) - 256; i += 256) fl[4 * WV + i] = tables[256 + i];
+    cf tw[16];                                               // W_256^(u k): lane constants
+#pragma unroll
+    for (int k = 0; k < 16; k++) tw[k] = cf_from(tables[k * 16 + u]);
     // history carry: last M-1 raw input samples into the other ping-pong buffer
     if (hist_out && blockIdx.x == 0)
         for (int i = tid; i < (M - 1) * 2; i += 256) hist_out[i] = stream_at<2>(hist, x, p.n + i / 2, i % 2, M, p.n);
     __syncthreads();
 
     const long nquads = (p.nblocks + 3) / 4;
-    const float2 *xc = reinterpret_cast<const float2 *>(x);
+    const float2 *xc = reinterpret_cast<const float2 *>(x), *hc = reinterpret_cast<const float2 *>(hist);
+    // window position j of block b <-> x index block_xs(b) + j;  phase rho sample mm sits at j = D mm + rho
+    auto block_xs = [&](long b) { return p.first + (long)D * (b * DF_LO - DF_V) - (D - 1); };
+    // ---- register prefetch of one block: pre[c] = window[64 c + lane], coalesced
+    constexpr int NL = 4 * D;                              // 8-byte loads per lane per block (256 D samples / 64 lanes)
+    constexpr int NPRE = NL <= 24 ? NL : NL / 2;           // registers spent on the prefetch; the rest of a long window loads late
+    cf pre[NPRE];
+    bool have = false;               // pre holds the next block (interior blocks only; edge blocks are staged late, below)
+    auto prefetch = [&](long b) {
+        const long xs = block_xs(b);
+        have = b < p.nblocks && xs >= 0 && xs + DF_N * D <= p.n;
+        if (have && !(p.dbg & 1)) {
+            const float2 *src = xc + xs + lane;
+#pragma unroll
+            for (int c = 0; c < NPRE; c++) pre[c] = cf_from(src[64 * c]);
+        }
+    };
+    prefetch((((long)blockIdx.x * p.rounds) * 4 + wave) * 4);
     for (int r = 0; r < p.rounds; r++) {
         const long quad = ((long)blockIdx.x * p.rounds + r) * 4 + wave;
         if (quad >= nquads) break;
         float T[4][8];                   // per block: partial sums over the full batches, 8 floats per lane after the row reduction
-        cf left[C > 0 ? C : 1][4][4];    // left-over phases: [c][block][cc] = sample mm = 16 (4 g + cc) + u of phase 4A + c
+        cf left[NC][4][4];               // left-over phases: [c][block][cc] = sample mm = 16 (4 g + cc) + u of phase 4A + c
 #pragma unroll
         for (int bq = 0; bq < 4; bq++) {
             const long b = quad * 4 + bq;
-            // ---- stage the block's 256 D input samples: window position j <-> x index xs + j
-            const long xs = p.first + (long)D * (b * DF_LO - DF_V) - (D - 1);
-            if (b < p.nblocks) {
-                cf ld[NL];
-                if (xs >= 0 && xs + DF_N * D <= p.n) {
+            // ---- stage the block's window in natural order.  Blocks past the end of a ragged last quad compute on whatever the
+            // window holds: rows never mix blocks and nothing of theirs is stored.
+            if (have && !(p.dbg & 2)) {
 #pragma unroll
-                    for (int c = 0; c < NL; c++) ld[c] = cf_from(xc[xs + 64 * c + lane]);
-                } else {
+                for (int c = 0; c < NPRE; c++) stg[64 * c + lane] = pre[c];
+                if (NPRE < NL) {
+                    const float2 *src = xc + block_xs(b) + lane;
 #pragma unroll
-                    for (int c = 0; c < NL; c++) {
-                        const long ps = xs + 64 * c + lane + (M - 1);        // stream position ([M-1 history | chunk]); before the history: 0
-                        ld[c] = cf{stream_at<2>(hist, x, ps, 0, M, p.n), stream_at<2>(hist, x, ps, 1, M, p.n)};
-                    }
+                    for (int c = NPRE; c < NL; c++) stg[64 * c + lane] = cf_from(src[64 * c]);
                 }
-#pragma unroll
-                for (int c = 0; c < NL; c++) stg[64 * c + lane] = ld[c];
+            } else if (b < p.nblocks) {
+                // edge blocks (touch the carried history, the zeros before it, or the end of the chunk): sample by sample, rolled
+                const long xs = block_xs(b);
+#pragma nounroll
+                for (int c = 0; c < NL; c++) stg[64 * c + lane] = df_sample_edge(hc, xc, xs + 64 * c + lane, M, p.n);
             }
-            // ---- full batches: row g transforms phase 4t + g (window position j = D mm + phase)
-            cf acc[16];
+            // ---- polyphase read-back: row g takes phase 4t + g, window position D mm + phase, mm = 16 i + u
+            cf cur[NV][16];
+            if (!(p.dbg & 2)) {
 #pragma unroll
-            for (int t = 0; t < A; t++) {
-                cf v[16];
-                if (b < p.nblocks) {
+                for (int t = 0; t < A; t++)
 #pragma unroll
-                    for (int i = 0; i < 16; i++) v[i] = stg[D * (16 * i + u) + 4 * t + g];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 16; i++) v[i] = cf{0.f, 0.f};
-                }
-                if (t == A - 1 && C > 0 && b < p.nblocks) {
-#pragma unroll
-                    for (int c = 0; c < C; c++)
-#pragma unroll
-                        for (int cc = 0; cc < 4; cc++) left[c][bq][cc] = stg[D * (16 * (4 * g + cc) + u) + 4 * A + c];
-                }
-                df_fft_fwd(ex, twA, v, g, u);
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const cf pr = cmul(v[k], Gf[t * 1024 + k * 64 + lane]);
-                    acc[k] = t == 0 ? pr : acc[k] + pr;
-                }
-            }
-            if (A == 0) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) acc[k] = cf{0.f, 0.f};
-                if (b < p.nblocks) {
-#pragma unroll
-                    for (int c = 0; c < C; c++)
-#pragma unroll
-                        for (int cc = 0; cc < 4; cc++) left[c][bq][cc] = stg[D * (16 * (4 * g + cc) + u) + c];
-                }
-            }
-            if (C > 0 && !(b < p.nblocks)) {
+                    for (int i = 0; i < 16; i++) cur[t][i] = stg[D * (16 * i + u) + 4 * t + g];
 #pragma unroll
                 for (int c = 0; c < C; c++)
 #pragma unroll
-                    for (int cc = 0; cc < 4; cc++) left[c][bq][cc] = cf{0.f, 0.f};
-            }
-            // ---- sum the four rows (phases): 32 floats -> 8 per lane; row g ends up with (Re Z[2t], Re Z[2t+1], Im Z[2t], Im Z[2t+1])[g]
+                    for (int cc = 0; cc < 4; cc++) left[c][bq][cc] = stg[D * (16 * (4 * g + cc) + u) + 4 * A + c];
+            } else {
 #pragma unroll
-            for (int t2 = 0; t2 < 8; t2++) {
-                float s0, s1;
-                {
-                    float a = acc[2 * t2].x, c = acc[2 * t2].y;
-                    swap32(a, c);
-                    s0 = a + c;
+                for (int t = 0; t < A; t++)
+#pragma unroll
+                    for (int i = 0; i < 16; i++) cur[t][i] = pre[(i + t) % NPRE];
+#pragma unroll
+                for (int c = 0; c < C; c++)
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) left[c][bq][cc] = pre[(16 + cc + c) % NPRE];
+            }
+            prefetch(bq < 3 ? b + 1 : (r + 1 < p.rounds ? (quad + 4) * 4 : p.nblocks));
+            if (A > 0 && (p.dbg & 4)) {
+#pragma unroll
+                for (int t2 = 0; t2 < 8; t2++) T[bq][t2] = cur[0][t2].x + cur[0][t2 + 8].y;
+            } else if (A > 0) {
+                // ---- full batches: row g transforms phase 4t + g
+                cf acc[16];
+#pragma unroll
+                for (int t = 0; t < A; t++) {
+                    dft16<1>(cur[t]);
+#pragma unroll
+                    for (int k = 1; k < 16; k++) cur[t][k] = cmul(cur[t][k], tw[k]);
+                    df_transpose(ex, cur[t], g, u);
+                    cf G[16];                               // requested before the second dft16, needed after it
+#pragma unroll
+                    for (int k = 0; k < 16; k++) G[k] = Gf[t * 1024 + k * 64 + lane];
+                    __builtin_amdgcn_sched_barrier(0);
+                    dft16<1>(cur[t]);
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const cf pr = cmul(cur[t][k], G[k]);
+                        acc[k] = t == 0 ? pr : acc[k] + pr;
+                    }
                 }
-                {
-                    float a = acc[2 * t2 + 1].x, c = acc[2 * t2 + 1].y;
-                    swap32(a, c);
-                    s1 = a + c;
+                // ---- sum the four rows (phases): 32 floats -> 8 per lane; row g keeps (Re Z[2t], Re Z[2t+1], Im Z[2t], Im Z[2t+1])[g]
+#pragma unroll
+                for (int t2 = 0; t2 < 8; t2++) {
+                    float a0 = acc[2 * t2].x, c0 = acc[2 * t2].y, a1 = acc[2 * t2 + 1].x, c1 = acc[2 * t2 + 1].y;
+                    swap32(a0, c0);
+                    swap32(a1, c1);
+                    float s0 = a0 + c0, s1 = a1 + c1;
+                    swap16(s0, s1);
+                    T[bq][t2] = s0 + s1;
                 }
-                swap16(s0, s1);
-                T[bq][t2] = s0 + s1;
             }
         }
         // ---- bring block b's sums to row b
         cf z[16];
+        if (A > 0) {
 #pragma unroll
-        for (int t2 = 0; t2 < 8; t2++) {
-            transpose_rows(T[0][t2], T[1][t2], T[2][t2], T[3][t2]);
-            z[2 * t2] = cf{T[0][t2], T[2][t2]};
-            z[2 * t2 + 1] = cf{T[1][t2], T[3][t2]};
+            for (int t2 = 0; t2 < 8; t2++) {
+                transpose_rows(T[0][t2], T[1][t2], T[2][t2], T[3][t2]);
+                z[2 * t2] = cf{T[0][t2], T[2][t2]};
+                z[2 * t2 + 1] = cf{T[1][t2], T[3][t2]};
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) z[k] = cf{0.f, 0.f};
         }
         // ---- left-over phases of the four blocks, row b = block b
 #pragma unroll
@@ -270,12 +313,20 @@ __global__ __launch_bounds__(256, 2) void fir_decfft_kernel(const float *__restr
                 v[8 + cc] = cf{r2, i2};
                 v[12 + cc] = cf{r3, i3};
             }
-            df_fft_fwd(ex, twA, v, g, u);
+            dft16<1>(v);
 #pragma unroll
-            for (int k = 0; k < 16; k++) z[k] = z[k] + cmul(v[k], Gl[c * 256 + k * 16 + u]);
+            for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw[k]);
+            df_transpose(ex, v, g, u);
+            cf G[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) G[k] = Gl[c * 256 + k * 16 + u];
+            __builtin_amdgcn_sched_barrier(0);
+            dft16<1>(v);
+#pragma unroll
+            for (int k = 0; k < 16; k++) z[k] = z[k] + cmul(v[k], G[k]);
         }
         // ---- inverse: row g = block quad*4 + g; z[i] = output window position w = 16 i + u
-        df_fft_inv(ex, twA, z, g, u);
+        if (!(p.dbg & 8)) df_fft_inv(ex, tw, z, g, u);
         const long b = quad * 4 + g;
         const long k0 = b * DF_LO - DF_V;            // output index of window position 0
         if (b < p.nblocks) {
@@ -288,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void fir_decfft_kernel(const float *__restr
                     const long k = k0 + 16 * i + u;
                     cf o = z[i];
                     if (p.rot_step_fx) o = cmul(o, cmul(base, rotT[16 * i + u]));
-                    if (k < p.n_out) yo[k] = cf_to(o);
+                    if (k < p.n_out && (!(p.dbg & 32) || o.x == 12345.678f)) yo[k] = cf_to(o);
                 }
             } else {
 #pragma unroll
@@ -298,7 +349,8 @@ __global__ __launch_bounds__(256, 2) void fir_decfft_kernel(const float *__restr
                     if (k == 0) prev = *disc_prev_in;
                     const float2 cur = cf_to(z[i]);
                     if (k < p.n_out) {
-                        y[k] = df_discriminate(cur, prev, p.cD, p.inv_gain, p.rot_step_fx, p.rot_count0 + (uint64_t)(p.first + (long)D * k), D);
+                        const float dv = (p.dbg & 16) ? cur.x + prev.y : df_discriminate(cur, prev, p.cD, p.inv_gain, p.rot_step_fx, p.rot_count0 + (uint64_t)(p.first + (long)D * k), D);
+                        if (!(p.dbg & 32) || dv == 12345.678f) y[k] = dv;
                         if (k == p.n_out - 1) *disc_prev_out = cur;
                     }
                 }

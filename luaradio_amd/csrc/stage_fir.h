@@ -32,7 +32,7 @@ struct FirStage : lrhip_stage {
     DeviceBuf d_dec_tables;
     int dec_blocks_per_cu = 0;
     double rot_omega = 0.0;
-    static bool decfft_supported(unsigned d, int m, int s) { return s == 2 && (d == 2 || d == 4 || d == 5 || d == 8 || d == 10) && (m + (int)d - 1) / (int)d <= DF_V && m >= 8; }
+    static bool decfft_supported(unsigned d, int m, int s) { return s == 2 && (d == 2 || d == 4 || d == 5 || d == 8) && (m + (int)d - 1) / (int)d <= DF_V && m >= 8; }
     // fused FrequencyDiscriminatorBlock in front (chains): input is ComplexFloat32, the filter runs on arg(c[i] conj c[i-1])/gain
     bool hist_in_kernel = false;          // set by a launch that also wrote the next history buffer
     bool pre_disc = false;
@@ -270,6 +270,7 @@ struct FirStage : lrhip_stage {
         const double wD = rot ? rot_omega * (double)DD : 0.0;
         pr.cD = make_float2((float)std::cos(wD), (float)std::sin(wD));
         pr.inv_gain = 1.0 / disc_gain;
+        pr.dbg = getenv("LRHIP_DECFFT_DBG") ? atoi(getenv("LRHIP_DECFFT_DBG")) : 0;      // ablation knob (tools/ab_decfft.py)
         const float *h = (const float *)hist[cur].p + hist_pad;
         float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
         auto go = [&](auto kern) -> int {
@@ -298,8 +299,7 @@ struct FirStage : lrhip_stage {
             case 2: return launch_decfft_d<2>(x, n, y, n_out);
             case 4: return launch_decfft_d<4>(x, n, y, n_out);
             case 5: return launch_decfft_d<5>(x, n, y, n_out);
-            case 8: return launch_decfft_d<8>(x, n, y, n_out);
-            default: return launch_decfft_d<10>(x, n, y, n_out);
+            default: return launch_decfft_d<8>(x, n, y, n_out);
         }
     }
 

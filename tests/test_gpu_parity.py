@@ -478,7 +478,7 @@ def test_discriminator_epilogue_equals_unfused_blocks(decim):
 
 # ---- decimating filters in overlap-save form: the polyphase FFT kernel (kernels_firdecfft.h), the reference's own default
 # arithmetic (firfilter.lua:57, :320-398) - Float32 FFT, so the bar is the f64 oracle to 1e-6, not the fmaf chain bit for bit
-@pytest.mark.parametrize("factor", [2, 4, 5, 8, 10])
+@pytest.mark.parametrize("factor", [2, 4, 5, 8])
 @pytest.mark.parametrize("ntaps", [128, 33])
 def test_decimator_polyphase_fft_vs_f64_oracle(factor, ntaps):
     rng = np.random.default_rng(700 + factor + ntaps)

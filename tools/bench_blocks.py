@@ -78,8 +78,15 @@ def main():
     run("FMDeemphasis f32", mk(lr.FMDeemphasisFilterBlock, [75e-6], False, 220500.0), False, 8)
     run("Decimator(5) cf32 (fused FIR+downsample)", mk(lr.DecimatorBlock, [5], True), True, 8 + 8 / 5, 4 * 128 / 5)
     run("Tuner(-250k,200k,5) (fused rot+FIR+downsample)", mk(lr.TunerBlock, [-250e3, 200e3, 5], True), True, 8 + 8 / 5, 4 * 128 / 5 + 6)
+    run("Decimator(5) cf32, polyphase FFT overlap-save", mk(lr.DecimatorBlock, [5, {"use_fft": "fast"}], True), True, 8 + 8 / 5, 62)
+    run("Tuner(-250k,200k,5), polyphase FFT overlap-save", mk(lr.TunerBlock, [-250e3, 200e3, 5, {"use_fft": "fast"}], True), True, 8 + 8 / 5, 62)
     run("Interpolator(5) cf32 (polyphase, input samples)", mk(lr.InterpolatorBlock, [5], True), True, 8 + 8 * 5, 4 * 128)
     run("RationalResampler(3, 2) cf32 (polyphase, input samples)", mk(lr.RationalResamplerBlock, [3, 2], True), True, 8 + 8 * 1.5, 4 * 128 * 1.5 / 3)
+    rx0 = lr.wbfm_mono_receiver(1102500.0, -250e3, use_fft=False)
+    cap = rx0.max_output(n)
+    ms = timeit(lambda: rx0.process_device(xc.data_ptr(), n, out.data_ptr(), cap))
+    rows.append({"block": "WBFM mono chain, direct-form tuner (RF samples in)", "MS/s": round(n / ms / 1e3, 1), "alg_GB/s": round(8.16 * n / ms / 1e6, 1),
+                 "frac_8TB/s": round(8.16 * n / ms / 1e6 / 8000, 4), "ms": round(ms, 4), "TFLOP/s": None, "launches": rx0.chain.last_launches})
     rx = lr.wbfm_mono_receiver(1102500.0, -250e3)
     cap = rx.max_output(n)
     ms = timeit(lambda: rx.process_device(xc.data_ptr(), n, out.data_ptr(), cap))
