@@ -35,6 +35,9 @@
 //     consecutive outputs.
 // No cross-wave exchange at all: the discriminator's previous output z[k-1] of a block's first output is position V-1 of the
 // same transform (valid, because V - 1 >= ceil(M/D) - 1), so neither edge buffer nor fix-up launch exists.
+// Also measured and dropped: the window by LDS-DMA (global_load_lds_dwordx4, 10 KB per wave in flight, awaited with vmcnt(0) right
+// before its read-back; one 8-wave workgroup per CU): the arithmetic alone got faster (0.122 ms, no prefetch registers), but the
+// input arrived at 2.9 TB/s against 4.6 TB/s for plain 8-byte loads in the same skeleton, whatever the block order - 0.24 ms.
 // The next block's samples are requested before the current block's arithmetic (register prefetch); the 15 stage twiddles
 // W_256^(u k) depend on the lane only and stay in registers; the G rows are read from LDS one dft16 ahead of their use.
 // LDS: per wave the staged window (256 D complex; the 4 x 16 x 17 transpose area is laid over it when a block has one full
@@ -122,20 +125,49 @@ __device__ __forceinline__ float row_prev(float cur, float before)
     return __int_as_float(__builtin_amdgcn_update_dpp(wrapped, __float_as_int(cur), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
 }
 
-// discriminator on UNROTATED filter outputs: arg(a conj(b) cD) / gain, cD = e^{j w D}.  Zero products take the reference's
-// sign-of-zero path (frequencydiscriminator.lua:74 with complexfloat32.lua:79-81) on the rotated samples - out of line, it
-// only runs for the very first output of a stream (zero previous sample) or an exactly silent input.
-__device__ __noinline__ float df_discriminate_zero(float2 a, float2 b, double inv_gain, uint64_t step_fx, uint64_t n_abs, unsigned D)
+struct DfParams {
+    int M;
+    long n, n_out, first;          // chunk length, outputs, carried downsampler index
+    long nblocks;
+    int rounds;                    // quads per wave (one-shot order)
+    uint64_t rot_step_fx, rot_count0;   // rot_step_fx = 0: no rotation
+    float2 cD;                     // e^{j w D}
+    double inv_gain;
+    const float *taps_rev;         // reversed taps (direct-form order), M floats or M {re, im} pairs: exact re-evaluation of single outputs
+    int taps_complex;
+    int dbg;                       // ablation bits for tools/ab_decfft.py (0 in production): 1 no global loads, 2 no staging, 4 no forward batches, 8 no inverse, 16 no epilogue arithmetic, 32 no stores
+};
+
+// discriminator on UNROTATED filter outputs: arg(a conj(b) cD) / gain, cD = e^{j w D}.
+// A product that is exactly zero (the first output of a stream: zero previous sample; or exact silence) is decided in the reference by
+// the SIGNS of the zeros (frequencydiscriminator.lua:74 with complexfloat32.lua:79-81), i.e. by the signs of the filter output's
+// components - which sit at the 1e-6 level of the FFT arithmetic when the filter has just started.  That one output is therefore
+// re-evaluated in direct form (rotated samples, fmaf chain in the reference's tap order: bit-identical to kernels_fir.h), out of line.
+__device__ __noinline__ float df_discriminate_zero(float2 b, const DfParams &p, const float *__restrict__ hist, const float *__restrict__ x, long k, unsigned D)
 {
-    const float2 ar = step_fx ? rotate_sample(a, step_fx, n_abs) : a;
-    const float2 br = (step_fx && (b.x != 0.f || b.y != 0.f)) ? rotate_sample(b, step_fx, n_abs - D) : b;
-    return discriminate(ar, br, inv_gain);
+    const long q = p.first + k * (long)D;                  // stream position ([M-1 history | chunk]) of the first tap's sample
+    float re = 0.f, im = 0.f;
+    for (int j = 0; j < p.M; j++) {
+        float2 sv = make_float2(stream_at<2>(hist, x, q + j, 0, p.M, p.n), stream_at<2>(hist, x, q + j, 1, p.M, p.n));
+        if (p.rot_step_fx) sv = rotate_sample(sv, p.rot_step_fx, p.rot_count0 + (uint64_t)(q + j - (p.M - 1)));
+        if (p.taps_complex) {
+            const float hr = p.taps_rev[2 * j], hi = p.taps_rev[2 * j + 1];
+            re = fmaf(sv.x, hr, re); re = fmaf(sv.y, -hi, re);
+            im = fmaf(sv.x, hi, im); im = fmaf(sv.y, hr, im);
+        } else {
+            const float h = p.taps_rev[j];
+            re = fmaf(sv.x, h, re); im = fmaf(sv.y, h, im);
+        }
+    }
+    float2 br = b;
+    if (p.rot_step_fx && (b.x != 0.f || b.y != 0.f)) br = rotate_sample(b, p.rot_step_fx, p.rot_count0 + (uint64_t)(q - D));
+    return discriminate(make_float2(re, im), br, p.inv_gain);
 }
-__device__ __forceinline__ float df_discriminate(float2 a, float2 b, float2 cD, double inv_gain, uint64_t step_fx, uint64_t n_abs, unsigned D)
+__device__ __forceinline__ float df_discriminate(float2 a, float2 b, const DfParams &p, const float *__restrict__ hist, const float *__restrict__ x, long k, unsigned D)
 {
     const float tr = fmaf(a.x, b.x, a.y * b.y), ti = fmaf(a.y, b.x, -a.x * b.y);
-    if (__builtin_expect(tr == 0.f && ti == 0.f, 0)) return df_discriminate_zero(a, b, inv_gain, step_fx, n_abs, D);
-    return fast_atan2f(fmaf(tr, cD.y, ti * cD.x), fmaf(tr, cD.x, -ti * cD.y)) * (float)inv_gain;
+    if (__builtin_expect(tr == 0.f && ti == 0.f, 0)) return df_discriminate_zero(b, p, hist, x, k, D);
+    return fast_atan2f(fmaf(tr, p.cD.y, ti * p.cD.x), fmaf(tr, p.cD.x, -ti * p.cD.y)) * (float)p.inv_gain;
 }
 
 // one sample of the stream [.. zeros | M-1 history | chunk | zeros ..] by its x index, branch-free (edge blocks only)
@@ -147,16 +179,6 @@ __device__ __forceinline__ cf df_sample_edge(const float2 *__restrict__ hc, cons
     return (inx || inh) ? cf{v.x, v.y} : cf{0.f, 0.f};
 }
 
-struct DfParams {
-    int M;
-    long n, n_out, first;          // chunk length, outputs, carried downsampler index
-    long nblocks;
-    int rounds;                    // quads per wave (one-shot order)
-    uint64_t rot_step_fx, rot_count0;   // rot_step_fx = 0: no rotation
-    float2 cD;                     // e^{j w D}
-    double inv_gain;
-    int dbg;                       // ablation bits for tools/ab_decfft.py (0 in production): 1 no global loads, 2 no staging, 4 no forward batches, 8 no inverse, 16 no epilogue arithmetic, 32 no stores
-};
 
 // EPI 0: ComplexFloat32 out (rotated when p.rot_step_fx != 0).  EPI 1: Float32 out = discriminator of the rotated outputs.
 template <int D, int EPI>
@@ -349,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void fir_decfft_kernel(const float *__restr
                     if (k == 0) prev = *disc_prev_in;
                     const float2 cur = cf_to(z[i]);
                     if (k < p.n_out) {
-                        const float dv = (p.dbg & 16) ? cur.x + prev.y : df_discriminate(cur, prev, p.cD, p.inv_gain, p.rot_step_fx, p.rot_count0 + (uint64_t)(p.first + (long)D * k), D);
+                        const float dv = (p.dbg & 16) ? cur.x + prev.y : df_discriminate(cur, prev, p, hist, x, k, D);
                         if (!(p.dbg & 32) || dv == 12345.678f) y[k] = dv;
                         if (k == p.n_out - 1) *disc_prev_out = cur;
                     }

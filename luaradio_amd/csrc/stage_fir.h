@@ -213,7 +213,9 @@ struct FirStage : lrhip_stage {
                 const int rounds_env = getenv("LRHIP_FFT_ROUNDS") ? atoi(getenv("LRHIP_FFT_ROUNDS")) : -1;      // A/B knob
                 // one-shot order with 8 batches per workgroup once the launch exceeds the resident slots: 316 GS/s against 263-314
                 // (run-to-run spread) for the persistent stride on 2^28 samples, same box, alternating
-                int rounds = rounds_env >= 0 ? rounds_env : 8;
+                // (only when the launch is many times the resident slots: a 2^26-sample chain's 1/5-rate audio filter, 1 873 workgroups
+                // on 768 slots, keeps the persistent walk - 8 batches per workgroup would leave two thirds of the CUs idle)
+                int rounds = rounds_env >= 0 ? rounds_env : (want >= 8 * slots ? 8 : 0);
                 if (want <= slots) rounds = 0;
                 unsigned grid = rounds > 0 ? (unsigned)((want + rounds - 1) / rounds) : (unsigned)(want < slots ? want : slots);
                 const float2 *dp = pre_disc ? (const float2 *)disc_prev.p + disc_cur : nullptr;
@@ -270,6 +272,7 @@ struct FirStage : lrhip_stage {
         const double wD = rot ? rot_omega * (double)DD : 0.0;
         pr.cD = make_float2((float)std::cos(wD), (float)std::sin(wD));
         pr.inv_gain = 1.0 / disc_gain;
+        pr.taps_rev = (const float *)d_taps.p; pr.taps_complex = taps_complex;
         pr.dbg = getenv("LRHIP_DECFFT_DBG") ? atoi(getenv("LRHIP_DECFFT_DBG")) : 0;      // ablation knob (tools/ab_decfft.py)
         const float *h = (const float *)hist[cur].p + hist_pad;
         float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
@@ -277,8 +280,10 @@ struct FirStage : lrhip_stage {
             if (!dec_blocks_per_cu && prepare_kernel(kern, lds_bytes, &dec_blocks_per_cu)) return -1;
             const long nquads = (pr.nblocks + 3) / 4, slots = (long)ctx().num_cus * dec_blocks_per_cu;
             const int rounds_env = getenv("LRHIP_DECFFT_ROUNDS") ? atoi(getenv("LRHIP_DECFFT_ROUNDS")) : 0;      // A/B knob
-            // one-shot order (common.h grid_for); more quads per wave only once the launch is several times the resident slots
-            int rounds = rounds_env > 0 ? rounds_env : (nquads > 16 * slots ? 2 : 1);
+            // one-shot order (common.h grid_for): workgroups of 4 waves x `rounds` consecutive quads, handed out in address order.  More
+            // quads per wave amortise the table load and the first (unhidden) window request; same-box A/B at 2^26 samples:
+            // rounds 1 / 2 / 4 = 0.171 / 0.167 / 0.164 ms
+            int rounds = rounds_env > 0 ? rounds_env : (nquads >= 16 * slots ? 4 : nquads >= 8 * slots ? 2 : 1);
             pr.rounds = rounds;
             const long wgs = (nquads + 4L * rounds - 1) / (4L * rounds);
             float2 *dp = (float2 *)disc_prev.p;

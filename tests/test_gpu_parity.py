@@ -558,6 +558,29 @@ def test_discriminator_behind_polyphase_fft_filter(rotate):
     assert got[0] == ora[0] or abs(float(got[0]) - float(ora[0])) < 1e-6          # sign-of-zero case of the very first sample
 
 
+def test_polyphase_fft_first_output_follows_the_direct_form_sign_rule():
+    """The first discriminator output of a stream multiplies by the zero initial sample: the reference's result (0 or +-pi/gain) is
+    decided by the SIGNS of the first filter output's components, which sit below the FFT form's 1e-6 when the filter has just
+    started.  The kernel re-evaluates that one output in direct form: same value as the direct-form chain, bit for bit."""
+    rate = 1102500.0
+    rng = np.random.default_rng(77)
+    for trial in range(12):
+        x = rand_c(rng, 6000)
+        x[0] = np.complex64(complex(rng.choice([-1.0, 1.0]) * (1 + 0.01 * rng.uniform()), rng.choice([-1.0, 1.0]) * 10.0 ** rng.uniform(-9, -3)))
+
+        def chain(use_fft):
+            top = lr.CompositeBlock()
+            top.connect(lr.TunerBlock(-250e3, 200e3, 5, {"use_fft": use_fft}), lr.FrequencyDiscriminatorBlock(1.25))
+            top.rate = rate
+            top.differentiate([types.ComplexFloat32])
+            top.initialize()
+            return top
+
+        a, b = chain("fast").process(x), chain(False).process(x)
+        assert a[0] == b[0], (trial, a[0], b[0], x[0])
+        assert G.max_abs_err(a[40:], b[40:]) < 1e-5
+
+
 @pytest.mark.parametrize("order", [5, 6, 7, 8])
 def test_iir_orders_five_to_eight_scan_paths(order):
     """orders up to 8 run the scan kernels (the transition powers live in device memory); short-memory poles take the
