@@ -207,6 +207,19 @@ void *lrhip_chain_ring_input(lrhip_chain_t *c);
 long lrhip_chain_collect(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
 /* Chunks submitted and not yet collected. */
 int  lrhip_chain_in_flight(const lrhip_chain_t *c);
+/* Chunk coalescing on top of the ring (what a DeviceChainBlock's process() calls): LuaRadio hands blocks whatever a read() returned,
+ * 8 192 samples from a file source (radio/blocks/sources/iqfile.lua:52), up to 131 072 from a pipe (radio/core/pipe.lua:495-533) -
+ * far too little for one launch set.  push() appends the caller's vector to the pinned input of the current ring slot and returns at
+ * once; a slot is launched (H2D, kernels, D2H, asynchronously as for submit()) when it holds max_chunk samples, and the outputs of
+ * slots that have finished are copied to out_host in stream order.  Sample VALUES are those of lrhip_chain_execute() on the same
+ * stream (block state does not depend on chunking); only the emission is delayed, as the reference's own FFT filter delays its
+ * output (firfilter.lua:361-398).  Returns the number of output samples written (>= 0, possibly 0) or < 0.
+ * out_capacity must be at least lrhip_chain_push_bound(c, n_in).
+ * lrhip_chain_flush(): launch the partly filled slot, wait for everything in flight and return the remaining outputs
+ * (out_capacity >= lrhip_chain_push_bound(c, 0)); the chain can be pushed to again afterwards.  Call at EOF / cleanup(). */
+long lrhip_chain_push(lrhip_chain_t *c, const void *in_host, unsigned long n_in, void *out_host, unsigned long out_capacity);
+long lrhip_chain_flush(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
+unsigned long lrhip_chain_push_bound(const lrhip_chain_t *c, unsigned long n_in);
 /* Number of kernels launched by the last chain execute (diagnostic for the fusion tests). */
 int lrhip_chain_last_launches(const lrhip_chain_t *c);
 

@@ -69,6 +69,9 @@ SIGNATURES = {
     "lrhip_chain_ring_input": (_vp, [_vp]),
     "lrhip_chain_collect": (C.c_long, [_vp, _vp, _ul]),
     "lrhip_chain_in_flight": (C.c_int, [_vp]),
+    "lrhip_chain_push": (C.c_long, [_vp, _vp, _ul, _vp, _ul]),
+    "lrhip_chain_flush": (C.c_long, [_vp, _vp, _ul]),
+    "lrhip_chain_push_bound": (_ul, [_vp, _ul]),
     "lrhip_malloc": (_vp, [_ul]),
     "lrhip_free": (None, [_vp]),
     "lrhip_memcpy_h2d": (C.c_int, [_vp, _vp, _ul]),

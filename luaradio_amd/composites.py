@@ -73,9 +73,11 @@ class Chain:
 
     # ---- pipelined host path (ring of pinned + device slots; H2D / kernels / D2H of neighbouring chunks overlap)
     def set_ring(self, depth, max_chunk):
-        _lib.check(_lib.load().lrhip_chain_set_ring(self._chain, depth, max_chunk), "chain:set_ring")
-        self._ring_chunk = int(max_chunk)
-        self._ring_out = np.empty(max_chunk + 64, dtype=self.out_type.dtype)
+        L = _lib.load()
+        _lib.check(L.lrhip_chain_set_ring(self._chain, depth, max_chunk), "chain:set_ring")
+        self._ring_chunk, self._ring_depth = int(max_chunk), int(depth)
+        # sized by the library's own bound (interpolating chains and block-framed FIRs emit more than they take in)
+        self._ring_out = np.empty(L.lrhip_chain_push_bound(self._chain, max_chunk), dtype=self.out_type.dtype)
 
     def submit(self, x):
         x, count = self._count(x)
@@ -101,14 +103,33 @@ class Chain:
     def in_flight(self):
         return _lib.load().lrhip_chain_in_flight(self._chain)
 
-    def stream(self, chunks, depth=3):
-        """Run an iterable of input vectors through the ring, yielding the outputs in order."""
+    def stream(self, chunks):
+        """Run an iterable of input vectors through the ring (one slot per vector), yielding the outputs in order."""
         for x in chunks:
-            if self.in_flight == depth:
+            if self.in_flight == self._ring_depth:
                 yield self.collect()
             self.submit(x)
         while self.in_flight:
             yield self.collect()
+
+    # ---- chunk coalescing: small process() vectors accumulate in the ring slot until it holds max_chunk samples
+    def push(self, x):
+        """Append one input vector; returns the outputs of the batches that have finished (possibly empty)."""
+        L = _lib.load()
+        x, count = self._count(x)
+        need = L.lrhip_chain_push_bound(self._chain, count)
+        if len(self._ring_out) < need:
+            self._ring_out = np.empty(need, dtype=self.out_type.dtype)
+        n = L.lrhip_chain_push(self._chain, x.ctypes.data_as(C.c_void_p), count, self._ring_out.ctypes.data_as(C.c_void_p), len(self._ring_out))
+        _lib.check(n, "chain:push")
+        return self._ring_out[:n].copy()
+
+    def flush(self):
+        """Launch the partly filled batch, wait, return everything still pending (EOF / cleanup)."""
+        L = _lib.load()
+        n = L.lrhip_chain_flush(self._chain, self._ring_out.ctypes.data_as(C.c_void_p), len(self._ring_out))
+        _lib.check(n, "chain:flush")
+        return self._ring_out[:n].copy()
 
 
 class CompositeBlock(Block):

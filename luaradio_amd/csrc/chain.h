@@ -24,7 +24,8 @@ struct lrhip_chain {
         long n_out = 0;
     };
     std::vector<std::unique_ptr<Slot>> ring;
-    unsigned long ring_chunk = 0;
+    unsigned long ring_chunk = 0, ring_out_cap = 0;      // input samples per slot; output samples a slot can hold
+    unsigned long fill = 0;                // lrhip_chain_push: samples accumulated in the head slot's pinned input, not yet launched
     unsigned head = 0, inflight = 0;       // next slot to submit into; chunks submitted and not collected
     hipStream_t s_in = nullptr, s_out = nullptr;
     ~lrhip_chain()

@@ -1,6 +1,7 @@
 // common.h - runtime plumbing for liblrhip.so: error channel, context/stream, device + pinned buffers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -42,6 +43,7 @@ inline int set_error(const char *fmt, ...)
 // ---- context: lazily created after fork (SURVEY.md section 7 hard part 2) -----------------------------------
 struct Context {
     bool ready = false;
+    long pid = 0;                   // process that created the stream: a forked child must not reuse the parent's handles
     int device = 0;
     int num_cus = 256;
     hipStream_t own_stream = nullptr;
@@ -55,7 +57,15 @@ inline Context &ctx()
 inline int ensure_init(int device = -1)
 {
     Context &c = ctx();
-    if (c.ready) return 0;
+    if (c.ready && c.pid == (long)getpid()) return 0;
+    if (c.ready) {
+        // forked since the stream was created (CompositeBlock forks one process per block after initialize(),
+        // radio/core/composite.lua:443 vs :569): the parent's stream handle means nothing here - forget it (do not destroy it:
+        // it belongs to the parent's context) and build this process's own
+        c.ready = false;
+        c.own_stream = nullptr;
+        c.stream = nullptr;
+    }
     int count = 0;
     LR_HIP(hipGetDeviceCount(&count));
     if (count < 1) return set_error("no HIP device visible");
@@ -69,6 +79,7 @@ inline int ensure_init(int device = -1)
     c.num_cus = prop.multiProcessorCount;
     LR_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
     c.stream = c.own_stream;
+    c.pid = (long)getpid();
     c.ready = true;
     return 0;
 }

@@ -604,6 +604,7 @@ int lrhip_chain_reset(lrhip_chain_t *c)
 {
     if (!c) return set_error("null chain");
     if (c->inflight) return set_error("chain reset: %u chunks still in flight", c->inflight);
+    c->fill = 0;
     if (ctx().ready) LR_HIP(hipStreamSynchronize(ctx().stream));
     for (auto &o : c->ops)
         if (o.stage->reset()) return -1;
@@ -659,6 +660,20 @@ int lrhip_chain_last_launches(const lrhip_chain_t *c) { return c ? c->last_launc
 
 int lrhip_chain_in_flight(const lrhip_chain_t *c) { return c ? (int)c->inflight : set_error("null chain"); }
 
+// Upper bound on what a stage emits for n inputs in ANY carried state (max_output() is evaluated in the current state).
+static unsigned long stage_output_bound(const lrhip_stage *s, unsigned long n)
+{
+    unsigned long m = s->max_output(n);
+    if (const FirStage *f = dynamic_cast<const FirStage *>(s))
+        if (f->use_fft) m = n + (unsigned long)f->L;            // block-emission framing: up to L - 1 retained samples come out as well
+    return (m > n ? m : n) + 64;
+}
+static unsigned long chain_output_bound(const lrhip_chain *c, unsigned long n)
+{
+    for (auto &o : c->ops) n = stage_output_bound(o.stage, n);
+    return n;
+}
+
 int lrhip_chain_set_ring(lrhip_chain_t *c, unsigned depth, unsigned long max_chunk)
 {
     if (!c) return set_error("null chain");
@@ -671,9 +686,9 @@ int lrhip_chain_set_ring(lrhip_chain_t *c, unsigned depth, unsigned long max_chu
     LR_HIP(hipStreamSynchronize(ctx().stream));
     c->ring.clear();
     int in_size = c->ops.front().stage->in_size, out_size = c->ops.back().stage->out_size;
-    // bound on the output of one chunk whatever the carried state (rate-changing stages may emit one extra sample)
-    unsigned long max_out = lrhip_chain_max_output(c, max_chunk) + 64;
-    if (max_out < max_chunk + 64) max_out = max_chunk + 64;
+    // bound on the output of one chunk WHATEVER the carried state: rate-changing stages may emit one extra sample, a FIR with the
+    // reference's block-emission framing up to a whole retained block (L - 1 samples) more than its stateless max_output() says
+    unsigned long max_out = chain_output_bound(c, max_chunk);
     for (unsigned i = 0; i < depth; i++) {
         std::unique_ptr<lrhip_chain::Slot> sl(new (std::nothrow) lrhip_chain::Slot());
         if (!sl) return set_error("out of memory");
@@ -687,11 +702,12 @@ int lrhip_chain_set_ring(lrhip_chain_t *c, unsigned depth, unsigned long max_chu
     // size the device-resident edges once, so no reallocation happens while chunks are in flight
     unsigned long nmax = max_chunk;
     for (size_t k = 0; k + 1 < c->ops.size(); k++) {
-        unsigned long grow = c->ops[k].stage->max_output(nmax);
-        nmax = (grow > nmax ? grow : nmax) + 64;
+        nmax = stage_output_bound(c->ops[k].stage, nmax);
         if (c->edges[k]->reserve((size_t)nmax * c->ops[k].stage->out_size + 16)) return -1;
     }
     c->ring_chunk = max_chunk;
+    c->ring_out_cap = max_out;
+    c->fill = 0;
     c->head = 0;
     c->inflight = 0;
     return 0;
@@ -703,6 +719,7 @@ long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_i
     if (c->ring.empty()) return set_error("chain has no ring: call lrhip_chain_set_ring first");
     if (n_in > c->ring_chunk) return set_error("chunk of %lu samples exceeds the ring's max_chunk %lu", n_in, c->ring_chunk);
     if (c->inflight == c->ring.size()) return set_error("ring full: collect a chunk first (%u in flight)", c->inflight);
+    if (c->fill) return set_error("chain has %lu pushed samples pending: flush before mixing submit() with push()", c->fill);
     lrhip_chain::Slot &sl = *c->ring[c->head];
     if (n_in && !in_host) return set_error("null input buffer");
     int in_size = c->ops.front().stage->in_size, out_size = c->ops.back().stage->out_size;
@@ -748,6 +765,93 @@ long lrhip_chain_collect(lrhip_chain_t *c, void *out_host, unsigned long out_cap
     if (sl.n_out) memcpy(out_host, sl.h_out.p, (size_t)sl.n_out * c->ops.back().stage->out_size);
     c->inflight--;
     return sl.n_out;
+}
+
+// ---- chunk coalescing on the ring ---------------------------------------------------------------------------------
+// launch the head slot with its `fill` accumulated samples (they already sit in the slot's pinned input)
+static long push_launch(lrhip_chain_t *c)
+{
+    unsigned long n = c->fill;
+    c->fill = 0;
+    return lrhip_chain_submit(c, c->ring[c->head]->h_in.p, n);
+}
+// copy the oldest slot's output out (waiting for it when `wait`); returns samples copied, -2 when it is not finished yet
+static long push_collect(lrhip_chain_t *c, char *out, unsigned long cap, bool wait)
+{
+    unsigned tail = (c->head + (unsigned)c->ring.size() - c->inflight) % c->ring.size();
+    lrhip_chain::Slot &sl = *c->ring[tail];
+    if (!wait) {
+        hipError_t q = hipEventQuery(sl.ev_out);
+        if (q == hipErrorNotReady) return -2;
+        if (q != hipSuccess) return set_error("hipEventQuery failed: %s", hipGetErrorString(q));
+    }
+    return lrhip_chain_collect(c, out, cap);
+}
+
+unsigned long lrhip_chain_push_bound(const lrhip_chain_t *c, unsigned long n_in)
+{
+    if (!c || c->ring.empty()) return 0;
+    // every slot in flight, the head slot, and the slots this call itself can fill
+    return (unsigned long)(c->ring.size() + 1 + n_in / c->ring_chunk + 1) * c->ring_out_cap;
+}
+
+long lrhip_chain_push(lrhip_chain_t *c, const void *in_host, unsigned long n_in, void *out_host, unsigned long out_capacity)
+{
+    if (!c) return set_error("null chain");
+    if (c->ring.empty()) return set_error("chain has no ring: call lrhip_chain_set_ring first");
+    if (n_in && !in_host) return set_error("null input buffer");
+    if (out_capacity < lrhip_chain_push_bound(c, n_in)) return set_error("output capacity %lu < lrhip_chain_push_bound() = %lu", out_capacity, lrhip_chain_push_bound(c, n_in));
+    const int in_size = c->ops.front().stage->in_size, out_size = c->ops.back().stage->out_size;
+    const char *src = (const char *)in_host;
+    char *dst = (char *)out_host;
+    long total = 0;
+    while (n_in) {
+        if (c->inflight == c->ring.size()) {                 // the head slot is still in flight: its turn to be collected
+            long got = push_collect(c, dst + (size_t)total * out_size, out_capacity - (unsigned long)total, true);
+            if (got < 0) return got;
+            total += got;
+        }
+        unsigned long take = c->ring_chunk - c->fill;
+        if (take > n_in) take = n_in;
+        memcpy((char *)c->ring[c->head]->h_in.p + (size_t)c->fill * in_size, src, (size_t)take * in_size);
+        c->fill += take; src += (size_t)take * in_size; n_in -= take;
+        if (c->fill == c->ring_chunk) {
+            long rc = push_launch(c);
+            if (rc < 0) return rc;
+        }
+    }
+    while (c->inflight) {                                    // whatever has finished meanwhile, in stream order, without waiting
+        long got = push_collect(c, dst + (size_t)total * out_size, out_capacity - (unsigned long)total, false);
+        if (got == -2) break;
+        if (got < 0) return got;
+        total += got;
+    }
+    return total;
+}
+
+long lrhip_chain_flush(lrhip_chain_t *c, void *out_host, unsigned long out_capacity)
+{
+    if (!c) return set_error("null chain");
+    if (c->ring.empty()) return 0;                           // nothing is ever pending without a ring
+    if (out_capacity < lrhip_chain_push_bound(c, 0)) return set_error("output capacity %lu < lrhip_chain_push_bound() = %lu", out_capacity, lrhip_chain_push_bound(c, 0));
+    const int out_size = c->ops.back().stage->out_size;
+    char *dst = (char *)out_host;
+    long total = 0;
+    if (c->fill) {
+        if (c->inflight == c->ring.size()) {
+            long got = push_collect(c, dst, out_capacity, true);
+            if (got < 0) return got;
+            total += got;
+        }
+        long rc = push_launch(c);
+        if (rc < 0) return rc;
+    }
+    while (c->inflight) {
+        long got = push_collect(c, dst + (size_t)total * out_size, out_capacity - (unsigned long)total, true);
+        if (got < 0) return got;
+        total += got;
+    }
+    return total;
 }
 
 // ---- memory helpers ----------------------------------------------------------------------------------------

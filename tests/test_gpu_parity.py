@@ -1392,7 +1392,7 @@ def test_chain_ring_pipelined_equals_synchronous():
     for depth in (1, 2, 4):
         rx = lr.wbfm_mono_receiver(fs, -250e3)
         rx.chain.set_ring(depth, 131072)
-        got = list(rx.chain.stream(chunks, depth=depth))
+        got = list(rx.chain.stream(chunks))
         assert len(got) == len(want)
         for g, w in zip(got, want):
             assert np.array_equal(g, w)
@@ -1409,6 +1409,74 @@ def test_chain_ring_pipelined_equals_synchronous():
     with pytest.raises(lr.LrhipError):
         rx.chain.submit(x[:10])
     rx.chain.collect(); rx.chain.collect()
+
+
+def test_chain_push_coalesces_small_chunks_values_unchanged():
+    """lrhip_chain_push / _flush: the reference's chunk sizes (8 192 samples from a file source, iqfile.lua:52; anything up to
+    131 072 from a pipe, pipe.lua:495-533) accumulate in the pinned ring slot and run as batches of max_chunk; the concatenated
+    output equals the synchronous per-chunk path sample for sample, emission only delayed; flush() returns the tail and the chain
+    keeps working afterwards"""
+    rng = np.random.default_rng(71)
+    fs = 1102500.0
+    x = rand_c(rng, 900001)
+    whole = lr.wbfm_mono_receiver(fs, -250e3).process(x)
+
+    def batched(a_end, batch):
+        """the synchronous path on the batches push() forms: cuts every `batch` samples up to the first flush, then again after it"""
+        ref, parts = lr.wbfm_mono_receiver(fs, -250e3), []
+        for lo, hi in ((0, a_end), (a_end, len(x))):
+            for k in range(lo, hi, batch):
+                parts.append(ref.process(x[k:min(k + batch, hi)]))
+        return np.concatenate(parts)
+
+    for depth, batch, sizes in ((3, 1 << 16, [8192] * 40 + [1, 0, 4095, 131072, 70000]), (2, 50000, [8192] * 109), (1, 1 << 17, [131072, 8192, 300000])):
+        rx = lr.wbfm_mono_receiver(fs, -250e3)
+        rx.chain.set_ring(depth, batch)
+        outs, a, emitted_early = [], 0, 0
+        for sz in sizes:
+            o = rx.chain.push(x[a:a + sz])
+            a += sz
+            outs.append(o)
+            emitted_early += len(o)
+        outs.append(rx.chain.flush())
+        assert len(rx.chain.flush()) == 0 and rx.chain.in_flight == 0
+        rest = rx.chain.push(x[a:])                 # still usable after a flush
+        outs += [rest, rx.chain.flush()]
+        got = np.concatenate(outs)
+        assert emitted_early > 0 or a < batch
+        # identical to the synchronous path on the same batches, bit for bit; and to one whole-vector call up to the Float32 rounding
+        # with which the overlap-save audio filter and the scan-form de-emphasis depend on where their blocks start
+        assert len(got) == len(whole) and np.array_equal(got, batched(a, batch))
+        assert G.max_abs_err(got, whole) < 1e-6
+
+
+def test_ring_output_sized_for_chains_that_emit_more_than_they_take():
+    """an interpolating chain and a FIR with the reference's block-emission framing both emit more samples for a chunk
+    than it holds (up to L - 1 retained ones); the ring's slots must be sized for that"""
+    rng = np.random.default_rng(72)
+    x = rand_c(rng, 40000)
+    interp = make(lr.InterpolatorBlock, [4], x)
+    want = interp.process(x)
+    interp2 = make(lr.InterpolatorBlock, [4], x)
+    interp2.chain.set_ring(2, 8192)
+    got = np.concatenate(list(interp2.chain.stream([x[a:a + 8192] for a in range(0, len(x), 8192)])))
+    assert np.array_equal(got, want)
+    taps = O.firwin_lowpass(128, 0.2).astype(np.float32)
+    framed = lr.Chain([make(lr.FIRFilterBlock, [taps, True], x)])          # use_fft = True: whole blocks of L = 897 only
+    ref = make(lr.FIRFilterBlock, [taps, True], x)
+    sizes = [100, 800, 5000, 896, 898, 12000, 3]
+    framed.set_ring(3, 12000)
+    chunks, a = [], 0
+    for sz in sizes:
+        chunks.append(x[a:a + sz])
+        a += sz
+    want = [ref.process(c) for c in chunks]
+    got = list(framed.stream(chunks))                       # one ring slot per chunk: identical chunking, identical bits
+    assert [len(g) for g in got] == [len(w) for w in want] and any(len(w) > len(c) for w, c in zip(want, chunks))
+    assert np.array_equal(np.concatenate(got), np.concatenate(want))
+    framed.reset()
+    pushed = np.concatenate([framed.push(c) for c in chunks] + [framed.flush()])       # batches of 12 000: other block starts, same values to rounding
+    assert len(pushed) == len(np.concatenate(want)) and G.max_abs_err(pushed, np.concatenate(want)) < 1e-6
 
 
 def test_error_paths_report_through_strerror():
@@ -1436,7 +1504,7 @@ def test_create_destroy_many_stages_returns_device_memory():
         rx = lr.wbfm_mono_receiver(1102500.0, -250e3)
         rx.process(x)
         rx.chain.set_ring(3, 1 << 16)
-        list(rx.chain.stream([x[:1 << 16]] * 4, depth=3))
+        list(rx.chain.stream([x[:1 << 16]] * 4))
         blk = make(lr.FIRFilterBlock, [O.firwin_lowpass(128, 0.2).astype(np.float32), "fast"], x)
         blk.process(x)
         w = lr.spectrum_utils.WelchSpectrum(types.ComplexFloat32, 1024, "hamming", 1e6, 0.5)
