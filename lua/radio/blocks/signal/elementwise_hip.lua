@@ -1,9 +1,10 @@
 ---
 -- Device variants of FrequencyTranslatorBlock (radio/blocks/signal/frequencytranslator.lua:32-53),
--- DownsamplerBlock (downsampler.lua:40-56), FrequencyDiscriminatorBlock (frequencydiscriminator.lua:33-64)
--- and IIRFilterBlock (iirfilter.lua:79-109). Each is the `if platform.features.hip then` branch of the
--- corresponding file; instantiate() and type signatures are unchanged.  Stages are created lazily on the
--- first process() because initialize() runs pre-fork (radio/core/composite.lua:443 vs :569).
+-- DownsamplerBlock (downsampler.lua:40-56), FrequencyDiscriminatorBlock (frequencydiscriminator.lua:33-64),
+-- IIRFilterBlock (iirfilter.lua:79-109) and the element-wise / one-tap blocks next to the path. Each is the
+-- `if platform.features.hip then` branch of the corresponding file; instantiate() and type signatures are unchanged.
+-- Every block gets create_stage() (lrhip.device_block): the stage is created lazily on the first process() because
+-- initialize() runs pre-fork (radio/core/composite.lua:443 vs :569), and DeviceChainBlock collects the same stages.
 
 local ffi = require('ffi')
 
@@ -12,13 +13,20 @@ local types = require('radio.types')
 
 local M = {}
 
-local function lazy(self, create)
-    if self.stage == nil then
-        lrhip.ensure()
-        self.stage = ffi.gc(lrhip.check_object(create(), "Creating lrhip " .. self.name .. " object"),
-                            lrhip.lib.lrhip_stage_destroy)
-    end
-    return self.stage
+local function is_complex(self)
+    return (self:get_input_type() == types.ComplexFloat32) and 1 or 0
+end
+
+-- one-input process(): execute the block's stage on the chunk
+local function process(self, x)
+    return lrhip.execute(self:create_stage(), x, self.out)
+end
+
+-- a numeric or ComplexFloat32 / Float32 constant -> re, im, is_complex (addconstant.lua:33-44, multiplyconstant.lua:33-44)
+local function split_constant(c)
+    if ffi.istype(types.ComplexFloat32, c) then return c.real, c.imag, 1 end
+    if type(c) == "number" then return c, 0, 0 end
+    return c.value, 0, 0
 end
 
 function M.patch_frequencytranslator(FrequencyTranslatorBlock)
@@ -26,46 +34,36 @@ function M.patch_frequencytranslator(FrequencyTranslatorBlock)
         self.omega = 2*math.pi*(self.offset/self:get_rate())
         self.out = types.ComplexFloat32.vector()
     end
-    function FrequencyTranslatorBlock:process(x)
-        local stage = lazy(self, function () return lrhip.lib.lrhip_rotator_create(self.omega) end)
-        return lrhip.execute(stage, x, self.out)
-    end
+    lrhip.device_block(FrequencyTranslatorBlock, function (self) return lrhip.lib.lrhip_rotator_create(self.omega) end)
+    FrequencyTranslatorBlock.process = process
 end
 
 function M.patch_downsampler(DownsamplerBlock)
     function DownsamplerBlock:initialize()
         self.out = self:get_input_type().vector()
     end
-    function DownsamplerBlock:process(x)
-        local stage = lazy(self, function ()
-            return lrhip.lib.lrhip_downsampler_create(self.factor, ffi.sizeof(self:get_input_type()))
-        end)
-        return lrhip.execute(stage, x, self.out)
-    end
+    lrhip.device_block(DownsamplerBlock, function (self)
+        return lrhip.lib.lrhip_downsampler_create(self.factor, ffi.sizeof(self:get_input_type()))
+    end)
+    DownsamplerBlock.process = process
 end
 
 function M.patch_frequencydiscriminator(FrequencyDiscriminatorBlock)
     function FrequencyDiscriminatorBlock:initialize()
         self.out = types.Float32.vector()
     end
-    function FrequencyDiscriminatorBlock:process(x)
-        local stage = lazy(self, function () return lrhip.lib.lrhip_fmdiscrim_create(self.gain) end)
-        return lrhip.execute(stage, x, self.out)
-    end
+    lrhip.device_block(FrequencyDiscriminatorBlock, function (self) return lrhip.lib.lrhip_fmdiscrim_create(self.gain) end)
+    FrequencyDiscriminatorBlock.process = process
 end
 
 function M.patch_iirfilter(IIRFilterBlock)
     function IIRFilterBlock:initialize()
         self.out = self:get_input_type().vector()
     end
-    local function process(self, x)
-        local stage = lazy(self, function ()
-            return lrhip.lib.lrhip_iir_create(ffi.cast("const float *", self.b_taps.data), self.b_taps.length,
-                                              ffi.cast("const float *", self.a_taps.data), self.a_taps.length,
-                                              (self:get_input_type() == types.ComplexFloat32) and 1 or 0)
-        end)
-        return lrhip.execute(stage, x, self.out)
-    end
+    lrhip.device_block(IIRFilterBlock, function (self)
+        return lrhip.lib.lrhip_iir_create(ffi.cast("const float *", self.b_taps.data), self.b_taps.length,
+                                          ffi.cast("const float *", self.a_taps.data), self.a_taps.length, is_complex(self))
+    end)
     IIRFilterBlock.process_complex = process
     IIRFilterBlock.process_real = process
 end
@@ -73,26 +71,16 @@ end
 -- One-input element-wise blocks (complexmagnitude.lua, complexphase.lua, complextoreal.lua, complextoimag.lua,
 -- complexconjugate.lua, realtocomplex.lua, absolutevalue.lua): M.patch_unary(ComplexMagnitudeBlock, "complexmagnitude")
 function M.patch_unary(Block, op)
-    function Block:process(x)
-        local stage = lazy(self, function ()
-            return lrhip.lib.lrhip_unary_create(op, 0, 0, 0, (self:get_input_type() == types.ComplexFloat32) and 1 or 0)
-        end)
-        return lrhip.execute(stage, x, self.out)
-    end
+    lrhip.device_block(Block, function (self) return lrhip.lib.lrhip_unary_create(op, 0, 0, 0, is_complex(self)) end)
+    Block.process = process
 end
 
 -- AddConstantBlock (addconstant.lua:26-75): the constant's type decides the arithmetic, as in the reference
 function M.patch_addconstant(AddConstantBlock)
-    local function process(self, x)
-        local stage = lazy(self, function ()
-            local c = self.constant
-            local cc = ffi.istype(types.ComplexFloat32, c)
-            return lrhip.lib.lrhip_unary_create("addconstant", cc and c.real or (type(c) == "number" and c or c.value),
-                                                cc and c.imag or 0, cc and 1 or 0,
-                                                (self:get_input_type() == types.ComplexFloat32) and 1 or 0)
-        end)
-        return lrhip.execute(stage, x, self.out)
-    end
+    lrhip.device_block(AddConstantBlock, function (self)
+        local re, im, cc = split_constant(self.constant)
+        return lrhip.lib.lrhip_unary_create("addconstant", re, im, cc, is_complex(self))
+    end)
     AddConstantBlock.process_complex_by_complex = process
     AddConstantBlock.process_complex_by_real = process
     AddConstantBlock.process_real_by_real = process
@@ -100,12 +88,10 @@ end
 
 -- DelayBlock (delay.lua:43-72), ComplexFloat32 / Float32 signatures
 function M.patch_delay(DelayBlock)
-    function DelayBlock:process(x)
-        local stage = lazy(self, function ()
-            return lrhip.lib.lrhip_delay_create(self.num_samples, ffi.sizeof(self:get_input_type()))
-        end)
-        return lrhip.execute(stage, x, self.out)
-    end
+    lrhip.device_block(DelayBlock, function (self)
+        return lrhip.lib.lrhip_delay_create(self.num_samples, ffi.sizeof(self:get_input_type()))
+    end)
+    DelayBlock.process = process
 end
 
 -- HilbertTransformBlock (hilberttransform.lua:100-160); self.hilbert_taps as computed by instantiate() (not reversed)
@@ -113,39 +99,30 @@ function M.patch_hilberttransform(HilbertTransformBlock)
     function HilbertTransformBlock:initialize()
         self.out = types.ComplexFloat32.vector()
     end
-    function HilbertTransformBlock:process(x)
-        local stage = lazy(self, function ()
-            return lrhip.lib.lrhip_hilbert_create(ffi.cast("const float *", self.hilbert_taps.data), self.hilbert_taps.length)
-        end)
-        return lrhip.execute(stage, x, self.out)
-    end
+    lrhip.device_block(HilbertTransformBlock, function (self)
+        return lrhip.lib.lrhip_hilbert_create(ffi.cast("const float *", self.hilbert_taps.data), self.hilbert_taps.length)
+    end)
+    HilbertTransformBlock.process = process
 end
 
 -- Two-input element-wise blocks (multiply.lua, multiplyconjugate.lua, add.lua, subtract.lua, floattocomplex.lua):
--- M.patch_binary(MultiplyBlock, "multiply")
+-- M.patch_binary(MultiplyBlock, "multiply").  Two inputs: not a member of linear device chains (DeviceChainBlock.collapse skips them).
 function M.patch_binary(Block, op)
-    local function process(self, x, y)
-        local stage = lazy(self, function ()
-            return lrhip.lib.lrhip_binary_create(op, (self:get_input_type() == types.ComplexFloat32) and 1 or 0)
-        end)
-        return lrhip.execute2(stage, x, y, self.out)
+    lrhip.device_block(Block, function (self) return lrhip.lib.lrhip_binary_create(op, is_complex(self)) end)
+    local function process2(self, x, y)
+        return lrhip.execute2(self:create_stage(), x, y, self.out)
     end
-    Block.process = process
-    Block.process_complex = process
-    Block.process_real = process
+    Block.process = process2
+    Block.process_complex = process2
+    Block.process_real = process2
 end
 
 -- MultiplyConstantBlock (multiplyconstant.lua:26-75), same constant-type rules as AddConstantBlock
 function M.patch_multiplyconstant(MultiplyConstantBlock)
-    local function process(self, x)
-        local stage = lazy(self, function ()
-            local c = self.constant
-            local cc = ffi.istype(types.ComplexFloat32, c)
-            return lrhip.lib.lrhip_multiply_constant_create(cc and c.real or (type(c) == "number" and c or c.value), cc and c.imag or 0,
-                                                            cc and 1 or 0, (self:get_input_type() == types.ComplexFloat32) and 1 or 0)
-        end)
-        return lrhip.execute(stage, x, self.out)
-    end
+    lrhip.device_block(MultiplyConstantBlock, function (self)
+        local re, im, cc = split_constant(self.constant)
+        return lrhip.lib.lrhip_multiply_constant_create(re, im, cc, is_complex(self))
+    end)
     MultiplyConstantBlock.process_complex_by_complex = process
     MultiplyConstantBlock.process_complex_by_real = process
     MultiplyConstantBlock.process_real_by_real = process
@@ -153,12 +130,10 @@ end
 
 -- UpsamplerBlock (upsampler.lua:45-53)
 function M.patch_upsampler(UpsamplerBlock)
-    function UpsamplerBlock:process(x)
-        local stage = lazy(self, function ()
-            return lrhip.lib.lrhip_upsampler_create(self.factor, ffi.sizeof(self:get_input_type()))
-        end)
-        return lrhip.execute(stage, x, self.out)
-    end
+    lrhip.device_block(UpsamplerBlock, function (self)
+        return lrhip.lib.lrhip_upsampler_create(self.factor, ffi.sizeof(self:get_input_type()))
+    end)
+    UpsamplerBlock.process = process
 end
 
 -- FrequencyModulatorBlock (frequencymodulator.lua:24-90)
@@ -166,21 +141,15 @@ function M.patch_frequencymodulator(FrequencyModulatorBlock)
     function FrequencyModulatorBlock:initialize()
         self.out = types.ComplexFloat32.vector()
     end
-    function FrequencyModulatorBlock:process(x)
-        local stage = lazy(self, function () return lrhip.lib.lrhip_fmmod_create(self.modulation_index) end)
-        return lrhip.execute(stage, x, self.out)
-    end
+    lrhip.device_block(FrequencyModulatorBlock, function (self) return lrhip.lib.lrhip_fmmod_create(self.modulation_index) end)
+    FrequencyModulatorBlock.process = process
 end
 
 -- AGCBlock (agc.lua:45-96): the two recurrences run as prefix scans on the device; alphas as computed in initialize()
 function M.patch_agc(AGCBlock)
-    local function process(self, x)
-        local stage = lazy(self, function ()
-            return lrhip.lib.lrhip_agc_create(self.power_alpha, self.gain_alpha, self.target, self.threshold,
-                                              (self:get_input_type() == types.ComplexFloat32) and 1 or 0)
-        end)
-        return lrhip.execute(stage, x, self.out)
-    end
+    lrhip.device_block(AGCBlock, function (self)
+        return lrhip.lib.lrhip_agc_create(self.power_alpha, self.gain_alpha, self.target, self.threshold, is_complex(self))
+    end)
     AGCBlock.process_real = process
     AGCBlock.process_complex = process
 end

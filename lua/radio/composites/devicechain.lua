@@ -1,21 +1,39 @@
 ---
 -- DeviceChainBlock: a maximal linear run of device-capable blocks collapsed into one block / one process /
 -- one lrhip_chain_t, so intermediate vectors never leave HBM (one H2D at the head, one D2H at the tail)
--- instead of crossing a UNIX socket per edge (radio/core/pipe.lua:53-69).
+-- instead of crossing a UNIX socket per edge (radio/core/pipe.lua:53-69), and adjacent stages fuse inside the library
+-- (rotator -> FIR -> downsampler -> discriminator = one launch).
 --
--- CompositeBlock:_prepare_to_run (radio/core/composite.lua:426) calls collapse() on the flattened
--- connection list right after _crawl_connections (:343): every run b1 -> b2 -> ... -> bk in which each
--- block has exactly one input, one output, a single downstream reader and an `lrhip_stage` constructor is
--- replaced by DeviceChainBlock(b1..bk).
+-- CompositeBlock:_prepare_to_run (radio/core/composite.lua:426) calls DeviceChainBlock.collapse() on the flattened
+-- connection table right after _crawl_connections (:434), before _connect_pipes (:437):
+--
+--     local all_connections = self:_crawl_connections()
+--     local device_chains = {}
+--     if platform.features.hip then
+--         all_connections, device_chains = require('radio.composites.devicechain').collapse(all_connections)
+--     end
+--     ...                                                  -- _connect_pipes, _validate_rates, _initialize: unchanged
+--     for _, chain in ipairs(device_chains) do chain:initialize() end      -- after self:_initialize() (:443)
+--
+-- Everything downstream (pipes, rate validation, the global evaluation order, control sockets, fork) sees an ordinary block.
+-- The member blocks stay in their composite's own evaluation order, so CompositeBlock:_initialize() still runs their
+-- host-side initialize() (tap design, omega); they simply no longer appear in the connection table, so they get no
+-- socket and no process.
 --
 -- @block DeviceChainBlock
 
 local ffi = require('ffi')
 
 local block = require('radio.core.block')
+local pipe = require('radio.core.pipe')
 local lrhip = require('radio.core.lrhip')
 
 local DeviceChainBlock = block.factory("DeviceChainBlock")
+
+-- batches the ring accumulates process() vectors into (samples), and its depth: IQFileSource hands over 8 192 samples per
+-- call (radio/blocks/sources/iqfile.lua:52), a pipe at most 131 072 (radio/core/pipe.lua:495-533)
+DeviceChainBlock.batch_samples = 1048576
+DeviceChainBlock.ring_depth = 3
 
 function DeviceChainBlock:instantiate(blocks)
     self.blocks = assert(blocks, "Missing argument #1 (blocks)")
@@ -28,31 +46,122 @@ function DeviceChainBlock:get_rate()
 end
 
 function DeviceChainBlock:initialize()
-    -- host-side initialisation of the members (tap design etc.); device objects are created post-fork
-    for _, b in ipairs(self.blocks) do b:initialize() end
+    -- the members' host-side initialize() (tap design etc.) has been run by their composite; device objects are created
+    -- post-fork, on the first process()
     self.out = self:get_output_type().vector()
     self.chain = nil
 end
 
 local function create_chain(self)
     lrhip.ensure()
+    local lib = lrhip.lib
     local stages = ffi.new("lrhip_stage_t *[?]", #self.blocks)
     for i, b in ipairs(self.blocks) do
-        stages[i-1] = b:create_stage()    -- each device block exposes its lazy constructor as create_stage()
+        stages[i-1] = b:create_stage()
     end
-    self.stages = stages
-    self.chain = ffi.gc(lrhip.check_object(lrhip.lib.lrhip_chain_create(stages, #self.blocks), "Creating lrhip chain object"),
-                        lrhip.lib.lrhip_chain_destroy)
+    self.stages = stages        -- keep the array (and through the members, the stages) alive as long as the chain
+    self.chain = ffi.gc(lrhip.check_object(lib.lrhip_chain_create(stages, #self.blocks), "Creating lrhip chain object"),
+                        lib.lrhip_chain_destroy)
+    if lib.lrhip_chain_set_ring(self.chain, self.ring_depth, self.batch_samples) ~= 0 then
+        error("lrhip_chain_set_ring: " .. ffi.string(lib.lrhip_strerror()))
+    end
 end
 
+-- process(): append the chunk to the current batch; returns the samples of the batches that have finished (an empty
+-- vector while the first ones are in flight - the reference's own FFT FIR delays its output the same way, firfilter.lua:361-398)
 function DeviceChainBlock:process(x)
     if self.chain == nil then create_chain(self) end
     local lib = lrhip.lib
-    local cap = tonumber(lib.lrhip_chain_max_output(self.chain, x.length))
+    local cap = tonumber(lib.lrhip_chain_push_bound(self.chain, x.length))
     self.out:resize(cap)
-    local n = tonumber(lib.lrhip_chain_execute(self.chain, x.data, x.length, self.out.data, cap))
-    if n < 0 then error("lrhip_chain_execute: " .. ffi.string(lib.lrhip_strerror())) end
+    local n = tonumber(lib.lrhip_chain_push(self.chain, x.data, x.length, self.out.data, cap))
+    if n < 0 then error("lrhip_chain_push: " .. ffi.string(lib.lrhip_strerror())) end
     return self.out:resize(n)
+end
+
+-- cleanup() runs when the input reached EOF (radio/core/block.lua:606): run the partly filled batch and hand the tail
+-- to the readers of the output port, as process() output would have been (block.lua:585-593)
+function DeviceChainBlock:cleanup()
+    if self.chain == nil then return end
+    local lib = lrhip.lib
+    local cap = tonumber(lib.lrhip_chain_push_bound(self.chain, 0))
+    self.out:resize(cap)
+    local n = tonumber(lib.lrhip_chain_flush(self.chain, self.out.data, cap))
+    if n < 0 then error("lrhip_chain_flush: " .. ffi.string(lib.lrhip_strerror())) end
+    if n > 0 then
+        local tail = self.out:resize(n)
+        for _, p in ipairs(self.outputs[1].pipes) do p:write(tail) end
+    end
+end
+
+-- a block the library can run as a chain stage: a device variant (create_stage), one input, one output
+local function chainable(b)
+    return type(b.create_stage) == "function" and #b.inputs == 1 and #b.outputs == 1
+end
+
+---
+-- Replace every maximal linear run of two or more chainable blocks in the flattened connection table
+-- {[InputPort] = OutputPort} (radio/core/composite.lua:343-384) by one DeviceChainBlock; returns the new table and the
+-- list of chain blocks created (to be initialized by the caller after the composite's own blocks).
+-- A run continues from block a to block b when a's output port has exactly one reader (b) and both are chainable.
+function DeviceChainBlock.collapse(connections)
+    -- readers of every output port
+    local readers = {}
+    for input, output in pairs(connections) do
+        readers[output] = readers[output] or {}
+        table.insert(readers[output], input)
+    end
+    local function sole_reader(b)       -- the block reading b's output port, if it is the only one
+        local r = readers[b.outputs[1]]
+        if r and #r == 1 then return r[1].owner end
+        return nil
+    end
+    local function sole_writer(b)       -- the block feeding b's input port
+        local output = connections[b.inputs[1]]
+        return output and output.owner or nil
+    end
+    local function links(a, b)          -- a -> b is an interior edge of a run
+        return a and b and chainable(a) and chainable(b) and sole_reader(a) == b
+    end
+
+    -- run heads: chainable blocks whose upstream edge is not a link
+    local seen, runs = {}, {}
+    for input, _ in pairs(connections) do
+        local b = input.owner
+        if not seen[b] and chainable(b) and not links(sole_writer(b), b) then
+            seen[b] = true
+            local run = {b}
+            while links(run[#run], sole_reader(run[#run])) do
+                run[#run + 1] = sole_reader(run[#run])
+                seen[run[#run]] = true
+            end
+            if #run >= 2 then runs[#runs + 1] = run end
+        end
+    end
+
+    local result, chains = {}, {}
+    for input, output in pairs(connections) do result[input] = output end
+    for _, run in ipairs(runs) do
+        local first, last = run[1], run[#run]
+        local chain = DeviceChainBlock(run)
+        chain:differentiate({first:get_input_type()})
+        -- upstream: the chain's input reads what the first member read
+        result[chain.inputs[1]] = connections[first.inputs[1]]
+        result[first.inputs[1]] = nil
+        -- downstream: every reader of the last member now reads the chain
+        for _, reader in ipairs(readers[last.outputs[1]] or {}) do
+            result[reader] = chain.outputs[1]
+        end
+        -- interior edges leave the table (no socket, no process); the members keep rate-only pipes so that their
+        -- get_rate() still walks upstream (radio/core/block.lua:383-390, radio/core/pipe.lua:36-38)
+        for i = 2, #run do
+            result[run[i].inputs[1]] = nil
+            run[i].inputs[1].pipe = pipe.Pipe(run[i-1].outputs[1], run[i].inputs[1])
+        end
+        first.inputs[1].pipe = {get_rate = function () return chain.inputs[1].pipe:get_rate() end}
+        chains[#chains + 1] = chain
+    end
+    return result, chains
 end
 
 return DeviceChainBlock

@@ -5,9 +5,11 @@
 -- same way radio/core/platform.lua:277-299 registers VOLK / liquid-dsp / FFTW3f: `platform.libs.hip` and
 -- `platform.features.hip`, with the `LUARADIO_DISABLE_HIP` escape hatch mirroring platform.lua:328-330.
 --
--- NOTE: LuaJIT is not installed in the build image, so this file is exercised only by the structural test
--- tests/test_host_cpu.py::test_lua_glue_declares_the_same_abi; the identical call sequence is exercised
--- through Python ctypes (luaradio_amd/_lib.py).
+-- NOTE: LuaJIT is not installed in the build image, so the Lua files cannot be executed there.  They are held to the
+-- C ABI and to each other by tests/test_lua_glue.py (a small Lua tokenizer: every lib.lrhip_* used is declared in the
+-- cdef below with the prototype of include/lrhip.h, every method called on a block is defined by a device variant or by
+-- the reference's Block class, every local function used is defined); the call sequence itself is replayed through
+-- Python ctypes (luaradio_amd/_lib.py) and through tools/host_path_driver.cpp.
 --
 -- @module radio.core.lrhip
 
@@ -70,6 +72,9 @@ long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_i
 void *lrhip_chain_ring_input(lrhip_chain_t *c);
 long lrhip_chain_collect(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
 int lrhip_chain_in_flight(const lrhip_chain_t *c);
+long lrhip_chain_push(lrhip_chain_t *c, const void *in_host, unsigned long n_in, void *out_host, unsigned long out_capacity);
+long lrhip_chain_flush(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
+unsigned long lrhip_chain_push_bound(const lrhip_chain_t *c, unsigned long n_in);
 
 void *lrhip_malloc(unsigned long bytes);
 void lrhip_free(void *dev_ptr);
@@ -122,6 +127,33 @@ function M.ensure()
         end
         initialized_pid = pid
     end
+end
+
+---
+-- Make `Block` a device block: `create(self)` returns a fresh lrhip_stage_t* built from the block's host-side
+-- parameters.  The stage is created lazily, in the process that runs the block (see ensure()), and exposed as
+-- Block:create_stage() - which is also what DeviceChainBlock collects to build one lrhip_chain_t for a run of blocks.
+function M.device_block(Block, create)
+    function Block:create_stage()
+        if self.stage == nil then
+            M.ensure()
+            self.stage = ffi.gc(M.check_object(create(self), "Creating lrhip " .. self.name .. " object"),
+                                M.lib.lrhip_stage_destroy)
+        end
+        return self.stage
+    end
+end
+
+---
+-- FIRFilterBlock's use_fft argument -> lrhip_fir_create's mode.  nil (the caller did not choose; the reference then
+-- picks FFT when FFTW is present, firfilter.lua:57) = 3, automatic: overlap-save arithmetic with one output per
+-- input from 48 taps up, direct form below.  true = 1, the reference's overlap-save INCLUDING its block-emission
+-- framing (firfilter.lua:361-398).  false = 0, direct form (bit-identical to the fmaf chain in tap order).
+-- "fast" = 2 and "auto" = 3 select the sample-exact overlap-save arithmetic explicitly.
+function M.fir_mode(use_fft)
+    if use_fft == nil or use_fft == "auto" then return 3 end
+    if use_fft == "fast" then return 2 end
+    return use_fft and 1 or 0
 end
 
 ---

@@ -525,8 +525,12 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
         static const bool no_disc_fusion = getenv("LRHIP_NO_DISC_FUSION") != nullptr;      // A/B knob
         unsigned after = j + 1 + (ds ? 1 : 0);
         // a filter that asked for overlap-save arithmetic keeps it when fused with a downsampler (polyphase FFT form, kernels_firdecfft.h)
-        const bool want_fft = fusable_fir && fir->fft_arith && ds && FirStage::decfft_supported((unsigned)ds->factor, fir->M, fir->S);
-        FmDiscrimStage *dsc_after = (!no_disc_fusion && fusable_fir && fir->S == 2 && !fir->taps_complex && (!fir->fft_arith || want_fft) && after < nstages)
+        // (only when the caller asked for it explicitly, mode 2: an automatic filter takes the direct form when it decimates - faster here)
+        const bool want_fft = fusable_fir && fir->fft_arith && fir->mode_req == 2 && ds && FirStage::decfft_supported((unsigned)ds->factor, fir->M, fir->S);
+        // overlap-save arithmetic the caller pinned (mode 2) stays; an automatic filter (mode 3) that gets a rotator or a downsampler
+        // fused takes the direct form, and then also the discriminator epilogue
+        const bool fft_pinned = fusable_fir && fir->fft_arith && !(fir->mode_req == 3 && (rot || ds));
+        FmDiscrimStage *dsc_after = (!no_disc_fusion && fusable_fir && fir->S == 2 && !fir->taps_complex && (!fft_pinned || want_fft) && after < nstages)
                                         ? dynamic_cast<FmDiscrimStage *>(stages[after]) : nullptr;
         if (fusable_fir && (rot || ds || dsc_after)) {
             unsigned D = ds ? (unsigned)ds->factor : 1;

@@ -29,6 +29,7 @@ struct FirStage : lrhip_stage {
     int fft_blocks_per_cu = 0;
     // decimating polyphase-FFT form (kernels_firdecfft.h): ComplexFloat32 stream, D >= 2, ceil(M / D) <= 32
     bool decfft = false;
+    int mode_req = 0;                     // use_fft as the caller passed it (0..3), before 3 = automatic was resolved
     DeviceBuf d_dec_tables;
     int dec_blocks_per_cu = 0;
     double rot_omega = 0.0;
@@ -474,10 +475,13 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
     if (!taps || ntaps < 1) { set_error("fir: need at least one tap"); return nullptr; }
     if (taps_complex && !input_complex) { set_error("fir: complex taps require ComplexFloat32 input (firfilter.lua:69-74)"); return nullptr; }
     if (decim < 1) { set_error("fir: decimation must be >= 1"); return nullptr; }
+    const int mode_req = use_fft;
     // decimating filters: overlap-save arithmetic exists in the polyphase form (kernels_firdecfft.h) for the complex stream
     bool want_decfft = false;
     if (decim > 1 && (use_fft == 2 || use_fft == 3)) {
-        want_decfft = FirStage::decfft_supported(decim, (int)ntaps, input_complex ? 2 : 1) && (use_fft == 2 || ntaps >= 32);
+        // automatic (3) keeps the direct form for decimating filters: on MI355X the Toeplitz MFMA kernel is the faster one there
+        // (Tuner + discriminator, 2^26 samples: 0.155 ms against 0.165 ms, same box) and it is bit-exact
+        want_decfft = use_fft == 2 && FirStage::decfft_supported(decim, (int)ntaps, input_complex ? 2 : 1);
         if (!want_decfft && use_fft == 2) { set_error("fir: no overlap-save form for %u taps at decimation %u on this input type", ntaps, decim); return nullptr; }
         use_fft = 0;
     }
@@ -488,7 +492,7 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
     if (ensure_init()) return nullptr;
     std::unique_ptr<FirStage> q(new (std::nothrow) FirStage());
     if (!q) { set_error("out of memory"); return nullptr; }
-    q->M = (int)ntaps; q->S = input_complex ? 2 : 1; q->taps_complex = taps_complex; q->D = decim;
+    q->M = (int)ntaps; q->S = input_complex ? 2 : 1; q->taps_complex = taps_complex; q->D = decim; q->mode_req = mode_req;
     q->use_fft = use_fft == 1; q->rot = rot;     // 1: reference emission framing; 2: FFT arithmetic, sample-exact emission
     q->in_size = q->out_size = 4 * q->S;
     int ts = taps_complex ? 2 : 1;

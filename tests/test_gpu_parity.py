@@ -1479,6 +1479,66 @@ def test_ring_output_sized_for_chains_that_emit_more_than_they_take():
     assert len(pushed) == len(np.concatenate(want)) and G.max_abs_err(pushed, np.concatenate(want)) < 1e-6
 
 
+def test_replay_of_devicechain_lua_call_sequence():
+    """The exact C-ABI call sequence lua/radio/composites/devicechain.lua makes for examples/rtlsdr_wbfm_mono.lua after
+    DeviceChainBlock.collapse(): lrhip_init, one create per member block in graph order with the arguments the Lua device variants
+    pass (use_fft nil -> mode 3), lrhip_chain_create, lrhip_chain_set_ring(depth 3, 2^20), then per process() call
+    lrhip_chain_push_bound + lrhip_chain_push with the file source's 8 192-sample chunks, lrhip_chain_flush in cleanup(),
+    lrhip_chain_destroy / lrhip_stage_destroy from ffi.gc - raw ctypes, no Python block classes.  Audio against the oracle chain."""
+    import ctypes as C
+    L = lr._lib.load()
+    fs, n = 1102500.0, 1 << 20
+    rng = np.random.default_rng(3)
+    t = np.arange(n) / fs
+    m = 0.5 * np.sin(2 * np.pi * 1e3 * t) + 0.5 * np.sin(2 * np.pi * 5e3 * t)
+    x = (np.exp(1j * (2 * np.pi * 250e3 * t + 2 * np.pi * 75e3 / fs * np.cumsum(m))) + 0.01 * rand_c(rng, n)).astype(np.complex64)
+    fp = C.POINTER(C.c_float)
+    assert L.lrhip_init(-1) == 0                                                   # lrhip.ensure()
+    t1 = lr.filter_utils.firwin_lowpass(128, 100e3 / (fs / 2))                      # host side, as the unchanged Lua blocks compute them
+    t1 = np.asarray(t1, np.float32)
+    t2 = np.asarray(lr.filter_utils.firwin_lowpass(128, 15e3 / (fs / 5 / 2)), np.float32)
+    b, a = O.fm_deemphasis_taps(75e-6, fs / 5)
+    b, a = np.asarray(b, np.float32), np.asarray(a, np.float32)
+    stages = [L.lrhip_rotator_create(2 * np.pi * (-250e3 / fs)),                    # FrequencyTranslatorBlock
+              L.lrhip_fir_create(t1.ctypes.data_as(fp), 128, 0, 1, 1, 3),           # LowpassFilterBlock, use_fft nil -> 3
+              L.lrhip_downsampler_create(5, 8),
+              L.lrhip_fmdiscrim_create(2 * np.pi * 1.25),
+              L.lrhip_fir_create(t2.ctypes.data_as(fp), 128, 0, 0, 1, 3),
+              L.lrhip_iir_create(b.ctypes.data_as(fp), 2, a.ctypes.data_as(fp), 2, 0),
+              L.lrhip_downsampler_create(5, 4)]
+    assert all(stages), L.lrhip_strerror()
+    arr = (C.c_void_p * len(stages))(*stages)
+    chain = L.lrhip_chain_create(arr, len(stages))
+    assert chain, L.lrhip_strerror()
+    assert L.lrhip_chain_set_ring(chain, 3, 1 << 20) == 0
+    out = np.empty(0, np.float32)
+    parts, calls_with_output = [], 0
+    for k in range(0, n, 8192):
+        chunk = x[k:k + 8192]
+        cap = L.lrhip_chain_push_bound(chain, len(chunk))
+        if len(out) < cap:
+            out = np.empty(cap, np.float32)                                         # self.out:resize(cap)
+        got = L.lrhip_chain_push(chain, chunk.ctypes.data_as(C.c_void_p), len(chunk), out.ctypes.data_as(C.c_void_p), cap)
+        assert got >= 0, L.lrhip_strerror()
+        calls_with_output += got > 0
+        parts.append(out[:got].copy())
+    cap = L.lrhip_chain_push_bound(chain, 0)
+    assert len(out) >= cap
+    got = L.lrhip_chain_flush(chain, out.ctypes.data_as(C.c_void_p), len(out))      # cleanup()
+    assert got >= 0, L.lrhip_strerror()
+    parts.append(out[:got].copy())
+    assert L.lrhip_chain_last_launches(chain) <= 4                                   # tuner+discriminator (+ fix-up), audio FIR, de-emphasis+downsampler
+    L.lrhip_chain_destroy(chain)
+    for st in stages:
+        L.lrhip_stage_destroy(st)
+    audio = np.concatenate(parts)
+    want = O.wbfm_mono_chain(fs, -250e3, mode=O.MODE_LUA, rot_mode=O.MODE_F64).process(x)
+    assert len(audio) == len(want)
+    err = audio.astype(np.float64) - want.astype(np.float64)
+    assert float(np.sqrt(np.mean(err ** 2))) <= 1e-5 and float(np.max(np.abs(err))) < 1e-4
+    assert calls_with_output <= 1          # 2^20 samples = one batch: everything comes out of the flush (or the 128th push)
+
+
 def test_error_paths_report_through_strerror():
     L = lr._lib.load()
     import ctypes as C
