@@ -339,7 +339,9 @@ def wbfm_mono_receiver(rate=1102500.0, tune_offset=-250e3, use_fft=False):
     0.218 ms against 0.246 ms per 2^26 samples for the whole chain, same box, tools/ab_chain.py), "fast" = polyphase FFT overlap-save."""
     top = CompositeBlock()
     af_filter = B.LowpassFilterBlock(128, 15e3)
-    af_filter.use_fft = 2        # overlap-save arithmetic, one output per input (the reference's default FIR form is FFT too)
+    # automatic: inside a chain the audio filter, the de-emphasis recurrence and the final downsampler become ONE launch on the
+    # register-window kernel (direct form, bit-exact fmaf chains); alone it would take the overlap-save arithmetic
+    af_filter.use_fft = 3
     top.connect(TunerBlock(tune_offset, 200e3, 5, {"use_fft": use_fft}), B.FrequencyDiscriminatorBlock(1.25), af_filter,
                 B.FMDeemphasisFilterBlock(75e-6), B.DownsamplerBlock(5))
     top.rate = rate

@@ -17,6 +17,8 @@
 #include "kernels_channelizer.h"
 #include "kernels_iir.h"
 #include "kernels_agc.h"
+#include "kernels_firwin.h"
+#include "kernels_firwin2.h"
 
 using namespace lrhip;
 
@@ -32,6 +34,7 @@ static int g_launches = 0;   // kernels enqueued since the counter was last clea
 #include "stage_fir.h"
 #include "stage_elem.h"
 #include "stage_iir.h"
+#include "stage_firwin.h"
 #include "stage_spectrum.h"
 #include "stage_elem2.h"
 #include "stage_resample.h"
@@ -555,6 +558,66 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
                 c->ops.push_back({fused, true});
                 i = j + (ds ? 2 : 1) + (with_disc ? 1 : 0);
                 continue;
+            }
+        }
+        // fusion: fir(Float32 stream, real taps) -> first-order iir -> [downsampler]: one launch on the register-window kernel, the
+        // recurrence runs on the filter's accumulators (kernels_firwin.h).  A filter pinned to overlap-save (use_fft 1 / 2) keeps it.
+        {
+            static const bool no_fir_iir_fusion = getenv("LRHIP_NO_FIR_IIR_FUSION") != nullptr;      // A/B knob
+            FirStage *f1 = dynamic_cast<FirStage *>(stages[i]);
+            IirStage *ii = (f1 && i + 1 < nstages) ? dynamic_cast<IirStage *>(stages[i + 1]) : nullptr;
+            if (!no_fir_iir_fusion && ii && f1->S == 1 && !f1->taps_complex && f1->D == 1 && !f1->rot && !f1->pre_disc && !f1->post_disc && !f1->use_fft &&
+                (f1->mode_req == 0 || f1->mode_req == 3) && FirWinRealStage::supported_taps(f1->M) && ii->S == 1 && ii->scan && ii->P == 1 && ii->nb <= 2 &&
+                ii->D == 1 && FirWinRealStage::warm_waves_for((double)ii->seq.a[1] / (double)ii->seq.a[0]) > 0) {
+                DownsamplerStage *ds3 = i + 2 < nstages ? dynamic_cast<DownsamplerStage *>(stages[i + 2]) : nullptr;
+                std::vector<float> taps((size_t)f1->M);
+                for (int t = 0; t < f1->M; t++) taps[t] = f1->taps_rev[f1->M - 1 - t];
+                // With a downsampler behind the recurrence only every D-th output of it is kept, and
+                //     y[n] = u[n] + p y[n-1]   =>   y[n] = sum_{k<D} p^k u[n-k]  +  p^D y[n-D]           (exact identity, p = -a1/a0)
+                // so the kept samples are a DECIMATING filter  g = h * b * (1, p, .., p^(D-1))  followed by the first-order recurrence with
+                // pole p^D at the LOW rate: 1/D of the multiply-adds, and the high-rate audio is never computed.  Same transfer function,
+                // different rounding: <= 1e-6 of the reference's arithmetic (the bar of the IIR blocks), not bit-identical to it.
+                static const bool no_polyphase_tail = getenv("LRHIP_NO_POLYPHASE_TAIL") != nullptr;      // A/B knob
+                if (!no_polyphase_tail && ds3 && ds3->factor >= 2 && ds3->factor <= 16) {
+                    const int D = (int)ds3->factor, nbb = ii->nb;
+                    const double a0 = (double)ii->seq.a[0];
+                    const double pp = -(double)(float)((double)ii->seq.a[1] / a0);      // the pole as the IIR kernels round it (IirCoeffs)
+                    std::vector<double> cpoly((size_t)(nbb + D - 1), 0.0);
+                    double pk = 1.0;
+                    for (int k = 0; k < D; k++, pk *= pp)
+                        for (int jb = 0; jb < nbb; jb++) cpoly[(size_t)(k + jb)] += pk * (double)(float)((double)ii->seq.b[jb] / a0);
+                    const int Mg0 = f1->M + nbb + D - 2, Mg = (Mg0 + 3) & ~3;            // zero taps at the far end: a multiple of four for the window kernel
+                    std::vector<float> g((size_t)Mg, 0.f);
+                    for (int t = 0; t < Mg0; t++) {
+                        double acc = 0.0;
+                        for (int c2 = 0; c2 < (int)cpoly.size(); c2++)
+                            if (t - c2 >= 0 && t - c2 < f1->M) acc += (double)taps[(size_t)(t - c2)] * cpoly[(size_t)c2];
+                        g[(size_t)t] = (float)acc;
+                    }
+                    FirStage *fd = fir_build(g.data(), (unsigned)Mg, 0, 0, (unsigned)D, 0, false, 0.0);
+                    const float b2[1] = {1.0f}, a2[2] = {1.0f, (float)(-pk)};          // pk = p^D after the loop
+                    // the low-rate recurrence runs on the filter's accumulators when the window kernel takes this shape ...
+                    if (fd && fd->fuse_iir1(b2[0], a2[1]) == 0) {
+                        c->ops.push_back({fd, true});
+                        i += 3;
+                        continue;
+                    }
+                    // ... and as its own launch otherwise
+                    lrhip_stage_t *i2 = fd ? lrhip_iir_create(b2, 1, a2, 2, 0) : nullptr;
+                    if (fd && i2) {
+                        c->ops.push_back({fd, true});
+                        c->ops.push_back({i2, true});
+                        i += 3;
+                        continue;
+                    }
+                    delete fd;
+                }
+                FirWinRealStage *fw = firwin_real_build(taps.data(), f1->M, ii->seq.b, ii->nb, ii->seq.a, ii->na, ds3 ? ds3->factor : 1);
+                if (fw) {
+                    c->ops.push_back({fw, true});
+                    i += ds3 ? 3 : 2;
+                    continue;
+                }
             }
         }
         // fusion: discriminator -> overlap-save FIR on the real stream: the discriminator runs in the FFT kernel's load stage

@@ -52,7 +52,8 @@ struct FirStage : lrhip_stage {
     }
     int reset() override
     {
-        cur = 0; index = 0; count = 0; fill = 0; disc_cur = 0;
+        cur = 0; index = 0; count = 0; fill = 0; disc_cur = 0; iir_cur = 0;
+        if (iir_fused && (zero_fill(iir_state[0], 4 * sizeof(float)) || zero_fill(iir_state[1], 4 * sizeof(float)))) return -1;
         if ((pre_disc || post_disc) && zero_fill(disc_prev, 4 * sizeof(float))) return -1;
         size_t hb = ((size_t)(M > 1 ? M - 1 : 1) * S + hist_pad) * sizeof(float);
         if (zero_fill(hist[0], hb) || zero_fill(hist[1], hb)) return -1;
@@ -324,6 +325,118 @@ struct FirStage : lrhip_stage {
         return 0;
     }
 
+    // Float32 stream at D = 1 on the register-window kernel (kernels_firwin.h): every issued packed FMA is useful work,
+    // against 89 % for the Toeplitz product
+    int win_blocks_per_cu = 0;
+    bool win_real_ok() const
+    {
+        static const bool off = getenv("LRHIP_NO_FIR_WIN") != nullptr;      // A/B knob
+        return !off && S == 1 && !taps_complex && D == 1 && !rot && !pre_disc && !post_disc && !fft_arith && (M == 32 || M == 64 || M == 128);
+    }
+    template <int MM>
+    int launch_win_real_m(const float *x, long n, float *y)
+    {
+        using G = FwrGeom<MM>;
+        const size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
+        auto kern = fir_win_real_kernel<MM, false>;
+        if (!win_blocks_per_cu && prepare_kernel(kern, lds_bytes, &win_blocks_per_cu)) return -1;
+        const long ntiles = (n + FWR_TILE - 1) / FWR_TILE;
+        const long slots = (long)ctx().num_cus * win_blocks_per_cu;
+        FwrParams pr;
+        memset(&pr, 0, sizeof(pr));
+        pr.hist = (const float *)hist[cur].p + hist_pad; pr.x = x; pr.n = n; pr.taps_rev = (const float *)d_taps.p; pr.y = y;
+        pr.hist_out = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
+        pr.run = (ntiles + slots - 1) / slots;
+        pr.dec = 1;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + pr.run - 1) / pr.run)), dim3(256), lds_bytes, ctx().stream, pr);
+        LR_LAUNCH_CHECK();
+        hist_in_kernel = pr.hist_out != nullptr;
+        return 0;
+    }
+    int launch_win_real(const float *x, long n, float *y)
+    {
+        return M == 32 ? launch_win_real_m<32>(x, n, y) : M == 64 ? launch_win_real_m<64>(x, n, y) : launch_win_real_m<128>(x, n, y);
+    }
+
+    // ComplexFloat32 stream with decimation (Decimator / Tuner [+ discriminator]) and the decimating Float32 filter with a fused
+    // first-order recurrence, on the register-window kernel (kernels_firwin2.h)
+    int winc_blocks_per_cu = 0;
+    bool iir_fused = false;               // pair mode: y[k] = iir_b0 v[k] + iir_na1 y[k-1] behind the filter
+    float iir_b0 = 1.f, iir_na1 = 0.f;
+    int iir_warm = 1;
+    DeviceBuf d_iir_ptab, iir_state[2];
+    int iir_cur = 0;
+    static bool win_off()
+    {
+        static const bool off = getenv("LRHIP_NO_FIR_WIN") != nullptr;      // A/B knob
+        return off;
+    }
+    bool win_cplx_ok() const { return !win_off() && S == 2 && !taps_complex && D == 5 && M == 128 && !fft_arith && !use_fft && !decfft && !pre_disc; }
+    bool win_pair_ok() const { return !win_off() && S == 1 && !taps_complex && D == 5 && M == 136 && !fft_arith && !use_fft && !rot && !pre_disc && !post_disc; }
+    // first-order recurrence behind the pair-mode filter: needs |a1|^(320 w) < 1e-12 for the in-launch warm-up (w waves of 64 lanes x 5 outputs)
+    int fuse_iir1(float b0, float a1)
+    {
+        if (!win_pair_ok()) return -1;
+        const double p = std::fabs((double)a1);
+        int w = 0;
+        for (int c = 1; c <= 4 && !w; c *= 2)
+            if (p < 1.0 && std::pow(p, 320.0 * c) < 1e-12) w = c;
+        if (!w) return -1;
+        std::vector<float> ptab(64);
+        double pR = 1.0, acc = 1.0;
+        for (int k = 0; k < 5; k++) pR *= -(double)a1;
+        for (int l = 0; l < 64; l++) { acc *= pR; ptab[(size_t)l] = (float)acc; }
+        if (upload(d_iir_ptab, ptab.data(), ptab.size() * sizeof(float))) return -1;
+        iir_fused = true; iir_b0 = b0; iir_na1 = -a1; iir_warm = w;
+        return reset();
+    }
+    template <int MM, int MODE>
+    int launch_win_cplx_m(const float *x, long n, float *y, long n_out)
+    {
+        using G = FwcGeom<5, 5, MM, MODE>;
+        const size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
+        auto kern = fir_win_cplx_kernel<5, 5, MM, MODE>;
+        if (!winc_blocks_per_cu && prepare_kernel(kern, lds_bytes, &winc_blocks_per_cu)) return -1;
+        FwcParams pr;
+        memset(&pr, 0, sizeof(pr));
+        pr.hist = (const float *)hist[cur].p + hist_pad; pr.x = x; pr.n = n; pr.taps_rev = (const float *)d_taps.p; pr.y = y;
+        pr.n_out = n_out; pr.first = (long)index;
+        pr.hist_out = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
+        pr.ntiles = G::PAIR ? (n_out + 2L * G::TO - 1) / (2L * G::TO) : (n_out + G::TA - 1) / G::TA;
+        pr.rot_step_fx = rot ? rot_step : 0; pr.rot_count0 = rot ? count : 0;
+        if (G::DISC) {
+            float2 *dp = (float2 *)disc_prev.p;
+            pr.prev_in = dp + disc_cur; pr.prev_out = dp + (disc_cur ^ 1);
+            pr.inv_gain = 1.0 / disc_gain;
+        }
+        const long slots = (long)ctx().num_cus * winc_blocks_per_cu;
+        unsigned grid;
+        if (G::IIR) {
+            pr.b0 = iir_b0; pr.na1 = iir_na1; pr.ptab = (const float *)d_iir_ptab.p; pr.warm_waves = iir_warm;
+            pr.state_in = (const float *)iir_state[iir_cur].p; pr.state_out = (float *)iir_state[iir_cur ^ 1].p;
+            pr.run = (pr.ntiles + slots - 1) / slots;
+            grid = (unsigned)((pr.ntiles + pr.run - 1) / pr.run);
+        } else {
+            pr.warm_waves = 4; pr.run = 1;
+            grid = (unsigned)(pr.ntiles < slots ? pr.ntiles : slots);
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, pr);
+        LR_LAUNCH_CHECK();
+        hist_in_kernel = pr.hist_out != nullptr;
+        if (G::DISC) disc_cur ^= 1;
+        if (G::IIR) iir_cur ^= 1;
+        return 0;
+    }
+    int launch_win_cplx(const float *x, long n, float *y, long n_out)
+    {
+        if (post_disc) return rot ? launch_win_cplx_m<128, FWC_ROT | FWC_DISC>(x, n, y, n_out) : launch_win_cplx_m<128, FWC_DISC>(x, n, y, n_out);
+        return rot ? launch_win_cplx_m<128, FWC_ROT>(x, n, y, n_out) : launch_win_cplx_m<128, 0>(x, n, y, n_out);
+    }
+    int launch_win_pair(const float *x, long n, float *y, long n_out)
+    {
+        return iir_fused ? launch_win_cplx_m<136, FWC_PAIR | FWC_IIR>(x, n, y, n_out) : launch_win_cplx_m<136, FWC_PAIR>(x, n, y, n_out);
+    }
+
     template <int SS>
     int dispatch_mfma(const float *x, long n, float *y, long n_out)
     {
@@ -343,7 +456,7 @@ struct FirStage : lrhip_stage {
 
     static bool mfma_supported_decim(unsigned d) { return (d >= 1 && d <= 8) || d == 10; }
     // the discriminator epilogue exists for the persistent instantiations of the complex-stream, real-taps kernel
-    bool can_post_disc() const { return decfft || (S == 2 && !taps_complex && !fft_arith && !use_fft && ((D == 1 && ksteps == 36) || (D == 5 && ksteps == 51))); }
+    bool can_post_disc() const { return decfft || win_cplx_ok() || (S == 2 && !taps_complex && !fft_arith && !use_fft && ((D == 1 && ksteps == 36) || (D == 5 && ksteps == 51))); }
 
     // filter n inputs (device), emit the retained outputs; advances history / index / count
     long core(const float *x, long n, float *y, unsigned long cap)
@@ -355,6 +468,9 @@ struct FirStage : lrhip_stage {
         if (n_out > 0) {
             int rc = (decfft && ((uintptr_t)x & 7) == 0) ? launch_decfft(x, n, y, n_out)
                      : fft_arith ? launch_fft(x, n, y, n_out)
+                     : win_real_ok() ? launch_win_real(x, n, y)
+                     : win_cplx_ok() ? launch_win_cplx(x, n, y, n_out)
+                     : win_pair_ok() ? launch_win_pair(x, n, y, n_out)
                      : !ksteps ? (decim_lds_ok() ? launch_decim_lds(x, n, y, n_out) : launch_direct(x, n, y, n_out))
                      : taps_complex ? dispatch_mfma_cc(x, n, y, n_out)
                      : S == 1 ? dispatch_mfma<1>(x, n, y, n_out) : dispatch_mfma<2>(x, n, y, n_out);
