@@ -612,7 +612,10 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
                     }
                     delete fd;
                 }
-                FirWinRealStage *fw = firwin_real_build(taps.data(), f1->M, ii->seq.b, ii->nb, ii->seq.a, ii->na, ds3 ? ds3->factor : 1);
+                // without a (small) decimation the recurrence can run on the accumulators of the D = 1 window kernel: one launch, but slower on
+                // MI355X than overlap-save filter + scan (0.068 against 0.060 ms on the WBFM audio tail) - opt-in, LRHIP_FIR_IIR_WIN=1
+                static const bool fir_iir_win = getenv("LRHIP_FIR_IIR_WIN") != nullptr;
+                FirWinRealStage *fw = fir_iir_win ? firwin_real_build(taps.data(), f1->M, ii->seq.b, ii->nb, ii->seq.a, ii->na, ds3 ? ds3->factor : 1) : nullptr;
                 if (fw) {
                     c->ops.push_back({fw, true});
                     i += ds3 ? 3 : 2;

@@ -330,8 +330,10 @@ struct FirStage : lrhip_stage {
     int win_blocks_per_cu = 0;
     bool win_real_ok() const
     {
-        static const bool off = getenv("LRHIP_NO_FIR_WIN") != nullptr;      // A/B knob
-        return !off && S == 1 && !taps_complex && D == 1 && !rot && !pre_disc && !post_disc && !fft_arith && (M == 32 || M == 64 || M == 128);
+        // opt-in (LRHIP_FIR_WIN_REAL=1): 128 taps on 2^26 Float32 samples run at 0.25 ms here against 0.19 ms on the Toeplitz-MFMA kernel
+        // (same box) - at D = 1 the Toeplitz product wastes only 11 % of its MACs and keeps more waves resident
+        static const bool on = getenv("LRHIP_FIR_WIN_REAL") != nullptr && getenv("LRHIP_NO_FIR_WIN") == nullptr;
+        return on && S == 1 && !taps_complex && D == 1 && !rot && !pre_disc && !post_disc && !fft_arith && (M == 32 || M == 64 || M == 128);
     }
     template <int MM>
     int launch_win_real_m(const float *x, long n, float *y)
@@ -371,7 +373,15 @@ struct FirStage : lrhip_stage {
         static const bool off = getenv("LRHIP_NO_FIR_WIN") != nullptr;      // A/B knob
         return off;
     }
-    bool win_cplx_ok() const { return !win_off() && S == 2 && !taps_complex && D == 5 && M == 128 && !fft_arith && !use_fft && !decfft && !pre_disc; }
+    // the ComplexFloat32 form is opt-in (LRHIP_FIR_WIN_CPLX=1): same-box A/B on the WBFM tuner + discriminator, 2^26 samples: 0.204 ms against
+    // 0.150 ms + 0.005 ms (fix-up) for the Toeplitz-MFMA kernel - both are bound by the shared MFMA / VALU datapath (rocprofv3: 1 250 VALU
+    // instructions per wave and 6 360-sample tile, 640 of them the filter), and the Toeplitz kernel keeps 3 workgroups per CU resident against 2
+    static bool win_cplx_on()
+    {
+        static const bool on = getenv("LRHIP_FIR_WIN_CPLX") != nullptr;
+        return on;
+    }
+    bool win_cplx_ok() const { return win_cplx_on() && !win_off() && S == 2 && !taps_complex && D == 5 && M == 128 && !fft_arith && !use_fft && !decfft && !pre_disc; }
     bool win_pair_ok() const { return !win_off() && S == 1 && !taps_complex && D == 5 && M == 136 && !fft_arith && !use_fft && !rot && !pre_disc && !post_disc; }
     // first-order recurrence behind the pair-mode filter: needs |a1|^(320 w) < 1e-12 for the in-launch warm-up (w waves of 64 lanes x 5 outputs)
     int fuse_iir1(float b0, float a1)
@@ -415,6 +425,7 @@ struct FirStage : lrhip_stage {
             pr.b0 = iir_b0; pr.na1 = iir_na1; pr.ptab = (const float *)d_iir_ptab.p; pr.warm_waves = iir_warm;
             pr.state_in = (const float *)iir_state[iir_cur].p; pr.state_out = (float *)iir_state[iir_cur ^ 1].p;
             pr.run = (pr.ntiles + slots - 1) / slots;
+            if (getenv("LRHIP_TAIL_RUN")) pr.run = atol(getenv("LRHIP_TAIL_RUN"));      // A/B knob
             grid = (unsigned)((pr.ntiles + pr.run - 1) / pr.run);
         } else {
             pr.warm_waves = 4; pr.run = 1;
