@@ -324,7 +324,7 @@ def main():
     lr.init(local_rank)
     L = lr._lib.load()
     # launch on torch's current stream so torch.cuda.synchronize()/barriers and the library's HIP events agree
-    L.lrhip_set_stream(torch.cuda.current_stream().cuda_stream)
+    lr.adopt_torch_stream()
 
     log2n = args.log2_samples or (28 if args.workload == "fir" else 26)
     n = 1 << log2n

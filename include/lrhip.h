@@ -38,7 +38,9 @@ int lrhip_init(int device);
 const char *lrhip_strerror(void);
 /* Number of visible HIP devices (for the fan-out scheduler), or < 0 on error. */
 int lrhip_device_count(void);
-/* Launch all subsequent work on an externally owned hipStream_t (NULL => the library's own stream). */
+/* Launch all subsequent work on an externally owned hipStream_t (NULL => the library's own non-blocking stream; HIP's explicit handles
+ * hipStreamLegacy = (hipStream_t)1 and hipStreamPerThread = (hipStream_t)2 are accepted - a host that keeps its vectors on the default
+ * stream passes 1).  Work already queued on the previous stream is ordered before whatever follows on the new one. */
 int lrhip_set_stream(void *hip_stream);
 /* Block until everything queued by this library has finished. */
 int lrhip_synchronize(void);
@@ -222,6 +224,53 @@ long lrhip_chain_flush(lrhip_chain_t *c, void *out_host, unsigned long out_capac
 unsigned long lrhip_chain_push_bound(const lrhip_chain_t *c, unsigned long n_in);
 /* Number of kernels launched by the last chain execute (diagnostic for the fusion tests). */
 int lrhip_chain_last_launches(const lrhip_chain_t *c);
+
+/* ---- time-axis sharding: G partitions of ONE stream, each on its own GPU (or as G virtual partitions on one) -------------------------
+ * The reference runs a block as one process over the whole stream (radio/core/block.lua:572-590); on a node with 8 GPUs a long
+ * recording can be cut into G contiguous partitions instead, because every piece of cross-chunk state of the hot path is either a
+ * closed-form function of the ABSOLUTE sample index (rotator phase = omega * n, frequencytranslator.lua:93-110; downsampler phase
+ * = n mod D, downsampler.lua:45-56) or a bounded memory of the input (filter history M-1 samples, firfilter.lua:244-250;
+ * the discriminator's previous sample, frequencydiscriminator.lua:74; a decaying recurrence's state, iirfilter.lua:113-181).
+ *   lrhip_stage_seek / lrhip_chain_seek(c, n0): forget all carried samples and set the absolute counters as if n0 input samples
+ *       had been consumed.  The next execute() is then sample n0 of the stream.
+ *   lrhip_chain_halo(c): the number of input samples H a partition has to replay in front of its first own sample - seek(n0 - H),
+ *       execute(x[n0-H .. n0)) with the output discarded - so that every carried state equals the uninterrupted stream's (filter
+ *       histories exactly; recurrences to Float32 underflow of their zero start).  -1 (with lrhip_strerror) when a stage of the
+ *       chain has unbounded memory (AGC, frequency modulator, a recurrence that does not decay): such a chain cannot be sharded
+ *       in time.  Outputs of the partition [n0, n1) are then the same VALUES as samples of the single-stream run; with partition
+ *       boundaries on multiples of lrhip_chain_shard_align(c) input samples also bit for bit.
+ *   lrhip_chain_shard_align(c): partition boundaries on multiples of this many input samples give every scan kernel of the chain the
+ *       tile grid of the uninterrupted run (1 for chains of filters / rotators / discriminators / downsamplers; 64 000 for the WBFM
+ *       receiver: 2 560 audio samples x 25). */
+int  lrhip_stage_seek(lrhip_stage_t *q, unsigned long long n0);
+int  lrhip_chain_seek(lrhip_chain_t *c, unsigned long long n0);
+long lrhip_chain_halo(const lrhip_chain_t *c);
+unsigned long lrhip_chain_shard_align(const lrhip_chain_t *c);
+
+/* ---- fan-out across processes / GPUs below the host language (radio/core/pipe.lua:617-627: one output port, several readers) -------
+ * LuaRadio runs every block in its own process; with one process per GPU the source's slab has to reach the other processes' devices
+ * without a host round trip.  These are the HIP primitives for that, wrapped so that a LuaJIT host needs no HIP headers:
+ *   a consumer process allocates its slab buffers (lrhip_malloc) and exports them (64-byte handles, sent over the control socket the
+ *   host already has); the producer opens them and pushes each slab with lrhip_peer_copy on its COPY stream, then records an
+ *   interprocess event the consumer waits on (on the GPU, lrhip_ipc_event_wait: no host synchronisation) before its chain reads the
+ *   slab.  Two slabs per consumer double-buffer the copy of slab k+1 against the kernels on slab k; a second event per slab, recorded
+ *   by the consumer after its chain and waited on by the producer, returns the buffer.  Over xGMI a receiving GPU is bounded by one
+ *   link (about 153 GB/s = 19 GS/s of ComplexFloat32). */
+enum { LRHIP_IPC_HANDLE_BYTES = 64 };          /* size of the opaque handles below */
+int   lrhip_ipc_export(const void *dev_ptr, void *handle_out);                 /* hipIpcGetMemHandle */
+void *lrhip_ipc_open(const void *handle);                                       /* hipIpcOpenMemHandle (lazy peer access) */
+int   lrhip_ipc_close(void *dev_ptr);
+typedef struct lrhip_ipc_event lrhip_ipc_event_t;
+lrhip_ipc_event_t *lrhip_ipc_event_create(void *handle_out);                   /* interprocess event + its 64-byte handle */
+lrhip_ipc_event_t *lrhip_ipc_event_open(const void *handle);
+void  lrhip_ipc_event_destroy(lrhip_ipc_event_t *e);
+int   lrhip_ipc_event_record(lrhip_ipc_event_t *e, int on_copy_stream);         /* on the copy stream (1) or the library stream (0) */
+int   lrhip_ipc_event_wait(lrhip_ipc_event_t *e, int on_copy_stream);           /* the stream waits on the GPU; the host does not block */
+int   lrhip_ipc_event_query(lrhip_ipc_event_t *e);                              /* 1 done, 0 pending, < 0 error */
+int   lrhip_ipc_event_synchronize(lrhip_ipc_event_t *e);                        /* host wait */
+/* dst/src may live on different devices (peer access is enabled on first use); asynchronous on the library's copy stream */
+int   lrhip_peer_copy(void *dst, int dst_device, const void *src, int src_device, unsigned long bytes);
+int   lrhip_copy_stream_synchronize(void);
 
 /* ---- device memory helpers for FFI callers that want resident vectors ------------------------------------- */
 void *lrhip_malloc(unsigned long bytes);

@@ -21,6 +21,7 @@ ffi.cdef[[
 typedef struct lrhip_stage lrhip_stage_t;
 typedef struct lrhip_chain lrhip_chain_t;
 typedef struct lrhip_timer lrhip_timer_t;
+typedef struct lrhip_ipc_event lrhip_ipc_event_t;
 
 int lrhip_init(int device);
 const char *lrhip_strerror(void);
@@ -89,6 +90,22 @@ void lrhip_timer_destroy(lrhip_timer_t *t);
 int lrhip_timer_start(lrhip_timer_t *t);
 int lrhip_timer_stop(lrhip_timer_t *t);
 double lrhip_timer_elapsed_ms(lrhip_timer_t *t);
+int lrhip_stage_seek(lrhip_stage_t *q, unsigned long long n0);
+int lrhip_chain_seek(lrhip_chain_t *c, unsigned long long n0);
+long lrhip_chain_halo(const lrhip_chain_t *c);
+unsigned long lrhip_chain_shard_align(const lrhip_chain_t *c);
+int lrhip_ipc_export(const void *dev_ptr, void *handle_out);
+void *lrhip_ipc_open(const void *handle);
+int lrhip_ipc_close(void *dev_ptr);
+lrhip_ipc_event_t *lrhip_ipc_event_create(void *handle_out);
+lrhip_ipc_event_t *lrhip_ipc_event_open(const void *handle);
+void lrhip_ipc_event_destroy(lrhip_ipc_event_t *e);
+int lrhip_ipc_event_record(lrhip_ipc_event_t *e, int on_copy_stream);
+int lrhip_ipc_event_wait(lrhip_ipc_event_t *e, int on_copy_stream);
+int lrhip_ipc_event_query(lrhip_ipc_event_t *e);
+int lrhip_ipc_event_synchronize(lrhip_ipc_event_t *e);
+int lrhip_peer_copy(void *dst, int dst_device, const void *src, int src_device, unsigned long bytes);
+int lrhip_copy_stream_synchronize(void);
 ]]
 
 local M = {available = false}

@@ -4,7 +4,7 @@ Python mirror of the reference's Lua host side (radio.block / radio.types / bloc
 C ABI of liblrhip.so (include/lrhip.h).  The Lua glue a LuaRadio checkout would use is under lua/.
 """
 from . import _lib, filter_utils, spectrum_utils, types, window_utils  # noqa: F401
-from ._lib import LrhipError, init  # noqa: F401
+from ._lib import LrhipError, adopt_torch_stream, init  # noqa: F401
 from .block import Block, Input, Output  # noqa: F401
 from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock, FIRFilterBlock,  # noqa: F401
                      FMDeemphasisFilterBlock, FrequencyDiscriminatorBlock, FrequencyTranslatorBlock,

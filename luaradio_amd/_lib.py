@@ -84,6 +84,22 @@ SIGNATURES = {
     "lrhip_timer_start": (C.c_int, [_vp]),
     "lrhip_timer_stop": (C.c_int, [_vp]),
     "lrhip_timer_elapsed_ms": (C.c_double, [_vp]),
+    "lrhip_stage_seek": (C.c_int, [_vp, C.c_ulonglong]),
+    "lrhip_chain_seek": (C.c_int, [_vp, C.c_ulonglong]),
+    "lrhip_chain_halo": (C.c_long, [_vp]),
+    "lrhip_chain_shard_align": (_ul, [_vp]),
+    "lrhip_ipc_export": (C.c_int, [_vp, _vp]),
+    "lrhip_ipc_open": (_vp, [_vp]),
+    "lrhip_ipc_close": (C.c_int, [_vp]),
+    "lrhip_ipc_event_create": (_vp, [_vp]),
+    "lrhip_ipc_event_open": (_vp, [_vp]),
+    "lrhip_ipc_event_destroy": (None, [_vp]),
+    "lrhip_ipc_event_record": (C.c_int, [_vp, C.c_int]),
+    "lrhip_ipc_event_wait": (C.c_int, [_vp, C.c_int]),
+    "lrhip_ipc_event_query": (C.c_int, [_vp]),
+    "lrhip_ipc_event_synchronize": (C.c_int, [_vp]),
+    "lrhip_peer_copy": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _ul]),
+    "lrhip_copy_stream_synchronize": (C.c_int, []),
 }
 
 
@@ -117,6 +133,15 @@ def check_ptr(p, what):
     if not p:
         raise LrhipError("%s: %s" % (what, last_error()))
     return p
+
+
+def adopt_torch_stream():
+    """Enqueue the library's work on torch's CURRENT stream, so that torch tensors handed to process_device() are ordered with the
+    kernels both ways.  torch's default stream has handle 0, which lrhip_set_stream() reads as "the library's own stream"; HIP's name
+    for that stream as an explicit handle is hipStreamLegacy = (hipStream_t)1."""
+    import torch
+    h = torch.cuda.current_stream().cuda_stream
+    check(load().lrhip_set_stream(C.c_void_p(h if h else 1)), "lrhip_set_stream")
 
 
 def init(device=-1):

@@ -110,6 +110,11 @@ class Block:
     def max_output(self, n_in):
         return _lib.load().lrhip_stage_max_output(self.stage_handle(), n_in)
 
+    def seek(self, n0):
+        """time-axis sharding (include/lrhip.h): continue as if n0 input samples of the stream had been consumed - zero history,
+        absolute rotator / decimation phase"""
+        _lib.check(_lib.load().lrhip_stage_seek(self.stage_handle(), int(n0)), "%s:seek" % type(self).__name__)
+
     def reset(self):
         _lib.check(_lib.load().lrhip_stage_reset(self.stage_handle()), "%s:reset" % self.name)
 

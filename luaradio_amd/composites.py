@@ -43,6 +43,19 @@ class Chain:
     def reset(self):
         _lib.check(_lib.load().lrhip_chain_reset(self._chain), "chain:reset")
 
+    def seek(self, n0):
+        """continue as if n0 input samples of the stream had been consumed (zero histories, absolute phases): lrhip_chain_seek"""
+        _lib.check(_lib.load().lrhip_chain_seek(self._chain, int(n0)), "chain:seek")
+
+    def halo(self):
+        """input samples a time partition replays in front of its first own sample (lrhip_chain_halo); raises if the chain
+        holds a stage with unbounded memory"""
+        return _lib.check(_lib.load().lrhip_chain_halo(self._chain), "chain:halo")
+
+    def shard_align(self):
+        """partition boundaries on multiples of this many input samples reproduce the single-stream run bit for bit"""
+        return int(_lib.load().lrhip_chain_shard_align(self._chain))
+
     def _count(self, x):
         """input vector -> (contiguous array, number of input samples)"""
         x = np.ascontiguousarray(x)
@@ -184,6 +197,15 @@ class CompositeBlock(Block):
 
     def reset(self):
         self._chain.reset()
+
+    def seek(self, n0):
+        self._chain.seek(n0)
+
+    def halo(self):
+        return self._chain.halo()
+
+    def shard_align(self):
+        return self._chain.shard_align()
 
     @property
     def chain(self):

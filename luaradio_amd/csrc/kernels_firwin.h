@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256, 2) void fir_win_real_kernel(const FwrParams pr
                     st = fmaf(pr.na1, st, u[i]);
                     u[i] = st;
                     const long g = c0 + i;
-                    if (g == n - 1) { pr.state_out[0] = st; pr.vhist_out[0] = v[i]; }
+                    // (a chunk that ends with the tile hands over C, the value the next tile of an uninterrupted run is given: below)
+                    if (g == n - 1) { if (n != (tt + 1) * FWR_TILE) pr.state_out[0] = st; pr.vhist_out[0] = v[i]; }
                     if (dec > 1 && g == g0 && g < n) { pr.y[k0] = st; k0++; g0 += dec; }
                 }
                 if (dec == 1) {
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void fir_win_real_kernel(const FwrParams pr
                     }
                 }
             }
+            if (emit && tid == 0 && n == (tt + 1) * FWR_TILE) pr.state_out[0] = C;
             carry = C;
             vprev = vnext;
         }

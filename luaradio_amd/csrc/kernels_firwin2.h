@@ -374,9 +374,12 @@ __global__ __launch_bounds__(256, 2) void fir_win_cplx_kernel(const FwcParams pr
                         st = __builtin_elementwise_fma(pp, st, u[i]);
                         if (ka + i < n_out) pr.y[ka + i] = st.x;
                         if (kbb + i < n_out) pr.y[kbb + i] = st.y;
-                        if (ka + i == n_out - 1) pr.state_out[0] = st.x;
-                        if (kbb + i == n_out - 1) pr.state_out[0] = st.y;
+                        // the carried state of a chunk that ends inside this tile; a chunk that ends WITH the tile hands over C below -
+                        // the value the next tile of an uninterrupted run would have been given (the scan and the re-run round differently)
+                        if (ka + i == n_out - 1 && n_out != kb + 2L * G::TO) pr.state_out[0] = st.x;
+                        if (kbb + i == n_out - 1 && n_out != kb + 2L * G::TO) pr.state_out[0] = st.y;
                     }
+                    if (tid == 0 && n_out == kb + 2L * G::TO) pr.state_out[0] = C;
                 }
                 carry = C;
             }

@@ -390,8 +390,15 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
                     st[c][0] = v;
                     u[c][i] = v;
                     long g = c0 + i;
-                    if (g < n && g >= n - P) state_out[c * P + (int)(n - 1 - g)] = v;
+                    // (a chunk that ends WITH this tile hands over the scanned tile end state instead - below - which is what the next tile
+                    // of an uninterrupted run is given: the scan and the re-run round differently, and time partitions must not see that)
+                    if (g < n && g >= n - P && n != (tt + 1) * TILE) state_out[c * P + (int)(n - 1 - g)] = v;
                 }
+            if (tid == 255 && n == (tt + 1) * TILE)
+#pragma unroll
+                for (int c = 0; c < S; c++)
+#pragma unroll
+                    for (int k = 0; k < P; k++) state_out[c * P + k] = (float)sst[c][255][k];
             if (tt == 0 && tid == 0 && n < P)
 #pragma unroll
                 for (int c = 0; c < S; c++)

@@ -65,7 +65,18 @@ int lrhip_device_count(void)
 int lrhip_set_stream(void *hip_stream)
 {
     if (ensure_init()) return -1;
-    ctx().stream = hip_stream ? (hipStream_t)hip_stream : ctx().own_stream;
+    // (void *)1 = hipStreamLegacy: the default ("null") stream, whose handle inside the library is plain 0 - every HIP entry point takes that
+    hipStream_t next = hip_stream == (void *)1 ? (hipStream_t) nullptr : hip_stream ? (hipStream_t)hip_stream : ctx().own_stream, prev = ctx().stream;
+    if (next != prev) {
+        // work already queued on the previous stream (reset() memsets, earlier chunks that carried state forward) is ordered
+        // before everything that follows on the new one
+        hipEvent_t ev = nullptr;
+        LR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e1 = hipEventRecord(ev, prev), e2 = e1 == hipSuccess ? hipStreamWaitEvent(next, ev, 0) : e1;
+        (void)hipEventDestroy(ev);
+        if (e2 != hipSuccess) return set_error("set_stream: ordering the streams failed: %s", hipGetErrorString(e2));
+    }
+    ctx().stream = next;
     return 0;
 }
 
@@ -1010,6 +1021,206 @@ double lrhip_timer_elapsed_ms(lrhip_timer_t *t)
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, t->a, t->b) != hipSuccess) return (double)set_error("hipEventElapsedTime failed");
     return (double)ms;
+}
+
+// ---- time-axis sharding ---------------------------------------------------------------------------------------------
+int lrhip_stage_seek(lrhip_stage_t *q, unsigned long long n0)
+{
+    if (!q) return set_error("null stage");
+    unsigned long long out = 0;
+    return q->seek(n0, &out);
+}
+
+int lrhip_chain_seek(lrhip_chain_t *c, unsigned long long n0)
+{
+    if (!c) return set_error("null chain");
+    if (c->inflight || c->fill) return set_error("chain seek: chunks still in flight or pushed and not flushed");
+    if (ctx().ready) LR_HIP(hipStreamSynchronize(ctx().stream));
+    unsigned long long n = n0;
+    for (auto &o : c->ops) {
+        unsigned long long nn = 0;
+        if (o.stage->seek(n, &nn)) return -1;
+        n = nn;
+    }
+    return 0;
+}
+
+long lrhip_chain_halo(const lrhip_chain_t *c)
+{
+    if (!c) return set_error("null chain");
+    // H = sum_k memory_k * (input samples of the chain per input sample of stage k), rounded up
+    long double scale = 1.0L, h = 0.0L;
+    for (auto &o : c->ops) {
+        const long m = o.stage->memory();
+        if (m < 0) return set_error("chain halo: stage '%s' has unbounded memory - this chain cannot be sharded in time", o.stage->kind());
+        h += (long double)m * scale;
+        unsigned long num = 1, den = 1;
+        o.stage->rate(&num, &den);
+        scale = scale * (long double)num / (long double)den;
+    }
+    return (long)ceill(h);
+}
+
+unsigned long lrhip_chain_shard_align(const lrhip_chain_t *c)
+{
+    if (!c) return 0;
+    // a chain-input count `a` reaches stage k as a * den / num samples (num / den = product of the rates before it); the smallest a that is
+    // a multiple of align_k there is align_k * num / gcd(align_k * num, den); the chain's alignment is the lcm over its stages
+    auto gcd = [](unsigned long long x, unsigned long long y) { while (y) { unsigned long long t = x % y; x = y; y = t; } return x; };
+    unsigned long long num = 1, den = 1, l = 1;
+    for (auto &o : c->ops) {
+        unsigned long long a = (unsigned long long)o.stage->align() * num;
+        a /= gcd(a, den);
+        l = l / gcd(l, a) * a;
+        unsigned long rn = 1, rd = 1;
+        o.stage->rate(&rn, &rd);
+        num *= rn; den *= rd;
+        unsigned long long g = gcd(num, den);
+        num /= g; den /= g;
+    }
+    return (unsigned long)l;
+}
+
+// ---- interprocess memory / events / peer copies --------------------------------------------------------------------
+struct lrhip_ipc_event {
+    hipEvent_t ev = nullptr;
+};
+static hipStream_t copy_stream()
+{
+    static hipStream_t s = nullptr;
+    static long pid = 0;
+    if (!s || pid != (long)getpid()) {
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+        pid = (long)getpid();
+    }
+    return s;
+}
+
+int lrhip_ipc_export(const void *dev_ptr, void *handle_out)
+{
+    static_assert(sizeof(hipIpcMemHandle_t) <= LRHIP_IPC_HANDLE_BYTES && sizeof(hipIpcEventHandle_t) <= LRHIP_IPC_HANDLE_BYTES, "handle size");
+    if (!dev_ptr || !handle_out) return set_error("ipc_export: null argument");
+    if (ensure_init()) return -1;
+    hipIpcMemHandle_t h;
+    LR_HIP(hipIpcGetMemHandle(&h, const_cast<void *>(dev_ptr)));
+    memset(handle_out, 0, LRHIP_IPC_HANDLE_BYTES);
+    memcpy(handle_out, &h, sizeof(h));
+    return 0;
+}
+
+void *lrhip_ipc_open(const void *handle)
+{
+    if (!handle) { set_error("ipc_open: null handle"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    void *p = nullptr;
+    LR_HIP_NULL(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    return p;
+}
+
+int lrhip_ipc_close(void *dev_ptr)
+{
+    if (!dev_ptr) return 0;
+    LR_HIP(hipIpcCloseMemHandle(dev_ptr));
+    return 0;
+}
+
+lrhip_ipc_event_t *lrhip_ipc_event_create(void *handle_out)
+{
+    if (!handle_out) { set_error("ipc_event_create: null handle buffer"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    std::unique_ptr<lrhip_ipc_event> e(new (std::nothrow) lrhip_ipc_event());
+    if (!e) { set_error("out of memory"); return nullptr; }
+    LR_HIP_NULL(hipEventCreateWithFlags(&e->ev, hipEventDisableTiming | hipEventInterprocess));
+    hipIpcEventHandle_t h;
+    if (hipIpcGetEventHandle(&h, e->ev) != hipSuccess) {
+        (void)hipEventDestroy(e->ev);
+        set_error("hipIpcGetEventHandle failed");
+        return nullptr;
+    }
+    memset(handle_out, 0, LRHIP_IPC_HANDLE_BYTES);
+    memcpy(handle_out, &h, sizeof(h));
+    return e.release();
+}
+
+lrhip_ipc_event_t *lrhip_ipc_event_open(const void *handle)
+{
+    if (!handle) { set_error("ipc_event_open: null handle"); return nullptr; }
+    if (ensure_init()) return nullptr;
+    std::unique_ptr<lrhip_ipc_event> e(new (std::nothrow) lrhip_ipc_event());
+    if (!e) { set_error("out of memory"); return nullptr; }
+    hipIpcEventHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    LR_HIP_NULL(hipIpcOpenEventHandle(&e->ev, h));
+    return e.release();
+}
+
+void lrhip_ipc_event_destroy(lrhip_ipc_event_t *e)
+{
+    if (!e) return;
+    if (e->ev) (void)hipEventDestroy(e->ev);
+    delete e;
+}
+
+int lrhip_ipc_event_record(lrhip_ipc_event_t *e, int on_copy_stream)
+{
+    if (!e) return set_error("null event");
+    hipStream_t s = on_copy_stream ? copy_stream() : ctx().stream;
+    if (!s) return set_error("no stream");
+    LR_HIP(hipEventRecord(e->ev, s));
+    return 0;
+}
+
+int lrhip_ipc_event_wait(lrhip_ipc_event_t *e, int on_copy_stream)
+{
+    if (!e) return set_error("null event");
+    hipStream_t s = on_copy_stream ? copy_stream() : ctx().stream;
+    if (!s) return set_error("no stream");
+    LR_HIP(hipStreamWaitEvent(s, e->ev, 0));
+    return 0;
+}
+
+int lrhip_ipc_event_query(lrhip_ipc_event_t *e)
+{
+    if (!e) return set_error("null event");
+    hipError_t r = hipEventQuery(e->ev);
+    if (r == hipSuccess) return 1;
+    if (r == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return set_error("hipEventQuery failed: %s", hipGetErrorString(r));
+}
+
+int lrhip_ipc_event_synchronize(lrhip_ipc_event_t *e)
+{
+    if (!e) return set_error("null event");
+    LR_HIP(hipEventSynchronize(e->ev));
+    return 0;
+}
+
+int lrhip_peer_copy(void *dst, int dst_device, const void *src, int src_device, unsigned long bytes)
+{
+    if (ensure_init()) return -1;
+    if (!bytes) return 0;
+    if (!dst || !src) return set_error("peer_copy: null pointer");
+    hipStream_t s = copy_stream();
+    if (!s) return set_error("peer_copy: no copy stream");
+    if (dst_device != src_device) {
+        int can = 0;
+        LR_HIP(hipDeviceCanAccessPeer(&can, src_device, dst_device));
+        if (!can) return set_error("peer_copy: device %d cannot reach device %d", src_device, dst_device);
+        LR_HIP(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, s));
+    } else {
+        LR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+int lrhip_copy_stream_synchronize(void)
+{
+    hipStream_t s = copy_stream();
+    if (!s) return set_error("no copy stream");
+    LR_HIP(hipStreamSynchronize(s));
+    return 0;
 }
 
 }  // extern "C"

@@ -15,6 +15,23 @@ struct lrhip_stage {
     virtual long run2(const void *, const void *, unsigned long, void *, unsigned long) { return set_error("%s is not a two-input stage", kind()); }
     virtual int reset() = 0;
     virtual const char *kind() const = 0;
+    // ---- time-axis sharding of one stream: a partition that starts at absolute input sample n0
+    // seek(): forget every carried sample (as reset()) and set the absolute counters - rotator phase, decimation phase - as if n0 input
+    // samples had been consumed; *n0_out = output samples this stage has emitted by then (the next stage's n0).
+    virtual int seek(unsigned long long n0, unsigned long long *n0_out)
+    {
+        if (reset()) return -1;
+        *n0_out = n0;
+        return 0;
+    }
+    // memory(): input samples after which a stage started from zero state carries exactly what the uninterrupted stream would
+    // (filter history, previous sample; a recurrence whose zero start has decayed out of Float32); -1 = unbounded (no time sharding)
+    virtual long memory() const { return 0; }
+    // align(): partitions that start on a multiple of this many input samples of the stage see the same tile grid in its scan kernels as the
+    // uninterrupted stream, which makes a recurrence's output bit-identical as well (1: the stage has no such grid)
+    virtual unsigned long align() const { return 1; }
+    // input samples per output sample as a ratio (decimation num/den), for mapping memories back to the chain input
+    virtual void rate(unsigned long *num, unsigned long *den) const { *num = 1; *den = 1; }
 };
 
 static int upload(DeviceBuf &b, const void *src, size_t bytes)

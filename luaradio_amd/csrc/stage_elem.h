@@ -17,6 +17,7 @@ struct RotatorStage : lrhip_stage {
     uint64_t step = 0, count = 0;
     const char *kind() const override { return "rotator"; }
     int reset() override { count = 0; return 0; }
+    int seek(unsigned long long n0, unsigned long long *n0_out) override { count = n0; *n0_out = n0; return 0; }      // phase = step * absolute index
     long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
     {
         if (n > cap) return set_error("rotator: output capacity %lu < %lu", cap, n);
@@ -39,6 +40,13 @@ struct DownsamplerStage : lrhip_stage {
     unsigned long factor = 1, index = 0;
     const char *kind() const override { return "downsampler"; }
     int reset() override { index = 0; return 0; }
+    int seek(unsigned long long n0, unsigned long long *n0_out) override
+    {
+        index = (unsigned long)((factor - n0 % factor) % factor);       // the kept samples are the absolute indices 0 mod factor
+        *n0_out = (n0 + factor - 1) / factor;
+        return 0;
+    }
+    void rate(unsigned long *num, unsigned long *den) const override { *num = factor; *den = 1; }
     unsigned long max_output(unsigned long n) const override { return n / factor + 1; }
     long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
     {
@@ -66,6 +74,7 @@ struct FmDiscrimStage : lrhip_stage {
     int cur = 0;
     const char *kind() const override { return "fmdiscrim"; }
     int reset() override { cur = 0; return zero_fill(prev, 4 * sizeof(float)); }
+    long memory() const override { return 1; }
     long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
     {
         if (n > cap) return set_error("fmdiscrim: output capacity %lu < %lu", cap, n);
@@ -89,6 +98,7 @@ struct FmModStage : lrhip_stage {
     int cur = 0;
     const char *kind() const override { return "fmmod"; }
     int reset() override { cur = 0; return zero_fill(phase, 2 * sizeof(uint64_t)); }
+    long memory() const override { return -1; }      // the phase is the integral of the whole input
     long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
     {
         if (n > cap) return set_error("fmmod: output capacity %lu < %lu", cap, n);

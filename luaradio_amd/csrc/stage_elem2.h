@@ -187,6 +187,8 @@ struct UpsamplerStage : lrhip_stage {
     unsigned long factor = 1;
     const char *kind() const override { return "upsampler"; }
     int reset() override { return 0; }
+    int seek(unsigned long long n0, unsigned long long *n0_out) override { *n0_out = n0 * factor; return 0; }
+    void rate(unsigned long *num, unsigned long *den) const override { *num = 1; *den = factor; }
     unsigned long max_output(unsigned long n) const override { return n * factor; }
     long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
     {

@@ -34,6 +34,7 @@ struct DelayStage : lrhip_stage {
     DeviceBuf state[2];
     int cur = 0;
     const char *kind() const override { return "delay"; }
+    long memory() const override { return (long)D; }
     int reset() override
     {
         cur = 0;
@@ -60,6 +61,7 @@ struct HilbertStage : lrhip_stage {
     std::unique_ptr<FirStage> fir;     // real taps, Float32 stream: the imaginary part
     DeviceBuf tmp;
     const char *kind() const override { return "hilbert"; }
+    long memory() const override { return fir->M - 1; }
     int reset() override { return fir->reset(); }
     long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
     {

@@ -60,6 +60,42 @@ struct FirStage : lrhip_stage {
         return 0;
     }
 
+    int seek(unsigned long long n0, unsigned long long *n0_out) override
+    {
+        if (use_fft && n0 % (unsigned long long)L) return set_error("fir(fft framing): a partition must start on a block boundary (multiple of %ld samples)", L);
+        if (reset()) return -1;
+        count = n0;                                                     // fused rotator: phase = step * absolute index
+        index = (unsigned long)((D - n0 % D) % D);                      // fused downsampler: kept outputs are the absolute indices 0 mod D
+        *n0_out = (n0 + D - 1) / D;
+        return 0;
+    }
+    long memory() const override
+    {
+        long m = M - 1 + (pre_disc ? 1 : 0);
+        if (post_disc) m += D;                                          // one filter output earlier
+        if (iir_fused) m += (long)D * 320 * iir_warm;                   // the low-rate recurrence's in-launch warm-up length, in outputs
+        return m;
+    }
+    void rate(unsigned long *num, unsigned long *den) const override { *num = D; *den = 1; }
+    unsigned long align() const override
+    {
+        if (iir_fused) return 2UL * 256 * 5 * D;                        // pair-mode tile: 2 x 256 lanes x 5 outputs
+        if (fft_arith) {
+            // overlap-save arithmetic: the 1024-point blocks advance by Lf samples from the start of a chunk (two blocks ride together on
+            // a Float32 stream); the same grid gives the same rounding
+            unsigned long l = 1;
+            const int nparts = (M + FFT_PART - 1) / FFT_PART;
+            for (int part = 0; part < nparts; part++) {
+                const int Mp = part + 1 < nparts ? FFT_PART : M - part * FFT_PART;
+                unsigned long a = (unsigned long)(FFTN - ((Mp - 1 + 63) / 64) * 64) * (S == 1 ? 2UL : 1UL), x = l, y = a;
+                while (y) { unsigned long t = x % y; x = y; y = t; }
+                l = l / x * a;
+            }
+            return l;
+        }
+        return 1UL;
+    }
+
     template <int SS, int DD, int NACC>
     int launch_mfma(const float *x, long n, float *y, long n_out)
     {

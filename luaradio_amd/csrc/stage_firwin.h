@@ -19,6 +19,16 @@ struct FirWinRealStage : lrhip_stage {
     int blocks_per_cu = 0;
     const char *kind() const override { return iir ? "fir+iir" : "firwin"; }
     unsigned long max_output(unsigned long n) const override { return D == 1 ? n : n / D + 1; }
+    int seek(unsigned long long n0, unsigned long long *n0_out) override
+    {
+        if (reset()) return -1;
+        index = (unsigned long)((D - n0 % D) % D);
+        *n0_out = (n0 + D - 1) / D;
+        return 0;
+    }
+    long memory() const override { return M - 1 + (iir ? 1024L * warm_waves + 1 : 0); }
+    void rate(unsigned long *num, unsigned long *den) const override { *num = D; *den = 1; }
+    unsigned long align() const override { return iir ? (unsigned long)FWR_TILE : 1UL; }
     int reset() override
     {
         cur = 0; index = 0;

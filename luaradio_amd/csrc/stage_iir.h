@@ -18,6 +18,17 @@ struct IirStage : lrhip_stage {
     unsigned long D = 1, index = 0;       // fused DownsamplerBlock behind the filter (chains)
     const char *kind() const override { return "iir"; }
     unsigned long max_output(unsigned long n) const override { return D == 1 ? n : n / D + 1; }
+    int seek(unsigned long long n0, unsigned long long *n0_out) override
+    {
+        if (reset()) return -1;
+        index = (unsigned long)((D - n0 % D) % D);
+        *n0_out = (n0 + D - 1) / D;
+        return 0;
+    }
+    // a recurrence forgets its start only if it decays: the single-launch form already requires A^(warm_tiles * TILE) to underflow Float32
+    long memory() const override { return warm_tiles > 0 ? (long)warm_tiles * IIR_TILE + nb : -1; }
+    void rate(unsigned long *num, unsigned long *den) const override { *num = D; *den = 1; }
+    unsigned long align() const override { return scan ? (unsigned long)IIR_TILE : 1UL; }
     int reset() override
     {
         cur = 0; index = 0;
@@ -112,6 +123,7 @@ struct AgcStage : lrhip_stage {
     DeviceBuf state, mapsP, mapsG, startP, startG;     // state: two (P, G) double pairs, ping-pong
     int cur = 0;
     const char *kind() const override { return "agc"; }
+    long memory() const override { return -1; }
     int reset() override { cur = 0; return zero_fill(state, 4 * sizeof(double)); }
     template <int SS>
     int go(const float *x, float *y, unsigned long n)

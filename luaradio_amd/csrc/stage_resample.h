@@ -15,6 +15,16 @@ struct ResampleStage : lrhip_stage {
     static constexpr int SPAN_MAX = 6144;
     const char *kind() const override { return "resample"; }
     unsigned long max_output(unsigned long n) const override { return (n * (unsigned long)L) / D + 2; }
+    int seek(unsigned long long n0, unsigned long long *n0_out) override
+    {
+        if (reset()) return -1;
+        Q0 = n0;
+        m0 = (n0 * (uint64_t)L + D - 1) / D;
+        *n0_out = m0;
+        return 0;
+    }
+    long memory() const override { return HQ; }
+    void rate(unsigned long *num, unsigned long *den) const override { *num = D; *den = (unsigned long)L; }
     static bool fits(int M, int L, unsigned long D) { return L >= 1 && 256 * D / (unsigned long)L + (unsigned long)((M - 1) / L) + 4 <= (unsigned long)SPAN_MAX; }
     int reset() override
     {
@@ -56,6 +66,8 @@ struct ResampleStage : lrhip_stage {
 // polyphase channelizer as a dense MFMA GEMM
 // =====================================================================================================
 struct ChannelizerStage : lrhip_stage {
+    int seek(unsigned long long, unsigned long long *) override { return set_error("seek: not supported by the channelizer stage"); }
+    long memory() const override { return -1; }
     int M = 0, K = 0;
     DeviceBuf W, hist[2];
     int cur = 0;

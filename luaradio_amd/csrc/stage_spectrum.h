@@ -6,6 +6,8 @@
 // DFT / IDFT / PSD
 // =====================================================================================================
 struct FftStage : lrhip_stage {
+    int seek(unsigned long long, unsigned long long *) override { return set_error("seek: not supported by framed (spectrum) stages"); }
+    long memory() const override { return -1; }
     int N = 0, inverse = 0, out_kind = FFT_OUT_COMPLEX, shift = 0, in_real = 0, fpw = 1;
     float out_scale = 1.f;
     bool has_window = false;
@@ -102,6 +104,8 @@ static FftStage *fft_build(unsigned n)
 // Welch-averaged spectrum (the arithmetic of GnuplotSpectrumSink)
 // =====================================================================================================
 struct WelchStage : lrhip_stage {
+    int seek(unsigned long long, unsigned long long *) override { return set_error("seek: not supported by framed (spectrum) stages"); }
+    long memory() const override { return -1; }
     std::unique_ptr<FftStage> psd;
     int N = 0, hop = 0;
     unsigned long P = 0;            // pending samples (< N once a frame could be cut)

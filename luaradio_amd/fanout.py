@@ -41,9 +41,14 @@ class DeviceBranch:
         self.produced = 0
 
     def process(self, slab):
-        """slab: 1-D float32 CUDA tensor of interleaved ComplexFloat32 samples"""
+        """slab: 1-D float32 CUDA tensor of interleaved ComplexFloat32 samples.  The kernels are enqueued on torch's CURRENT stream
+        (lrhip_set_stream orders it behind whatever the library had queued before), so they follow the broadcast that filled the slab
+        and precede any torch consumer of the returned view."""
+        import torch
+        from . import _lib
         if not slab.is_cuda:
             raise RuntimeError("DeviceBranch needs a CUDA tensor: there is no CPU path in luaradio_amd")
+        _lib.adopt_torch_stream()
         n = slab.numel() // 2
         got = self.block.process_device(slab.data_ptr(), n, self.out.data_ptr(), self.cap)
         self.produced += got
@@ -74,6 +79,65 @@ class FanOut:
             self.dist.broadcast(slab, src=self.src)
         self.slabs += 1
         return {b: ex.process(slab) for b, ex in self.branches.items()}
+
+    def stream(self, slabs, slab_floats):
+        """Double-buffered fan-out: `slabs` yields the source's slabs (1-D float32 tensors of `slab_floats` values on the source rank;
+        on the other ranks only the count matters - pass any iterable of the same length, e.g. range(k)).  The broadcast of slab k+1
+        runs on its own communication stream while the branches work on slab k: two receive buffers, an event per buffer and direction
+        (filled -> the compute stream may read; consumed -> the next broadcast may overwrite).  Yields {branch_index: output} per slab;
+        an output view is valid until the next slab is requested.  With CPU tensors (gloo, tests) the same bookkeeping runs with
+        asynchronous broadcast handles instead of streams."""
+        import torch
+        multi = self.dist is not None and self.world > 1
+        cuda = multi and self.dist.get_backend() == "nccl" or (not multi and torch.cuda.is_available())
+        dev = "cuda" if cuda else "cpu"
+        bufs = [torch.empty(slab_floats, dtype=torch.float32, device=dev) for _ in range(2)]
+        comm = torch.cuda.Stream() if cuda else None
+        filled = [torch.cuda.Event() if cuda else None for _ in range(2)]
+        consumed = [torch.cuda.Event() if cuda else None for _ in range(2)]
+        used = [False, False]
+        handles = [None, None]
+        it = iter(slabs)
+
+        def launch(k, item):
+            """copy / broadcast slab `item` into buffer k on the communication stream"""
+            b = bufs[k]
+            if cuda:
+                if self.rank == self.src:
+                    comm.wait_stream(torch.cuda.current_stream())      # the slab may still be being written on the compute stream
+                with torch.cuda.stream(comm):
+                    if used[k]:
+                        comm.wait_event(consumed[k])
+                    if self.rank == self.src:
+                        b.copy_(item, non_blocking=True)
+                    if multi:
+                        self.dist.broadcast(b, src=self.src)
+                    filled[k].record(comm)
+            else:
+                if self.rank == self.src:
+                    b.copy_(item)
+                handles[k] = self.dist.broadcast(b, src=self.src, async_op=True) if multi else None
+            used[k] = True
+
+        nxt = next(it, None)
+        k = 0
+        if nxt is not None:
+            launch(0, nxt)
+        while nxt is not None:
+            cur_k = k
+            nxt = next(it, None)
+            if nxt is not None:
+                launch(cur_k ^ 1, nxt)                  # slab k+1 travels while slab k is processed
+            if cuda:
+                torch.cuda.current_stream().wait_event(filled[cur_k])
+            elif handles[cur_k] is not None:
+                handles[cur_k].wait()
+            self.slabs += 1
+            out = {b: ex.process(bufs[cur_k]) for b, ex in self.branches.items()}
+            if cuda:
+                consumed[cur_k].record(torch.cuda.current_stream())
+            yield out
+            k ^= 1
 
     def timed(self, fn, sync):
         """max-over-ranks wall time of fn(), bracketed by sync() (barrier + device synchronize) on both sides"""

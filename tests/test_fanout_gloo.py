@@ -89,3 +89,69 @@ def test_fanout_two_ranks_gloo(tmp_path, nbranches):
 def test_fanout_rejects_wrong_ownership():
     with pytest.raises(ValueError):
         fanout.FanOut(None, 0, 2, 4, {1: object()})
+
+
+def _stream_worker(rank, world, port, nbranches, outdir):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fs, n, nslabs = 1102500.0, 6000, 5
+    offs = fanout.branch_offsets(nbranches)
+    mine = {b: _OracleBranch(offs[b], fs) for b in fanout.local_branches(nbranches, world, rank)}
+    fo = fanout.FanOut(dist, rank, world, nbranches, mine, src=0)
+    rng = np.random.default_rng(99)
+
+    def source():
+        for _ in range(nslabs):
+            x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+            yield torch.from_numpy(x.view(np.float32).copy())
+
+    outs = {b: [] for b in mine}
+    for got in fo.stream(source() if rank == 0 else range(nslabs), 2 * n):     # double-buffered: slab k+1 travels while slab k is processed
+        for b, y in got.items():
+            outs[b].append(y.clone())
+    assert fo.slabs == nslabs
+    for b, parts in outs.items():
+        np.save(os.path.join(outdir, "sbranch%d.npy" % b), torch.cat(parts).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fanout_double_buffered_stream_two_ranks_gloo(tmp_path):
+    from oracle import oracle as O
+    world, nbranches = 2, 4
+    mp.spawn(_stream_worker, args=(world, _free_port(), nbranches, str(tmp_path)), nprocs=world, join=True)
+    fs, n = 1102500.0, 6000
+    rng = np.random.default_rng(99)
+    x = np.concatenate([(rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64) for _ in range(5)])
+    for b, off in enumerate(fanout.branch_offsets(nbranches)):
+        want = O.tuner(off, 100e3, 5, fs, mode=O.MODE_FMA, rot_mode=O.MODE_F64).process(x)
+        got = np.load(os.path.join(str(tmp_path), "sbranch%d.npy" % b)).view(np.complex64)
+        assert np.array_equal(got, want), b
+
+
+@pytest.mark.gpu
+def test_fanout_stream_on_the_device_equals_push():
+    """one process, one GPU: the double-buffered form (communication stream + events) gives the slabs' outputs in order, same bits as
+    push(); the branch kernels are ordered behind the copy that fills the buffer (DeviceBranch adopts torch's current stream)"""
+    import luaradio_amd as lr
+    from luaradio_amd import types
+    fs, n, nslabs = 1102500.0, 1 << 18, 6
+    g = torch.Generator(device="cuda").manual_seed(3)
+    slabs = [torch.rand(2 * n, dtype=torch.float32, device="cuda", generator=g) * 2 - 1 for _ in range(nslabs)]
+
+    def branch():
+        tun = lr.TunerBlock(-350e3, 100e3, 5)
+        tun.rate = fs
+        tun.differentiate([types.ComplexFloat32])
+        tun.initialize()
+        return fanout.DeviceBranch(tun, n)
+
+    a = fanout.FanOut(None, 0, 1, 1, {0: branch()})
+    want = torch.cat([a.push(s)[0].clone() for s in slabs])
+    b = fanout.FanOut(None, 0, 1, 1, {0: branch()})
+    got = torch.cat([o[0].clone() for o in b.stream(iter(slabs), 2 * n)])
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)

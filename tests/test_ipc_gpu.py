@@ -1,0 +1,118 @@
+"""Fan-out below the host language (include/lrhip.h lrhip_ipc_* / lrhip_peer_copy): a producer process pushes slabs into a consumer
+process's device buffers (double-buffered, interprocess events both ways) and the consumer runs its Tuner branch on them - two processes
+on ONE device here (gpurun exposes one GPU); with one device per process the same calls move the slabs over xGMI."""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NSLAB, N = 5, 1 << 16
+
+
+def _slab(k):
+    rng = np.random.default_rng(100 + k)
+    return (rng.uniform(-1, 1, N) + 1j * rng.uniform(-1, 1, N)).astype(np.complex64)
+
+
+def _consumer(conn):
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import luaradio_amd as lr
+    from luaradio_amd import _lib, ipc, types
+    lr.init(0)
+    L = _lib.load()
+    bufs = [_lib.check_ptr(L.lrhip_malloc(8 * N), "malloc") for _ in range(2)]
+    out_dev = _lib.check_ptr(L.lrhip_malloc(8 * N), "malloc")
+    filled = [ipc.Event.create() for _ in range(2)]          # recorded by the producer after its copy
+    consumed = [ipc.Event.create() for _ in range(2)]        # recorded here after the branch has read the slab
+    conn.send({"mem": [ipc.export_memory(b) for b in bufs], "filled": [e.handle for e in filled], "consumed": [e.handle for e in consumed]})
+    tun = lr.TunerBlock(-250e3, 100e3, 5)
+    tun.rate = 1102500.0
+    tun.differentiate([types.ComplexFloat32])
+    tun.initialize()
+    outs = []
+    for k in range(NSLAB):
+        assert conn.recv() == ("pushed", k)                  # control message only: the data went device to device
+        filled[k & 1].wait()                                 # the library stream waits on the GPU for the producer's copy
+        got = tun.process_device(bufs[k & 1], N, out_dev, N)
+        consumed[k & 1].record()
+        conn.send(("consumed", k))
+        host = np.empty(got, np.complex64)
+        _lib.check(L.lrhip_memcpy_d2h(host.ctypes.data_as(C.c_void_p), out_dev, 8 * got), "d2h")
+        outs.append(host)
+    conn.send(np.concatenate(outs))
+    conn.recv()
+    conn.close()
+
+
+def _producer(conn):
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import luaradio_amd as lr
+    from luaradio_amd import _lib, ipc
+    lr.init(0)
+    L = _lib.load()
+    hs = conn.recv()
+    bufs = [ipc.open_memory(h) for h in hs["mem"]]
+    filled = [ipc.Event.open(h) for h in hs["filled"]]
+    consumed = [ipc.Event.open(h) for h in hs["consumed"]]
+    src = _lib.check_ptr(L.lrhip_malloc(8 * N * NSLAB), "malloc")
+    for k in range(NSLAB):
+        s = _slab(k)
+        _lib.check(L.lrhip_memcpy_h2d(src + 8 * N * k, s.ctypes.data_as(C.c_void_p), 8 * N), "h2d")
+    _lib.check(L.lrhip_synchronize(), "sync")
+    for k in range(NSLAB):
+        if k >= 2:
+            assert conn.recv() == ("consumed", k - 2)
+            consumed[k & 1].wait(on_copy_stream=True)        # do not overwrite a slab the branch is still reading
+        ipc.peer_copy(bufs[k & 1], 0, src + 8 * N * k, 0, 8 * N)
+        filled[k & 1].record(on_copy_stream=True)
+        conn.send(("pushed", k))
+    ipc.copy_stream_synchronize()
+    for k in range(max(0, NSLAB - 2), NSLAB):
+        assert conn.recv() == ("consumed", k)
+    conn.send("done")
+    for b in bufs:
+        ipc.close_memory(b)
+    conn.close()
+
+
+def test_two_processes_one_device_double_buffered_slabs():
+    ctx = mp.get_context("spawn")
+    # parent relays control messages between the two children (it stands in for the host's control socket) and never touches the device
+    pc, cc = ctx.Pipe()
+    pp, cp = ctx.Pipe()
+    cons = ctx.Process(target=_consumer, args=(cc,))
+    prod = ctx.Process(target=_producer, args=(cp,))
+    cons.start()
+    prod.start()
+    try:
+        pp.send(pc.recv())                                   # handles: consumer -> producer
+        result = None
+        done = 0
+        while done < 2:
+            for src, dst in ((pp, pc), (pc, pp)):
+                if src.poll(0.01):
+                    m = src.recv()
+                    if isinstance(m, np.ndarray):
+                        result = m
+                        done += 1
+                        pc.send("bye")
+                    elif m == "done":
+                        done += 1
+                    else:
+                        dst.send(m)
+            assert cons.is_alive() or prod.is_alive() or done == 2
+    finally:
+        cons.join(60)
+        prod.join(60)
+    assert cons.exitcode == 0 and prod.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    want = O.tuner(-250e3, 100e3, 5, 1102500.0, mode=O.MODE_FMA, rot_mode=O.MODE_F64).process(np.concatenate([_slab(k) for k in range(NSLAB)]))
+    assert result is not None and len(result) == len(want)
+    assert float(np.max(np.abs(result - want))) < 2e-6

@@ -8,7 +8,7 @@ import numpy as np, torch
 import luaradio_amd as lr
 lr.init(0)
 L = lr._lib.load()
-L.lrhip_set_stream(torch.cuda.current_stream().cuda_stream)
+lr.adopt_torch_stream()
 dev = torch.device("cuda")
 fs, n = 1102500.0, 1 << 26
 t = torch.arange(n, dtype=torch.float64, device=dev) / fs

@@ -9,7 +9,7 @@ import luaradio_amd as lr
 from luaradio_amd import types
 lr.init(0)
 L = lr._lib.load()
-L.lrhip_set_stream(torch.cuda.current_stream().cuda_stream)
+lr.adopt_torch_stream()
 n = 1 << 26
 g = torch.Generator(device="cuda").manual_seed(1)
 x = torch.rand(2 * n, device="cuda", generator=g) * 2 - 1

@@ -12,7 +12,7 @@ import luaradio_amd as lr
 from luaradio_amd import types
 lr.init(0)
 L = lr._lib.load()
-L.lrhip_set_stream(torch.cuda.current_stream().cuda_stream)
+lr.adopt_torch_stream()
 dev = torch.device("cuda")
 g = torch.Generator(device=dev).manual_seed(7)
 tag = "nofuse" if os.environ.get("LRHIP_NO_FIR_IIR_FUSION") else "fused"

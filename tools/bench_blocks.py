@@ -24,7 +24,7 @@ def main():
 
     lr.init(0)
     L = lr._lib.load()
-    L.lrhip_set_stream(torch.cuda.current_stream().cuda_stream)
+    lr.adopt_torch_stream()
     n = 1 << args.log2_samples
     g = torch.Generator(device="cuda").manual_seed(1)
     xc = torch.rand(2 * n, device="cuda", generator=g) * 2 - 1

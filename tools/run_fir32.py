@@ -8,7 +8,7 @@ import luaradio_amd as lr
 from luaradio_amd import types
 lr.init(0)
 L = lr._lib.load()
-L.lrhip_set_stream(torch.cuda.current_stream().cuda_stream)
+lr.adopt_torch_stream()
 n = 1 << 26
 x = torch.rand(n, dtype=torch.float32, device="cuda") * 2 - 1
 y = torch.empty(n + 64, dtype=torch.float32, device="cuda")
