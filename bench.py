@@ -323,7 +323,8 @@ def main():
             dist.init_process_group(backend="gloo")
     lr.init(local_rank)
     L = lr._lib.load()
-    # launch on torch's current stream so torch.cuda.synchronize()/barriers and the library's HIP events agree
+    # launch on torch's current stream (its default stream has handle 0 = hipStreamLegacy for the library) so torch.cuda.synchronize()/barriers,
+    # torch tensors handed to process_device() and the library's HIP events are all ordered on one stream
     lr.adopt_torch_stream()
 
     log2n = args.log2_samples or (28 if args.workload == "fir" else 26)
@@ -401,10 +402,13 @@ def main():
             tun.differentiate([types.ComplexFloat32])
             tun.initialize()
             mine[b] = fanout.DeviceBranch(tun, n)
-        fo = fanout.FanOut(dist, rank, world, nbranches, mine, src=0)
+        fo = fanout.FanOut(dist, rank, world, nbranches, mine, src=0, device="cuda")
+        # double-buffered: the broadcast of slab k+1 (communication stream) overlaps the branch kernels on slab k (FanOut.stream)
+        import itertools
+        slab_iter = fo.stream(itertools.repeat(x), 2 * n)
 
         def step():
-            fo.push(x)
+            next(slab_iter)
 
         out_per_step = n
         alg_bytes = 9.6 * n
@@ -422,11 +426,16 @@ def main():
 
     # clock ramp: a GPU that has been idle runs its first ~100 ms of work well below the sustained clocks (measured on the gpurun
     # pool: 1.02 ms for the first timed FIR passes of a process, 0.85 ms from then on) - untimed, before the W warm-up steps
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < args.prewarm_ms / 1e3:
-        for _ in range(4):
+    if args.workload == "fanout" and world > 1:
+        for _ in range(8):            # a step holds a collective: every rank must run the SAME number of them (no time-based loop here)
             step()
         torch.cuda.synchronize()
+    else:
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < args.prewarm_ms / 1e3:
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -440,10 +449,14 @@ def main():
     wall = time.perf_counter() - t0
     ev_ms = L.lrhip_timer_elapsed_ms(timer)
     L.lrhip_timer_destroy(timer)
+    per_rank_wall = [wall]
     if dist is not None:
-        tt = torch.tensor([wall], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
+        cdev = dev if args.dist_backend == "nccl" else "cpu"
+        mine_t = torch.tensor([wall], dtype=torch.float64, device=cdev)
+        allw = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(allw, mine_t)
+        per_rank_wall = [float(w.item()) for w in allw]
+        wall = max(per_rank_wall)
 
     verification = None
     if rank == 0 and world == 1 and args.workload == "fir" and not args.no_verify:
@@ -491,6 +504,14 @@ def main():
                          "fp32_tflops": round(flops / launch_s / 1e12, 2), "fp32_peak_tflops": FP32_PEAK_TFLOPS,
                          "fp32_frac": round(flops / launch_s / 1e12 / FP32_PEAK_TFLOPS, 4)},
         }
+        if args.workload == "fanout":
+            # every receiving GPU takes the whole slab over ONE xGMI link from the source (point-to-point links, 7 x ~153 GB/s per GPU):
+            # 8 B per ComplexFloat32 sample -> at most ~19.1 GS/s per receiver, far below what a branch filters (the fanout leg of the N = 1 line)
+            res["fanout_links"] = {"per_rank_received_GB/s": [None if r == 0 else round(8.0 * n * args.steps / per_rank_wall[r] / 1e9, 1) for r in range(world)],
+                                   "source_sent_GB/s": round(8.0 * n * args.steps * max(world - 1, 0) / wall / 1e9, 1),
+                                   "xgmi_link_GB/s": 153.0, "xgmi_link_bound_MSps": 19125.0, "double_buffered": True,
+                                   "note": "RCCL broadcast of each slab on a communication stream, overlapped with the branch kernels on the previous slab; "
+                                           "a receiver is bounded by one link, so fan-out throughput is link-bound by construction"}
         if yard_gbs:
             res["roofline"]["streaming_yardstick"] = {"kernel": "multiply_constant_vec4_kernel<0> (MultiplyConstantBlock: 16 B per lane, one item per thread; 8 B in + 8 B out per sample, same buffers)",
                                                       "GB/s": round(yard_gbs, 1), "frac_of_yardstick": round(achieved / yard_gbs, 4)}

@@ -63,8 +63,9 @@ class FanOut:
               .process(slab_tensor)
     """
 
-    def __init__(self, dist, rank, world_size, num_branches, branches, src=0):
+    def __init__(self, dist, rank, world_size, num_branches, branches, src=0, device=None):
         self.dist, self.rank, self.world, self.src = dist, rank, world_size, src
+        self.device = device          # "cuda" / "cpu" for stream()'s slab buffers; None = cuda with RCCL or a single GPU process, cpu otherwise
         self.num_branches = num_branches
         mine = local_branches(num_branches, world_size, rank)
         if sorted(branches) != mine:
@@ -89,7 +90,10 @@ class FanOut:
         asynchronous broadcast handles instead of streams."""
         import torch
         multi = self.dist is not None and self.world > 1
-        cuda = multi and self.dist.get_backend() == "nccl" or (not multi and torch.cuda.is_available())
+        if self.device is not None:
+            cuda = self.device == "cuda"
+        else:
+            cuda = multi and self.dist.get_backend() == "nccl" or (not multi and torch.cuda.is_available())
         dev = "cuda" if cuda else "cpu"
         bufs = [torch.empty(slab_floats, dtype=torch.float32, device=dev) for _ in range(2)]
         comm = torch.cuda.Stream() if cuda else None
