@@ -25,12 +25,12 @@ class Output:
 class Block:
     name = "Block"
 
-    def __init__(self, *args):
+    def __init__(self, *args, **kwargs):
         self.type_signatures = []
         self.signature = None
         self.rate = None          # set by the graph (upstream propagation) or by the caller
         self._stage = None
-        self.instantiate(*args)
+        self.instantiate(*args, **kwargs)
 
     # ---- hooks (block.lua:459-485)
     def instantiate(self, *args):

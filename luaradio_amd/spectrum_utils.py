@@ -144,3 +144,67 @@ class WelchSpectrum(_Transform):
             return None
         self.frames = int(frames)
         return out - np.float32(self.reference_level)
+
+
+def value_to_pixel(value):
+    """radio/blocks/sinks/gnuplotwaterfall.lua:151-182 on a vector: normalised magnitude in [0, 1] -> RGB, five linear segments
+    black -> blue -> green -> yellow -> red -> white (Lua doubles, math.floor)"""
+    v = np.asarray(value, np.float64)
+    norm = lambda x, lo, hi: (np.maximum(np.minimum(x, hi), lo) - lo) / (hi - lo)
+    rgb = np.zeros(v.shape + (3,), np.uint8)
+    seg = np.minimum((v * 5).astype(np.int64), 4)
+    seg = np.where(v < 1 / 5, 0, np.where(v < 2 / 5, 1, np.where(v < 3 / 5, 2, np.where(v < 4 / 5, 3, 4))))
+    c = [np.floor(255 * norm(v, k / 5, (k + 1) / 5)).astype(np.int64) for k in range(5)]
+    z, f = np.zeros_like(c[0]), np.full_like(c[0], 255)
+    table = [(z, z, c[0]), (z, c[1], 255 - c[1]), (c[2], f, z), (f, 255 - c[3], z), (f, c[4], c[4])]
+    for k, (r, g, b) in enumerate(table):
+        m = seg == k
+        rgb[m, 0], rgb[m, 1], rgb[m, 2] = r[m], g[m], b[m]
+    return rgb
+
+
+class WaterfallSpectrum:
+    """The arithmetic of GnuplotWaterfallSink (radio/blocks/sinks/gnuplotwaterfall.lua:184-236): Welch frames as in WelchSpectrum (on the
+    device), every `num_psd_averages` frames one new pixel row - averaged log PSD, clamped to [min_magnitude, max_magnitude], mapped through
+    value_to_pixel - pushed into a `rows` x num_samples RGB image that scrolls up.  The gnuplot pipe itself stays on the host, out of scope.
+
+    WaterfallSpectrum(data_type[, num_samples=1024[, window[, sample_rate[, overlap=0.0[, num_psd_averages=1[, min_magnitude=-150[,
+                      max_magnitude=0[, rows=64]]]]]]]])
+    process(x) -> number of rows added; .pixels is the image (uint8 [rows][columns][3])."""
+
+    def __init__(self, data_type, num_samples=1024, window=None, sample_rate=None, overlap=0.0, num_psd_averages=1, min_magnitude=-150.0,
+                 max_magnitude=0.0, rows=64):
+        if not overlap < 1:
+            raise AssertionError("Overlap should be a fraction in [0.00, 1.00)")        # gnuplotwaterfall.lua:60
+        self.welch = WelchSpectrum(data_type, num_samples, window, sample_rate, overlap, 0.0)
+        self.num_samples, self.columns, self.rows = self.welch.num_samples, self.welch.num_samples, int(rows)
+        self.num_psd_averages = int(num_psd_averages)
+        self.min_magnitude, self.max_magnitude = float(min_magnitude), float(max_magnitude)
+        self.hop = self.num_samples - self.welch.num_overlap
+        self.fill, self.frames = 0, 0                   # host mirror of the device's frame counters (no read-back needed to know them)
+        self.pixels = np.zeros((self.rows, self.columns, 3), np.uint8)
+
+    def process(self, x):
+        x = np.ascontiguousarray(x, dtype=self.welch.data_type.dtype)
+        i, added = 0, 0
+        while i < len(x):
+            # samples that complete exactly the frames still missing for the next row
+            m = (self.num_samples - self.fill) + (self.num_psd_averages - self.frames - 1) * self.hop
+            take = min(m, len(x) - i)
+            self.welch.process(x[i:i + take])
+            i += take
+            total = self.fill + take
+            if total >= self.num_samples:
+                f = (total - self.num_samples) // self.hop + 1
+                self.fill = total - f * self.hop
+                self.frames += f
+            else:
+                self.fill = total
+            if self.frames == self.num_psd_averages:
+                avg = self.welch.average()              # mean of the frames' log PSDs (gnuplotwaterfall.lua:213-216), fftshifted
+                value = (np.maximum(np.minimum(avg.astype(np.float64), self.max_magnitude), self.min_magnitude) - self.min_magnitude) / (self.max_magnitude - self.min_magnitude)
+                self.pixels[:-1] = self.pixels[1:]      # :219 shift pixels one row up
+                self.pixels[-1] = value_to_pixel(value)
+                self.frames = 0
+                added += 1
+        return added

@@ -7,6 +7,7 @@ import ctypes as C
 import os
 import subprocess
 
+import math
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -408,6 +409,47 @@ class WelchSpectrum:
         self.acc[:] = 0
         self.count = 0
         return out
+
+
+class Waterfall:
+    """GnuplotWaterfallSink's process loop, radio/blocks/sinks/gnuplotwaterfall.lua:184-236 (rows of value_to_pixel(normalize(mean log PSD)),
+    :147-182), restated with the oracle's PSD.  The reference holds no vector for the sink (it writes to a gnuplot pipe): unpinned beyond the
+    PSD / fftshift vectors."""
+
+    def __init__(self, is_complex, num_samples=1024, window_type="hamming", sample_rate=2.0, overlap=0.0, num_psd_averages=1, min_magnitude=-150.0,
+                 max_magnitude=0.0, rows=64):
+        self.w = WelchSpectrum(is_complex, num_samples, window_type, sample_rate, overlap, 0.0)
+        self.navg, self.lo, self.hi = num_psd_averages, float(min_magnitude), float(max_magnitude)
+        self.pixels = np.zeros((rows, num_samples, 3), np.uint8)
+        self.rows_added = 0
+
+    @staticmethod
+    def _normalize(value, lo, hi):
+        return (max(min(value, hi), lo) - lo) / (hi - lo)
+
+    @classmethod
+    def value_to_pixel(cls, value):
+        n = cls._normalize
+        if value < 1 / 5:
+            c = math.floor(255 * n(value, 0, 1 / 5)); return (0, 0, c)
+        if value < 2 / 5:
+            c = math.floor(255 * n(value, 1 / 5, 2 / 5)); return (0, c, 255 - c)
+        if value < 3 / 5:
+            c = math.floor(255 * n(value, 2 / 5, 3 / 5)); return (c, 255, 0)
+        if value < 4 / 5:
+            c = math.floor(255 * n(value, 3 / 5, 4 / 5)); return (255, 255 - c, 0)
+        c = math.floor(255 * n(value, 4 / 5, 5 / 5)); return (255, c, c)
+
+    def process(self, x):
+        # one sample at a time keeps the reference's loop order (a frame completes, then the row check, :191-235) without restating its
+        # index arithmetic; sizes in the tests are small
+        for k in range(len(x)):
+            self.w.process(x[k:k + 1])
+            if self.w.count == self.navg:
+                avg = self.w.average()
+                self.pixels[:-1] = self.pixels[1:]
+                self.pixels[-1] = [self.value_to_pixel(self._normalize(float(v), self.lo, self.hi)) for v in avg]
+                self.rows_added += 1
 
 
 def multiply_conjugate(a, b):

@@ -21,6 +21,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2-samples", type=int, default=26)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--trials", type=int, default=0, help="> 0: the suite's own protocol instead of HIP-event timing - ZeroSource -> block -> "
+                    "BenchmarkSink(JSON), that many trials of --trial-seconds each, mean and sigma of OUTPUT samples per second "
+                    "(luaradio_benchmark.lua:690-738); the zero vector is resident in HBM, 2^log2-samples per process()")
+    ap.add_argument("--trial-seconds", type=float, default=0.5)
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -59,6 +63,25 @@ def main():
     rows = []
 
     def run(name, published, blk, cplx):
+        if args.trials > 0:
+            from luaradio_amd import meters
+            src = lr.ZeroSource(types.ComplexFloat32 if cplx else types.Float32, 1.0, n)
+            src.initialize()
+            ptr, cnt = src.process_device()
+            cap = blk.max_output(cnt)
+
+            def make_top(results):
+                snk = lr.BenchmarkSink(results, True)
+                snk.differentiate([types.ComplexFloat32 if cplx else types.Float32])
+                snk.initialize()
+                return (lambda: snk.process(int(blk.process_device(ptr, cnt, out.data_ptr(), cap)))), snk
+
+            r = meters.run_trials(make_top, args.trials, args.trial_seconds, sync=torch.cuda.synchronize)
+            src.cleanup()
+            rows.append({"benchmark": name, "MS/s (output)": round(r["samples_per_second"] / 1e6, 1), "sigma": round(r["samples_per_second_stdev"] / 1e6, 1),
+                         "trials": args.trials, "reference_i5_MS/s": published,
+                         "ratio": round(r["samples_per_second"] / 1e6 / published, 1) if published else None})
+            return
         x = xc if cplx else xr
         cap = blk.max_output(n)
         ms = timeit(lambda: blk.process_device(x.data_ptr(), n, out.data_ptr(), cap))
