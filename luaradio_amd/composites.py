@@ -165,6 +165,11 @@ class CompositeBlock(Block):
         return self
 
     def differentiate(self, input_types):
+        # block.lua:238-352: a composite that declares signatures accepts only those input types
+        if self.type_signatures and not any(len(ins) == len(input_types) and all(i.data_type is t for i, t in zip(ins, input_types))
+                                            for ins, _, _ in self.type_signatures):
+            raise TypeError("No compatible type signatures found for block %s with input types [%s]."
+                            % (self.name, ", ".join(map(str, input_types))))
         t = list(input_types)
         for b in self._blocks:
             b.differentiate(t)

@@ -131,6 +131,8 @@ class DeviceGraph:
     def initialize(self):
         L = _lib.load()
         nodes = self._nodes
+        for nd in nodes.values():          # initialize() may be called again after further connect() calls: start from a clean slate
+            nd.inputs, nd.consumers, nd.out, nd.pending, nd.runner, nd.merged_into = {}, [], [], {}, None, None
         # resolve port names: needs every signature's port list; use the first signature's names (they do not depend on type)
         for src, oname, dst, iname in self._edges_named:
             s, d = nodes[id(src)], nodes[id(dst)]
@@ -246,7 +248,10 @@ class DeviceGraph:
             if n.merged_into is not None:
                 continue
             if isinstance(b, GraphInput):
-                x = np.ascontiguousarray(inputs[b.label], dtype=b.data_type.dtype)
+                x = np.asarray(inputs[b.label])
+                if x.dtype != b.data_type.dtype:          # as Block._execute: no silent casts (complex128 -> complex64, complex -> real part)
+                    raise TypeError("graph input '%s' expects %s, got %s" % (b.label, b.data_type, x.dtype))
+                x = np.ascontiguousarray(x)
                 n.out[0][0].reserve(max(x.nbytes, 1))
                 if len(x):
                     _lib.check(L.lrhip_memcpy_h2d(n.out[0][0].ptr, x.ctypes.data_as(C.c_void_p), x.nbytes), "h2d")

@@ -51,10 +51,11 @@ class _FileSource(Block):
         """One chunk, or None at end of file (iqfile.lua:82-96)."""
         raw = self._fh.read(self.chunk_size * self.record_size)
         num_samples = len(raw) // self.record_size
+        if num_samples == 0 and self.repeat_on_eof:
+            self._fh.seek(0)                  # iqfile.lua:86-90: rewind once and read again; a file without one whole record still ends
+            raw = self._fh.read(self.chunk_size * self.record_size)
+            num_samples = len(raw) // self.record_size
         if num_samples == 0:
-            if self.repeat_on_eof:
-                self._fh.seek(0)
-                return self.process()
             return None
         L = _lib.load()
         buf = np.frombuffer(raw, dtype=np.uint8, count=num_samples * self.record_size)

@@ -159,3 +159,24 @@ def test_device_graph_construction_errors_need_no_gpu():
     g.connect(b2, b1)
     with pytest.raises(ValueError, match="cycle"):
         g.initialize()
+
+
+def test_file_source_shorter_than_one_record_ends_even_with_repeat():
+    """repeat_on_eof on an empty / truncated file recursed forever; the reference returns nil when the read after the rewind
+    still yields nothing (iqfile.lua:86-96)"""
+    import luaradio_amd as lr
+    for blob in (b"", b"\x01"):
+        src = lr.IQFileSource(blob, "s16le", 1e6, True)
+        src._fh = __import__("io").BytesIO(blob)       # initialize() needs the device for its format stage; the read loop does not
+        src._stage = None
+        assert src.process() is None
+
+
+def test_composite_checks_its_own_type_signatures():
+    import luaradio_amd as lr
+    from luaradio_amd import types
+    import pytest
+    t = lr.TunerBlock(1e3, 1e3, 5)
+    t.rate = 1e6
+    with pytest.raises(TypeError, match="No compatible type signatures"):
+        t.differentiate([types.Float32])
