@@ -35,4 +35,6 @@ python profiles/summarize_rocpd.py "$OUT/kt" > "$OUT/summary_kernel_trace.txt" 2
 python profiles/summarize_rocpd.py "$OUT/pmc_fir" fir_ > "$OUT/summary_pmc_fir.txt" 2>&1
 python profiles/summarize_rocpd.py "$OUT/pmc_direct" fir_ > "$OUT/summary_pmc_direct.txt" 2>&1
 python profiles/summarize_rocpd.py "$OUT/pmc_wbfm" lrhip > "$OUT/summary_pmc_wbfm.txt" 2>&1
+# the rocpd databases are large (gpurun copies at most 64 MiB back): keep the summaries only
+find "$OUT" -name "*.db" -delete
 tail -n 45 "$OUT/summary_kernel_trace.txt"
