@@ -26,6 +26,9 @@
 // Accuracy: f32 FFT arithmetic, not the fmaf chain of the direct form; error vs the f64 oracle is ~3e-7 for
 // |x| <= 1 and unity-gain taps (tests hold it to the reference's 1e-6).
 #pragma once
+#ifndef LRHIP_FFT_NT
+#define LRHIP_FFT_NT 1      /* 1 = non-temporal output stores (same-box A/B at 2^28 samples: 0.849 against 0.855 ms), 2 = + non-temporal loads (0.871: the 12.5 % block overlap is re-read from L2) */
+#endif
 #include "common.h"
 #include "kernels_fir.h"
 #include "pk_math.h"
@@ -239,7 +242,11 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             if (xlo >= 0 && xlo + FFTN <= n) {
                 const cf *src = reinterpret_cast<const cf *>(x) + xlo + lane;
 #pragma unroll
+#if LRHIP_FFT_NT >= 2
+                for (int i = 0; i < 16; i++) v[i] = __builtin_nontemporal_load(src + 64 * i);
+#else
                 for (int i = 0; i < 16; i++) v[i] = src[64 * i];
+#endif
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
@@ -317,7 +324,14 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             if (o0 + FFTN <= n_out) {
 #pragma unroll
                 for (int i = 0; i < 16; i++)
-                    if (64 * i >= V) dst[64 * i] = accumulate ? dst[64 * i] + v[i] : v[i];            // wave-uniform: whole rows only
+                    if (64 * i >= V) {                                                                // wave-uniform: whole rows only
+#if LRHIP_FFT_NT >= 1
+                        if (!accumulate) __builtin_nontemporal_store(v[i], dst + 64 * i);
+                        else dst[64 * i] = dst[64 * i] + v[i];
+#else
+                        dst[64 * i] = accumulate ? dst[64 * i] + v[i] : v[i];
+#endif
+                    }
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; i++) {

@@ -750,6 +750,39 @@ def test_wbfm_mono_chain_rms_within_1e5():
     assert spec[band].max() > 100 * np.median(spec)
 
 
+def test_wbfm_chain_full_bench_size_vs_oracle_slabs():
+    """BASELINE.json configs[2] at the size the bench times (2^26 RF samples): the device audio of the WHOLE vector against the oracle chain on
+    eight slabs from the first to the last sample; a slab away from the start runs the oracle from zero state 100 000 samples early (multiple
+    of 25; de-emphasis pole 0.941^4000 and the filter transients are long gone).  Bar: RMS <= 1e-5 (north_star), measured ~2e-8."""
+    import torch
+    fs, n = 1102500.0, 1 << 26
+    t = torch.arange(n, dtype=torch.float64, device="cuda") / fs
+    m = 0.5 * torch.sin(2 * np.pi * 1e3 * t) + 0.5 * torch.sin(2 * np.pi * 5e3 * t)
+    ph = 2 * np.pi * 250e3 * t + 2 * np.pi * 75e3 / fs * torch.cumsum(m, 0)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.stack([torch.cos(ph).float(), torch.sin(ph).float()], 1).reshape(-1)
+    x += 0.01 * (torch.rand(2 * n, dtype=torch.float32, device="cuda", generator=g) * 2 - 1)
+    del t, m, ph
+    rx = lr.wbfm_mono_receiver(fs, -250e3)
+    cap = rx.max_output(n)
+    y = torch.empty(cap + 16, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    got_n = rx.process_device(x.data_ptr(), n, y.data_ptr(), cap)
+    lr._lib.load().lrhip_synchronize()
+    assert got_n == (n + 24) // 25
+    slab, warm, nsl = 262150, 100000, 8
+    se, cnt, worst = 0.0, 0, 0.0
+    for s0 in [0] + [int((n - slab) * k / (nsl - 1)) // 25 * 25 for k in range(1, nsl)]:
+        lo = max(0, s0 - warm)
+        xs = x[2 * lo:2 * (s0 + slab)].cpu().numpy().view(np.complex64)
+        want = O.wbfm_mono_chain(fs, -250e3, mode=O.MODE_LUA, rot_mode=O.MODE_F64).process(xs)[(s0 - lo) // 25:]
+        got = y[s0 // 25:s0 // 25 + len(want)].cpu().numpy()
+        k = min(len(got), len(want))
+        err = got[:k].astype(np.float64) - want[:k].astype(np.float64)
+        se += float(np.sum(err ** 2)); cnt += k; worst = max(worst, float(np.max(np.abs(err))))
+    assert cnt > 80000 and (se / cnt) ** 0.5 <= 1e-5 and worst < 1e-4
+
+
 # --------------------------------------------------------------------------------------------- properties at size
 def test_fir_properties_at_full_tile_sizes():
     """size-independent checks on 2^24 samples (the oracle is too slow there): impulse response == taps,
@@ -788,7 +821,8 @@ def test_fir_properties_at_full_tile_sizes():
 
 
 def test_fir_overlap_save_properties_at_bench_size():
-    """BASELINE.json configs[1] size (2^28 cf32, 2 GiB in / 2 GiB out) - the oracle cannot run there, so:
+    """BASELINE.json configs[1] size (2^28 cf32, 2 GiB in / 2 GiB out): (0) both kernels against the oracle on nine slabs spread over the
+    vector; and, since the oracle cannot cover all 2^28 samples in a test's time,
     (1) the overlap-save kernel agrees with the bit-exact direct-form kernel to 1e-6 on every one of 2^28 samples,
     (2) impulses across FFT-block and tile boundaries reproduce the taps, (3) the history carry across two
     half-size launches gives the same values as one launch."""
@@ -810,6 +844,21 @@ def test_fir_overlap_save_properties_at_bench_size():
     for o in range(0, 2 * n, 1 << 27):
         worst = max(worst, float((y_fft[o:o + (1 << 27)] - y_dir[o:o + (1 << 27)]).abs().max()))
     assert worst < 1e-6, worst
+    # (0) both kernels against the ORACLE on nine slabs of 2^18 samples spread over the 2 GiB vector (first, last, middle = byte offset 2^30,
+    # odd offsets, around the 2^27-sample mark): direct form bit for bit against the fmaf-chain restatement, overlap-save <= 1e-6 of the f64 one
+    M, ln = len(taps), 1 << 18
+    for o in sorted({0, 1, n // 7 | 1, (1 << 27) - ln // 2, n // 2 - ln // 2, n // 2, (5 * n // 8) | 1, n - ln - 4097, n - ln}):
+        lo = max(0, o - (M - 1))
+        xs = x[2 * lo:2 * (o + ln)].cpu().numpy().view(np.complex64)
+        skip = o - lo
+        want_fma = O.FIR(taps, True, O.MODE_FMA).process(xs)[skip:]
+        want_f64 = O.FIR(taps, True, O.MODE_F64).process(xs)[skip:]
+        # (a slab at the very start has less than M-1 samples in front of it: the oracle then starts from zero history exactly like the device)
+        got_dir = y_dir[2 * o:2 * (o + ln)].cpu().numpy().view(np.complex64)
+        got_fft = y_fft[2 * o:2 * (o + ln)].cpu().numpy().view(np.complex64)
+        assert skip == (M - 1 if lo > 0 else o)
+        assert np.array_equal(got_dir, want_fma), o
+        assert float(np.max(np.abs(got_fft - want_f64))) < 1e-6, o
     # (3) two launches of n/2 == one launch of n (history of M-1 samples carried on the device)
     fft.reset()
     h = n // 2 + 12345
