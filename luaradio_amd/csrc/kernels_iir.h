@@ -287,6 +287,10 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
     const bool from_true_state = tb <= 0;
     if (tb < 0) tb = 0;
     if (tid < S * P) carry[tid / P][tid % P] = from_true_state ? (ST)state_in[tid] : (ST)0;
+    // first order: every thread keeps the carried state in a register (it computes it anyway), no LDS word to race on
+    ST creg[S];
+#pragma unroll
+    for (int c = 0; c < S; c++) creg[c] = (P == 1 && from_true_state) ? (ST)state_in[c] : (ST)0;
     __syncthreads();
 
     for (long tt = tb; tt < first_tile + run && tt * TILE < n; tt++) {
@@ -348,6 +352,43 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
                 st[c][0] = v;
             }
         }
+        if constexpr (P == 1) {
+            // first-order recurrences (every single-pole filter of the reference's receivers): the scan over the 256 chunk end states runs inside
+            // the waves with shuffles and across the four waves through four LDS words - 2 barriers per tile instead of 18.  tpow[l] = p^(16 * 2^l),
+            // tpow[9 + l] = p^(16 (l + 1)) (host, from double).
+            const int lane = tid & 63, wave = tid >> 6;
+            ST zs[S], Sx[S], Ew[S];
+#pragma unroll
+            for (int c = 0; c < S; c++) {
+                zs[c] = (ST)st[c][0];
+                if (tid == 0) zs[c] += fma(tpow[0], creg[c], (ST)0);
+#pragma unroll
+                for (int l = 0; l < 6; l++) {
+                    const ST prev = __shfl_up(zs[c], 1 << l);
+                    if (lane >= (1 << l)) zs[c] += fma(tpow[l], prev, (ST)0);
+                }
+                if (lane == 63) sst[c][wave][0] = zs[c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < S; c++) {
+                ST E = 0;
+                Ew[c] = 0;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    if (w == wave) Ew[c] = E;
+                    E = sst[c][w][0] + fma(tpow[6], E, (ST)0);
+                }
+                Sx[c] = zs[c] + fma(tpow[9 + lane], Ew[c], (ST)0);          // true end state of this chunk
+                const ST up = __shfl_up(Sx[c], 1);
+                st[c][0] = (float)(tid == 0 ? creg[c] : lane ? up : Ew[c]);
+                creg[c] = E;                                                // state at the end of the tile = the next tile's carry
+            }
+            __syncthreads();                                                // the wave totals are read: the next tile may overwrite them
+            if (tid == 255)
+#pragma unroll
+                for (int c = 0; c < S; c++) sst[c][255][0] = creg[c];       // read below (by this thread) when the chunk ends with this tile
+        } else {
 #pragma unroll
         for (int c = 0; c < S; c++) {
             ST z[P];
@@ -377,6 +418,7 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
             for (int c = 0; c < S; c++)
 #pragma unroll
                 for (int k = 0; k < P; k++) carry[c][k] = sst[c][255][k];
+        }
         if (emit) {
 #pragma unroll
             for (int c = 0; c < S; c++)

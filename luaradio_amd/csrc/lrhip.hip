@@ -158,10 +158,15 @@ lrhip_stage_t *lrhip_iir_create(const float *b, unsigned nb, const float *a, uns
         for (int s = 1; s < IIR_LC; s <<= 1) matmul(T, T, T, P);      // A^LC (LC is a power of two)
         std::vector<float> tpow((size_t)9 * P * P);
         std::vector<double> tpow64((size_t)9 * P * P);
+        const double p16 = P == 1 ? T[0] : 0.0;                     // first order: A^LC is the scalar p^16
         for (int k = 0; k <= 8; k++) {
             for (int i = 0; i < P * P; i++) { tpow[(size_t)k * P * P + i] = (float)T[i]; tpow64[(size_t)k * P * P + i] = T[i]; }
             if (k == 8) q->Ttile = T;
             matmul(T, T, T, P);
+        }
+        if (P == 1) {                                               // p^(16 (l + 1)), l < 64: the per-lane powers of the single-launch kernel's wave scan
+            double acc = 1.0;
+            for (int l = 0; l < 64; l++) { acc *= p16; tpow.push_back((float)acc); }
         }
         if (P > 4 ? upload(q->d_tpow, tpow64.data(), tpow64.size() * sizeof(double)) : upload(q->d_tpow, tpow.data(), tpow.size() * sizeof(float))) return nullptr;
         if (upload(q->d_ttile, q->Ttile.data(), q->Ttile.size() * sizeof(double))) return nullptr;
