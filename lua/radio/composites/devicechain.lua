@@ -94,6 +94,22 @@ function DeviceChainBlock:cleanup()
     end
 end
 
+-- Time partitions (INTEGRATION.md 3a; include/lrhip.h "time-axis sharding"): a DeviceChainBlock that starts in the middle of a recording.
+-- start_at(first_sample) positions the chain on an aligned sample at or before (first_sample - halo) and returns (seek_sample, discard):
+-- the source has to deliver the stream from seek_sample on, and the first `discard` OUTPUT-producing input samples are replayed state only -
+-- process() drops what they produce.  Chains holding a stage with unbounded memory (AGC, ...) raise an error: they cannot be sharded.
+function DeviceChainBlock:start_at(first_sample)
+    if self.chain == nil then create_chain(self) end
+    local lib = lrhip.lib
+    local halo = tonumber(lib.lrhip_chain_halo(self.chain))
+    if halo < 0 then error("lrhip_chain_halo: " .. ffi.string(lib.lrhip_strerror())) end
+    local align = tonumber(lib.lrhip_chain_shard_align(self.chain))
+    local s = math.max(0, first_sample - halo)
+    s = s - s % align
+    if lib.lrhip_chain_seek(self.chain, s) ~= 0 then error("lrhip_chain_seek: " .. ffi.string(lib.lrhip_strerror())) end
+    return s, first_sample - s
+end
+
 -- a block the library can run as a chain stage: a device variant (create_stage), one input, one output
 local function chainable(b)
     return type(b.create_stage) == "function" and #b.inputs == 1 and #b.outputs == 1
