@@ -67,7 +67,7 @@ struct FwcParams {
     float2 *prev_out;
     double inv_gain;
     // pair mode + recurrence
-    float b0, na1;
+    float b0, na1, na1_lo;       // y[k] = b0 v[k] + (na1 + na1_lo) y[k-1]: the pole as a Float32 pair (see fuse_iir1)
     const float *ptab;           // ptab[l] = (-a1)^(R (l+1)), l < 64
     const float *state_in;
     float *state_out;
@@ -343,11 +343,11 @@ __global__ __launch_bounds__(256, 2) void fir_win_cplx_kernel(const FwcParams pr
             } else {
                 // y[k] = b0 v[k] + p y[k-1], p = -a1: zero-state run over the lane's chunk of each half ...
                 cf u[R], z = cf{0.f, 0.f};
-                const cf pp = cf{pr.na1, pr.na1}, bb = cf{pr.b0, pr.b0};
+                const cf pp = cf{pr.na1, pr.na1}, pl = cf{pr.na1_lo, pr.na1_lo}, bb = cf{pr.b0, pr.b0};
 #pragma unroll
                 for (int i = 0; i < R; i++) {
                     u[i] = __builtin_elementwise_fma(bb, acc[i], cf{0.f, 0.f});
-                    z = __builtin_elementwise_fma(pp, z, u[i]);
+                    z = __builtin_elementwise_fma(pp, z, __builtin_elementwise_fma(pl, z, u[i]));
                 }
                 // ... inclusive scan of the chunk end states inside the wave (both halves at once) ...
 #pragma unroll
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void fir_win_cplx_kernel(const FwcParams pr
                 if (emit) {
 #pragma unroll
                     for (int i = 0; i < R; i++) {
-                        st = __builtin_elementwise_fma(pp, st, u[i]);
+                        st = __builtin_elementwise_fma(pp, st, __builtin_elementwise_fma(pl, st, u[i]));
                         if (ka + i < n_out) pr.y[ka + i] = st.x;
                         if (kbb + i < n_out) pr.y[kbb + i] = st.y;
                         // the carried state of a chunk that ends inside this tile; a chunk that ends WITH the tile hands over C below -

@@ -613,13 +613,15 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
                     FirStage *fd = fir_build(g.data(), (unsigned)Mg, 0, 0, (unsigned)D, 0, false, 0.0);
                     const float b2[1] = {1.0f}, a2[2] = {1.0f, (float)(-pk)};          // pk = p^D after the loop
                     // the low-rate recurrence runs on the filter's accumulators when the window kernel takes this shape ...
-                    if (fd && fd->fuse_iir1(b2[0], a2[1]) == 0) {
+                    if (fd && fd->fuse_iir1(1.0, pk) == 0) {
                         c->ops.push_back({fd, true});
                         i += 3;
                         continue;
                     }
-                    // ... and as its own launch otherwise
-                    lrhip_stage_t *i2 = fd ? lrhip_iir_create(b2, 1, a2, 2, 0) : nullptr;
+                    // ... and as its own launch otherwise - if the pole p^D survives rounding to ONE Float32: that moves the DC gain by
+                    // 2^-24 q / (1 - q), held below 3e-7 here (the fused form above carries the pole as a Float32 pair instead)
+                    const bool pole_ok = std::fabs(pk) * 5.96e-8 <= 3e-7 * (1.0 - std::fabs(pk));
+                    lrhip_stage_t *i2 = (fd && pole_ok) ? lrhip_iir_create(b2, 1, a2, 2, 0) : nullptr;
                     if (fd && i2) {
                         c->ops.push_back({fd, true});
                         c->ops.push_back({i2, true});

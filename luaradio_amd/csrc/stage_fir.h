@@ -400,7 +400,7 @@ struct FirStage : lrhip_stage {
     // first-order recurrence, on the register-window kernel (kernels_firwin2.h)
     int winc_blocks_per_cu = 0;
     bool iir_fused = false;               // pair mode: y[k] = iir_b0 v[k] + iir_na1 y[k-1] behind the filter
-    float iir_b0 = 1.f, iir_na1 = 0.f;
+    float iir_b0 = 1.f, iir_na1 = 0.f, iir_na1_lo = 0.f;
     int iir_warm = 1;
     DeviceBuf d_iir_ptab, iir_state[2];
     int iir_cur = 0;
@@ -420,10 +420,12 @@ struct FirStage : lrhip_stage {
     bool win_cplx_ok() const { return win_cplx_on() && !win_off() && S == 2 && !taps_complex && D == 5 && M == 128 && !fft_arith && !use_fft && !decfft && !pre_disc; }
     bool win_pair_ok() const { return !win_off() && S == 1 && !taps_complex && D == 5 && M == 136 && !fft_arith && !use_fft && !rot && !pre_disc && !post_disc; }
     // first-order recurrence behind the pair-mode filter: needs |a1|^(320 w) < 1e-12 for the in-launch warm-up (w waves of 64 lanes x 5 outputs)
-    int fuse_iir1(float b0, float a1)
+    // The pole q (a double: p^D of the polyphase identity) is carried as a Float32 pair hi + lo: rounded to one Float32 its relative error of
+    // 2^-24 moves the DC gain by 2^-24 q / (1 - q), which for a slow filter is far above the 1e-6 parity bar of the recurrence it replaces.
+    int fuse_iir1(double b0, double q)
     {
         if (!win_pair_ok()) return -1;
-        const double p = std::fabs((double)a1);
+        const double a1 = -q, p = std::fabs(q);
         int w = 0;
         for (int c = 1; c <= 4 && !w; c *= 2)
             if (p < 1.0 && std::pow(p, 320.0 * c) < 1e-12) w = c;
@@ -433,7 +435,7 @@ struct FirStage : lrhip_stage {
         for (int k = 0; k < 5; k++) pR *= -(double)a1;
         for (int l = 0; l < 64; l++) { acc *= pR; ptab[(size_t)l] = (float)acc; }
         if (upload(d_iir_ptab, ptab.data(), ptab.size() * sizeof(float))) return -1;
-        iir_fused = true; iir_b0 = b0; iir_na1 = -a1; iir_warm = w;
+        iir_fused = true; iir_b0 = (float)b0; iir_na1 = (float)q; iir_na1_lo = (float)(q - (double)iir_na1); iir_warm = w;
         return reset();
     }
     template <int MM, int MODE>
@@ -458,7 +460,7 @@ struct FirStage : lrhip_stage {
         const long slots = (long)ctx().num_cus * winc_blocks_per_cu;
         unsigned grid;
         if (G::IIR) {
-            pr.b0 = iir_b0; pr.na1 = iir_na1; pr.ptab = (const float *)d_iir_ptab.p; pr.warm_waves = iir_warm;
+            pr.b0 = iir_b0; pr.na1 = iir_na1; pr.na1_lo = iir_na1_lo; pr.ptab = (const float *)d_iir_ptab.p; pr.warm_waves = iir_warm;
             pr.state_in = (const float *)iir_state[iir_cur].p; pr.state_out = (float *)iir_state[iir_cur ^ 1].p;
             pr.run = (pr.ntiles + slots - 1) / slots;
             if (getenv("LRHIP_TAIL_RUN")) pr.run = atol(getenv("LRHIP_TAIL_RUN"));      // A/B knob

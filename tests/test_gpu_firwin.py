@@ -144,3 +144,22 @@ def test_toeplitz_kernel_nonfinite_sample_poisons_whole_output_blocks(cplx):
     extra = np.flatnonzero(bad_got & ~bad_ref)
     assert extra.size <= 96 and (extra.size == 0 or (extra.min() >= pos - 48 and extra.max() <= pos + M + 48))
     assert np.array_equal(got[~bad_got], want[~bad_got])
+
+
+def test_slow_recurrence_is_not_rewritten_in_polyphase_form():
+    """The polyphase identity moves the pole to p^D; rounded to one Float32 that shifts the DC gain by 2^-24 q / (1 - q) - for a slow filter
+    (50 Hz single-pole lowpass at 220.5 kHz: p = 0.9986) two orders above the recurrence's 1e-6 bar.  Such a chain keeps the blocks' own
+    kernels (the fused window form carries the pole as a Float32 pair but needs the recurrence to decay within its warm-up)."""
+    rng = np.random.default_rng(31)
+    n = 5 * 4096 + 77
+    x = (rng.uniform(-1, 1, n) + 0.5).astype(np.float32)            # with a DC component: the gain error would show
+    taps = O.firwin_lowpass(128, 0.2).astype(np.float32)
+    x0 = np.zeros(1, np.float32)
+    blocks = [make(lr.FIRFilterBlock, [taps, "auto"], x0, rate=220500.0), make(lr.SinglepoleLowpassFilterBlock, [50.0], x0, rate=220500.0),
+              make(lr.DownsamplerBlock, [5], x0, rate=220500.0)]
+    chain = lr.Chain(blocks)
+    got = chain.process(x)
+    assert chain.last_launches >= 2
+    b, a = O.singlepole_lowpass_taps(50.0, 220500.0)
+    want = O.IIR(b, a, False, O.MODE_F64).process(O.FIR(taps, False, O.MODE_F64).process(x))[::5]
+    assert len(got) == len(want) and G.max_abs_err(got, want) < 2e-6
