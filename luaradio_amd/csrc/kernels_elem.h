@@ -109,8 +109,13 @@ __global__ __launch_bounds__(256) void rotator_kernel(const float2 *__restrict__
         const float4 *x4 = reinterpret_cast<const float4 *>(x);
         float4 *y4 = reinterpret_cast<float4 *>(y);
         unsigned long n2 = n / 2;
-        for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride)
-            y4[i] = rotate_pair(x4[i], step_fx, count0 + 2 * i, tab);
+        // two 16-byte items per thread, both loads in flight before the first phasor is evaluated (the grid covers n2 / 2 items)
+        for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += 2 * stride) {
+            const unsigned long j = i + stride;
+            const float4 a = x4[i], b = j < n2 ? x4[j] : a;
+            y4[i] = rotate_pair(a, step_fx, count0 + 2 * i, tab);
+            if (j < n2) y4[j] = rotate_pair(b, step_fx, count0 + 2 * j, tab);
+        }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = rotate_sample(x[n - 1], step_fx, count0 + n - 1);
     } else {
         for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -191,6 +196,32 @@ __global__ __launch_bounds__(256) void fmdiscrim_vec2_kernel(const float2 *__res
         const float2 a = x[n - 1], p = n > 1 ? x[n - 2] : *prev_in;
         y[n - 1] = discriminate(a, p, inv_gain);
         *prev_out = a;
+    }
+}
+
+// 32 B in / 16 B out per lane: samples 4i .. 4i+3 (two 16-byte loads) and one 16-byte store of their four angles - the 8-byte stores of the
+// vec2 form are the narrow side of that kernel.  Needs 16-B aligned x and y; the n % 4 tail samples go to the last thread.
+__global__ __launch_bounds__(256) void fmdiscrim_vec4_kernel(const float2 *__restrict__ x, float *__restrict__ y,
+                                                             unsigned long n, double inv_gain,
+                                                             const float2 *__restrict__ prev_in, float2 *__restrict__ prev_out)
+{
+    const unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x, n4 = n / 4;
+    if (i < n4) {
+        const float4 v0 = reinterpret_cast<const float4 *>(x)[2 * i], v1 = reinterpret_cast<const float4 *>(x)[2 * i + 1];
+        const float2 p = i ? x[4 * i - 1] : *prev_in;
+        const float2 a = make_float2(v0.x, v0.y), b = make_float2(v0.z, v0.w), c = make_float2(v1.x, v1.y), d = make_float2(v1.z, v1.w);
+        reinterpret_cast<float4 *>(y)[i] = make_float4(discriminate(a, p, inv_gain), discriminate(b, a, inv_gain), discriminate(c, b, inv_gain),
+                                                       discriminate(d, c, inv_gain));
+        if (4 * i + 4 == n) *prev_out = d;
+    }
+    if (i == n4 && (n & 3)) {        // tail samples
+        float2 p = n4 ? x[4 * n4 - 1] : *prev_in;
+        for (unsigned long k = 4 * n4; k < n; k++) {
+            const float2 a = x[k];
+            y[k] = discriminate(a, p, inv_gain);
+            p = a;
+        }
+        *prev_out = p;
     }
 }
 

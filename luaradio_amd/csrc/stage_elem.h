@@ -24,7 +24,7 @@ struct RotatorStage : lrhip_stage {
         if (!n) return 0;
         unsigned grid = grid_for(n, 256);
         if ((((uintptr_t)in_dev | (uintptr_t)out_dev) & 15) == 0)
-            hipLaunchKernelGGL(rotator_kernel<2>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n, step, count);
+            hipLaunchKernelGGL(rotator_kernel<2>, dim3(grid_for((n / 2 + 1) / 2 + 1, 256)), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n, step, count);
         else
             hipLaunchKernelGGL(rotator_kernel<1>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n, step, count);
         LR_LAUNCH_CHECK();
@@ -80,7 +80,11 @@ struct FmDiscrimStage : lrhip_stage {
         if (n > cap) return set_error("fmdiscrim: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
         float2 *p = (float2 *)prev.p;
-        if ((((uintptr_t)in_dev & 15) | ((uintptr_t)out_dev & 7)) == 0)
+        static const bool disc_vec2 = getenv("LRHIP_DISC_VEC2") != nullptr;      // A/B knob: the 8-byte-store form
+        if (!disc_vec2 && (((uintptr_t)in_dev | (uintptr_t)out_dev) & 15) == 0)
+            hipLaunchKernelGGL(fmdiscrim_vec4_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float *)out_dev, n, 1.0 / gain,
+                               (const float2 *)(p + cur), p + (cur ^ 1));
+        else if ((((uintptr_t)in_dev & 15) | ((uintptr_t)out_dev & 7)) == 0)
             hipLaunchKernelGGL(fmdiscrim_vec2_kernel, dim3(grid_for(n / 2 + 1, 256)), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float *)out_dev, n, 1.0 / gain,
                                (const float2 *)(p + cur), p + (cur ^ 1));
         else
