@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void iir_scan_kernel(const float *__restrict__
 template <int S, int P, int NBT>
 __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict__ x, float *__restrict__ y, long n,
                                                          const float *__restrict__ xhist, const float *__restrict__ state_in,
-                                                         float *__restrict__ state_out, long dec, long dfirst, int run, int warm, IirCoeffs co,
+                                                         float *__restrict__ state_out, long dec, long dfirst, int run, int warm, int warm_chunks, IirCoeffs co,
                                                          float *__restrict__ xhist_out, const typename IirScanT<P>::T *__restrict__ tpow)
 {
     using ST = typename IirScanT<P>::T;
@@ -296,10 +296,19 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
     for (long tt = tb; tt < first_tile + run && tt * TILE < n; tt++) {
         const bool emit = tt >= first_tile;
         const long c0 = tt * TILE + (long)tid * LC;
+        // a warm-up tile only has to cover the recurrence's memory: with warm_chunks > 0 just its last warm_chunks chunks are read and run (the
+        // others count as zero input), so a workgroup that owns ONE tile re-reads 16 * warm_chunks samples instead of 4096 - which is what lets the
+        // launch be one-shot, a workgroup per tile in address order (the DRAM pages in flight stay compact: common.h grid_for)
+        const bool skip = !emit && !from_true_state && warm_chunks > 0 && tid < 256 - warm_chunks;
         // ---- load (as iir_scan_kernel)
         float xs[S][PV + LC];
         const bool vec = (c0 + LC <= n) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-        if (vec) {
+        if (skip) {
+#pragma unroll
+            for (int i = 0; i < PV + LC; i++)
+#pragma unroll
+                for (int c = 0; c < S; c++) xs[c][i] = 0.f;
+        } else if (vec) {
             const float4 *src = reinterpret_cast<const float4 *>(x + c0 * S);
 #pragma unroll
             for (int q = 0; q < LC * S / 4; q++) {
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
             for (int c = 0; c < S; c++) {
                 long g = c0 - j;
                 float v = 0.f;
-                if (j < nb && c0 < n) v = g >= 0 ? x[g * S + c] : xhist[(g + (nb - 1)) * S + c];
+                if (j < nb && c0 < n && !skip) v = g >= 0 ? x[g * S + c] : xhist[(g + (nb - 1)) * S + c];
                 xs[c][PV - j] = v;
             }
         float u[S][LC];

@@ -164,6 +164,13 @@ lrhip_stage_t *lrhip_iir_create(const float *b, unsigned nb, const float *a, uns
             if (k == 8) q->Ttile = T;
             matmul(T, T, T, P);
         }
+        if (P == 1 && std::fabs(p16) < 1.0 && p16 != 0.0) {
+            // chunks of 16 samples after which a zero start has decayed to 1e-12: the partial warm-up of the one-shot launch
+            const int wc = (int)std::ceil(std::log(1e-12) / std::log(std::fabs(p16)));
+            if (wc >= 1 && wc <= 128) q->warm_chunks = wc;
+        } else if (P == 1 && p16 == 0.0) {
+            q->warm_chunks = 1;
+        }
         if (P == 1) {                                               // p^(16 (l + 1)), l < 64: the per-lane powers of the single-launch kernel's wave scan
             double acc = 1.0;
             for (int l = 0; l < 64; l++) { acc *= p16; tpow.push_back((float)acc); }

@@ -13,6 +13,7 @@ struct IirStage : lrhip_stage {
     IirSeqCoeffs seq;
     std::vector<double> Ttile;            // A^TILE in double (row-major PxP) for the per-launch carry powers
     int warm_tiles = 0;                   // > 0: A^(warm_tiles*TILE) underflows Float32 -> single-launch iir_stream_kernel
+    int warm_chunks = 0;                  // > 0 (first order): |p|^(16 warm_chunks) < 1e-12 with at most half a tile -> one-shot launch, a workgroup per tile
     DeviceBuf xhist[2], state[2], tile_end, tile_start, seq_xs, seq_ys;
     int cur = 0;
     unsigned long D = 1, index = 0;       // fused DownsamplerBlock behind the filter (chains)
@@ -53,9 +54,12 @@ struct IirStage : lrhip_stage {
             int run = (int)(ntiles / slots);
             run = run < 1 ? 1 : run > 8 ? 8 : run;
             if (run < 2 * warm_tiles && ntiles > 4 * warm_tiles) run = 2 * warm_tiles;      // bound the re-read overhead
+            int wc = 0;
+            static const bool no_oneshot = getenv("LRHIP_IIR_NO_ONESHOT") != nullptr;      // A/B knob
+            if (warm_chunks > 0 && !no_oneshot) { run = 1; wc = warm_chunks; }             // one-shot: a workgroup per tile, partial warm-up tile
             unsigned grid = (unsigned)((ntiles + run - 1) / run);
             hipLaunchKernelGGL((iir_stream_kernel<SS, PP, NBT>), dim3(grid), dim3(256), 0, ctx().stream, x, y, n, xh, st, st_out, (long)D, (long)index, run,
-                               warm_tiles, co, (float *)xhist[cur ^ 1].p, tp);
+                               wc ? 1 : warm_tiles, wc, co, (float *)xhist[cur ^ 1].p, tp);
             LR_LAUNCH_CHECK();
             cur ^= 1;
             return 0;
