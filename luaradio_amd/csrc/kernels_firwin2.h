@@ -73,7 +73,28 @@ struct FwcParams {
     float *state_out;
     int warm_waves;
     long run;                    // tiles per workgroup (contiguous; recurrence mode)
+    // pair mode behind the Toeplitz tuner + discriminator kernel (fir_mfma_persistent_kernel, EPI = 1): that kernel leaves the first output of
+    // every wave's 256-output range to be fixed from its edge records (disc_epilogue).  Instead of a fix-up launch, the consumer patches those
+    // samples as it stages them: x[256 w] = discriminate(edge[2w], w ? edge[2(w-1)+1] : *fix_prev).  Null = nothing to fix.
+    const float2 *fix_edge;      // ALWAYS a readable address (the kernel loads from it unconditionally, see prefetch()); fix_on says whether it means anything
+    const float2 *fix_prev;
+    double fix_inv_gain;
+    int fix_on;
 };
+
+// sample x[g] of a Float32 stream whose wave-first samples are still to be fixed (see FwcParams::fix_edge)
+__device__ __forceinline__ float fwc_fix_value(const FwcParams &pr, long g)
+{
+    const long w = g >> 8;
+    const float2 e0 = pr.fix_edge[2 * w], ep = w ? pr.fix_edge[2 * (w - 1) + 1] : *pr.fix_prev;
+    return discriminate(e0, ep, pr.fix_inv_gain);
+}
+__device__ __forceinline__ float fwc_stream_at_fixed(const FwcParams &pr, const float *__restrict__ hist, const float *__restrict__ x, long p, int M, long n)
+{
+    const long g = p - (M - 1);
+    if (pr.fix_on && g >= 0 && g < n && (g & 255) == 0) return fwc_fix_value(pr, g);
+    return stream_at<1>(hist, x, p, 0, M, n);
+}
 
 template <int HI>
 __device__ __forceinline__ void fw_step5(cf (&a)[5], cf t, cf w0, cf w1, cf w2, cf w3, cf w4)
@@ -131,7 +152,8 @@ __global__ __launch_bounds__(256, 2) void fir_win_cplx_kernel(const FwcParams pr
     const float *__restrict__ x = pr.x;
     const float *__restrict__ hist = pr.hist;
     if (pr.hist_out && blockIdx.x == 0)
-        for (int i = tid; i < (M - 1) * S; i += 256) pr.hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
+        for (int i = tid; i < (M - 1) * S; i += 256)
+            pr.hist_out[i] = PAIR ? fwc_stream_at_fixed(pr, hist, x, n + i, M, n) : stream_at<S>(hist, x, n + i / S, i % S, M, n);
     for (int i = tid; i < M; i += 256) ldsT[i] = pr.taps_rev[i];
 
     // tile t: first window output kb(t) (negative for tile 0 with the discriminator overlap), stream position of window coordinate 0
@@ -153,6 +175,8 @@ __global__ __launch_bounds__(256, 2) void fir_win_cplx_kernel(const FwcParams pr
     f32x4 pre[G::NPRE];                                              // (ext_vector type: usable as an inline-asm operand)
     bool have = false, prot_blocks = false;
     int pe = 0, pa4 = 0;                                             // of the prefetched tile
+    int fpos = -1, fhalf = 0;                                        // pair mode with fix_edge: the staged sample this thread patches, and its records
+    cf fe0 = cf{0.f, 0.f}, fep = cf{0.f, 0.f};
     auto prefetch = [&](long t) {
         have = interior(t);
         pe = 0;
@@ -167,6 +191,19 @@ __global__ __launch_bounds__(256, 2) void fir_win_cplx_kernel(const FwcParams pr
                 idx = idx < G::NF4 ? idx : G::NF4 - 1;
                 pre[2 * u] = sa[idx];
                 pre[2 * u + 1] = sb[idx];
+            }
+            // the edge records of the (at most 26 per half) wave-first samples in this window: threads 0..63, one sample each.  The two loads
+            // are UNCONDITIONAL (clamped address) and their registers are touched only at the staging point, like pre[]: behind a branch the
+            // compiler merges them with the "no fix" values right here and waits for the whole prefetch before the filter starts (+18 us per step)
+            {
+                fhalf = (tid >> 5) & 1;
+                const long lo_h = lo + (fhalf ? (long)D * G::TO : 0L);
+                const long g = ((lo_h <= 0 ? 0 : (lo_h + 255) >> 8) + (tid & 31)) << 8;
+                const bool ok = pr.fix_on && tid < 64 && g < lo_h + 4L * G::NF4 && g < n;
+                const long w = ok ? g >> 8 : 0;
+                fpos = ok ? (int)(g - lo_h) : -1;
+                fe0 = *reinterpret_cast<const cf *>(pr.fix_edge + 2 * w);
+                fep = *reinterpret_cast<const cf *>(w ? pr.fix_edge + 2 * (w - 1) + 1 : pr.fix_prev);
             }
         } else if constexpr (ROT) {
             // a thread owns whole ALIGNED blocks of 8 samples (absolute index = 0 mod 8): one phasor polynomial serves 8 samples
@@ -231,6 +268,11 @@ __global__ __launch_bounds__(256, 2) void fir_win_cplx_kernel(const FwcParams pr
                         ldsX4[2 * idx + 1] = make_float4(a.z, b.z, a.w, b.w);
                     }
                 }
+                if (pr.fix_on) {                                      // kernel-uniform
+                    asm volatile("" : "+v"(fe0), "+v"(fep));
+                    __syncthreads();                                  // the unfixed values are in place: patch over them
+                    if (fpos >= 0) ldsX[2 * (G::GUARD + fpos) + fhalf] = discriminate(make_float2(fe0.x, fe0.y), make_float2(fep.x, fep.y), pr.fix_inv_gain);
+                }
             } else if constexpr (ROT) {
                 const long lo = qb - (M - 1) - ce;
 #pragma unroll
@@ -262,8 +304,8 @@ __global__ __launch_bounds__(256, 2) void fir_win_cplx_kernel(const FwcParams pr
             for (int c = tid; c < G::SPAN; c += 256) {
                 float a, b;
                 if constexpr (PAIR) {
-                    a = stream_at<1>(hist, x, qb + c, 0, M, n);
-                    b = stream_at<1>(hist, x, qb + (long)D * G::TO + c, 0, M, n);
+                    a = stream_at<1>(hist, x, qb + c, 0, M, n);          // (wave-first samples are patched below, not here: a dependent
+                    b = stream_at<1>(hist, x, qb + (long)D * G::TO + c, 0, M, n);      // load inside this loop costs ~2 us per hit, 13 hits per wave)
                 } else {
                     a = stream_at<2>(hist, x, qb + c, 0, M, n);
                     b = stream_at<2>(hist, x, qb + c, 1, M, n);
@@ -273,6 +315,15 @@ __global__ __launch_bounds__(256, 2) void fir_win_cplx_kernel(const FwcParams pr
                     }
                 }
                 *reinterpret_cast<float2 *>(ldsX + 2 * (G::GUARD + c)) = make_float2(a, b);
+            }
+            if constexpr (PAIR) {
+                if (pr.fix_on) {                                      // the same patch as on the prefetched path, records loaded here
+                    __syncthreads();
+                    const int h = (tid >> 5) & 1;
+                    const long lo_h = qb - (M - 1) + (h ? (long)D * G::TO : 0L);       // x index of window coordinate 0 of this half (slack 0)
+                    const long g = ((lo_h <= 0 ? 0 : (lo_h + 255) >> 8) + (tid & 31)) << 8;
+                    if (tid < 64 && g < lo_h + G::SPAN && g < n) ldsX[2 * (G::GUARD + (int)(g - lo_h)) + h] = fwc_fix_value(pr, g);
+                }
             }
         }
         __syncthreads();

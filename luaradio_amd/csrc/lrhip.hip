@@ -684,6 +684,17 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
         c->ops.push_back({stages[i], false});
         i++;
     }
+    // a Toeplitz tuner + discriminator stage directly in front of the pair-mode window filter hands its wave-boundary fix-up to that filter's
+    // staging (kernels_firwin2.h FwcParams::fix_edge): the WBFM receiver is then two launches
+    static const bool no_fixup_fold = getenv("LRHIP_NO_FIXUP_FOLD") != nullptr;      // A/B knob
+    for (size_t k = 0; k + 1 < c->ops.size() && !no_fixup_fold; k++) {
+        FirStage *prod = c->ops[k].owned ? dynamic_cast<FirStage *>(c->ops[k].stage) : nullptr;
+        FirStage *cons = c->ops[k + 1].owned ? dynamic_cast<FirStage *>(c->ops[k + 1].stage) : nullptr;
+        if (prod && cons && prod->post_disc && !prod->decfft && !prod->win_cplx_ok() && cons->iir_fused && cons->win_pair_ok()) {
+            prod->defer_fixup = true;
+            cons->fix_src = prod;
+        }
+    }
     for (size_t k = 0; k + 1 < c->ops.size(); k++) c->edges.emplace_back(new DeviceBuf());
     return c.release();
 }

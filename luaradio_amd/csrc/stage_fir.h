@@ -40,6 +40,11 @@ struct FirStage : lrhip_stage {
     // fused FrequencyDiscriminatorBlock behind the filter (chains): ComplexFloat32 in, Float32 out (persistent MFMA kernel epilogue)
     bool post_disc = false;
     DeviceBuf edge;
+    // fix-up of the wave-first discriminator outputs (disc_epilogue): done by fir_disc_fixup_kernel, or - defer_fixup - left to the next
+    // stage of the chain, a pair-mode window filter that patches the samples as it stages them (FwcParams::fix_edge): one launch less
+    bool defer_fixup = false, fix_ready = false;
+    const float2 *fix_prev_ptr = nullptr;
+    FirStage *fix_src = nullptr;           // consumer side: the stage whose edge records are to be applied
     double disc_gain = 1.0;
     DeviceBuf disc_prev;
     int disc_cur = 0;
@@ -164,9 +169,15 @@ struct FirStage : lrhip_stage {
                     if (rc2) return rc2;
                     LR_LAUNCH_CHECK();
                     float2 *dp = (float2 *)disc_prev.p;
-                    hipLaunchKernelGGL(fir_disc_fixup_kernel, dim3((unsigned)((4 * ntiles + 255) / 256)), dim3(256), 0, ctx().stream, (const float2 *)edge.p,
-                                       4 * ntiles, TILE_OUT / 4, y, n_out, (const float2 *)(dp + disc_cur), 1.0 / disc_gain);
-                    LR_LAUNCH_CHECK();
+                    static_assert(TILE_OUT / 4 == 256 || DD != 5, "the deferred fix-up assumes 256 outputs per wave");
+                    if (defer_fixup && TILE_OUT / 4 == 256) {
+                        fix_ready = true;
+                        fix_prev_ptr = (const float2 *)(dp + disc_cur);
+                    } else {
+                        hipLaunchKernelGGL(fir_disc_fixup_kernel, dim3((unsigned)((4 * ntiles + 255) / 256)), dim3(256), 0, ctx().stream, (const float2 *)edge.p,
+                                           4 * ntiles, TILE_OUT / 4, y, n_out, (const float2 *)(dp + disc_cur), 1.0 / disc_gain);
+                        LR_LAUNCH_CHECK();
+                    }
                     disc_cur ^= 1;
                     return 0;
                 }
@@ -462,6 +473,13 @@ struct FirStage : lrhip_stage {
         if (G::IIR) {
             pr.b0 = iir_b0; pr.na1 = iir_na1; pr.na1_lo = iir_na1_lo; pr.ptab = (const float *)d_iir_ptab.p; pr.warm_waves = iir_warm;
             pr.state_in = (const float *)iir_state[iir_cur].p; pr.state_out = (float *)iir_state[iir_cur ^ 1].p;
+            pr.fix_edge = pr.fix_prev = (const float2 *)d_iir_ptab.p;          // readable dummies (64 floats): the kernel loads unconditionally
+            pr.fix_inv_gain = 1.0;
+            if (fix_src && fix_src->fix_ready) {
+                pr.fix_edge = (const float2 *)fix_src->edge.p; pr.fix_prev = fix_src->fix_prev_ptr; pr.fix_inv_gain = 1.0 / fix_src->disc_gain;
+                pr.fix_on = 1;
+                fix_src->fix_ready = false;
+            }
             pr.run = (pr.ntiles + slots - 1) / slots;
             if (getenv("LRHIP_TAIL_RUN")) pr.run = atol(getenv("LRHIP_TAIL_RUN"));      // A/B knob
             grid = (unsigned)((pr.ntiles + pr.run - 1) / pr.run);
@@ -512,6 +530,7 @@ struct FirStage : lrhip_stage {
     {
         if (n <= 0) return 0;
         hist_in_kernel = false;
+        fix_ready = false;
         long n_out = (unsigned long)n > index ? (long)((n - index + D - 1) / D) : 0;
         if ((unsigned long)n_out > cap) return set_error("fir: output capacity %lu < %ld", cap, n_out);
         if (n_out > 0) {

@@ -93,12 +93,20 @@ def test_fir_iir_fused_many_tiles_many_workgroups():
         assert G.max_abs_err(g, want[:len(g)]) < 1e-6, s0
 
 
-def test_wbfm_receiver_is_two_launches_plus_fixup():
-    rx = lr.wbfm_mono_receiver(1102500.0, -250e3)
+def test_wbfm_receiver_is_two_launches():
+    """tuner + discriminator (Toeplitz MFMA) and the audio tail (pair-mode window kernel, which also applies the tuner's wave-boundary fix-up while
+    it stages its window); ragged chunks exercise the patched history and edge tiles, against the oracle chain"""
+    fs = 1102500.0
+    rx = lr.wbfm_mono_receiver(fs, -250e3)
     rng = np.random.default_rng(9)
-    x = (rng.uniform(-1, 1, 1 << 18) + 1j * rng.uniform(-1, 1, 1 << 18)).astype(np.complex64)
-    rx.process(x)
-    assert rx.chain.last_launches <= 3
+    n = 1 << 19
+    x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+    got = chunked(rx, x, [1, 2, 1281, 70001, 70002, 300000])
+    assert rx.chain.last_launches == 2
+    want = O.wbfm_mono_chain(fs, -250e3, mode=O.MODE_LUA, rot_mode=O.MODE_F64).process(x)
+    assert len(got) == len(want)
+    err = got.astype(np.float64) - want.astype(np.float64)
+    assert float(np.sqrt(np.mean(err ** 2))) <= 1e-5 and float(np.max(np.abs(err))) < 1e-4
 
 
 def test_complex_window_kernel_chains_bit_equal_in_a_child_process():
