@@ -169,7 +169,6 @@ struct FirStage : lrhip_stage {
                     if (rc2) return rc2;
                     LR_LAUNCH_CHECK();
                     float2 *dp = (float2 *)disc_prev.p;
-                    static_assert(TILE_OUT / 4 == 256 || DD != 5, "the deferred fix-up assumes 256 outputs per wave");
                     if (defer_fixup && TILE_OUT / 4 == 256) {
                         fix_ready = true;
                         fix_prev_ptr = (const float2 *)(dp + disc_cur);
@@ -512,7 +511,10 @@ struct FirStage : lrhip_stage {
             case 2: return launch_mfma<SS, 2, 4>(x, n, y, n_out);
             case 3: return launch_mfma<SS, 3, 2>(x, n, y, n_out);
             case 4: return launch_mfma<SS, 4, 2>(x, n, y, n_out);
-            case 5: return launch_mfma<SS, 5, 2>(x, n, y, n_out);
+            case 5: {
+                static const int nacc5 = getenv("LRHIP_FIR_D5_NACC") ? atoi(getenv("LRHIP_FIR_D5_NACC")) : 2;      // A/B knob: accumulators per wave at D = 5
+                return nacc5 == 1 ? launch_mfma<SS, 5, 1>(x, n, y, n_out) : launch_mfma<SS, 5, 2>(x, n, y, n_out);
+            }
             case 6: return launch_mfma<SS, 6, 1>(x, n, y, n_out);
             case 7: return launch_mfma<SS, 7, 1>(x, n, y, n_out);
             case 8: return launch_mfma<SS, 8, 1>(x, n, y, n_out);
