@@ -29,7 +29,7 @@ def build_chain(path_or_bytes, fmt, rate, offset):
     src.initialize()
     blocks = [src, lr.FrequencyTranslatorBlock(offset), lr.LowpassFilterBlock(128, 100e3), lr.DownsamplerBlock(5),
               lr.FrequencyDiscriminatorBlock(1.25), lr.LowpassFilterBlock(128, 15e3), lr.FMDeemphasisFilterBlock(75e-6), lr.DownsamplerBlock(5)]
-    blocks[5].use_fft = 2                     # audio filter: overlap-save arithmetic (the reference's default FIR form is FFT too)
+    blocks[5].use_fft = 3                     # audio filter: automatic - in this chain it merges with the de-emphasis and the downsampler
     r, t = src.get_rate(), src.get_output_type()
     for b in blocks[1:]:                      # what CompositeBlock does before run(): types and rates downstream (composite.lua:443-470)
         b.rate = r

@@ -197,3 +197,21 @@ def test_halo_refuses_chains_with_unbounded_memory():
     chain = lr.Chain([agc])
     with pytest.raises(lr.LrhipError, match="unbounded memory"):
         chain.halo()
+
+
+@pytest.mark.gpu
+def test_example_timeshard_wbfm_selftest_and_file_mode(tmp_path):
+    """examples/timeshard_wbfm.py: --selftest, and a ComplexFloat32 recording cut into 3 partitions == the receiver on the whole file"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ex = os.path.join(root, "examples", "timeshard_wbfm.py")
+    r = subprocess.run([sys.executable, ex, "--selftest"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr[-2000:]
+    import luaradio_amd as lr
+    x = _rand_c(5, 300000)
+    rec, out = tmp_path / "rec.cf32", tmp_path / "audio.f32"
+    x.tofile(rec)
+    r = subprocess.run([sys.executable, ex, str(rec), str(out), "--parts", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = lr.wbfm_mono_receiver(1102500.0, -250e3).process(x)
+    assert np.array_equal(np.fromfile(out, np.float32), want)
