@@ -136,8 +136,11 @@ __device__ __forceinline__ void fwc_taps(const float *ldsT, const float *base, c
 
 __device__ __forceinline__ float4 f4(f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
 
+#ifndef FWC_PAIR_WAVES
+#define FWC_PAIR_WAVES 2      /* A/B: resident workgroups per CU the pair-mode instantiation is register-budgeted for */
+#endif
 template <int D, int R, int M, int MODE>
-__global__ __launch_bounds__(256, 2) void fir_win_cplx_kernel(const FwcParams pr)
+__global__ __launch_bounds__(256, (MODE & FWC_PAIR) ? FWC_PAIR_WAVES : 2) void fir_win_cplx_kernel(const FwcParams pr)
 {
     using G = FwcGeom<D, R, M, MODE>;
     constexpr bool ROT = G::ROT, DISC = G::DISC, PAIR = G::PAIR, IIR = G::IIR;
