@@ -21,6 +21,9 @@
 #ifndef LRHIP_FIR_PIPE
 #define LRHIP_FIR_PIPE 0
 #endif
+#ifndef LRHIP_DISC_EPI_LDS
+#define LRHIP_DISC_EPI_LDS 0      /* 1: discriminator epilogue of the persistent Toeplitz kernel through LDS (fewer VALU instructions, two more barriers per tile: 0.206-0.208 against 0.201-0.202 ms for the WBFM receiver, same box) */
+#endif
 
 namespace lrhip {
 
@@ -349,6 +352,54 @@ __device__ __forceinline__ void disc_epilogue(float *__restrict__ y, long tile_k
         if (k + 1 == n_out - 1) *prev_out = o1;
         if (a == 0 && lane == 0) edge_tile[2 * wave] = o0;
         if (a == NACC - 1 && lane == 63) edge_tile[2 * wave + 1] = o1;
+    }
+}
+
+// Discriminator epilogue through LDS (LRHIP_DISC_EPI_LDS = 1; measured slower than the in-register form, kept as the A/B variant): after the re/im exchange every lane writes its two ComplexFloat32 outputs of
+// each accumulator as ONE 16-byte word into the (now free) window area - tile-local output l at float 2 l, a wave writes 1 KB contiguous per
+// accumulator - and after a barrier thread t turns outputs 4t .. 4t+3 (with 4t-1 from its neighbour's word) into four angles and one 16-byte store.
+// 205 VALU instructions per wave and tile against 292 for the in-register form (its ds_bpermute shuffles, selects and 8-byte stores), and only the
+// FIRST output of a TILE needs another workgroup's data: edge[2t] / edge[2t+1] = first / last output of tile t, fixed afterwards as before.
+template <int D, int NACC>
+__device__ __forceinline__ void disc_epilogue_lds(float *__restrict__ y, float *ldsO, long tile_k0, long n_out, f32x4 (&acc)[1][NACC],
+                                                  float2 *__restrict__ edge_tile, float2 *__restrict__ prev_out, double inv_gain)
+{
+    using G = FirMfmaGeom<2, D>;
+    constexpr int TILE_OUT = G::tile_out(NACC);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const bool odd = col & 1;
+    __syncthreads();                                   // every wave is done reading the window: its first TILE_OUT * 8 bytes become the out-area
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+        const float a0 = acc[0][a][0], a1 = acc[0][a][1], a2 = acc[0][a][2], a3 = acc[0][a][3];
+        const float recv0 = __shfl_xor(odd ? a0 : a2, 1);
+        const float recv1 = __shfl_xor(odd ? a1 : a3, 1);
+        const float4 o = odd ? make_float4(recv0, a2, recv1, a3) : make_float4(a0, recv0, a1, recv1);      // two consecutive outputs
+        const int l = 16 * ((wave * NACC + a) * G::BPA + (col >> 1)) + 4 * kq + (odd ? 2 : 0);
+        *reinterpret_cast<float4 *>(ldsO + 2 * l) = o;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l0 = 4 * tid; l0 < TILE_OUT; l0 += 1024) {
+        const long k = tile_k0 + l0;
+        if (k >= n_out) break;
+        const float4 u = *reinterpret_cast<const float4 *>(ldsO + 2 * l0), v = *reinterpret_cast<const float4 *>(ldsO + 2 * l0 + 4);
+        const float2 p = l0 ? *reinterpret_cast<const float2 *>(ldsO + 2 * l0 - 2) : make_float2(0.f, 0.f);       // tile-first: fixed afterwards
+        const float2 o0 = make_float2(u.x, u.y), o1 = make_float2(u.z, u.w), o2 = make_float2(v.x, v.y), o3 = make_float2(v.z, v.w);
+        const float4 d = make_float4(discriminate(o0, p, inv_gain), discriminate(o1, o0, inv_gain), discriminate(o2, o1, inv_gain), discriminate(o3, o2, inv_gain));
+        if (k + 3 < n_out && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+            *reinterpret_cast<float4 *>(y + k) = d;
+        } else {
+            y[k] = d.x;
+            if (k + 1 < n_out) y[k + 1] = d.y;
+            if (k + 2 < n_out) y[k + 2] = d.z;
+            if (k + 3 < n_out) y[k + 3] = d.w;
+        }
+        const long last = n_out - 1 - k;                // the chunk's last output, if it is one of these four
+        if (last >= 0 && last < 4) *prev_out = last == 0 ? o0 : last == 1 ? o1 : last == 2 ? o2 : o3;
+        if (l0 == 0) edge_tile[0] = o0;
+        if (l0 == TILE_OUT - 4) edge_tile[1] = o3;
     }
 }
 
@@ -718,7 +769,11 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
             store_tile<S, D, NACC, 1>(y, tile_k0, n_out, out_aligned, acc);
         } else {
             static_assert(S == 2, "discriminator epilogue: complex stream");
+#if LRHIP_DISC_EPI_LDS
+            disc_epilogue_lds<D, NACC>(y, ldsX, tile_k0, n_out, acc, edge + 2 * t, prev_out, inv_gain);
+#else
             disc_epilogue<D, NACC>(y, tile_k0, n_out, out_aligned, acc, edge + 8 * t, prev_out, inv_gain);
+#endif
         }
         __syncthreads();      // everyone is done reading ldsX before it is overwritten
     }

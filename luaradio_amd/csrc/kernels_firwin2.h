@@ -80,19 +80,20 @@ struct FwcParams {
     const float2 *fix_prev;
     double fix_inv_gain;
     int fix_on;
+    int fix_shift;               // a record pair per 2^fix_shift outputs of the producer (8: per wave, 10: per tile)
 };
 
 // sample x[g] of a Float32 stream whose wave-first samples are still to be fixed (see FwcParams::fix_edge)
 __device__ __forceinline__ float fwc_fix_value(const FwcParams &pr, long g)
 {
-    const long w = g >> 8;
+    const long w = g >> pr.fix_shift;
     const float2 e0 = pr.fix_edge[2 * w], ep = w ? pr.fix_edge[2 * (w - 1) + 1] : *pr.fix_prev;
     return discriminate(e0, ep, pr.fix_inv_gain);
 }
 __device__ __forceinline__ float fwc_stream_at_fixed(const FwcParams &pr, const float *__restrict__ hist, const float *__restrict__ x, long p, int M, long n)
 {
     const long g = p - (M - 1);
-    if (pr.fix_on && g >= 0 && g < n && (g & 255) == 0) return fwc_fix_value(pr, g);
+    if (pr.fix_on && g >= 0 && g < n && (g & ((1L << pr.fix_shift) - 1)) == 0) return fwc_fix_value(pr, g);
     return stream_at<1>(hist, x, p, 0, M, n);
 }
 
@@ -201,9 +202,10 @@ __global__ __launch_bounds__(256, (MODE & FWC_PAIR) ? FWC_PAIR_WAVES : 2) void f
             {
                 fhalf = (tid >> 5) & 1;
                 const long lo_h = lo + (fhalf ? (long)D * G::TO : 0L);
-                const long g = ((lo_h <= 0 ? 0 : (lo_h + 255) >> 8) + (tid & 31)) << 8;
+                const int sh = pr.fix_shift;
+                const long g = ((lo_h <= 0 ? 0 : (lo_h + (1L << sh) - 1) >> sh) + (tid & 31)) << sh;
                 const bool ok = pr.fix_on && tid < 64 && g < lo_h + 4L * G::NF4 && g < n;
-                const long w = ok ? g >> 8 : 0;
+                const long w = ok ? g >> sh : 0;
                 fpos = ok ? (int)(g - lo_h) : -1;
                 fe0 = *reinterpret_cast<const cf *>(pr.fix_edge + 2 * w);
                 fep = *reinterpret_cast<const cf *>(w ? pr.fix_edge + 2 * (w - 1) + 1 : pr.fix_prev);
@@ -324,7 +326,8 @@ __global__ __launch_bounds__(256, (MODE & FWC_PAIR) ? FWC_PAIR_WAVES : 2) void f
                     __syncthreads();
                     const int h = (tid >> 5) & 1;
                     const long lo_h = qb - (M - 1) + (h ? (long)D * G::TO : 0L);       // x index of window coordinate 0 of this half (slack 0)
-                    const long g = ((lo_h <= 0 ? 0 : (lo_h + 255) >> 8) + (tid & 31)) << 8;
+                    const int sh = pr.fix_shift;
+                    const long g = ((lo_h <= 0 ? 0 : (lo_h + (1L << sh) - 1) >> sh) + (tid & 31)) << sh;
                     if (tid < 64 && g < lo_h + G::SPAN && g < n) ldsX[2 * (G::GUARD + (int)(g - lo_h)) + h] = fwc_fix_value(pr, g);
                 }
             }

@@ -43,6 +43,7 @@ struct FirStage : lrhip_stage {
     // fix-up of the wave-first discriminator outputs (disc_epilogue): done by fir_disc_fixup_kernel, or - defer_fixup - left to the next
     // stage of the chain, a pair-mode window filter that patches the samples as it stages them (FwcParams::fix_edge): one launch less
     bool defer_fixup = false, fix_ready = false;
+    int fix_shift = 8;                     // log2 of the outputs per edge record pair
     const float2 *fix_prev_ptr = nullptr;
     FirStage *fix_src = nullptr;           // consumer side: the stage whose edge records are to be applied
     double disc_gain = 1.0;
@@ -169,12 +170,17 @@ struct FirStage : lrhip_stage {
                     if (rc2) return rc2;
                     LR_LAUNCH_CHECK();
                     float2 *dp = (float2 *)disc_prev.p;
-                    if (defer_fixup && TILE_OUT / 4 == 256) {
+                    // records per unit of FIX_UNIT outputs: a wave's range in the in-register epilogue, a whole tile in the LDS one
+                    constexpr int FIX_UNIT = LRHIP_DISC_EPI_LDS ? TILE_OUT : TILE_OUT / 4;
+                    const long nunits = LRHIP_DISC_EPI_LDS ? ntiles : 4 * ntiles;
+                    if (defer_fixup && (FIX_UNIT & (FIX_UNIT - 1)) == 0) {
                         fix_ready = true;
                         fix_prev_ptr = (const float2 *)(dp + disc_cur);
+                        fix_shift = 0;
+                        while ((1 << fix_shift) < FIX_UNIT) fix_shift++;
                     } else {
-                        hipLaunchKernelGGL(fir_disc_fixup_kernel, dim3((unsigned)((4 * ntiles + 255) / 256)), dim3(256), 0, ctx().stream, (const float2 *)edge.p,
-                                           4 * ntiles, TILE_OUT / 4, y, n_out, (const float2 *)(dp + disc_cur), 1.0 / disc_gain);
+                        hipLaunchKernelGGL(fir_disc_fixup_kernel, dim3((unsigned)((nunits + 255) / 256)), dim3(256), 0, ctx().stream, (const float2 *)edge.p,
+                                           nunits, FIX_UNIT, y, n_out, (const float2 *)(dp + disc_cur), 1.0 / disc_gain);
                         LR_LAUNCH_CHECK();
                     }
                     disc_cur ^= 1;
@@ -477,6 +483,7 @@ struct FirStage : lrhip_stage {
             if (fix_src && fix_src->fix_ready) {
                 pr.fix_edge = (const float2 *)fix_src->edge.p; pr.fix_prev = fix_src->fix_prev_ptr; pr.fix_inv_gain = 1.0 / fix_src->disc_gain;
                 pr.fix_on = 1;
+                pr.fix_shift = fix_src->fix_shift;
                 fix_src->fix_ready = false;
             }
             pr.run = (pr.ntiles + slots - 1) / slots;
