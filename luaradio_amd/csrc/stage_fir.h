@@ -387,7 +387,7 @@ struct FirStage : lrhip_stage {
         static const bool on = getenv("LRHIP_FIR_WIN_REAL") != nullptr && getenv("LRHIP_NO_FIR_WIN") == nullptr;
         return on && S == 1 && !taps_complex && D == 1 && !rot && !pre_disc && !post_disc && !fft_arith && (M == 32 || M == 64 || M == 128);
     }
-    template <int MM>
+    template <int MM, bool ONESHOT = false>
     int launch_win_real_m(const float *x, long n, float *y)
     {
         using G = FwrGeom<MM>;
@@ -400,7 +400,7 @@ struct FirStage : lrhip_stage {
         memset(&pr, 0, sizeof(pr));
         pr.hist = (const float *)hist[cur].p + hist_pad; pr.x = x; pr.n = n; pr.taps_rev = (const float *)d_taps.p; pr.y = y;
         pr.hist_out = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
-        pr.run = (ntiles + slots - 1) / slots;
+        pr.run = ONESHOT ? 1 : (ntiles + slots - 1) / slots;
         pr.dec = 1;
         hipLaunchKernelGGL(kern, dim3((unsigned)((ntiles + pr.run - 1) / pr.run)), dim3(256), lds_bytes, ctx().stream, pr);
         LR_LAUNCH_CHECK();
@@ -454,12 +454,12 @@ struct FirStage : lrhip_stage {
         iir_fused = true; iir_b0 = (float)b0; iir_na1 = (float)q; iir_na1_lo = (float)(q - (double)iir_na1); iir_warm = w;
         return reset();
     }
-    template <int MM, int MODE>
+    template <int MM, int MODE, int DD = 5, bool ONESHOT = false>
     int launch_win_cplx_m(const float *x, long n, float *y, long n_out)
     {
-        using G = FwcGeom<5, 5, MM, MODE>;
+        using G = FwcGeom<DD, 5, MM, MODE>;
         const size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
-        auto kern = fir_win_cplx_kernel<5, 5, MM, MODE>;
+        auto kern = fir_win_cplx_kernel<DD, 5, MM, MODE>;
         if (!winc_blocks_per_cu && prepare_kernel(kern, lds_bytes, &winc_blocks_per_cu)) return -1;
         FwcParams pr;
         memset(&pr, 0, sizeof(pr));
@@ -491,7 +491,8 @@ struct FirStage : lrhip_stage {
             grid = (unsigned)((pr.ntiles + pr.run - 1) / pr.run);
         } else {
             pr.warm_waves = 4; pr.run = 1;
-            grid = (unsigned)(pr.ntiles < slots ? pr.ntiles : slots);
+            // ONESHOT: a workgroup per tile, handed out in address order (short filters are a streaming problem: common.h grid_for)
+            grid = (unsigned)((ONESHOT || pr.ntiles < slots) ? pr.ntiles : slots);
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, pr);
         LR_LAUNCH_CHECK();
@@ -505,6 +506,21 @@ struct FirStage : lrhip_stage {
         if (post_disc) return rot ? launch_win_cplx_m<128, FWC_ROT | FWC_DISC>(x, n, y, n_out) : launch_win_cplx_m<128, FWC_DISC>(x, n, y, n_out);
         return rot ? launch_win_cplx_m<128, FWC_ROT>(x, n, y, n_out) : launch_win_cplx_m<128, 0>(x, n, y, n_out);
     }
+    // short filters on the ComplexFloat32 stream at D = 1 (the reference suite's 16-tap entries): at 16 taps the filter is 16 packed FMAs per
+    // output - nothing against its 16 B of traffic - and the Toeplitz product pays its fixed 16-output blocks (K = 15 + 16, half of it zeros).
+    // One-shot window kernel, same box, 2^26 samples: 16 taps 0.175 against 0.222 ms (6.1 TB/s = the copy yardstick), 32 taps 0.233 / 0.260,
+    // 64 taps 0.301 / 0.326 (there the overlap-save kernel, 0.221, is what `automatic` picks)
+    bool win_short_ok() const
+    {
+        static const bool off = getenv("LRHIP_NO_FIR_WIN_SHORT") != nullptr;      // A/B knob
+        return !off && !win_off() && S == 2 && !taps_complex && D == 1 && (M == 16 || M == 32 || M == 64) && !rot && !fft_arith && !use_fft && !pre_disc && !post_disc;
+    }
+    int launch_win_short(const float *x, long n, float *y, long n_out)
+    {
+        return M == 16 ? launch_win_cplx_m<16, 0, 1, true>(x, n, y, n_out) : M == 32 ? launch_win_cplx_m<32, 0, 1, true>(x, n, y, n_out)
+                                                                            : launch_win_cplx_m<64, 0, 1, true>(x, n, y, n_out);
+    }
+    // (the Float32-stream window kernel was measured the same way and lost: 0.153 / 0.150 ms against 0.136 / 0.136 for the Toeplitz kernel at 16 / 32 taps)
     int launch_win_pair(const float *x, long n, float *y, long n_out)
     {
         return iir_fused ? launch_win_cplx_m<136, FWC_PAIR | FWC_IIR>(x, n, y, n_out) : launch_win_cplx_m<136, FWC_PAIR>(x, n, y, n_out);
@@ -547,6 +563,7 @@ struct FirStage : lrhip_stage {
                      : fft_arith ? launch_fft(x, n, y, n_out)
                      : win_real_ok() ? launch_win_real(x, n, y)
                      : win_cplx_ok() ? launch_win_cplx(x, n, y, n_out)
+                     : win_short_ok() ? launch_win_short(x, n, y, n_out)
                      : win_pair_ok() ? launch_win_pair(x, n, y, n_out)
                      : !ksteps ? (decim_lds_ok() ? launch_decim_lds(x, n, y, n_out) : launch_direct(x, n, y, n_out))
                      : taps_complex ? dispatch_mfma_cc(x, n, y, n_out)
