@@ -297,4 +297,47 @@ __global__ __launch_bounds__(256, 2) void fir_win_real_kernel(const FwrParams pr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Short filters on the Float32 stream, D = 1 (the reference suite's "16 Real taps, Real input"): a streaming problem.  One thread = four
+// consecutive outputs = one 16-byte store; its M + 3 input samples are HALO / 4 + 1 aligned 16-byte loads whose lines the neighbouring lanes
+// share through L1; taps from scalar loads; one-shot grid.  The same fmaf chain per output as every other direct form (bit-exact).
+// ------------------------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256) void fir_short_real_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_rev,
+                                                             float *__restrict__ y, long n, float *__restrict__ hist_out)
+{
+    constexpr int HALO = ((M - 1 + 3) / 4) * 4, NV = HALO / 4 + 1;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x, n0 = 4 * t;
+    if (hist_out && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < M - 1; i += 256) hist_out[i] = stream_at<1>(hist, x, n + i, 0, M, n);
+    if (n0 >= n) return;
+    float w[4 * NV];                                   // w[i] = x[n0 - HALO + i]
+    const bool vec = n0 - HALO >= 0 && n0 + 4 <= n && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (vec) {
+        const float4 *src = reinterpret_cast<const float4 *>(x + n0 - HALO);
+#pragma unroll
+        for (int q = 0; q < NV; q++) {
+            const float4 v = src[q];
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4 * NV; i++) w[i] = stream_at<1>(hist, x, n0 - HALO + i + (M - 1), 0, M, n);
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        const float h = taps_rev[j];
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = fmaf(w[HALO - (M - 1) + i + j], h, acc[i]);      // s[n0 + i + j], s = [history | chunk]
+    }
+    if (n0 + 4 <= n && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+        *reinterpret_cast<float4 *>(y + n0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (n0 + i < n) y[n0 + i] = acc[i];
+    }
+}
+
 }  // namespace lrhip

@@ -492,7 +492,8 @@ struct FirStage : lrhip_stage {
         } else {
             pr.warm_waves = 4; pr.run = 1;
             // ONESHOT: a workgroup per tile, handed out in address order (short filters are a streaming problem: common.h grid_for)
-            grid = (unsigned)((ONESHOT || pr.ntiles < slots) ? pr.ntiles : slots);
+            static const bool oneshot_env = getenv("LRHIP_FIR_WIN_ONESHOT") != nullptr;      // A/B knob
+            grid = (unsigned)((ONESHOT || oneshot_env || pr.ntiles < slots) ? pr.ntiles : slots);
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, pr);
         LR_LAUNCH_CHECK();
@@ -520,7 +521,24 @@ struct FirStage : lrhip_stage {
         return M == 16 ? launch_win_cplx_m<16, 0, 1, true>(x, n, y, n_out) : M == 32 ? launch_win_cplx_m<32, 0, 1, true>(x, n, y, n_out)
                                                                             : launch_win_cplx_m<64, 0, 1, true>(x, n, y, n_out);
     }
-    // (the Float32-stream window kernel was measured the same way and lost: 0.153 / 0.150 ms against 0.136 / 0.136 for the Toeplitz kernel at 16 / 32 taps)
+    // (the Float32-stream window kernel was measured the same way and lost: 0.153 / 0.150 ms against 0.136 / 0.136 for the Toeplitz kernel at 16 / 32 taps;
+    // what wins there is the plain streaming form, fir_short_real_kernel: four outputs per thread, loads shared through L1)
+    bool short_real_ok() const
+    {
+        static const bool off = getenv("LRHIP_NO_FIR_WIN_SHORT") != nullptr;
+        return !off && S == 1 && !taps_complex && D == 1 && (M == 16 || M == 32) && !rot && !fft_arith && !use_fft && !pre_disc && !post_disc;
+    }
+    int launch_short_real(const float *x, long n, float *y)
+    {
+        const float *h = (const float *)hist[cur].p + hist_pad, *t = (const float *)d_taps.p;
+        float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
+        const unsigned grid = grid_for((unsigned long)((n + 3) / 4), 256);
+        if (M == 16) hipLaunchKernelGGL(fir_short_real_kernel<16>, dim3(grid), dim3(256), 0, ctx().stream, h, x, t, y, n, ho);
+        else hipLaunchKernelGGL(fir_short_real_kernel<32>, dim3(grid), dim3(256), 0, ctx().stream, h, x, t, y, n, ho);
+        LR_LAUNCH_CHECK();
+        hist_in_kernel = ho != nullptr;
+        return 0;
+    }
     int launch_win_pair(const float *x, long n, float *y, long n_out)
     {
         return iir_fused ? launch_win_cplx_m<136, FWC_PAIR | FWC_IIR>(x, n, y, n_out) : launch_win_cplx_m<136, FWC_PAIR>(x, n, y, n_out);
@@ -564,6 +582,7 @@ struct FirStage : lrhip_stage {
                      : win_real_ok() ? launch_win_real(x, n, y)
                      : win_cplx_ok() ? launch_win_cplx(x, n, y, n_out)
                      : win_short_ok() ? launch_win_short(x, n, y, n_out)
+                     : short_real_ok() ? launch_short_real(x, n, y)
                      : win_pair_ok() ? launch_win_pair(x, n, y, n_out)
                      : !ksteps ? (decim_lds_ok() ? launch_decim_lds(x, n, y, n_out) : launch_direct(x, n, y, n_out))
                      : taps_complex ? dispatch_mfma_cc(x, n, y, n_out)

@@ -171,3 +171,31 @@ def test_slow_recurrence_is_not_rewritten_in_polyphase_form():
     b, a = O.singlepole_lowpass_taps(50.0, 220500.0)
     want = O.IIR(b, a, False, O.MODE_F64).process(O.FIR(taps, False, O.MODE_F64).process(x))[::5]
     assert len(got) == len(want) and G.max_abs_err(got, want) < 2e-6
+
+
+@pytest.mark.parametrize("cplx,ntaps", [(True, 16), (True, 32), (True, 64), (False, 16), (False, 32)])
+def test_short_filter_streaming_kernels_tile_edges_and_unaligned_pointers(cplx, ntaps):
+    """the one-shot kernels for short filters (ComplexFloat32: register-window kernel, a workgroup per 1280-output tile; Float32: four outputs per
+    thread): sizes around the tile / vector boundaries, device pointers off the 16-byte grid, one sample per call - bit-exact fmaf chains"""
+    import torch
+    rng = np.random.default_rng(ntaps + cplx)
+    n = 5 * 1280 + 3
+    mk = lambda m: ((rng.uniform(-1, 1, m) + 1j * rng.uniform(-1, 1, m)).astype(np.complex64) if cplx else rng.uniform(-1, 1, m).astype(np.float32))
+    x = mk(n + 8)
+    taps = (rng.uniform(-1, 1, ntaps) / ntaps).astype(np.float32)
+    for m in (1, 3, 4, 5, 1279, 1280, 1281, n):
+        blk = make(lr.FIRFilterBlock, [taps], x)
+        assert np.array_equal(blk.process(x[:m]), O.FIR(taps, cplx, O.MODE_FMA).process(x[:m])), m
+    blk = make(lr.FIRFilterBlock, [taps], x)
+    got = np.concatenate([blk.process(x[i:i + 1]) for i in range(200)])
+    assert np.array_equal(got, O.FIR(taps, cplx, O.MODE_FMA).process(x[:200]))
+    es = 8 if cplx else 4
+    xd = torch.from_numpy(x.view(np.float32)).cuda()
+    yd = torch.zeros((n + 16) * (2 if cplx else 1), dtype=torch.float32, device="cuda")
+    for off_in, off_out in ((1, 0), (0, 1), (3, 2)):
+        blk = make(lr.FIRFilterBlock, [taps], x)
+        assert blk.process_device(xd.data_ptr() + es * off_in, n, yd.data_ptr() + es * off_out, n) == n
+        torch.cuda.synchronize()
+        out = yd.cpu().numpy()
+        out = out.view(np.complex64) if cplx else out
+        assert np.array_equal(out[off_out:off_out + n], O.FIR(taps, cplx, O.MODE_FMA).process(x[off_in:off_in + n])), (off_in, off_out)

@@ -148,7 +148,7 @@ def test_golden_spectrum_utils():
 
 # --------------------------------------------------------------------------------------------- FIR vs oracle
 @pytest.mark.parametrize("cplx", [True, False])
-@pytest.mark.parametrize("ntaps", [1, 2, 5, 16, 31, 64, 127, 128, 129, 255, 500])
+@pytest.mark.parametrize("ntaps", [1, 2, 5, 16, 31, 32, 64, 127, 128, 129, 255, 500])
 def test_fir_real_taps_bit_exact_vs_fma_oracle(cplx, ntaps):
     rng = np.random.default_rng(ntaps * 2 + cplx)
     n = 20000
