@@ -7,7 +7,7 @@ then produces exactly the audio samples the single-process run would have produc
 
     python examples/timeshard_wbfm.py recording.cf32 audio.f32 [--parts 8]          # the partitions run one after the other on this GPU
     torchrun --nproc-per-node 8 examples/timeshard_wbfm.py recording.cf32 audio.f32 # one partition per GPU (rank r writes audio.f32.part<r>)
-    python examples/timeshard_wbfm.py --selftest                                     # synthetic FM, 2 / 4 / 8 partitions == one stream, bit for bit
+    python examples/timeshard_wbfm.py --selftest                                     # synthetic FM, 2 / 4 / 8 partitions == one stream, bit for bit (boundaries on the receiver's shard_align)
 """
 import argparse
 import os

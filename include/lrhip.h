@@ -240,8 +240,9 @@ int lrhip_chain_last_launches(const lrhip_chain_t *c);
  *       in time.  Outputs of the partition [n0, n1) are then the same VALUES as samples of the single-stream run; with partition
  *       boundaries on multiples of lrhip_chain_shard_align(c) input samples also bit for bit.
  *   lrhip_chain_shard_align(c): partition boundaries on multiples of this many input samples give every scan kernel of the chain the
- *       tile grid of the uninterrupted run (1 for chains of filters / rotators / discriminators / downsamplers; 64 000 for the WBFM
- *       receiver: 2 560 audio samples x 25). */
+ *       tile grid of the uninterrupted run (1 for chains of filters / rotators / discriminators / downsamplers; 5 120 for a tuner
+ *       fused with the discriminator behind it, whose tiles are rotated relative to their first sample; 128 000 for the WBFM receiver:
+ *       the lcm of that and of the 2 560 audio samples x 25 of its tail). */
 int  lrhip_stage_seek(lrhip_stage_t *q, unsigned long long n0);
 int  lrhip_chain_seek(lrhip_chain_t *c, unsigned long long n0);
 long lrhip_chain_halo(const lrhip_chain_t *c);

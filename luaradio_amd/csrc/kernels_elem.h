@@ -130,37 +130,43 @@ __global__ __launch_bounds__(256) void rotator_kernel(const float2 *__restrict__
 // sample of the chunk to prev_out (ping-pong, so no block reads what another writes).
 // Algorithmic traffic: 12 B/sample (8 in + 4 out); the x[n-1] re-read hits L1/L2.
 // ------------------------------------------------------------------------------------------------
-// atan2 for finite inputs: one reciprocal-based division onto [0,1], the Cephes atanf split at tan(pi/8) with its
-// degree-9 odd minimax polynomial, then the octant/quadrant fix-ups.  |error| <= 2.7e-7 rad (checked against a double
-// arctan2 over 2e5 random points incl. tiny arguments); atan2(0, 0) = 0 like libm.  ~25 VALU ops instead of the
-// general libm routine - matters when the discriminator is fused into the FFT kernel's load stage.
+// atan2 for finite inputs: the Cephes atanf split at tan(pi/8) with its degree-9 odd minimax polynomial, then the octant/quadrant fix-ups.  The split
+// is decided on the operands (mn > tan(pi/8) mx) and both ranges share ONE hardware reciprocal: t = mn / mx or (mn - mx) / (mn + mx).
+// |error| <= 3.0e-7 rad (Float32 emulation with a 1-ulp reciprocal against a double arctan2 over 2e6 points, magnitudes 1e-12 .. 1e6); atan2(0, 0) = 0
+// like libm.  ~30 VALU ops; hipcc expands __fdividef to the full IEEE division sequence (10 instructions), which made the two-division form of
+// round 1 twice as long.  v_rcp_f32 flushes denormal inputs: the caller routes max(|x|, |y|) < 2^-60 to fast_atan2f_tiny.
 __device__ __forceinline__ float fast_atan2f(float y, float x)
 {
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float a = mx > 0.f ? __fdividef(mn, mx) : 0.f;
-    const bool big = a > 0.41421356237f;
-    const float t = big ? __fdividef(a - 1.0f, a + 1.0f) : a;
+    const bool big = mn > 0.41421356237f * mx;
+    const float num = big ? mn - mx : mn, den = big ? mn + mx : mx;
+    const float t = mx > 0.f ? num * __builtin_amdgcn_rcpf(den) : 0.f;
     const float z = t * t;
     float p = fmaf(fmaf(fmaf(fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f) * z, t, t);
     float r = big ? p + 0.785398163397448f : p;
     r = ay > ax ? 1.5707963267948966f - r : r;
     r = x < 0.f ? 3.14159265358979f - r : r;
-    return y < 0.f ? -r : r;
+    return copysignf(r, y);
 }
+// operands below 2^-60 (down to denormals): rescaled by 2^80 first - the angle does not change
+__device__ __noinline__ float fast_atan2f_tiny(float y, float x) { return fast_atan2f(y * 0x1p+80f, x * 0x1p+80f); }
 
 __device__ __forceinline__ float discriminate(float2 a, float2 b, double inv_gain)
 {
     // a * conj(b); f32 fused products: the residual (<= 1 ulp of the larger product) moves the angle by < 1e-7 rad
     float tr = fmaf(a.x, b.x, a.y * b.y), ti = fmaf(a.y, b.x, -a.x * b.y);
-    if (tr == 0.f && ti == 0.f) {
-        // zero product (first sample after the zero initial state, or an exactly silent input): the reference's angle is
-        // then decided by the SIGNS of the zeros, atan2(+-0, -0) = +-pi (frequencydiscriminator.lua:74 -> complexfloat32.lua:79-81
-        // operation order: re = ar*br - ai*(-bi), im = ar*(-bi) + ai*br)
-        float nb = -b.y;
-        float zr = __fsub_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, nb)), zi = __fadd_rn(__fmul_rn(a.x, nb), __fmul_rn(a.y, b.x));
-        float r = __builtin_signbit(zr) ? 3.14159265358979f : 0.f;
-        return copysignf(r, zi) * (float)inv_gain;
+    if (__builtin_expect(fmaxf(fabsf(tr), fabsf(ti)) < 0x1p-60f, 0)) {
+        if (tr == 0.f && ti == 0.f) {
+            // zero product (first sample after the zero initial state, or an exactly silent input): the reference's angle is
+            // then decided by the SIGNS of the zeros, atan2(+-0, -0) = +-pi (frequencydiscriminator.lua:74 -> complexfloat32.lua:79-81
+            // operation order: re = ar*br - ai*(-bi), im = ar*(-bi) + ai*br)
+            float nb = -b.y;
+            float zr = __fsub_rn(__fmul_rn(a.x, b.x), __fmul_rn(a.y, nb)), zi = __fadd_rn(__fmul_rn(a.x, nb), __fmul_rn(a.y, b.x));
+            float r = __builtin_signbit(zr) ? 3.14159265358979f : 0.f;
+            return copysignf(r, zi) * (float)inv_gain;
+        }
+        return fast_atan2f_tiny(ti, tr) * (float)inv_gain;
     }
     return fast_atan2f(ti, tr) * (float)inv_gain;
 }

@@ -154,7 +154,15 @@ __device__ __forceinline__ void lds_put4(float *ldsX, int i4, float4 v)
 }
 
 // edge tiles (touch the carried history, the end of the chunk, or an unaligned source): per-sample staging
-template <int S, int D, bool ROT>
+// the phasor of window position k under the relative rotator staging of fir_mfma_persistent_kernel (REL): the product the interior tiles keep in
+// registers, float4 i4 = k / 2 = tid + 256 u -> P(2 tid) * P(512 u + (k & 1)); edge tiles evaluate it per sample, same bits
+__device__ __forceinline__ cf rel_window_phasor(uint64_t step_fx, int k)
+{
+    const int i4 = k >> 1;
+    return cmul(phasor_poly(step_fx * (uint64_t)(2 * (i4 & 255))), phasor_poly(step_fx * (uint64_t)(512 * (i4 >> 8) + (k & 1))));
+}
+
+template <int S, int D, bool ROT, bool REL = false>
 __device__ __forceinline__ void stage_edge(float *ldsX, const float *__restrict__ hist, const float *__restrict__ x,
                                            long base, int span, int M, long n, uint64_t rot_step_fx, uint64_t rot_count0)
 {
@@ -163,7 +171,11 @@ __device__ __forceinline__ void stage_edge(float *ldsX, const float *__restrict_
         long p = base + r;
         float v0 = stream_at<S>(hist, x, p, 0, M, n);
         float v1 = S == 2 ? stream_at<S>(hist, x, p, 1, M, n) : 0.f;
-        if (ROT) {
+        if (REL) {
+            const cf o = cmul(cf{v0, v1}, rel_window_phasor(rot_step_fx, r));
+            v0 = o.x;
+            v1 = o.y;
+        } else if (ROT) {
             // absolute sample index of stream position p is rot_count0 + p - (M-1); history before the
             // start of the stream is zero, so its phase is irrelevant
             float2 o = rotate_sample(make_float2(v0, v1), rot_step_fx, rot_count0 + (uint64_t)(p - (M - 1)));
@@ -318,14 +330,17 @@ __device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, 
 // (or, for lane 0, in the previous accumulator), one ds_bpermute away.  Only the first output of a WAVE needs another
 // wave's data: each wave records (first, last) in `edge` and fir_disc_fixup_kernel rewrites those samples afterwards.
 // The last valid output of the chunk is published as the carried previous sample.
-template <int D, int NACC>
+template <int D, int NACC, bool REL = false>
 __device__ __forceinline__ void disc_epilogue(float *__restrict__ y, long tile_k0, long n_out, int out_aligned, f32x4 (&acc)[1][NACC],
-                                              float2 *__restrict__ edge_tile, float2 *__restrict__ prev_out, double inv_gain)
+                                              float2 *__restrict__ edge_tile, float2 *__restrict__ prev_out, double inv_gain, cf pt = cf{1.f, 0.f})
 {
     using G = FirMfmaGeom<2, D>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const bool odd = col & 1;
+    // pt: the tile's outputs carry a common phasor the angles do not see (relative rotator staging); what LEAVES the tile as a ComplexFloat32
+    // sample - the edge records, the carried previous sample - is multiplied by it
+    auto leave = [&](float2 o) { return REL ? cf_to(cmul(cf_from(o), pt)) : o; };
     // lane that owns the output just before this lane's first one (lane 0: previous accumulator, handled below)
     const int src = odd ? lane - 1 : kq ? lane - 15 : col ? col + 47 : 63;
     const long wave_k0 = tile_k0 + (long)wave * (NACC * G::BPA * 16);
@@ -348,10 +363,10 @@ __device__ __forceinline__ void disc_epilogue(float *__restrict__ y, long tile_k
             if (k < n_out) y[k] = d.x;
             if (k + 1 < n_out) y[k + 1] = d.y;
         }
-        if (k == n_out - 1) *prev_out = o0;
-        if (k + 1 == n_out - 1) *prev_out = o1;
-        if (a == 0 && lane == 0) edge_tile[2 * wave] = o0;
-        if (a == NACC - 1 && lane == 63) edge_tile[2 * wave + 1] = o1;
+        if (k == n_out - 1) *prev_out = leave(o0);
+        if (k + 1 == n_out - 1) *prev_out = leave(o1);
+        if (a == 0 && lane == 0) edge_tile[2 * wave] = leave(o0);
+        if (a == NACC - 1 && lane == 63) edge_tile[2 * wave + 1] = leave(o1);
     }
 }
 
@@ -670,7 +685,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
 // after the loop.  Edge tiles (first tile: history; last tiles: end of chunk) are staged synchronously.
 // EPI = 1 (S = 2, real taps): fused FrequencyDiscriminatorBlock BEHIND the filter (frequencydiscriminator.lua:68-88): the
 // ComplexFloat32 outputs never leave the registers, y receives arg(o[k] conj(o[k-1])) / gain as Float32 (disc_epilogue).
-template <int S, int D, int NACC, bool ROT, int KS, int EPI = 0>
+template <int S, int D, int NACC, bool ROT, int KS, int EPI = 0, bool REL = false>
 __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persistent_kernel(
     const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_pad, float *__restrict__ y,
     int M, long n, long n_out, long first, int e, long ntiles, int out_aligned,
@@ -700,19 +715,34 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
     // = 0 mod 8), so one phasor polynomial serves 8 samples; the block grid is shifted by a4 float4 against the window, the
     // same for every tile because the tile advance TILE_OUT * D is a multiple of 8 samples.
     static_assert(!ROT || (S == 2 && (TILE_OUT * D) % 8 == 0), "rotator staging: complex stream, tile advance = 0 mod 8 samples");
-    constexpr int NB = ROT ? NF4 / 4 + 2 : 0;                 // blocks that can touch the window
+    // Tuner with the discriminator epilogue (REL): the window is rotated RELATIVE to its first sample, W(k) = exp(j omega k), k = 2 tid + 512 u + j
+    // for float4 tid + 256 u - the same for every tile, so a thread keeps its 2 UX phasors in registers (the block-of-8 staging needs four more
+    // prefetch registers and two phasor tables): ONE packed complex multiply per sample, no polynomial per tile.  The filter is linear, so every output of the tile
+    // carries the common phasor P(window start); an angle arg(o[k] conj(o[k-1])) does not see it, and the samples that leave the tile (edge records,
+    // carried previous sample) are multiplied by it in the epilogue.  The rounding now depends on where the tiles fall: chunkings agree to Float32
+    // rounding of the filter outputs instead of bit for bit (FirStage::align() names the grid for time partitions; LRHIP_TUNER_EXACT=1 in the
+    // environment keeps the block-of-8 staging, whose phasors are those of the stand-alone FrequencyTranslatorBlock bit for bit).
+    static_assert(!REL || (ROT && EPI != 0 && !LRHIP_DISC_EPI_LDS), "relative rotator staging: rotator + in-register discriminator epilogue");
+    constexpr int NB = ROT && !REL ? NF4 / 4 + 2 : 0;         // blocks that can touch the window
     constexpr int UB = (NB + 255) / 256;
-    constexpr int NPRE = ROT ? 4 * UB : UX;
+    constexpr int NPRE = ROT && !REL ? 4 * UB : UX;
     RotTab rot_t;
     int a4 = 0;
     // odd absolute offset (an odd number of samples consumed so far): float4 pairs straddle the blocks; same thread mapping
     // with a4 = 0 and the general rotate_pair (correct, slower - the reference's own chunk sizes are even)
     const bool rot_blocks = ROT && (((rot_count0 + (uint64_t)xlo_of(0)) & 1) == 0);
-    if (ROT) {
+    if (ROT && !REL) {
         rot_t = rot_tab(rot_step_fx);
         if (rot_blocks) a4 = (int)(((rot_count0 + (uint64_t)xlo_of(0)) & 7) >> 1);      // window float4 0 is float4 a4 of its block
     }
-    auto i4_of = [&](int u) { return ROT ? 4 * (tid + 256 * (u >> 2)) + (u & 3) - a4 : tid + 256 * u; };
+    auto i4_of = [&](int u) { return ROT && !REL ? 4 * (tid + 256 * (u >> 2)) + (u & 3) - a4 : tid + 256 * u; };
+    cf rel_w[REL ? UX : 1][2];
+    if constexpr (REL) {
+#pragma unroll
+        for (int u = 0; u < UX; u++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) rel_w[u][j] = rel_window_phasor(rot_step_fx, 2 * (tid + 256 * u) + j);
+    }
 
     float4 pre[NPRE];
     long t = blockIdx.x;
@@ -733,7 +763,14 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
         const long tile_k0 = t * (long)TILE_OUT;
         if (have) {
             const long xlo = xlo_of(t);
-            if constexpr (ROT) {
+            if constexpr (REL) {
+#pragma unroll
+                for (int u = 0; u < UX; u++) {
+                    const int i4 = tid + u * 256;
+                    const cf a = cmul(cf{pre[u].x, pre[u].y}, rel_w[u][0]), b = cmul(cf{pre[u].z, pre[u].w}, rel_w[u][1]);
+                    if (i4 < NF4) lds_put4<S, D>(ldsX, i4, make_float4(a.x, a.y, b.x, b.y));
+                }
+            } else if constexpr (ROT) {
 #pragma unroll
                 for (int v = 0; v < UB; v++) {
                     const int i40 = 4 * (tid + 256 * v) - a4;                 // first float4 of this thread's block
@@ -758,7 +795,7 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
                 }
             }
         } else {
-            stage_edge<S, D, ROT>(ldsX, hist, x, first + tile_k0 * D - e, SPAN, M, n, rot_step_fx, rot_count0);
+            stage_edge<S, D, ROT, REL>(ldsX, hist, x, first + tile_k0 * D - e, SPAN, M, n, rot_step_fx, rot_count0);
         }
         __syncthreads();
         // prefetch the next tile while this one is multiplied
@@ -772,7 +809,9 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
 #if LRHIP_DISC_EPI_LDS
             disc_epilogue_lds<D, NACC>(y, ldsX, tile_k0, n_out, acc, edge + 2 * t, prev_out, inv_gain);
 #else
-            disc_epilogue<D, NACC>(y, tile_k0, n_out, out_aligned, acc, edge + 8 * t, prev_out, inv_gain);
+            cf pt = cf{1.f, 0.f};
+            if constexpr (REL) pt = phasor_poly(rot_step_fx * (rot_count0 + (uint64_t)xlo_of(t)));
+            disc_epilogue<D, NACC, REL>(y, tile_k0, n_out, out_aligned, acc, edge + 8 * t, prev_out, inv_gain, pt);
 #endif
         }
         __syncthreads();      // everyone is done reading ldsX before it is overwritten

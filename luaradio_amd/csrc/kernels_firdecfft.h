@@ -167,7 +167,9 @@ __device__ __forceinline__ float df_discriminate(float2 a, float2 b, const DfPar
 {
     const float tr = fmaf(a.x, b.x, a.y * b.y), ti = fmaf(a.y, b.x, -a.x * b.y);
     if (__builtin_expect(tr == 0.f && ti == 0.f, 0)) return df_discriminate_zero(b, p, hist, x, k, D);
-    return fast_atan2f(fmaf(tr, p.cD.y, ti * p.cD.x), fmaf(tr, p.cD.x, -ti * p.cD.y)) * (float)p.inv_gain;
+    const float ry = fmaf(tr, p.cD.y, ti * p.cD.x), rx = fmaf(tr, p.cD.x, -ti * p.cD.y);
+    if (__builtin_expect(fmaxf(fabsf(rx), fabsf(ry)) < 0x1p-60f, 0)) return fast_atan2f_tiny(ry, rx) * (float)p.inv_gain;      // v_rcp_f32 flushes denormals
+    return fast_atan2f(ry, rx) * (float)p.inv_gain;
 }
 
 // one sample of the stream [.. zeros | M-1 history | chunk | zeros ..] by its x index, branch-free (edge blocks only)

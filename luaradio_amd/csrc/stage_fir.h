@@ -18,6 +18,9 @@ struct FirStage : lrhip_stage {
     int cur = 0;
     unsigned long index = 0;              // carried downsampler index (downsampler.lua:53)
     bool rot = false;                     // fused rotator in front
+    // rotator + discriminator epilogue on the persistent Toeplitz kernel: window-relative phasors (kernels_fir.h, REL) unless the environment asks
+    // for the stand-alone rotator's phasors bit for bit
+    bool rel_rot = !LRHIP_DISC_EPI_LDS && getenv("LRHIP_TUNER_EXACT") == nullptr;
     uint64_t rot_step = 0, count = 0;     // absolute index of the next input sample
     // overlap-save emission framing (firfilter.lua:451-485)
     long L = 0, fill = 0;
@@ -99,6 +102,13 @@ struct FirStage : lrhip_stage {
             }
             return l;
         }
+        if (rot && post_disc && !decfft && !win_cplx_ok() && rel_rot) {
+            // tuner + discriminator on the persistent Toeplitz kernel: a tile's window is rotated relative to its first sample
+            // (kernels_fir.h, REL), so the rounding follows the tile grid, which starts with the chunk
+            const int nacc5 = getenv("LRHIP_FIR_D5_NACC") ? atoi(getenv("LRHIP_FIR_D5_NACC")) : 2;
+            if (D == 1) return (unsigned long)FirMfmaGeom<2, 1>::tile_out(LRHIP_FIR_D1_NACC);
+            if (D == 5) return 5UL * FirMfmaGeom<2, 5>::tile_out(nacc5 == 1 ? 1 : 2);
+        }
         return 1UL;
     }
 
@@ -166,7 +176,9 @@ struct FirStage : lrhip_stage {
             int rc2;
             if constexpr (SS == 2 && (DD == 1 || DD == 5)) {
                 if (post_disc) {
-                    rc2 = rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS, 1>);
+                    if constexpr (LRHIP_DISC_EPI_LDS) rc2 = rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS, 1>);
+                    else rc2 = !rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS, 1>)
+                             : rel_rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1, true>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1, false>);
                     if (rc2) return rc2;
                     LR_LAUNCH_CHECK();
                     float2 *dp = (float2 *)disc_prev.p;

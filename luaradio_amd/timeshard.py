@@ -12,8 +12,9 @@ thrown away, and then produces exactly the samples [a_g, b_g) of the single-stre
                                       is run_partition_device)
     rank_partition(n, world, rank) -> (a, b) for one process per GPU (torchrun): no collective on the data path
 Boundaries on multiples of chain.shard_align() input samples make the result bit-identical to the single-stream run as well (the
-tile grids of the scan kernels then coincide: 64 000 for the WBFM receiver, 1 for filter / rotator / discriminator / downsampler
-chains); any other boundary gives the same values to Float32 rounding of the recurrences and exactly for everything else.
+tile grids of the kernels then coincide: 128 000 for the WBFM receiver - 64 000 for its tail's scan, 5 120 for its tuner, whose tiles
+rotate relative to their first sample in front of the discriminator - and 1 for plain filter / rotator / discriminator / downsampler
+chains); any other boundary gives the same values to Float32 rounding of those two and exactly for everything else.
 """
 
 ALIGN = 65536      # default cut granularity when the caller does not ask the chain (any multiple of chain.shard_align() is bit-exact)

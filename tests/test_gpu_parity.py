@@ -36,6 +36,19 @@ def rand_r(rng, n):
     return rng.uniform(-1, 1, n).astype(np.float32)
 
 
+def disc_err(got, want, o, gain):
+    """largest difference between two evaluations of FrequencyDiscriminator(gain) behind the same filter whose ComplexFloat32 outputs o agree to
+    Float32 rounding only (the tuner's window-relative phasors, kernels_fir.h REL): the angle of a small product is ill-conditioned,
+    |d angle| <= |do[k]| / |o[k]| + |do[k-1]| / |o[k-1]|, so a difference is weighed with min(|o[k]|, |o[k-1]|) / rms(o) (at most 1); a difference
+    of a whole turn (a product next to the negative real axis) counts as none"""
+    turn = 2 * np.pi / gain
+    d = got.astype(np.float64) - want.astype(np.float64)
+    d = (d + turn / 2) % turn - turn / 2
+    mag = np.abs(o).astype(np.float64)
+    w = np.minimum(mag, np.concatenate([mag[:1], mag[:-1]])) / np.sqrt(np.mean(mag ** 2))
+    return float(np.max(np.abs(d) * np.minimum(w, 1.0)))
+
+
 def chunked(blk, x, cuts):
     parts, a = [], 0
     for b in list(cuts) + [len(x)]:
@@ -442,11 +455,15 @@ def test_tuner_fused_rotator_fir_downsampler():
     assert np.array_equal(got, ds.process(lpf.process(rot.process(x))))
 
 
-@pytest.mark.parametrize("decim", [5, 1])
-def test_discriminator_epilogue_equals_unfused_blocks(decim):
+@pytest.mark.parametrize("decim,exact", [(5, False), (5, True), (1, True)])
+def test_discriminator_epilogue_equals_unfused_blocks(decim, exact, monkeypatch):
     """[rotator] -> FIR(128 real taps) -> [downsampler] -> discriminator in a chain runs the discriminator as the epilogue of
     the persistent MFMA kernel (wave-boundary samples fixed up afterwards, previous sample carried across calls): same bits
-    as the separate device blocks, for chunkings that cut inside and across waves (256 outputs) and tiles"""
+    as the separate device blocks, for chunkings that cut inside and across waves (256 outputs) and tiles.  With the rotator in front the
+    kernel rotates a tile's window relative to its first sample by default (the filter outputs then agree with the separate blocks to Float32
+    rounding, the angles as well as that allows); LRHIP_TUNER_EXACT=1 keeps the stand-alone rotator's phasors and with them the bits."""
+    if decim == 5 and exact:
+        monkeypatch.setenv("LRHIP_TUNER_EXACT", "1")
     rng = np.random.default_rng(31 + decim)
     rate = 1102500.0
     n = 300000 if decim == 5 else 120000
@@ -467,9 +484,13 @@ def test_discriminator_epilogue_equals_unfused_blocks(decim):
     ref = blocks()
     want = x
     for b in ref:
-        want = b.process(want)
+        o, want = want, b.process(want)
     assert len(got) == len(want) == (n + decim - 1) // decim
-    assert np.array_equal(got, want)
+    if exact:
+        assert np.array_equal(got, want)
+    else:
+        assert disc_err(got, want, o, 1.25) < 2e-6
+        assert np.median(np.abs(got - want)) < 2e-7
     ora = O.FMDiscriminator(1.25).process(O.tuner(-250e3, 200e3, 5, rate, mode=O.MODE_FMA, rot_mode=O.MODE_F64).process(x)) if decim == 5 else None
     if ora is not None:
         # the angle of tiny filter outputs is ill-conditioned; compare where the FIR output is not tiny
@@ -652,7 +673,8 @@ def test_polyphase_resampler_fusion_bit_equal_to_zero_stuffed_chain(L, D, cplx):
 @pytest.mark.parametrize("seed", range(6))
 def test_randomized_chunkings_fused_chains_equal_unfused_blocks(seed):
     """stress: random chunk boundaries (including empty and 1-sample chunks) through every fusing chain shape vs the same
-    blocks run one by one; the fused kernels reuse the unfused device functions, so the bits must match"""
+    blocks run one by one; the fused kernels reuse the unfused device functions, so the bits must match (the tuner in front of a discriminator
+    rotates relative to its tiles: Float32 rounding of the filter outputs, see test_discriminator_epilogue_equals_unfused_blocks)"""
     rng = np.random.default_rng(1000 + seed)
     rate = 1102500.0
     n = int(rng.integers(20000, 90000))
@@ -688,10 +710,12 @@ def test_randomized_chunkings_fused_chains_equal_unfused_blocks(seed):
         got = chunked(fused, x, cuts)
         want = x
         for b in ref:
-            want = b.process(want)
+            o, want = want, b.process(want)
         assert len(got) == len(want), name
         if name == "disc+fftfir+iir+down":
             assert G.max_abs_err(got, want) < 2e-6, name       # the FFT kernel's blocks fall differently per chunking
+        elif name == "tuner+disc":
+            assert disc_err(got, want, o, 1.25) < 2e-6, name   # window-relative phasors: the tiles fall differently per chunking
         else:
             assert np.array_equal(got, want), name
 

@@ -160,7 +160,8 @@ def test_virtual_partitions_on_one_device_bit_equal_to_the_single_stream(name):
         h = chain.halo()
         assert 0 < h < 200000 or name == "translate+downsample"
         align = chain.shard_align()
-        assert align == {"wbfm": 64000, "deemphasis": 4096, "disc+lowpass+deemphasis": 4096 * 7}.get(name, 1)
+        # tuner + discriminator: the tile grid of the window-relative rotator staging (1024 outputs x 5); the WBFM receiver = lcm with its tail's 64000
+        assert align == {"tuner+disc": 5120, "wbfm": 128000, "deemphasis": 4096, "disc+lowpass+deemphasis": 4096 * 7}.get(name, 1)
         got = np.concatenate([timeshard.run_partition(chain, x, a, b) for a, b in timeshard.bounds(n, parts, 4096 * align if align == 1 else align)])
         assert len(got) == len(whole), (name, parts)
         if name == "disc+lowpass+deemphasis":
@@ -173,17 +174,21 @@ def test_virtual_partitions_on_one_device_bit_equal_to_the_single_stream(name):
 
 @pytest.mark.gpu
 def test_unaligned_partition_boundaries_same_values():
-    """any boundary: filters / rotators / discriminators / downsamplers exactly, the recurrences of the WBFM tail to Float32 rounding"""
+    """any boundary: filters / rotators / downsamplers exactly; the tuner in front of a discriminator and the recurrences of the WBFM tail to
+    Float32 rounding (the angle of a small filter output is ill-conditioned: median and a robust maximum)"""
     n = 1 << 20
     x = _rand_c(22, n)
-    for name, tol in (("tuner+disc", 0.0), ("wbfm", 2e-7)):
+    for name, tol in (("tuner", 0.0), ("tuner+disc", 1e-3), ("wbfm", 5e-5)):
         build = _chains()[name]
         whole = build().process(x)
         chain = build()
         cuts = [0, 100001, 333333, 700007, n]
         got = np.concatenate([timeshard.run_partition(chain, x, a, b) for a, b in zip(cuts, cuts[1:])])
         assert len(got) == len(whole)
-        assert float(np.max(np.abs(got - whole))) <= tol, name
+        d = np.abs(got - whole)
+        d = np.minimum(d, np.abs(2 * np.pi / 1.25 - d)) if name == "tuner+disc" else d      # a whole turn is no difference
+        assert float(np.max(d)) <= tol, name
+        assert float(np.median(d)) <= min(tol, 1e-7), name
 
 
 @pytest.mark.gpu
