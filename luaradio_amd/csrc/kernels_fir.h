@@ -19,7 +19,7 @@
 #include "kernels_elem.h"
 
 #ifndef LRHIP_FIR_PIPE
-#define LRHIP_FIR_PIPE 0
+#define LRHIP_FIR_PIPE 2      /* explicit one-step software pipeline of the persistent kernel's MFMA loop - 0: never, 1: always, 2: decimating instantiations (WBFM receiver 0.167 -> 0.162 ms, same box; no gain at D = 1) */
 #endif
 #ifndef LRHIP_DISC_EPI_LDS
 #define LRHIP_DISC_EPI_LDS 0      /* 1: discriminator epilogue of the persistent Toeplitz kernel through LDS (fewer VALU instructions, two more barriers per tile: 0.206-0.208 against 0.201-0.202 ms for the WBFM receiver, same box) */
@@ -129,9 +129,10 @@ struct FirMfmaGeom {
     static constexpr int PAD = 2 * S;             // floats of padding per row
     static constexpr int BPA = 16 / S;            // blocks per accumulator
     static constexpr int GROUP = 4 * D;           // MFMA steps per LDS row of t
-    __host__ __device__ static constexpr int tile_out(int nacc) { return 4 * nacc * BPA * 16; }
+    // nw = waves per workgroup (4; 1: a wave stages its own window - no barrier couples it to others, fir_mfma_persistent_kernel NW)
+    __host__ __device__ static constexpr int tile_out(int nacc, int nw = 4) { return nw * nacc * BPA * 16; }
     // samples staged per tile for `ksteps` MFMA steps
-    __host__ __device__ static constexpr int span(int nacc, int ksteps) { return 16 * D * (4 * nacc * BPA - 1) + 4 * ksteps; }
+    __host__ __device__ static constexpr int span(int nacc, int ksteps, int nw = 4) { return 16 * D * (nw * nacc * BPA - 1) + 4 * ksteps; }
     __host__ __device__ static constexpr int phys(int a) { return a + PAD * (a / ROW); }
 };
 
@@ -155,24 +156,25 @@ __device__ __forceinline__ void lds_put4(float *ldsX, int i4, float4 v)
 
 // edge tiles (touch the carried history, the end of the chunk, or an unaligned source): per-sample staging
 // the phasor of window position k under the relative rotator staging of fir_mfma_persistent_kernel (REL): the product the interior tiles keep in
-// registers, float4 i4 = k / 2 = tid + 256 u -> P(2 tid) * P(512 u + (k & 1)); edge tiles evaluate it per sample, same bits
+// registers, float4 i4 = k / 2 = tid + NT u -> P(2 tid) * P(2 NT u + (k & 1)); edge tiles evaluate it per sample, same bits
+template <int NT>
 __device__ __forceinline__ cf rel_window_phasor(uint64_t step_fx, int k)
 {
     const int i4 = k >> 1;
-    return cmul(phasor_poly(step_fx * (uint64_t)(2 * (i4 & 255))), phasor_poly(step_fx * (uint64_t)(512 * (i4 >> 8) + (k & 1))));
+    return cmul(phasor_poly(step_fx * (uint64_t)(2 * (i4 % NT))), phasor_poly(step_fx * (uint64_t)(2 * NT * (i4 / NT) + (k & 1))));
 }
 
-template <int S, int D, bool ROT, bool REL = false>
+template <int S, int D, bool ROT, bool REL = false, int NT = 256>
 __device__ __forceinline__ void stage_edge(float *ldsX, const float *__restrict__ hist, const float *__restrict__ x,
                                            long base, int span, int M, long n, uint64_t rot_step_fx, uint64_t rot_count0)
 {
     using G = FirMfmaGeom<S, D>;
-    for (int r = threadIdx.x; r < span; r += 256) {
+    for (int r = threadIdx.x; r < span; r += NT) {
         long p = base + r;
         float v0 = stream_at<S>(hist, x, p, 0, M, n);
         float v1 = S == 2 ? stream_at<S>(hist, x, p, 1, M, n) : 0.f;
         if (REL) {
-            const cf o = cmul(cf{v0, v1}, rel_window_phasor(rot_step_fx, r));
+            const cf o = cmul(cf{v0, v1}, rel_window_phasor<NT>(rot_step_fx, r));
             v0 = o.x;
             v1 = o.y;
         } else if (ROT) {
@@ -223,7 +225,7 @@ __device__ __forceinline__ void mfma_tile(const float *ldsT, int tlen, int e, co
             for (int o = 0; o < NOUT; o++) acc[o][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[o], bv, acc[o][a], 0, 0, 0);
         }
     };
-    if constexpr (KS > 0 && LRHIP_FIR_PIPE) {
+    if constexpr (KS > 0 && (LRHIP_FIR_PIPE == 1 || (LRHIP_FIR_PIPE == 2 && D > 1))) {
         // explicit one-step software pipeline: the fragments of step s+1 are in flight while step s is multiplied.  The
         // sched_barriers keep hipcc from sinking each ds_read next to its MFMA (where it waits for it at once).
         float av[2][NOUT], bv[2][NACC];
@@ -685,27 +687,31 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
 // after the loop.  Edge tiles (first tile: history; last tiles: end of chunk) are staged synchronously.
 // EPI = 1 (S = 2, real taps): fused FrequencyDiscriminatorBlock BEHIND the filter (frequencydiscriminator.lua:68-88): the
 // ComplexFloat32 outputs never leave the registers, y receives arg(o[k] conj(o[k-1])) / gain as Float32 (disc_epilogue).
-template <int S, int D, int NACC, bool ROT, int KS, int EPI = 0, bool REL = false>
-__global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persistent_kernel(
+template <int S, int D, int NACC, bool ROT, int KS, int EPI = 0, bool REL = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persistent_kernel(
     const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_pad, float *__restrict__ y,
     int M, long n, long n_out, long first, int e, long ntiles, int out_aligned,
     uint64_t rot_step_fx, uint64_t rot_count0, float2 *__restrict__ edge, float2 *__restrict__ prev_out, double inv_gain, float *__restrict__ hist_out)
 {
     using G = FirMfmaGeom<S, D>;
-    constexpr int TILE_OUT = G::tile_out(NACC);
-    constexpr int SPAN = G::span(NACC, KS);
+    // NW = 1: one wave per workgroup, three such workgroups per SIMD - every wave stages the window of its own 256 outputs (7 % more samples staged
+    // than a quarter of the four-wave window) and no barrier couples it to other waves
+    constexpr int NT = 64 * NW;
+    static_assert(NW == 4 || (NW == 1 && REL), "one-wave workgroups: relative rotator staging + discriminator epilogue only");
+    constexpr int TILE_OUT = G::tile_out(NACC, NW);
+    constexpr int SPAN = G::span(NACC, KS, NW);
     // history carry (fir_history_kernel's job, saved launch): the other ping-pong buffer, raw (unrotated) samples
     if (hist_out && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < (M - 1) * S; i += 256) hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
+        for (int i = threadIdx.x; i < (M - 1) * S; i += NT) hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
     constexpr int NF4 = SPAN * S / 4;
-    constexpr int UX = (NF4 + 255) / 256;
+    constexpr int UX = (NF4 + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TLEN = fir_taps_len(D, KS);
     float *ldsT = lds;
     float *ldsX = lds + TLEN;
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < TLEN; i += 256) ldsT[i] = taps_pad[i];
+    for (int i = tid; i < TLEN; i += NT) ldsT[i] = taps_pad[i];
 
     auto xlo_of = [&](long t) { return first + t * (long)TILE_OUT * D - e - (M - 1); };
     auto interior = [&](long t) { long lo = xlo_of(t); return t < ntiles && lo >= 0 && lo + SPAN <= n; };
@@ -724,7 +730,7 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
     // environment keeps the block-of-8 staging, whose phasors are those of the stand-alone FrequencyTranslatorBlock bit for bit).
     static_assert(!REL || (ROT && EPI != 0 && !LRHIP_DISC_EPI_LDS), "relative rotator staging: rotator + in-register discriminator epilogue");
     constexpr int NB = ROT && !REL ? NF4 / 4 + 2 : 0;         // blocks that can touch the window
-    constexpr int UB = (NB + 255) / 256;
+    constexpr int UB = (NB + NT - 1) / NT;
     constexpr int NPRE = ROT && !REL ? 4 * UB : UX;
     RotTab rot_t;
     int a4 = 0;
@@ -735,13 +741,18 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
         rot_t = rot_tab(rot_step_fx);
         if (rot_blocks) a4 = (int)(((rot_count0 + (uint64_t)xlo_of(0)) & 7) >> 1);      // window float4 0 is float4 a4 of its block
     }
-    auto i4_of = [&](int u) { return ROT && !REL ? 4 * (tid + 256 * (u >> 2)) + (u & 3) - a4 : tid + 256 * u; };
+    auto i4_of = [&](int u) { return ROT && !REL ? 4 * (tid + NT * (u >> 2)) + (u & 3) - a4 : tid + NT * u; };
     cf rel_w[REL ? UX : 1][2];
     if constexpr (REL) {
+        // rel_window_phasor(2 (tid + NT u) + j) = P(2 tid) * P(2 NT u + j): the second factor is wave-uniform - lane 2u + j evaluates it once and the
+        // others fetch it (2 polynomials per thread instead of 2 + 2 UX; same operands, same bits as the per-sample form of the edge tiles)
+        static_assert(2 * UX <= 64, "one lane per uniform phasor");
+        const int l = tid & 63;
+        const cf pt = phasor_poly(rot_step_fx * (uint64_t)(2 * tid)), pu = phasor_poly(rot_step_fx * (uint64_t)(2 * NT * (l >> 1) + (l & 1)));
 #pragma unroll
         for (int u = 0; u < UX; u++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) rel_w[u][j] = rel_window_phasor(rot_step_fx, 2 * (tid + 256 * u) + j);
+            for (int j = 0; j < 2; j++) rel_w[u][j] = cmul(pt, cf{__shfl(pu.x, 2 * u + j), __shfl(pu.y, 2 * u + j)});
     }
 
     float4 pre[NPRE];
@@ -766,14 +777,14 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
             if constexpr (REL) {
 #pragma unroll
                 for (int u = 0; u < UX; u++) {
-                    const int i4 = tid + u * 256;
+                    const int i4 = tid + u * NT;
                     const cf a = cmul(cf{pre[u].x, pre[u].y}, rel_w[u][0]), b = cmul(cf{pre[u].z, pre[u].w}, rel_w[u][1]);
                     if (i4 < NF4) lds_put4<S, D>(ldsX, i4, make_float4(a.x, a.y, b.x, b.y));
                 }
             } else if constexpr (ROT) {
 #pragma unroll
                 for (int v = 0; v < UB; v++) {
-                    const int i40 = 4 * (tid + 256 * v) - a4;                 // first float4 of this thread's block
+                    const int i40 = 4 * (tid + NT * v) - a4;                 // first float4 of this thread's block
                     if (!rot_blocks) {
 #pragma unroll
                         for (int j = 0; j < 4; j++)
@@ -790,12 +801,12 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
             } else {
 #pragma unroll
                 for (int u = 0; u < UX; u++) {
-                    const int i4 = tid + u * 256;
+                    const int i4 = tid + u * NT;
                     if (i4 < NF4) lds_put4<S, D>(ldsX, i4, pre[u]);
                 }
             }
         } else {
-            stage_edge<S, D, ROT, REL>(ldsX, hist, x, first + tile_k0 * D - e, SPAN, M, n, rot_step_fx, rot_count0);
+            stage_edge<S, D, ROT, REL, NT>(ldsX, hist, x, first + tile_k0 * D - e, SPAN, M, n, rot_step_fx, rot_count0);
         }
         __syncthreads();
         // prefetch the next tile while this one is multiplied
@@ -811,7 +822,7 @@ __global__ __launch_bounds__(256, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persis
 #else
             cf pt = cf{1.f, 0.f};
             if constexpr (REL) pt = phasor_poly(rot_step_fx * (rot_count0 + (uint64_t)xlo_of(t)));
-            disc_epilogue<D, NACC, REL>(y, tile_k0, n_out, out_aligned, acc, edge + 8 * t, prev_out, inv_gain, pt);
+            disc_epilogue<D, NACC, REL>(y, tile_k0, n_out, out_aligned, acc, edge + 2 * NW * t, prev_out, inv_gain, pt);
 #endif
         }
         __syncthreads();      // everyone is done reading ldsX before it is overwritten

@@ -21,6 +21,7 @@ struct FirStage : lrhip_stage {
     // rotator + discriminator epilogue on the persistent Toeplitz kernel: window-relative phasors (kernels_fir.h, REL) unless the environment asks
     // for the stand-alone rotator's phasors bit for bit
     bool rel_rot = !LRHIP_DISC_EPI_LDS && getenv("LRHIP_TUNER_EXACT") == nullptr;
+    bool rel_nw1 = getenv("LRHIP_TUNER_NW1") != nullptr;      // A/B knob: one-wave workgroups for that kernel (every wave stages its own window, no barriers: measured equal)
     uint64_t rot_step = 0, count = 0;     // absolute index of the next input sample
     // overlap-save emission framing (firfilter.lua:451-485)
     long L = 0, fill = 0;
@@ -107,7 +108,7 @@ struct FirStage : lrhip_stage {
             // (kernels_fir.h, REL), so the rounding follows the tile grid, which starts with the chunk
             const int nacc5 = getenv("LRHIP_FIR_D5_NACC") ? atoi(getenv("LRHIP_FIR_D5_NACC")) : 2;
             if (D == 1) return (unsigned long)FirMfmaGeom<2, 1>::tile_out(LRHIP_FIR_D1_NACC);
-            if (D == 5) return 5UL * FirMfmaGeom<2, 5>::tile_out(nacc5 == 1 ? 1 : 2);
+            if (D == 5) return 5UL * FirMfmaGeom<2, 5>::tile_out(nacc5 == 1 ? 1 : 2, ksteps == 51 && rel_nw1 ? 1 : 4);
         }
         return 1UL;
     }
@@ -139,11 +140,15 @@ struct FirStage : lrhip_stage {
         return 0;
     }
 
-    template <int SS, int DD, int NACC, int KS>
+    template <int SS, int DD, int NACC, int KS, int NW = 4>
     int launch_mfma_ks(const float *x, long n, float *y, long n_out)
     {
         using G = FirMfmaGeom<SS, DD>;
-        constexpr int TILE_OUT = G::tile_out(NACC);
+        constexpr int TILE_OUT = G::tile_out(NACC, NW);
+        if constexpr (NW == 4 && SS == 2 && DD == 5 && KS == 51) {
+            // tuner + discriminator with window-relative phasors: one-wave workgroups (every wave stages its own window, no barriers)
+            if (rot && post_disc && rel_rot && rel_nw1) return launch_mfma_ks<SS, DD, NACC, KS, 1>(x, n, y, n_out);
+        }
         // alignment slack so that the tile's first staged sample is 16-B aligned in global memory
         if (((uintptr_t)x % (4 * SS)) != 0) {
             if (rot || post_disc) return set_error("fir: fused rotator / discriminator needs a sample-aligned input pointer");
@@ -153,7 +158,7 @@ struct FirStage : lrhip_stage {
         int q = 4 / SS;
         long v = sample_addr + (long)index - (M - 1);
         int e = (int)(((v % q) + q) % q);
-        int span = G::span(NACC, ksteps);
+        int span = G::span(NACC, ksteps, NW);
         size_t lds_floats = (size_t)fir_taps_len(DD, ksteps) + (size_t)G::phys(SS * span) + G::PAD + 8;
         size_t lds_bytes = lds_floats * sizeof(float);
         long ntiles = (n_out + TILE_OUT - 1) / TILE_OUT;
@@ -163,12 +168,12 @@ struct FirStage : lrhip_stage {
         uint64_t rs = rot ? rot_step : 0, rc = rot ? count : 0;
         if constexpr (KS > 0) {
             auto launch = [&](auto kern) -> int {
-                if (!mfma_blocks_per_cu && prepare_kernel(kern, lds_bytes, &mfma_blocks_per_cu)) return -1;     // queried once per stage
+                if (!mfma_blocks_per_cu && prepare_kernel(kern, lds_bytes, &mfma_blocks_per_cu, 64 * NW)) return -1;     // queried once per stage
                 long slots = (long)ctx().num_cus * mfma_blocks_per_cu;
                 unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
-                if (post_disc && edge.reserve((size_t)ntiles * 8 * sizeof(float2))) return -1;
+                if (post_disc && edge.reserve((size_t)ntiles * 2 * NW * sizeof(float2))) return -1;
                 float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, atab, y, M, n, n_out, (long)index, e,
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, ctx().stream, h, x, atab, y, M, n, n_out, (long)index, e,
                                    ntiles, out_aligned, rs, rc, (float2 *)edge.p, post_disc ? (float2 *)disc_prev.p + (disc_cur ^ 1) : nullptr, 1.0 / disc_gain, ho);
                 hist_in_kernel = ho != nullptr;
                 return 0;
@@ -176,16 +181,18 @@ struct FirStage : lrhip_stage {
             int rc2;
             if constexpr (SS == 2 && (DD == 1 || DD == 5)) {
                 if (post_disc) {
-                    if constexpr (LRHIP_DISC_EPI_LDS) rc2 = rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS, 1>);
+                    if constexpr (NW == 1) rc2 = launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1, true, 1>);
+                    else if constexpr (LRHIP_DISC_EPI_LDS) rc2 = rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS, 1>);
                     else rc2 = !rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS, 1>)
                              : rel_rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1, true>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1, false>);
                     if (rc2) return rc2;
                     LR_LAUNCH_CHECK();
                     float2 *dp = (float2 *)disc_prev.p;
                     // records per unit of FIX_UNIT outputs: a wave's range in the in-register epilogue, a whole tile in the LDS one
-                    constexpr int FIX_UNIT = LRHIP_DISC_EPI_LDS ? TILE_OUT : TILE_OUT / 4;
-                    const long nunits = LRHIP_DISC_EPI_LDS ? ntiles : 4 * ntiles;
-                    if (defer_fixup && (FIX_UNIT & (FIX_UNIT - 1)) == 0) {
+                    constexpr int FIX_UNIT = LRHIP_DISC_EPI_LDS ? TILE_OUT : TILE_OUT / NW;
+                    const long nunits = LRHIP_DISC_EPI_LDS ? ntiles : NW * ntiles;
+                    // (the consumer patches at most 32 samples per half window: a record pair per >= 256 outputs)
+                    if (defer_fixup && (FIX_UNIT & (FIX_UNIT - 1)) == 0 && FIX_UNIT >= 256) {
                         fix_ready = true;
                         fix_prev_ptr = (const float2 *)(dp + disc_cur);
                         fix_shift = 0;

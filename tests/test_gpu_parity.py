@@ -455,14 +455,17 @@ def test_tuner_fused_rotator_fir_downsampler():
     assert np.array_equal(got, ds.process(lpf.process(rot.process(x))))
 
 
-@pytest.mark.parametrize("decim,exact", [(5, False), (5, True), (1, True)])
+@pytest.mark.parametrize("decim,exact", [(5, False), (5, "nw1"), (5, True), (1, True)])
 def test_discriminator_epilogue_equals_unfused_blocks(decim, exact, monkeypatch):
     """[rotator] -> FIR(128 real taps) -> [downsampler] -> discriminator in a chain runs the discriminator as the epilogue of
     the persistent MFMA kernel (wave-boundary samples fixed up afterwards, previous sample carried across calls): same bits
     as the separate device blocks, for chunkings that cut inside and across waves (256 outputs) and tiles.  With the rotator in front the
     kernel rotates a tile's window relative to its first sample by default (the filter outputs then agree with the separate blocks to Float32
     rounding, the angles as well as that allows); LRHIP_TUNER_EXACT=1 keeps the stand-alone rotator's phasors and with them the bits."""
-    if decim == 5 and exact:
+    if exact == "nw1":
+        monkeypatch.setenv("LRHIP_TUNER_NW1", "1")       # A/B variant: one-wave workgroups, every wave stages its own window
+        exact = False
+    elif decim == 5 and exact:
         monkeypatch.setenv("LRHIP_TUNER_EXACT", "1")
     rng = np.random.default_rng(31 + decim)
     rate = 1102500.0
