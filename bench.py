@@ -384,7 +384,7 @@ def main():
         config = {"workload": "configs[2]: examples/rtlsdr_wbfm_mono.lua chain (Tuner -> FrequencyDiscriminator -> Lowpass -> "
                               "FMDeemphasis -> Downsampler) on 2^%d synthetic FM IQ samples @ 1.1025 MS/s, device-resident" % log2n,
                   "samples_per_step_per_gpu": n, "counted": "RF input samples", "parallelism": "independent streams x%d" % world}
-        dominant = "fir_mfma_persistent_kernel<2,5,2,true,51>"
+        dominant = "fir_mfma_persistent_kernel<2,5,2,true,51,1,true>"
     else:
         # fan-out: rank 0 owns the IQ slab; every step it is broadcast over RCCL/xGMI and each rank runs its own
         # Tuner branch (offsets -350 kHz .. +350 kHz step 100 kHz)
@@ -416,7 +416,7 @@ def main():
         config = {"workload": "configs[3]: one IQ slab of 2^%d samples broadcast from rank 0 (RCCL) to %d Tuner(offset_k, 100e3, 5) "
                               "branches, one per GPU" % (log2n, world),
                   "samples_per_step_per_gpu": n, "counted": "branch input samples", "parallelism": "fan-out x%d" % world}
-        dominant = "fir_mfma_persistent_kernel<2,5,2,true,51>"
+        dominant = "fir_mfma_persistent_kernel<2,5,2,true,51,1,true>"
 
     def sync_all():
         torch.cuda.synchronize()

@@ -36,6 +36,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef LRHIP_FIR_SCHED
 #define LRHIP_FIR_SCHED 0
 #endif
+#ifndef LRHIP_FIR_XCD_MAP
+#define LRHIP_FIR_XCD_MAP 0       /* 1: XCD-contiguous tile order in the persistent kernel.  Measured (same box): HBM reads of the WBFM tuner 550.5 -> 537.7 MB (1.025x -> 1.001x of its
+                                     input) and of the direct-form headline 2.215 -> 2.163 GB, but the receiver step 0.161 -> 0.164 ms and the headline unchanged (1.267 / 1.270 ms):
+                                     neither kernel is HBM-bound, so the plain stride stays */
+#endif
 #ifndef LRHIP_FIR_WAVES_PER_SIMD
 #define LRHIP_FIR_WAVES_PER_SIMD 3
 #endif
@@ -755,8 +760,20 @@ __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_pe
             for (int j = 0; j < 2; j++) rel_w[u][j] = cmul(pt, cf{__shfl(pu.x, 2 * u + j), __shfl(pu.y, 2 * u + j)});
     }
 
+    // Tile order: plain stride, or (LRHIP_FIR_XCD_MAP) one contiguous eighth of the tiles per XCD - workgroup b is observed to run on XCD b % 8
+    // (nothing promises it; only speed depends on it), its workgroups stride through their eighth side by side, and the M - 1 samples two
+    // neighbouring tiles share come from HBM once and from that XCD's L2 the second time.
+    const bool xmap = LRHIP_FIR_XCD_MAP && (gridDim.x & 7) == 0;
+    const long xt8 = (ntiles + 7) >> 3, xper = gridDim.x >> 3;
+    const long xbase = (long)(blockIdx.x & 7) * xt8, xj = blockIdx.x >> 3;
+    auto tile_of = [&](long k) -> long {
+        if (!xmap) return blockIdx.x + k * (long)gridDim.x;
+        const long tl = xj + k * xper;
+        return tl < xt8 ? xbase + tl : ntiles;
+    };
     float4 pre[NPRE];
-    long t = blockIdx.x;
+    long tk = 0;
+    long t = tile_of(0);
     bool have = false;
     auto prefetch = [&](long tt) {
         have = interior(tt);
@@ -770,7 +787,7 @@ __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_pe
         }
     };
     prefetch(t);
-    for (; t < ntiles; t += gridDim.x) {
+    for (; t < ntiles; t = tile_of(++tk)) {
         const long tile_k0 = t * (long)TILE_OUT;
         if (have) {
             const long xlo = xlo_of(t);
@@ -810,7 +827,7 @@ __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_pe
         }
         __syncthreads();
         // prefetch the next tile while this one is multiplied
-        prefetch(t + gridDim.x);
+        prefetch(tile_of(tk + 1));
         f32x4 acc[1][NACC];
         mfma_tile<S, D, NACC, KS, 1>(ldsT, TLEN, e, ldsX, KS, acc);
         if constexpr (EPI == 0) {
