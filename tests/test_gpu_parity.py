@@ -334,6 +334,31 @@ def test_discriminator_vs_oracle():
         assert G.max_abs_err(chunked(blk, x, [1, 2, 65536, 65537]), want) < 1e-6
 
 
+def test_discriminator_small_and_large_magnitudes():
+    """the angle does not depend on the level: fast_atan2f divides with one v_rcp_f32, which flushes denormals, so products below 2^-60 take a
+    rescaled path (kernels_elem.h discriminate) - weak signals (1e-10: products ~1e-20), products in the denormal range (3e-20), strong ones (1e15:
+    products ~1e30), each against the oracle on the same samples; and an exactly silent stretch inside the stream gives the reference's +-pi / 0"""
+    rng = np.random.default_rng(77)
+    base = rand_c(rng, 40000)
+    for scale, tol in ((1e-10, 1e-6), (1e15, 1e-6), (3e-20, None)):
+        x = (base * np.complex64(scale)).astype(np.complex64)
+        blk = make(lr.FrequencyDiscriminatorBlock, [1.25], x)
+        got = chunked(blk, x, [1, 4097])
+        assert np.all(np.isfinite(got)) and float(np.max(np.abs(got))) <= np.pi / 1.25 + 1e-6, scale
+        if tol is not None:
+            assert G.max_abs_err(got, O.FMDiscriminator(1.25).process(x)) < tol, scale
+        else:
+            # products of ~1e-39: a few bits of a denormal are left of each, so only the bulk can agree
+            want = O.FMDiscriminator(1.25).process(x)
+            d = np.abs(got - want)
+            d = np.minimum(d, 2 * np.pi / 1.25 - d)
+            assert float(np.median(d)) < 0.2, float(np.median(d))
+    x = base.copy()
+    x[1000:1200] = 0                                   # zero products: sign rules of the reference (frequencydiscriminator.lua:74)
+    blk = make(lr.FrequencyDiscriminatorBlock, [1.25], x)
+    assert G.max_abs_err(chunked(blk, x, [1100]), O.FMDiscriminator(1.25).process(x)) < 1e-6
+
+
 @pytest.mark.parametrize("factor", [1, 2, 5, 7, 256, 1000])
 def test_downsampler_vs_oracle_bit_exact(factor):
     rng = np.random.default_rng(11 + factor)
