@@ -416,7 +416,7 @@ def main():
         config = {"workload": "configs[3]: one IQ slab of 2^%d samples broadcast from rank 0 (RCCL) to %d Tuner(offset_k, 100e3, 5) "
                               "branches, one per GPU" % (log2n, world),
                   "samples_per_step_per_gpu": n, "counted": "branch input samples", "parallelism": "fan-out x%d" % world}
-        dominant = "fir_mfma_persistent_kernel<2,5,2,true,51,1,true>"
+        dominant = "fir_mfma_persistent_kernel<2,5,2,true,51>"
 
     def sync_all():
         torch.cuda.synchronize()
