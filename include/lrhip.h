@@ -180,7 +180,13 @@ long lrhip_stage_execute2_device(lrhip_stage_t *q, const void *in1_dev, const vo
 /* A maximal linear run of device-capable blocks collapsed into one object (what CompositeBlock's
  * _prepare_to_run would build, radio/core/composite.lua:426): one H2D at the head, one D2H at the tail,
  * intermediate vectors never leave HBM.  The chain borrows the stages (caller keeps ownership) and fuses
- * adjacent stages where a fused kernel exists (rotator -> FIR -> downsampler, FIR -> downsampler). */
+ * adjacent stages where a fused kernel exists (rotator -> FIR -> downsampler, FIR -> downsampler, ... -> discriminator, the 1/5-rate
+ * audio tail of the FM receivers).  A chain gives the values of its blocks run one by one - the same bits, with three stated exceptions:
+ * overlap-save filters (Float32 FFT arithmetic: the blocks of a chunk fall where the chunk starts, <= 1e-6), the polyphase audio tail
+ * (FIR -> single-pole IIR -> downsampler as one decimating filter, ~2e-8 RMS), and a frequency translator fused in front of a filter
+ * whose output only the discriminator sees: there a tile's window is rotated relative to its first sample, which leaves the angles
+ * unchanged to Float32 rounding of the filter outputs (LRHIP_TUNER_EXACT=1 in the environment at stage creation keeps the stand-alone
+ * translator's phasors and the bits, at 0.19 instead of 0.16 ms per 2^26 samples of the WBFM receiver). */
 lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages);
 void lrhip_chain_destroy(lrhip_chain_t *c);
 /* Back to the initial state (zero history, phase, indices) for every stage of the chain, including the fused ones it built. */
