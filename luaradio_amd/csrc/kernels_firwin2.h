@@ -24,7 +24,7 @@
 
 namespace lrhip {
 
-enum { FWC_ROT = 1, FWC_DISC = 2, FWC_PAIR = 4, FWC_IIR = 8 };
+enum { FWC_ROT = 1, FWC_DISC = 2, FWC_PAIR = 4, FWC_IIR = 8, FWC_CTAPS = 16 };      // CTAPS: ComplexFloat32 taps (taps_rev = (re, im, -im, re) per tap)
 #ifndef FWC_LA
 #define FWC_LA 6
 #endif
@@ -32,7 +32,9 @@ enum { FWC_ROT = 1, FWC_DISC = 2, FWC_PAIR = 4, FWC_IIR = 8 };
 template <int D, int R, int M, int MODE>
 struct FwcGeom {
     static constexpr bool ROT = (MODE & FWC_ROT) != 0, DISC = (MODE & FWC_DISC) != 0, PAIR = (MODE & FWC_PAIR) != 0, IIR = (MODE & FWC_IIR) != 0;
-    static_assert(!(PAIR && (ROT || DISC)) && (!IIR || PAIR), "mode combination");
+    static constexpr bool CTAPS = (MODE & FWC_CTAPS) != 0;
+    static constexpr int TF = CTAPS ? 4 : 1;                   // floats per tap in LDS
+    static_assert(!(PAIR && (ROT || DISC)) && (!IIR || PAIR) && !(CTAPS && (PAIR || ROT || DISC)), "mode combination");
     static_assert(M % 4 == 0, "taps are read four at a time");
     static constexpr int DR = D * R, PADS = (DR & 1) ? 0 : 1, LS = DR + PADS;      // lane stride in window samples (odd)
     static_assert(PADS == 0, "choose R so that D R is odd: the window then needs no padding and staging is a straight 16-byte copy");
@@ -50,7 +52,7 @@ struct FwcGeom {
     static constexpr int GUARD = 8;                            // samples in front of staged float4 0 (a rotator block may start up to 3 float4 early)
     static constexpr int XN = GUARD + SPF * (NF4 + 4) + 8;     // window samples in LDS (8 B each)
     static constexpr int ON = PAIR ? 0 : TO + 2;               // out-area samples (complex modes)
-    static constexpr int LDS_FLOATS = 2 * XN + 2 * ON + 32 + M;
+    static constexpr int LDS_FLOATS = 2 * XN + 2 * ON + 32 + TF * M;
 };
 
 struct FwcParams {
@@ -135,6 +137,40 @@ __device__ __forceinline__ void fwc_taps(const float *ldsT, const float *base, c
     });
 }
 
+// complex taps: acc_i += w_i.re * (h.re, h.im);  acc_i += w_i.im * (-h.im, h.re) - per component the order of fir_direct_kernel<2>
+// (re += xr hr; re += xi (-hi); im += xr hi; im += xi hr), so the bits are those of the other complex-taps paths
+__device__ __forceinline__ void fw_cstep5(cf (&a)[5], cf tlo, cf thi, cf w0, cf w1, cf w2, cf w3, cf w4)
+{
+    asm("v_pk_fma_f32 %0, %7, %5, %0 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %1, %8, %5, %1 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %2, %9, %5, %2 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %3, %10, %5, %3 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %4, %11, %5, %4 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %7, %6, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %1, %8, %6, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %2, %9, %6, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %3, %10, %6, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %4, %11, %6, %4 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4])
+        : "v"(tlo), "v"(thi), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4));
+}
+
+template <int D, int R, int M>
+__device__ __forceinline__ void fwc_ctaps(const float *ldsT, const float *base, cf (&acc)[R])
+{
+    static_assert(R == 5, "accumulators per lane");
+    constexpr int LA = FWC_LA, C = D * (R - 1) + 1 + LA;
+    cf W[C];
+    float4 T[2];
+    auto ld = [&](int r) { return *reinterpret_cast<const cf *>(base + 2 * r); };
+#pragma unroll
+    for (int i = 0; i < R; i++) acc[i] = cf{0.f, 0.f};
+    static_for<D *(R - 1) + LA>([&](auto I) { constexpr int r = decltype(I)::value; W[r % C] = ld(r); });
+    T[0] = *reinterpret_cast<const float4 *>(ldsT);
+    static_for<M>([&](auto J) {
+        constexpr int j = decltype(J)::value, rn = D * (R - 1) + j + LA;
+        if constexpr (j + 1 < M) T[(j + 1) & 1] = *reinterpret_cast<const float4 *>(ldsT + 4 * (j + 1));
+        if constexpr (rn <= D * (R - 1) + M - 1) W[rn % C] = ld(rn);
+        const float4 tq = T[j & 1];
+        fw_cstep5(acc, cf{tq.x, tq.y}, cf{tq.z, tq.w}, W[j % C], W[(D + j) % C], W[(2 * D + j) % C], W[(3 * D + j) % C], W[(4 * D + j) % C]);
+    });
+}
+
 __device__ __forceinline__ float4 f4(f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
 
 #ifndef FWC_PAIR_WAVES
@@ -158,7 +194,7 @@ __global__ __launch_bounds__(256, (MODE & FWC_PAIR) ? FWC_PAIR_WAVES : 2) void f
     if (pr.hist_out && blockIdx.x == 0)
         for (int i = tid; i < (M - 1) * S; i += 256)
             pr.hist_out[i] = PAIR ? fwc_stream_at_fixed(pr, hist, x, n + i, M, n) : stream_at<S>(hist, x, n + i / S, i % S, M, n);
-    for (int i = tid; i < M; i += 256) ldsT[i] = pr.taps_rev[i];
+    for (int i = tid; i < G::TF * M; i += 256) ldsT[i] = pr.taps_rev[i];
 
     // tile t: first window output kb(t) (negative for tile 0 with the discriminator overlap), stream position of window coordinate 0
     auto kb_of = [&](long t) { return PAIR ? t * 2L * G::TO : t * (long)G::TA - G::OV; };
@@ -348,7 +384,8 @@ __global__ __launch_bounds__(256, (MODE & FWC_PAIR) ? FWC_PAIR_WAVES : 2) void f
         const bool emit = !IIR || t >= first_emit;
         const bool active = emit || wave >= 4 - pr.warm_waves;          // warm-up tile: only the last waves (of half B) matter
         if (active) {
-            fwc_taps<D, R, M>(ldsT, ldsX + 2 * (G::GUARD + ce + G::DR * tid), acc);
+            if constexpr (G::CTAPS) fwc_ctaps<D, R, M>(ldsT, ldsX + 2 * (G::GUARD + ce + G::DR * tid), acc);
+            else fwc_taps<D, R, M>(ldsT, ldsX + 2 * (G::GUARD + ce + G::DR * tid), acc);
         } else {
 #pragma unroll
             for (int i = 0; i < R; i++) acc[i] = cf{0.f, 0.f};

@@ -10,7 +10,7 @@ struct FirStage : lrhip_stage {
     unsigned D = 1;
     bool use_fft = false;
     std::vector<float> taps_rev;          // host copy, reversed (firfilter.lua:234-238)
-    DeviceBuf d_taps, d_atab;
+    DeviceBuf d_taps, d_atab, d_ctaps4;
     int ksteps = 0;                       // 0 => MFMA path unavailable for this (M, D)
     int mfma_blocks_per_cu = 0;           // resident workgroups of the persistent kernel (occupancy query, cached)
     int hist_pad = 0;                     // leading pad floats in the history buffers (1 for complex taps, see launch_mfma_cc)
@@ -473,6 +473,17 @@ struct FirStage : lrhip_stage {
         iir_fused = true; iir_b0 = (float)b0; iir_na1 = (float)q; iir_na1_lo = (float)(q - (double)iir_na1); iir_warm = w;
         return reset();
     }
+    // short ComplexFloat32-taps filters at D = 1 (the reference suite's 16-complex-taps entry): 2 M packed FMAs per output on the window kernel,
+    // a streaming problem like the real-taps case (the two-Toeplitz-filter form pays 2 x 2 M taps in fixed 16-output blocks)
+    bool win_short_c_ok() const
+    {
+        static const bool off = getenv("LRHIP_NO_FIR_WIN_SHORT") != nullptr;      // A/B knob
+        return !off && !win_off() && S == 2 && taps_complex && D == 1 && (M == 16 || M == 32) && d_ctaps4.p && !rot && !fft_arith && !use_fft && !pre_disc && !post_disc;
+    }
+    int launch_win_short_c(const float *x, long n, float *y, long n_out)
+    {
+        return M == 16 ? launch_win_cplx_m<16, FWC_CTAPS, 1, true>(x, n, y, n_out) : launch_win_cplx_m<32, FWC_CTAPS, 1, true>(x, n, y, n_out);
+    }
     template <int MM, int MODE, int DD = 5, bool ONESHOT = false>
     int launch_win_cplx_m(const float *x, long n, float *y, long n_out)
     {
@@ -482,7 +493,7 @@ struct FirStage : lrhip_stage {
         if (!winc_blocks_per_cu && prepare_kernel(kern, lds_bytes, &winc_blocks_per_cu)) return -1;
         FwcParams pr;
         memset(&pr, 0, sizeof(pr));
-        pr.hist = (const float *)hist[cur].p + hist_pad; pr.x = x; pr.n = n; pr.taps_rev = (const float *)d_taps.p; pr.y = y;
+        pr.hist = (const float *)hist[cur].p + hist_pad; pr.x = x; pr.n = n; pr.taps_rev = (const float *)(G::CTAPS ? d_ctaps4.p : d_taps.p); pr.y = y;
         pr.n_out = n_out; pr.first = (long)index;
         pr.hist_out = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
         pr.ntiles = G::PAIR ? (n_out + 2L * G::TO - 1) / (2L * G::TO) : (n_out + G::TA - 1) / G::TA;
@@ -601,6 +612,7 @@ struct FirStage : lrhip_stage {
                      : win_real_ok() ? launch_win_real(x, n, y)
                      : win_cplx_ok() ? launch_win_cplx(x, n, y, n_out)
                      : win_short_ok() ? launch_win_short(x, n, y, n_out)
+                     : win_short_c_ok() ? launch_win_short_c(x, n, y, n_out)
                      : short_real_ok() ? launch_short_real(x, n, y)
                      : win_pair_ok() ? launch_win_pair(x, n, y, n_out)
                      : !ksteps ? (decim_lds_ok() ? launch_decim_lds(x, n, y, n_out) : launch_direct(x, n, y, n_out))
@@ -756,6 +768,15 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
             if (upload(q->d_atab, tab.data(), tab.size() * sizeof(float))) return nullptr;
             q->ksteps = ks;
         }
+    }
+    if (taps_complex && decim == 1 && input_complex && (ntaps == 16 || ntaps == 32)) {
+        // short complex filters as a streaming kernel (launch_win_short_c): (re, im, -im, re) per reversed tap
+        std::vector<float> t4((size_t)4 * ntaps);
+        for (unsigned j = 0; j < ntaps; j++) {
+            const float hr = q->taps_rev[2 * j], hi = q->taps_rev[2 * j + 1];
+            t4[4 * j] = hr; t4[4 * j + 1] = hi; t4[4 * j + 2] = -hi; t4[4 * j + 3] = hr;
+        }
+        if (upload(q->d_ctaps4, t4.data(), t4.size() * sizeof(float))) return nullptr;
     }
     if (taps_complex && decim <= 5) {
         // taps'_re = interleave(hr_rev, -hi_rev), taps'_im = interleave(hi_rev, hr_rev) over the float stream

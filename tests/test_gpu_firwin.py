@@ -173,16 +173,19 @@ def test_slow_recurrence_is_not_rewritten_in_polyphase_form():
     assert len(got) == len(want) and G.max_abs_err(got, want) < 2e-6
 
 
-@pytest.mark.parametrize("cplx,ntaps", [(True, 16), (True, 32), (True, 64), (False, 16), (False, 32)])
+@pytest.mark.parametrize("cplx,ntaps", [(True, 16), (True, 32), (True, 64), (False, 16), (False, 32), ("ctaps", 16), ("ctaps", 32)])
 def test_short_filter_streaming_kernels_tile_edges_and_unaligned_pointers(cplx, ntaps):
-    """the one-shot kernels for short filters (ComplexFloat32: register-window kernel, a workgroup per 1280-output tile; Float32: four outputs per
-    thread): sizes around the tile / vector boundaries, device pointers off the 16-byte grid, one sample per call - bit-exact fmaf chains"""
+    """the one-shot kernels for short filters (ComplexFloat32: register-window kernel, a workgroup per 1280-output tile, real or ComplexFloat32
+    taps; Float32: four outputs per thread): sizes around the tile / vector boundaries, device pointers off the 16-byte grid, one sample per call -
+    bit-exact fmaf chains"""
     import torch
-    rng = np.random.default_rng(ntaps + cplx)
+    ctaps = cplx == "ctaps"
+    cplx = bool(cplx)
+    rng = np.random.default_rng(ntaps + cplx + 7 * ctaps)
     n = 5 * 1280 + 3
     mk = lambda m: ((rng.uniform(-1, 1, m) + 1j * rng.uniform(-1, 1, m)).astype(np.complex64) if cplx else rng.uniform(-1, 1, m).astype(np.float32))
     x = mk(n + 8)
-    taps = (rng.uniform(-1, 1, ntaps) / ntaps).astype(np.float32)
+    taps = (mk(ntaps) / ntaps).astype(np.complex64) if ctaps else (rng.uniform(-1, 1, ntaps) / ntaps).astype(np.float32)
     for m in (1, 3, 4, 5, 1279, 1280, 1281, n):
         blk = make(lr.FIRFilterBlock, [taps], x)
         assert np.array_equal(blk.process(x[:m]), O.FIR(taps, cplx, O.MODE_FMA).process(x[:m])), m

@@ -179,7 +179,7 @@ def test_fir_real_taps_bit_exact_vs_fma_oracle(cplx, ntaps):
     assert G.max_abs_err(got, O.FIR(taps, cplx, O.MODE_F64).process(x)) < 1e-6
 
 
-@pytest.mark.parametrize("ntaps", [1, 8, 33, 128])
+@pytest.mark.parametrize("ntaps", [1, 8, 16, 32, 33, 128])
 def test_fir_complex_taps_bit_exact_vs_fma_oracle(ntaps):
     rng = np.random.default_rng(100 + ntaps)
     x = rand_c(rng, 5000)
