@@ -11,6 +11,15 @@ namespace lrhip {
 
 enum { FFT_OUT_COMPLEX = 0, FFT_OUT_REAL = 1, FFT_OUT_PSD = 2, FFT_OUT_PSD_LOG = 3 };
 
+// 10 log10(p) on the hardware log2 (v_log_f32, 1 ulp): libm's log10f is a dozen instructions per bin.  v_log_f32 flushes denormal inputs, so
+// powers below 1e-30 are scaled by 2^64 first; p = 0 gives -inf as in the reference (spectrum_utils.lua:636).
+__device__ __forceinline__ float psd_db(float p)
+{
+    const bool tiny = p < 1e-30f;
+    const float l2 = __builtin_amdgcn_logf(tiny ? p * 0x1p+64f : p) - (tiny ? 64.0f : 0.0f);
+    return 3.0102999566398120f * l2;
+}
+
 // in-LDS autosort (Stockham) FFT over `frames` independent frames laid out back to back (N complex each) in buffer a;
 // b is scratch of the same size; tw = W_N^m, m < N/2, in LDS.  Radix-4 passes (half the barriers and LDS round trips of
 // radix-2), one radix-2 pass when log2 N is odd.  Returns the buffer holding the result.  All 256 threads call it.
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(256) void fft_frames_kernel(const float *__restrict
         } else {
             // spectrum_utils.lua:631-638: abs_squared()/scale, optionally 10*log10
             float p = fmaf(v.x, v.x, v.y * v.y) * out_scale;
-            y[g] = out_kind == FFT_OUT_PSD_LOG ? 10.0f * log10f(p) : p;
+            y[g] = out_kind == FFT_OUT_PSD_LOG ? psd_db(p) : p;
         }
     }
 }

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, 3) void spectrum1024_kernel(const float *__res
                         reinterpret_cast<cf *>(y)[f * FFTN + pos] = X * cf{out_scale, out_scale};
                     } else {
                         float p = fmaf(X.x, X.x, X.y * X.y) * out_scale;       // spectrum_utils.lua:631-638
-                        y[f * FFTN + pos] = mode == SPEC_FWD_PSD_LOG ? 10.0f * log10f(p) : p;
+                        y[f * FFTN + pos] = mode == SPEC_FWD_PSD_LOG ? psd_db(p) : p;
                     }
                 }
         } else {

@@ -955,6 +955,20 @@ def test_psd_many_frames_vs_oracle():
             assert np.max(np.abs(out - want) / np.max(want)) < 1e-5
 
 
+@pytest.mark.parametrize("N", [1024, 256])
+def test_psd_log_of_very_weak_and_silent_frames(N):
+    """10 log10 runs on the hardware log2, which flushes denormals: powers below 1e-30 take the rescaled branch (kernels_fft.h psd_db) - a frame at
+    1e-14 of full scale (p ~ 1e-34) against the oracle, and an all-zero frame gives -inf like the reference's log10(0) (spectrum_utils.lua:636)"""
+    rng = np.random.default_rng(41 + N)
+    x = np.concatenate([rand_c(rng, N) * np.complex64(1e-14), np.zeros(N, np.complex64), rand_c(rng, N)])
+    out = np.empty(3 * N, np.float32)
+    spectrum_utils.PSD(x, out, "hamming", 1102500.0, True, frames=3).compute()
+    want = np.concatenate([O.psd(x[i * N:(i + 1) * N], "hamming", 1102500.0, True) for i in (0, 2)])
+    assert -400 < float(np.max(out[:N])) < -300
+    assert G.max_abs_err(np.concatenate([out[:N], out[2 * N:]]), want) < 1e-2          # dB
+    assert np.all(np.isneginf(out[N:2 * N]))
+
+
 @pytest.mark.parametrize("N", [8, 16, 32, 64, 128, 256, 512, 2048, 4096])
 def test_dft_idft_psd_other_frame_sizes_vs_oracle(N):
     """power-of-two frame lengths other than 1024 run the LDS radix-4 (+ one radix-2) Stockham kernel: forward / inverse,
