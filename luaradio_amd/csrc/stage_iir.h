@@ -90,7 +90,9 @@ struct IirStage : lrhip_stage {
     template <int SS, int PP>
     int run_scan(const float *x, float *y, long n)
     {
-        return nb <= 2 ? run_scan_nb<SS, PP, 2>(x, y, n) : run_scan_nb<SS, PP, 16>(x, y, n);
+        // the feed-forward loop is unrolled to NBT taps (terms beyond nb are predicated off, not free): 2 = single-pole filters, 4 = biquads and the
+        // reference suite's 4-ff-tap entry, 16 = the rest
+        return nb <= 2 ? run_scan_nb<SS, PP, 2>(x, y, n) : nb <= 4 ? run_scan_nb<SS, PP, 4>(x, y, n) : run_scan_nb<SS, PP, 16>(x, y, n);
     }
     long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
     {
