@@ -1,0 +1,153 @@
+// kernels_interp.h - polyphase interpolator on the register-window scheme of kernels_firwin2.h
+// (part of liblrhip.so; included by lrhip.hip, one translation unit)
+//
+// radio/composites/interpolator.lua:31-34: [MultiplyConstant(L)] -> Upsampler(L) -> LowpassFilter(128, 1/L) on a ComplexFloat32 stream.
+// Output n = q L + p of input position q is
+//     y[q L + p] = sum_{j = J-1 .. 0} h[p + j L] * (c x[q - j]),        J = ceil(M / L), h zero-padded to J L taps
+// - the nonzero terms of the zero-stuffed direct form in its own order (oldest sample first), so the bits are those of the unfused chain
+// and of fir_resample_kernel (a zero tap adds exactly +-0 to a finite sum).
+//
+// fir_resample_kernel computes one output per thread and reads a tap and a sample from LDS for every two FMAs (Interpolator(5): 2.2 ms
+// for 2^26 input samples, 18 % of the HBM roof).  Here a lane owns R = 5 consecutive input positions and all L phases of them: L R
+// accumulators (ComplexFloat32 in a register pair), one 8-byte window read and L broadcast taps per tap step feed L R packed FMAs
+// (fw_step5: the tap enters through op_sel, the window is a compile-time indexed register ring).  The 5 L outputs of a lane are
+// contiguous in y; they go through LDS (the window's space, reused) so that the stores are 16 bytes per lane, consecutive lanes
+// consecutive addresses.  Persistent workgroups over tiles of 1280 input positions.
+#pragma once
+#include "kernels_firwin2.h"
+
+namespace lrhip {
+
+template <int L, int J>
+struct FipGeom {
+    static constexpr int R = 5;                                // input positions per lane (odd: lane stride of 5 samples = 40 B, conflict-free 8-byte reads)
+    static constexpr int TQ = 256 * R;                         // input positions per tile
+    static constexpr int LP = (L + 3) & ~3;                    // taps per step in LDS, padded to float4s
+    static constexpr int NQ = LP / 4;
+    static constexpr int WN = TQ + J - 1;                      // window samples: position i <-> input q = qb - (J - 1) + i
+    static constexpr int XN = WN + FWC_LA + 8;
+    static constexpr int ON = TQ * L;                          // outputs per tile
+    static constexpr int BUF = (XN > ON ? XN : ON) * 2;        // floats: window, then (after the tap loop) the tile's outputs
+    static constexpr int LDS_FLOATS = BUF + J * LP;
+};
+
+// ttab[s * LP + p] = h[p + (J - 1 - s) L] (0 beyond the filter or the phase count): step s = 0 is the oldest sample
+// dbg (LRHIP_INTERP_DBG in the environment, ablation only): 1 = no tap loop, 2 = no stores, 4 = plain instead of non-temporal stores.  At L = 5, 2^26 input
+// samples: 0.71 ms whole, 0.60 without the tap loop, 0.48 without the stores - the 2.7 GB of output set the pace, the arithmetic hides under them in part.
+template <int L, int J>
+__global__ __launch_bounds__(256, 3) void fir_interp_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ ttab,
+                                                             float *__restrict__ y, long n_in, int HQ, float c, float *__restrict__ hist_out, int dbg)
+{
+    using G = FipGeom<L, J>;
+    constexpr int R = G::R, LA = FWC_LA, C = R + LA;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ldsX = lds;
+    float *ldsT = lds + G::BUF;
+    const int tid = threadIdx.x;
+    // history carry: the last HQ raw input samples of [hist | x] (fir_resample_kernel's layout)
+    if (hist_out && blockIdx.x == 0)
+        for (int i = tid; i < HQ * 2; i += 256) {
+            const long g = n_in - HQ + i / 2;
+            hist_out[i] = g >= 0 ? x[g * 2 + i % 2] : hist[(g + HQ) * 2 + i % 2];
+        }
+    for (int i = tid; i < J * G::LP; i += 256) ldsT[i] = ttab[i];
+
+    // Persistent workgroups, register prefetch: the loads of the NEXT tile are issued before this tile's tap loop - ahead of its 51 KB of output
+    // stores in the CU's memory queue - and the stores of tile t drain while tile t + 1 is filtered (one tile per workgroup measured 0.98 ms for
+    // 2^26 input samples at L = 5: 0.54 ms of stores + 0.27 ms of arithmetic + 0.3 ms of load latency and launch, almost nothing overlapped).
+    const long ntiles = (n_in + G::TQ - 1) / G::TQ;
+    constexpr int NPRE = (G::WN + 255) / 256;
+    cf pre[NPRE];
+    bool have = false;
+    auto prefetch = [&](long tt) {
+        const long lo = tt * G::TQ - (J - 1);
+        have = tt < ntiles && lo >= 0 && lo + G::WN <= n_in;
+        if (have) {
+            const cf *src = reinterpret_cast<const cf *>(x) + lo;
+#pragma unroll
+            for (int u = 0; u < NPRE; u++) {
+                const int idx = tid + 256 * u;
+                pre[u] = src[idx < G::WN ? idx : G::WN - 1];      // clamped, unconditional
+            }
+        }
+    };
+    long t = blockIdx.x;
+    prefetch(t);
+    for (; t < ntiles; t += gridDim.x) {
+        const long qb = t * G::TQ;                              // first input position of the tile (chunk-relative)
+        if (have) {
+#pragma unroll
+            for (int u = 0; u < NPRE; u++) {
+                asm volatile("" : "+v"(pre[u]));                // the loaded registers are touched here and not earlier (hipcc would wait for them before the tap loop)
+                const int i = tid + 256 * u;
+                if (i < G::WN) *reinterpret_cast<cf *>(ldsX + 2 * i) = pre[u] * c;      // multiplyconstant.lua: Float32 product, rounded once
+            }
+        } else {
+            for (int i = tid; i < G::WN; i += 256) {
+                const long g = qb - (J - 1) + i;
+                cf v = cf{0.f, 0.f};
+                if (g >= 0) { if (g < n_in) v = reinterpret_cast<const cf *>(x)[g]; }
+                else if (g + HQ >= 0) v = cf{hist[(g + HQ) * 2], hist[(g + HQ) * 2 + 1]};
+                *reinterpret_cast<cf *>(ldsX + 2 * i) = v * c;
+            }
+        }
+        __syncthreads();
+        prefetch(t + gridDim.x);
+
+        cf acc[L][R];
+#pragma unroll
+        for (int p = 0; p < L; p++)
+#pragma unroll
+            for (int i = 0; i < R; i++) acc[p][i] = cf{0.f, 0.f};
+        if (!(dbg & 1)) {
+            const float *base = ldsX + 2 * (R * tid);           // lane's window: sample r at base + 2 r, r = i + s for position i at step s
+            cf W[C];
+            float4 T[2][G::NQ];
+            auto ld = [&](int r) { return *reinterpret_cast<const cf *>(base + 2 * r); };
+            static_for<R - 1 + LA>([&](auto I) { constexpr int r = decltype(I)::value; W[r % C] = ld(r); });
+#pragma unroll
+            for (int k = 0; k < G::NQ; k++) T[0][k] = *reinterpret_cast<const float4 *>(ldsT + 4 * k);
+            static_for<J>([&](auto Sx) {
+                constexpr int s = decltype(Sx)::value, rn = R - 1 + s + LA;
+                if constexpr (s + 1 < J) {
+#pragma unroll
+                    for (int k = 0; k < G::NQ; k++) T[(s + 1) & 1][k] = *reinterpret_cast<const float4 *>(ldsT + (s + 1) * G::LP + 4 * k);
+                }
+                if constexpr (rn <= R - 1 + J - 1) W[rn % C] = ld(rn);
+                static_for<L>([&](auto Px) {
+                    constexpr int p = decltype(Px)::value;
+                    const float4 tq = T[s & 1][p >> 2];
+                    const cf tp = (p & 2) ? cf{tq.z, tq.w} : cf{tq.x, tq.y};
+                    fw_step5<(p & 1)>(acc[p], tp, W[s % C], W[(s + 1) % C], W[(s + 2) % C], W[(s + 3) % C], W[(s + 4) % C]);
+                });
+            });
+        }
+        __syncthreads();                                        // every wave is done with the window: its space becomes the out-area
+#pragma unroll
+        for (int i = 0; i < R; i++)
+#pragma unroll
+            for (int p = 0; p < L; p++) *reinterpret_cast<cf *>(ldsX + 2 * ((R * tid + i) * L + p)) = acc[p][i];
+        __syncthreads();
+        const long o0 = qb * L, n_out = n_in * L;
+        const long cnt = n_out - o0 < G::ON ? n_out - o0 : G::ON;   // outputs of this tile
+        float *yo = y + 2 * o0;
+        if (!(dbg & 2)) {
+            if ((reinterpret_cast<uintptr_t>(yo) & 15) == 0) {
+                for (int k = tid; 2 * k < cnt; k += 256) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(ldsX + 4 * k);
+                    if (2 * k + 1 < cnt) {
+                        if (dbg & 4) *reinterpret_cast<f32x4 *>(yo + 4 * k) = v;
+                        else __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(yo + 4 * k));      // written once, never re-read here: 0.710 against 0.724 ms
+                    } else {
+                        *reinterpret_cast<float2 *>(yo + 4 * k) = make_float2(v[0], v[1]);
+                    }
+                }
+            } else {
+                for (int k = tid; k < cnt; k += 256) *reinterpret_cast<float2 *>(yo + 2 * k) = *reinterpret_cast<const float2 *>(ldsX + 2 * k);
+            }
+        }
+        __syncthreads();                                        // the out-area is read: the next tile's window may be staged over it
+    }
+}
+
+}  // namespace lrhip

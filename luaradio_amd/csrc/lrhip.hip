@@ -19,6 +19,7 @@
 #include "kernels_agc.h"
 #include "kernels_firwin.h"
 #include "kernels_firwin2.h"
+#include "kernels_interp.h"
 
 using namespace lrhip;
 
@@ -530,6 +531,19 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
                     std::vector<float> taps((size_t)rf->M);
                     for (int t = 0; t < rf->M; t++) taps[t] = rf->taps_rev[rf->M - 1 - t];
                     if (upload(q->d_taps, taps.data(), taps.size() * sizeof(float)) || q->reset()) return nullptr;
+                    static const bool no_interp_win = getenv("LRHIP_NO_INTERP_WIN") != nullptr;      // A/B knob: one output per thread (fir_resample_kernel)
+                    if (!no_interp_win && q->S == 2 && D == 1 && q->M == 128 && L >= 2 && L <= 5) {
+                        // tap table of fir_interp_kernel: ttab[s * LP + p] = h[p + (J - 1 - s) L], step 0 = the oldest sample
+                        const int J = (q->M + L - 1) / L, LP = (L + 3) & ~3;
+                        std::vector<float> tt((size_t)J * LP, 0.f);
+                        for (int st = 0; st < J; st++)
+                            for (int p = 0; p < L; p++) {
+                                const int t = p + (J - 1 - st) * L;
+                                if (t < q->M) tt[(size_t)st * LP + p] = taps[t];
+                            }
+                        if (upload(q->d_ttab, tt.data(), tt.size() * sizeof(float))) return nullptr;
+                        q->interp_J = J;
+                    }
                     c->ops.push_back({q.release(), true});
                     i = k + 2 + (rd ? 1 : 0);
                     continue;

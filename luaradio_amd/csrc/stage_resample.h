@@ -9,9 +9,11 @@ struct ResampleStage : lrhip_stage {
     int S = 2, M = 0, L = 1, HQ = 0;
     unsigned long D = 1;
     float c = 1.f;
-    DeviceBuf d_taps, hist[2];
+    DeviceBuf d_taps, d_ttab, hist[2];
     int cur = 0;
     uint64_t Q0 = 0, m0 = 0;          // absolute input samples consumed / outputs emitted so far
+    int interp_J = 0;                 // > 0: the register-window interpolator kernel applies (kernels_interp.h), taps per phase
+    int interp_blocks_per_cu = 0;     // its resident workgroups per CU (occupancy query, cached)
     static constexpr int SPAN_MAX = 6144;
     const char *kind() const override { return "resample"; }
     unsigned long max_output(unsigned long n) const override { return (n * (unsigned long)L) / D + 2; }
@@ -42,6 +44,30 @@ struct ResampleStage : lrhip_stage {
         if ((unsigned long)n_out > cap) return set_error("resample: output capacity %lu < %ld", cap, n_out);
         const float *h = (const float *)hist[cur].p;
         float *ho = (float *)hist[cur ^ 1].p;
+        if (interp_J > 0 && ((uintptr_t)in_dev & 7) == 0 && ((uintptr_t)out_dev & 7) == 0) {
+            // ComplexFloat32 Interpolator(L), 128 taps: a lane owns 5 input positions and all L phases (fir_interp_kernel)
+            auto gi = [&](auto kern, size_t lds_bytes, int tq) -> int {
+                if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                if (!interp_blocks_per_cu) {
+                    int nb = 0;
+                    LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds_bytes));
+                    interp_blocks_per_cu = nb < 1 ? 1 : nb;
+                }
+                const long ntiles = ((long)n + tq - 1) / tq, slots = (long)ctx().num_cus * interp_blocks_per_cu;
+                hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < slots ? ntiles : slots)), dim3(256), lds_bytes, ctx().stream, h, (const float *)in_dev, (const float *)d_ttab.p,
+                                   (float *)out_dev, (long)n, HQ, c, ho, getenv("LRHIP_INTERP_DBG") ? atoi(getenv("LRHIP_INTERP_DBG")) : 0);
+                return 0;
+            };
+#define LR_INTERP(LL, JJ) gi(fir_interp_kernel<LL, JJ>, (size_t)FipGeom<LL, JJ>::LDS_FLOATS * sizeof(float), FipGeom<LL, JJ>::TQ)
+            int rc = L == 2 ? LR_INTERP(2, 64) : L == 3 ? LR_INTERP(3, 43) : L == 4 ? LR_INTERP(4, 32) : LR_INTERP(5, 26);
+#undef LR_INTERP
+            if (rc) return rc;
+            LR_LAUNCH_CHECK();
+            cur ^= 1;
+            Q0 += n;
+            m0 = m_end;
+            return n_out;
+        }
         // per-workgroup input span: 256 outputs advance 256*D/L input samples, plus the (M-1)/L samples of filter memory
         int span_cap = (int)(256 * D / (unsigned long)L) + (M - 1) / L + 4;
         size_t lds_bytes = ((size_t)((((M - 1) / L + 1) * L + 3) & ~3) + (size_t)span_cap * S) * sizeof(float);
