@@ -185,9 +185,28 @@ long lrhip_stage_execute2_device(lrhip_stage_t *q, const void *in1_dev, const vo
  * overlap-save filters (Float32 FFT arithmetic: the blocks of a chunk fall where the chunk starts, <= 1e-6), the polyphase audio tail
  * (FIR -> single-pole IIR -> downsampler as one decimating filter, ~2e-8 RMS), and a frequency translator fused in front of a filter
  * whose output only the discriminator sees: there a tile's window is rotated relative to its first sample, which leaves the angles
- * unchanged to Float32 rounding of the filter outputs (LRHIP_TUNER_EXACT=1 in the environment at stage creation keeps the stand-alone
- * translator's phasors and the bits, at 0.19 instead of 0.16 ms per 2^26 samples of the WBFM receiver). */
+ * unchanged to Float32 rounding of the filter outputs.  lrhip_chain_create_ex() below switches each of the last two off per chain. */
 lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages);
+/* The numerical contract per chain (what a LuaRadio script sets as DeviceChainBlock.exact, lua/radio/composites/devicechain.lua).
+ * lrhip_chain_create(stages, n) == lrhip_chain_create_ex(stages, n, 0).  Flags:
+ *   LRHIP_CHAIN_EXACT_ROTATOR      a frequency translator fused in front of a filter keeps the stand-alone translator's phasors
+ *                                  (block-of-8 staging): fused == unfused and chunked == unchunked bit for bit, at 0.19 instead of
+ *                                  0.16 ms per 2^26 samples of the WBFM receiver;
+ *   LRHIP_CHAIN_NO_POLYPHASE_TAIL  FIR -> single-pole IIR -> downsampler keeps the blocks' own arithmetic (filter at the high rate,
+ *                                  recurrence, gather) instead of ONE decimating filter with the recurrence at the low rate;
+ *   LRHIP_CHAIN_NO_FUSION          every stage runs its own kernels (edges still device-resident);
+ *   LRHIP_CHAIN_NO_SINGLE_LAUNCH   the FM receivers keep tuner + discriminator and audio tail as two launches (the round-2 form).
+ * LRHIP_CHAIN_EXACT = EXACT_ROTATOR | NO_POLYPHASE_TAIL | NO_SINGLE_LAUNCH: the chain computes what its blocks compute one by one (bit for bit
+ * for direct-form filters; overlap-save filters stay within 1e-6, as in the reference).  The environment variables LRHIP_TUNER_EXACT,
+ * LRHIP_NO_POLYPHASE_TAIL, ... of DESIGN.md 4.5 remain as process-wide overrides for A/B measurements.  Unknown bits -> NULL. */
+enum {
+    LRHIP_CHAIN_EXACT_ROTATOR = 1,
+    LRHIP_CHAIN_NO_POLYPHASE_TAIL = 2,
+    LRHIP_CHAIN_NO_FUSION = 4,
+    LRHIP_CHAIN_NO_SINGLE_LAUNCH = 8,
+    LRHIP_CHAIN_EXACT = 1 | 2 | 8
+};
+lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, unsigned flags);
 void lrhip_chain_destroy(lrhip_chain_t *c);
 /* Back to the initial state (zero history, phase, indices) for every stage of the chain, including the fused ones it built. */
 int   lrhip_chain_reset(lrhip_chain_t *c);
@@ -228,6 +247,11 @@ int  lrhip_chain_in_flight(const lrhip_chain_t *c);
 long lrhip_chain_push(lrhip_chain_t *c, const void *in_host, unsigned long n_in, void *out_host, unsigned long out_capacity);
 long lrhip_chain_flush(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
 unsigned long lrhip_chain_push_bound(const lrhip_chain_t *c, unsigned long n_in);
+/* Latency bound for LIVE flow graphs (an SDR source at 1.1 MS/s needs ~1 s to fill a 2^20-sample batch; an audio-rate chain minutes):
+ * when the oldest sample pushed and not yet launched has waited max_seconds (wall clock, checked at every push), push() launches the
+ * partial batch and returns its output from the same call.  0 (the default) = batches run only when full (file / benchmark sources,
+ * which deliver faster than real time).  Sample values do not depend on where batches are cut. */
+int  lrhip_chain_set_latency(lrhip_chain_t *c, double max_seconds);
 /* Number of kernels launched by the last chain execute (diagnostic for the fusion tests). */
 int lrhip_chain_last_launches(const lrhip_chain_t *c);
 
@@ -253,6 +277,11 @@ int  lrhip_stage_seek(lrhip_stage_t *q, unsigned long long n0);
 int  lrhip_chain_seek(lrhip_chain_t *c, unsigned long long n0);
 long lrhip_chain_halo(const lrhip_chain_t *c);
 unsigned long lrhip_chain_shard_align(const lrhip_chain_t *c);
+/* All of the above for a partition that owns the stream from `first_sample` on: seeks to the aligned sample s <= first_sample - halo
+ * (returned in *seek_sample: the source has to deliver the stream from s on) and arms the chain to DROP the output of the first
+ * (first_sample - s) input samples it is given - by execute, submit or push alike - so the caller's first output sample is the one the
+ * single-stream run produces for input sample first_sample.  < 0 for chains with unbounded memory. */
+int  lrhip_chain_start_at(lrhip_chain_t *c, unsigned long long first_sample, unsigned long long *seek_sample);
 
 /* ---- fan-out across processes / GPUs below the host language (radio/core/pipe.lua:617-627: one output port, several readers) -------
  * LuaRadio runs every block in its own process; with one process per GPU the source's slab has to reach the other processes' devices

@@ -1,8 +1,12 @@
 ---
 -- Device variants of FrequencyTranslatorBlock (radio/blocks/signal/frequencytranslator.lua:32-53),
 -- DownsamplerBlock (downsampler.lua:40-56), FrequencyDiscriminatorBlock (frequencydiscriminator.lua:33-64),
--- IIRFilterBlock (iirfilter.lua:79-109) and the element-wise / one-tap blocks next to the path. Each is the
--- `if platform.features.hip then` branch of the corresponding file; instantiate() and type signatures are unchanged.
+-- IIRFilterBlock (iirfilter.lua:79-109) and the element-wise / one-tap blocks next to the path.  Each patch is applied by
+-- ONE line directly above the reference file's final `return <Block>` - require('radio.core.lrhip').patch('<file>', <Block>) -
+-- i.e. after every top-level statement of that file (several define initialize()/process() outside any feature ladder, e.g.
+-- downsampler.lua:40-56, and firfilter.lua:400-402 assigns methods after its ladder); instantiate() and the type signatures are
+-- unchanged.  A patch sets every function a type signature of the block can bind (add_type_signature's process_func argument, or
+-- `process` by default - radio/core/block.lua:283-288); tests/test_lua_glue.py checks that against the reference files.
 -- Every block gets create_stage() (lrhip.device_block): the stage is created lazily on the first process() because
 -- initialize() runs pre-fork (radio/core/composite.lua:443 vs :569), and DeviceChainBlock collects the same stages.
 
@@ -81,6 +85,7 @@ function M.patch_addconstant(AddConstantBlock)
         local re, im, cc = split_constant(self.constant)
         return lrhip.lib.lrhip_unary_create("addconstant", re, im, cc, is_complex(self))
     end)
+    AddConstantBlock.process = process                       -- addconstant.lua:45,47: the default process() of two signatures
     AddConstantBlock.process_complex_by_complex = process
     AddConstantBlock.process_complex_by_real = process
     AddConstantBlock.process_real_by_real = process
@@ -88,10 +93,19 @@ end
 
 -- DelayBlock (delay.lua:43-72), ComplexFloat32 / Float32 signatures
 function M.patch_delay(DelayBlock)
+    local reference_process = DelayBlock.process
     lrhip.device_block(DelayBlock, function (self)
         return lrhip.lib.lrhip_delay_create(self.num_samples, ffi.sizeof(self:get_input_type()))
     end)
-    DelayBlock.process = process
+    -- the Bit / Byte signatures (delay.lua:32-33) are not sample streams of the device path: they keep the reference's loop
+    function DelayBlock:device_capable()
+        local data_type = self:get_input_type()
+        return data_type == types.ComplexFloat32 or data_type == types.Float32
+    end
+    function DelayBlock:process(x)
+        if not self:device_capable() then return reference_process(self, x) end
+        return process(self, x)
+    end
 end
 
 -- HilbertTransformBlock (hilberttransform.lua:100-160); self.hilbert_taps as computed by instantiate() (not reversed)
@@ -123,6 +137,7 @@ function M.patch_multiplyconstant(MultiplyConstantBlock)
         local re, im, cc = split_constant(self.constant)
         return lrhip.lib.lrhip_multiply_constant_create(re, im, cc, is_complex(self))
     end)
+    MultiplyConstantBlock.process = process                  -- multiplyconstant.lua:46,48: the default process() of two signatures
     MultiplyConstantBlock.process_complex_by_complex = process
     MultiplyConstantBlock.process_complex_by_real = process
     MultiplyConstantBlock.process_real_by_real = process
@@ -152,6 +167,15 @@ function M.patch_agc(AGCBlock)
     end)
     AGCBlock.process_real = process
     AGCBlock.process_complex = process
+end
+
+-- PowerSquelchBlock (powersquelch.lua:24-80): alpha and the linearised threshold as computed by the reference's initialize()
+function M.patch_powersquelch(PowerSquelchBlock)
+    lrhip.device_block(PowerSquelchBlock, function (self)
+        return lrhip.lib.lrhip_powersquelch_create(self.alpha, self.threshold, is_complex(self))
+    end)
+    PowerSquelchBlock.process_real = process
+    PowerSquelchBlock.process_complex = process
 end
 
 return M

@@ -1,12 +1,19 @@
 ---
--- Device variant of FIRFilterBlock's process path. In a LuaRadio checkout this is one more branch of the
--- `if platform.features.volk ... elseif platform.features.liquid ... else` ladder of
--- radio/blocks/signal/firfilter.lua:88,165,228, placed first:
+-- Device variant of FIRFilterBlock's process path.  Applied by ONE line directly above the final `return FIRFilterBlock` of
+-- radio/blocks/signal/firfilter.lua (i.e. after :492):
 --
---     if platform.features.hip then  <the functions below>  elseif platform.features.volk then ...
+--     require('radio.core.lrhip').patch('firfilter', FIRFilterBlock)
 --
+-- NOT as a first branch of the dot-product ladder at :88: the file's second ladder (:313-492) assigns
+-- FIRFilterBlock.process_fft_* = FIRFilterBlock.process_fft at :400-402 / :488-490, after the first one, and instantiate()
+-- (:56-66) binds exactly those names whenever use_fft is truthy - the default with FFTW installed.  At the end of the file
+-- nothing runs after the patch, and every name a type signature can bind (six process_* functions) is the device function.
 -- The type signatures (firfilter.lua:59-74) are unchanged; instantiate() is wrapped only to remember whether the
--- caller chose use_fft at all (nil = let the library pick the fast arithmetic, lrhip.fir_mode()).
+-- caller chose use_fft at all (nil = let the library pick the fast arithmetic, lrhip.fir_mode()); initialize() never builds the
+-- FFTW plans of initialize_fft() (:320-359) nor the VOLK state of initialize_dotprod().
+-- A stand-alone FIRFilterBlock(taps, true) therefore runs mode 1: the library's overlap-save kernel WITH the reference's block
+-- framing (only whole blocks of N - M + 1 samples are emitted, firfilter.lua:361-398); nil runs mode 3 (overlap-save arithmetic,
+-- one output per input, from 48 taps up).
 
 local ffi = require('ffi')
 

@@ -34,6 +34,14 @@ local DeviceChainBlock = block.factory("DeviceChainBlock")
 -- call (radio/blocks/sources/iqfile.lua:52), a pipe at most 131 072 (radio/core/pipe.lua:495-533)
 DeviceChainBlock.batch_samples = 1048576
 DeviceChainBlock.ring_depth = 3
+-- LIVE flow graphs: a batch is also launched once its oldest sample has waited this long (seconds, wall clock), so an RTL-SDR at
+-- 1.1 MS/s sees ~22 000-sample batches every 20 ms instead of waiting a second for 2^20 samples, and an audio-rate chain does not
+-- sit on minutes of samples; file and benchmark sources deliver faster than real time and still fill whole batches.  0 = off.
+DeviceChainBlock.max_latency = 0.02
+-- the chain's numerical contract (lrhip_chain_create_ex flags): false = fused kernels with the three stated roundings of
+-- include/lrhip.h; true = lrhip.CHAIN_EXACT, what the member blocks compute one by one; or a flag number.
+-- Set on the class before top:run(), or per chain on the object collapse() returns.
+DeviceChainBlock.exact = false
 
 function DeviceChainBlock:instantiate(blocks)
     self.blocks = assert(blocks, "Missing argument #1 (blocks)")
@@ -60,10 +68,14 @@ local function create_chain(self)
         stages[i-1] = b:create_stage()
     end
     self.stages = stages        -- keep the array (and through the members, the stages) alive as long as the chain
-    self.chain = ffi.gc(lrhip.check_object(lib.lrhip_chain_create(stages, #self.blocks), "Creating lrhip chain object"),
+    local flags = (self.exact == true) and lrhip.CHAIN_EXACT or (tonumber(self.exact) or 0)
+    self.chain = ffi.gc(lrhip.check_object(lib.lrhip_chain_create_ex(stages, #self.blocks, flags), "Creating lrhip chain object"),
                         lib.lrhip_chain_destroy)
     if lib.lrhip_chain_set_ring(self.chain, self.ring_depth, self.batch_samples) ~= 0 then
         error("lrhip_chain_set_ring: " .. ffi.string(lib.lrhip_strerror()))
+    end
+    if lib.lrhip_chain_set_latency(self.chain, self.max_latency) ~= 0 then
+        error("lrhip_chain_set_latency: " .. ffi.string(lib.lrhip_strerror()))
     end
 end
 
@@ -95,24 +107,26 @@ function DeviceChainBlock:cleanup()
 end
 
 -- Time partitions (INTEGRATION.md 3a; include/lrhip.h "time-axis sharding"): a DeviceChainBlock that starts in the middle of a recording.
--- start_at(first_sample) positions the chain on an aligned sample at or before (first_sample - halo) and returns (seek_sample, discard):
--- the source has to deliver the stream from seek_sample on, and the first `discard` OUTPUT-producing input samples are replayed state only -
--- process() drops what they produce.  Chains holding a stage with unbounded memory (AGC, ...) raise an error: they cannot be sharded.
+-- start_at(first_sample) positions the chain on an aligned sample at or before (first_sample - halo) and returns that sample: the source
+-- has to deliver the stream from there on.  The library drops what the replayed samples in front of first_sample produce
+-- (lrhip_chain_start_at arms the chain; process() / cleanup() need no special case), so the first sample this block emits is the one
+-- the single-process run emits for input sample first_sample.  Chains holding a stage with unbounded memory (AGC, ...) raise an
+-- error: they cannot be sharded.
 function DeviceChainBlock:start_at(first_sample)
     if self.chain == nil then create_chain(self) end
     local lib = lrhip.lib
-    local halo = tonumber(lib.lrhip_chain_halo(self.chain))
-    if halo < 0 then error("lrhip_chain_halo: " .. ffi.string(lib.lrhip_strerror())) end
-    local align = tonumber(lib.lrhip_chain_shard_align(self.chain))
-    local s = math.max(0, first_sample - halo)
-    s = s - s % align
-    if lib.lrhip_chain_seek(self.chain, s) ~= 0 then error("lrhip_chain_seek: " .. ffi.string(lib.lrhip_strerror())) end
-    return s, first_sample - s
+    local seek_sample = ffi.new("unsigned long long[1]")
+    if lib.lrhip_chain_start_at(self.chain, first_sample, seek_sample) ~= 0 then
+        error("lrhip_chain_start_at: " .. ffi.string(lib.lrhip_strerror()))
+    end
+    return tonumber(seek_sample[0])
 end
 
 -- a block the library can run as a chain stage: a device variant (create_stage), one input, one output
 local function chainable(b)
-    return type(b.create_stage) == "function" and #b.inputs == 1 and #b.outputs == 1
+    if type(b.create_stage) ~= "function" or #b.inputs ~= 1 or #b.outputs ~= 1 then return false end
+    if type(b.device_capable) == "function" and not b:device_capable() then return false end      -- e.g. DelayBlock on a Bit stream
+    return true
 end
 
 ---

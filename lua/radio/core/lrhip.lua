@@ -62,6 +62,7 @@ long lrhip_stage_execute2(lrhip_stage_t *q, const void *in1_host, const void *in
 long lrhip_stage_execute2_device(lrhip_stage_t *q, const void *in1_dev, const void *in2_dev, unsigned long n_in, void *out_dev, unsigned long out_capacity);
 
 lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages);
+lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, unsigned flags);
 void lrhip_chain_destroy(lrhip_chain_t *c);
 int lrhip_chain_reset(lrhip_chain_t *c);
 unsigned long lrhip_chain_max_output(const lrhip_chain_t *c, unsigned long n_in);
@@ -76,6 +77,7 @@ int lrhip_chain_in_flight(const lrhip_chain_t *c);
 long lrhip_chain_push(lrhip_chain_t *c, const void *in_host, unsigned long n_in, void *out_host, unsigned long out_capacity);
 long lrhip_chain_flush(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
 unsigned long lrhip_chain_push_bound(const lrhip_chain_t *c, unsigned long n_in);
+int lrhip_chain_set_latency(lrhip_chain_t *c, double max_seconds);
 
 void *lrhip_malloc(unsigned long bytes);
 void lrhip_free(void *dev_ptr);
@@ -94,6 +96,7 @@ int lrhip_stage_seek(lrhip_stage_t *q, unsigned long long n0);
 int lrhip_chain_seek(lrhip_chain_t *c, unsigned long long n0);
 long lrhip_chain_halo(const lrhip_chain_t *c);
 unsigned long lrhip_chain_shard_align(const lrhip_chain_t *c);
+int lrhip_chain_start_at(lrhip_chain_t *c, unsigned long long first_sample, unsigned long long *seek_sample);
 int lrhip_ipc_export(const void *dev_ptr, void *handle_out);
 void *lrhip_ipc_open(const void *handle);
 int lrhip_ipc_close(void *dev_ptr);
@@ -109,6 +112,13 @@ int lrhip_copy_stream_synchronize(void);
 ]]
 
 local M = {available = false}
+
+-- lrhip_chain_create_ex flags (include/lrhip.h): the numerical contract of a collapsed run of blocks
+M.CHAIN_EXACT_ROTATOR = 1
+M.CHAIN_NO_POLYPHASE_TAIL = 2
+M.CHAIN_NO_FUSION = 4
+M.CHAIN_NO_SINGLE_LAUNCH = 8
+M.CHAIN_EXACT = 11
 
 if not os.getenv("LUARADIO_DISABLE_HIP") then
     local ok, lib = pcall(ffi.load, "lrhip")
@@ -162,13 +172,52 @@ function M.device_block(Block, create)
 end
 
 ---
--- FIRFilterBlock's use_fft argument -> lrhip_fir_create's mode.  nil (the caller did not choose; the reference then
--- picks FFT when FFTW is present, firfilter.lua:57) = 3, automatic: overlap-save arithmetic with one output per
--- input from 48 taps up, direct form below.  true = 1, the reference's overlap-save INCLUDING its block-emission
+-- The ONE line a block file of the checkout gains, directly above its final `return <Block>`:
+--
+--     require('radio.core.lrhip').patch('firfilter', FIRFilterBlock)
+--
+-- At that point every top-level statement of the reference file has run - including ladders that (re)assign methods
+-- late, e.g. radio/blocks/signal/firfilter.lua:400-402 / :488-490, which set process_fft_* AFTER the dot-product
+-- ladder of :88-307 - so nothing can overwrite what the patch installs, and derived classes copy the patched methods
+-- when block.factory(name, parent) runs (radio/core/class.lua:18-40 copies the parent's functions at factory time;
+-- the derived file require()s the parent file first).  Without the library (or with LUARADIO_DISABLE_HIP) it is a no-op.
+-- `name` is the reference file's base name; tools/apply_lua_binding.py inserts the lines, tests/test_lua_glue.py
+-- models the load order.
+local unary_ops = {complexmagnitude = true, complexphase = true, complextoreal = true, complextoimag = true,
+                   complexconjugate = true, realtocomplex = true, absolutevalue = true}
+local binary_ops = {multiply = true, multiplyconjugate = true, add = true, subtract = true, floattocomplex = true}
+function M.patch(name, Block)
+    if not M.available then return Block end
+    if name == "firfilter" then
+        require('radio.blocks.signal.firfilter_hip')(Block)
+        return Block
+    end
+    local elementwise = require('radio.blocks.signal.elementwise_hip')
+    if unary_ops[name] then
+        elementwise.patch_unary(Block, name)
+    elseif binary_ops[name] then
+        elementwise.patch_binary(Block, name)
+    else
+        local patch = elementwise["patch_" .. name]
+        if patch == nil then error("radio.core.lrhip: no device variant for " .. name) end
+        patch(Block)
+    end
+    return Block
+end
+
+---
+-- FIRFilterBlock's use_fft argument -> lrhip_fir_create's mode (the same table as luaradio_amd/block.py fir_mode).
+-- nil (the caller did not choose; the reference then picks FFT when FFTW is present, firfilter.lua:57) = 3, automatic:
+-- overlap-save arithmetic with one output per input from 48 taps up, direct form below - and 0 under tests.jigs, as there.  true = 1, the reference's overlap-save INCLUDING its block-emission
 -- framing (firfilter.lua:361-398).  false = 0, direct form (bit-identical to the fmaf chain in tap order).
 -- "fast" = 2 and "auto" = 3 select the sample-exact overlap-save arithmetic explicitly.
 function M.fir_mode(use_fft)
-    if use_fft == nil or use_fft == "auto" then return 3 end
+    if use_fft == nil then
+        -- firfilter.lua:57: under the reference's unit-test jig an unspecified use_fft means the direct form
+        if package.loaded['tests.jigs'] then return 0 end
+        return 3
+    end
+    if use_fft == "auto" then return 3 end
     if use_fft == "fast" then return 2 end
     return use_fft and 1 or 0
 end

@@ -58,6 +58,7 @@ SIGNATURES = {
     "lrhip_stage_execute": (C.c_long, [_vp, _vp, _ul, _vp, _ul]),
     "lrhip_stage_execute_device": (C.c_long, [_vp, _vp, _ul, _vp, _ul]),
     "lrhip_chain_create": (_vp, [C.POINTER(_vp), C.c_uint]),
+    "lrhip_chain_create_ex": (_vp, [C.POINTER(_vp), C.c_uint, C.c_uint]),
     "lrhip_chain_destroy": (None, [_vp]),
     "lrhip_chain_reset": (C.c_int, [_vp]),
     "lrhip_chain_max_output": (_ul, [_vp, _ul]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "lrhip_chain_push": (C.c_long, [_vp, _vp, _ul, _vp, _ul]),
     "lrhip_chain_flush": (C.c_long, [_vp, _vp, _ul]),
     "lrhip_chain_push_bound": (_ul, [_vp, _ul]),
+    "lrhip_chain_set_latency": (C.c_int, [_vp, C.c_double]),
     "lrhip_malloc": (_vp, [_ul]),
     "lrhip_free": (None, [_vp]),
     "lrhip_memcpy_h2d": (C.c_int, [_vp, _vp, _ul]),
@@ -88,6 +90,7 @@ SIGNATURES = {
     "lrhip_chain_seek": (C.c_int, [_vp, C.c_ulonglong]),
     "lrhip_chain_halo": (C.c_long, [_vp]),
     "lrhip_chain_shard_align": (_ul, [_vp]),
+    "lrhip_chain_start_at": (C.c_int, [_vp, C.c_ulonglong, C.POINTER(C.c_ulonglong)]),
     "lrhip_ipc_export": (C.c_int, [_vp, _vp]),
     "lrhip_ipc_open": (_vp, [_vp]),
     "lrhip_ipc_close": (C.c_int, [_vp]),
@@ -101,6 +104,11 @@ SIGNATURES = {
     "lrhip_peer_copy": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _ul]),
     "lrhip_copy_stream_synchronize": (C.c_int, []),
 }
+
+
+# lrhip_chain_create_ex flags (include/lrhip.h)
+CHAIN_EXACT_ROTATOR, CHAIN_NO_POLYPHASE_TAIL, CHAIN_NO_FUSION, CHAIN_NO_SINGLE_LAUNCH = 1, 2, 4, 8
+CHAIN_EXACT = CHAIN_EXACT_ROTATOR | CHAIN_NO_POLYPHASE_TAIL | CHAIN_NO_SINGLE_LAUNCH
 
 
 def load():

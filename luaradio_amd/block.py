@@ -135,3 +135,27 @@ def as_taps(taps):
     if isinstance(taps, (list, tuple)) or (isinstance(taps, np.ndarray) and taps.dtype.kind == "f"):
         return types.Float32.vector_from_array(taps)
     raise TypeError("Unsupported taps type")
+
+
+# firfilter.lua:57: `use_fft == nil` means "FFT form when available ... and not package.loaded['tests.jigs']" - the reference's unit-test
+# jig expects one output per input from filters it did not explicitly ask FFT framing of.  tests/conftest.py (this repository's jig)
+# sets the flag the same way; the Lua glue reads package.loaded['tests.jigs'] itself.
+TESTS_JIGS_LOADED = False
+
+
+def fir_mode(use_fft):
+    """FIRFilterBlock's use_fft argument -> lrhip_fir_create's mode: the ONE table of every front end (lrhip.fir_mode in
+    lua/radio/core/lrhip.lua is the same, tests/test_host_cpu.py holds the two together).  None (the caller did not choose; the
+    reference then picks its FFT form when FFTW is present - except under its unit-test jig, firfilter.lua:57) = 3 automatic, 0 under
+    the jig; "auto" = 3; "fast" = 2 overlap-save
+    arithmetic, one output per input; True = 1 the reference's overlap-save INCLUDING its block-emission framing
+    (firfilter.lua:361-398); False = 0 direct form (bit-identical to the fmaf chain in tap order)."""
+    if use_fft is None:
+        return 0 if TESTS_JIGS_LOADED else 3
+    if use_fft == "auto":
+        return 3
+    if use_fft == "fast":
+        return 2
+    if use_fft in (0, 1, 2, 3) and not isinstance(use_fft, bool):
+        return int(use_fft)             # already a mode number (blk.use_fft pokes of the tools)
+    return 1 if use_fft else 0

@@ -7,21 +7,22 @@ import math
 import numpy as np
 
 from . import _lib, filter_utils, types
-from .block import Block, Input, Output, _fptr, as_taps
+from .block import Block, Input, Output, _fptr, as_taps, fir_mode
 
 
 class FIRFilterBlock(Block):
     """radio/blocks/signal/firfilter.lua.  FIRFilterBlock(taps[, use_fft]).
 
-    use_fft=True is the reference's overlap-save (firfilter.lua:320-398: only whole L = N-M+1 blocks are
-    emitted, tail retained); use_fft="fast" runs the same overlap-save arithmetic (fused FFT kernel) but emits one
-    output per input; "auto" picks "fast" from 48 taps up and the direct form below; the default (False) is the direct
-    form on the f32 matrix cores, bit-identical to the fmaf chain in the reference's tap order."""
+    use_fft (block.fir_mode, the same table as the Lua glue's lrhip.fir_mode): True is the reference's overlap-save
+    (firfilter.lua:320-398: only whole L = N-M+1 blocks are emitted, tail retained); "fast" runs the same overlap-save
+    arithmetic (fused FFT kernel) but emits one output per input; None (the default, as `nil` in the reference, which then picks
+    its FFT form when FFTW is present, firfilter.lua:57) and "auto" pick "fast" from 48 taps up and the direct form below; False
+    is the direct form on the f32 matrix cores, bit-identical to the fmaf chain in the reference's tap order."""
     name = "FIRFilterBlock"
 
     def instantiate(self, taps, use_fft=None):
         self.taps = as_taps(taps)
-        self.use_fft = 2 if use_fft == "fast" else 3 if use_fft == "auto" else (1 if use_fft else 0)
+        self.use_fft = fir_mode(use_fft)
         self.decimation = 1
         if self.taps.dtype == np.complex64:      # firfilter.lua:68-74
             self.add_type_signature([Input("in", types.ComplexFloat32)], [Output("out", types.ComplexFloat32)])

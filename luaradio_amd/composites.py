@@ -12,18 +12,23 @@ import ctypes as C
 import numpy as np
 
 from . import _lib, types
-from .block import Block, Input, Output
+from .block import Block, Input, Output, fir_mode
 from . import blocks as B
 
 
 class Chain:
     """A linear run of initialized device blocks executed as one lrhip_chain_t."""
 
-    def __init__(self, blocks):
+    def __init__(self, blocks, exact=False):
+        """exact: the chain's numerical contract, as DeviceChainBlock.exact in lua/radio/composites/devicechain.lua - False = fused
+        kernels with the stated roundings of include/lrhip.h, True = _lib.CHAIN_EXACT (what the blocks compute one by one), or a
+        number of lrhip_chain_create_ex flags (_lib.CHAIN_*)."""
         self.blocks = list(blocks)
+        self.flags = _lib.CHAIN_EXACT if exact is True else int(exact or 0)
+        self._ring_out = None
         L = _lib.load()
         arr = (C.c_void_p * len(self.blocks))(*[b.stage_handle() for b in self.blocks])
-        self._chain = _lib.check_ptr(L.lrhip_chain_create(arr, len(self.blocks)), "Creating lrhip chain object")
+        self._chain = _lib.check_ptr(L.lrhip_chain_create_ex(arr, len(self.blocks), self.flags), "Creating lrhip chain object")
         # a chain may start with a file source's format stage: its input is then RAW file records (uint8, record_size bytes each)
         self.in_record = getattr(self.blocks[0], "record_size", None)
         self.in_type = None if self.in_record else self.blocks[0].get_input_type()
@@ -55,6 +60,17 @@ class Chain:
     def shard_align(self):
         """partition boundaries on multiples of this many input samples reproduce the single-stream run bit for bit"""
         return int(_lib.load().lrhip_chain_shard_align(self._chain))
+
+    def start_at(self, first_sample):
+        """lrhip_chain_start_at: seek to the aligned sample s <= first_sample - halo (returned: feed the stream from s on); the library
+        drops the output of the replayed samples in front of first_sample (DeviceChainBlock:start_at in the Lua glue)"""
+        s = C.c_ulonglong(0)
+        _lib.check(_lib.load().lrhip_chain_start_at(self._chain, int(first_sample), C.byref(s)), "chain:start_at")
+        return int(s.value)
+
+    def set_latency(self, max_seconds):
+        """live sources: a pushed sample waits at most this long (wall clock) for its batch to be launched (lrhip_chain_set_latency)"""
+        _lib.check(_lib.load().lrhip_chain_set_latency(self._chain, float(max_seconds)), "chain:set_latency")
 
     def _count(self, x):
         """input vector -> (contiguous array, number of input samples)"""
@@ -131,7 +147,7 @@ class Chain:
         L = _lib.load()
         x, count = self._count(x)
         need = L.lrhip_chain_push_bound(self._chain, count)
-        if len(self._ring_out) < need:
+        if self._ring_out is None or len(self._ring_out) < need:      # no ring: need == 0 and the library reports "chain has no ring"
             self._ring_out = np.empty(need, dtype=self.out_type.dtype)
         n = L.lrhip_chain_push(self._chain, x.ctypes.data_as(C.c_void_p), count, self._ring_out.ctypes.data_as(C.c_void_p), len(self._ring_out))
         _lib.check(n, "chain:push")
@@ -140,6 +156,8 @@ class Chain:
     def flush(self):
         """Launch the partly filled batch, wait, return everything still pending (EOF / cleanup)."""
         L = _lib.load()
+        if self._ring_out is None:
+            self._ring_out = np.empty(max(1, L.lrhip_chain_push_bound(self._chain, 0)), dtype=self.out_type.dtype)
         n = L.lrhip_chain_flush(self._chain, self._ring_out.ctypes.data_as(C.c_void_p), len(self._ring_out))
         _lib.check(n, "chain:flush")
         return self._ring_out[:n].copy()
@@ -189,7 +207,7 @@ class CompositeBlock(Block):
         self._propagate_rates()
         for b in self._blocks:
             b.initialize()
-        self._chain = Chain(self._blocks)
+        self._chain = Chain(self._blocks, getattr(self, "exact", False))     # composite.exact = True: lrhip_chain_create_ex(LRHIP_CHAIN_EXACT)
 
     def process(self, x):
         return self._chain.process(x)
@@ -218,11 +236,12 @@ class CompositeBlock(Block):
 
 
 def _fft_option(options):
-    """options["use_fft"] of the decimating composites: False / None = direct form (bit-identical to the fmaf chain), "fast" /
-    "auto" = overlap-save arithmetic (the reference's own default FIR form, firfilter.lua:57); fused with the downsampler it
-    becomes the polyphase FFT kernel (kernels_firdecfft.h)."""
-    v = options.get("use_fft")
-    return 2 if v in ("fast", True) else 3 if v == "auto" else 0
+    """options["use_fft"] of the decimating composites, through the ONE mapping every front end shares (block.fir_mode, the same table
+    as lrhip.fir_mode in lua/radio/core/lrhip.lua): None / "auto" = 3 (the library picks: direct form on the matrix cores for a
+    decimating filter, which is the faster one on MI355X and bit-exact), False = 0 direct form, "fast" = 2 overlap-save arithmetic
+    (fused with the downsampler: the polyphase FFT kernel, kernels_firdecfft.h; direct form where no such kernel exists),
+    True = 1 the reference's block-emission framing (firfilter.lua:361-398; the filter then runs unfused in front of the downsampler)."""
+    return fir_mode(options.get("use_fft"))
 
 
 class DecimatorBlock(CompositeBlock):

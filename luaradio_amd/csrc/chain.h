@@ -15,6 +15,10 @@ struct lrhip_chain {
     PinnedBuf h_in, h_out;
     DeviceBuf d_in, d_out;
     int last_launches = 0;
+    unsigned flags = 0;                    // lrhip_chain_create_ex
+    unsigned long long discard_in = 0;     // lrhip_chain_start_at: input samples whose output is still to be thrown away
+    DeviceBuf d_discard;
+    double max_latency = 0.0, fill_t0 = 0.0;   // lrhip_chain_set_latency: bound on how long a pushed sample waits for its batch
     // ---- pipelined ring (lrhip_chain_set_ring)
     struct Slot {
         PinnedBuf h_in, h_out;

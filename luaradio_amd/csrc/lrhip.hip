@@ -494,9 +494,19 @@ long lrhip_stage_execute2(lrhip_stage_t *q, const void *in1_host, const void *in
 }
 
 // ---- chains ---------------------------------------------------------------------------------------------
-lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
+lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages) { return lrhip_chain_create_ex(stages, nstages, 0u); }
+
+lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, unsigned flags)
 {
     if (!stages || nstages < 1) { set_error("chain: need at least one stage"); return nullptr; }
+    if (flags & ~(unsigned)(LRHIP_CHAIN_EXACT_ROTATOR | LRHIP_CHAIN_NO_POLYPHASE_TAIL | LRHIP_CHAIN_NO_FUSION | LRHIP_CHAIN_NO_SINGLE_LAUNCH)) {
+        set_error("chain: unknown flag bits 0x%x", flags);
+        return nullptr;
+    }
+    // the numerical contract is a property of the chain (flags); the environment variables of the same names stay as process-wide
+    // overrides for A/B runs
+    const bool exact_rotator = (flags & LRHIP_CHAIN_EXACT_ROTATOR) != 0;
+    const bool no_fusion = (flags & LRHIP_CHAIN_NO_FUSION) != 0;
     for (unsigned i = 0; i < nstages; i++)
         if (!stages[i]) { set_error("chain: stage %u is null", i); return nullptr; }
     for (unsigned i = 0; i + 1 < nstages; i++)
@@ -507,8 +517,14 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
         }
     std::unique_ptr<lrhip_chain> c(new (std::nothrow) lrhip_chain());
     if (!c) { set_error("out of memory"); return nullptr; }
+    c->flags = flags;
     unsigned i = 0;
     while (i < nstages) {
+        if (no_fusion) {                                    // every block runs its own kernels; edges stay on the device
+            c->ops.push_back({stages[i], false});
+            i++;
+            continue;
+        }
         // fusion: [multiplyconstant(real)] upsampler fir(real taps, plain) [downsampler]  ->  one polyphase resampling launch
         {
             static const bool no_resample_fusion = getenv("LRHIP_NO_RESAMPLE_FUSION") != nullptr;      // A/B knob
@@ -586,6 +602,7 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
             bool with_disc = fused && dsc_after && fused->can_post_disc();
             if (fused && !rot && !ds && !with_disc) { delete fused; fused = nullptr; }      // nothing was fused
             if (fused) {
+                if (exact_rotator) fused->rel_rot = false;     // block-of-8 staging with the stand-alone rotator's phasors: fused == unfused bit for bit
                 if (with_disc) {
                     fused->post_disc = true;
                     fused->disc_gain = dsc_after->gain;
@@ -614,7 +631,8 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages)
                 // so the kept samples are a DECIMATING filter  g = h * b * (1, p, .., p^(D-1))  followed by the first-order recurrence with
                 // pole p^D at the LOW rate: 1/D of the multiply-adds, and the high-rate audio is never computed.  Same transfer function,
                 // different rounding: <= 1e-6 of the reference's arithmetic (the bar of the IIR blocks), not bit-identical to it.
-                static const bool no_polyphase_tail = getenv("LRHIP_NO_POLYPHASE_TAIL") != nullptr;      // A/B knob
+                static const bool no_polyphase_tail_env = getenv("LRHIP_NO_POLYPHASE_TAIL") != nullptr;      // A/B knob
+                const bool no_polyphase_tail = no_polyphase_tail_env || (flags & LRHIP_CHAIN_NO_POLYPHASE_TAIL);
                 if (!no_polyphase_tail && ds3 && ds3->factor >= 2 && ds3->factor <= 16) {
                     const int D = (int)ds3->factor, nbb = ii->nb;
                     const double a0 = (double)ii->seq.a[0];
@@ -725,6 +743,7 @@ int lrhip_chain_reset(lrhip_chain_t *c)
     if (!c) return set_error("null chain");
     if (c->inflight) return set_error("chain reset: %u chunks still in flight", c->inflight);
     c->fill = 0;
+    c->discard_in = 0;
     if (ctx().ready) LR_HIP(hipStreamSynchronize(ctx().stream));
     for (auto &o : c->ops)
         if (o.stage->reset()) return -1;
@@ -739,10 +758,27 @@ unsigned long lrhip_chain_max_output(const lrhip_chain_t *c, unsigned long n_in)
     return n;
 }
 
+static unsigned long chain_output_bound(const lrhip_chain *c, unsigned long n);
+
 long lrhip_chain_execute_device(lrhip_chain_t *c, const void *in_dev, unsigned long n_in, void *out_dev, unsigned long out_capacity)
 {
     if (!c) return set_error("null chain");
     g_launches = 0;
+    if (c->discard_in && n_in) {
+        // lrhip_chain_start_at(): the first samples after the seek are the partition's replayed halo - state only, their output is dropped
+        const unsigned long k = c->discard_in < n_in ? (unsigned long)c->discard_in : n_in;
+        const unsigned long bound = chain_output_bound(c, k);
+        if (c->d_discard.reserve((size_t)bound * c->ops.back().stage->out_size + 16)) return -1;
+        c->discard_in -= k;
+        const unsigned long long left = c->discard_in;
+        c->discard_in = 0;
+        long rc = lrhip_chain_execute_device(c, in_dev, k, c->d_discard.p, bound);
+        c->discard_in = left;
+        if (rc < 0) return rc;
+        in_dev = (const char *)in_dev + (size_t)k * c->ops.front().stage->in_size;
+        n_in -= k;
+        if (!n_in) return 0;
+    }
     const void *cur = in_dev;
     unsigned long n = n_in;
     for (size_t k = 0; k < c->ops.size(); k++) {
@@ -892,8 +928,25 @@ long lrhip_chain_collect(lrhip_chain_t *c, void *out_host, unsigned long out_cap
 static long push_launch(lrhip_chain_t *c)
 {
     unsigned long n = c->fill;
-    c->fill = 0;
-    return lrhip_chain_submit(c, c->ring[c->head]->h_in.p, n);
+    c->fill = 0;                        // lrhip_chain_submit() refuses to run while pushed samples are pending
+    long rc = lrhip_chain_submit(c, c->ring[c->head]->h_in.p, n);
+    if (rc < 0) c->fill = n;            // nothing was launched: the samples are still in the slot, the caller may collect and retry
+    else c->fill_t0 = 0.0;
+    return rc;
+}
+static double monotonic_seconds()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int lrhip_chain_set_latency(lrhip_chain_t *c, double max_seconds)
+{
+    if (!c) return set_error("null chain");
+    if (!(max_seconds >= 0.0)) return set_error("latency bound must be >= 0 (0 = batches run when full)");
+    c->max_latency = max_seconds;
+    return 0;
 }
 // copy the oldest slot's output out (waiting for it when `wait`); returns samples copied, -2 when it is not finished yet
 static long push_collect(lrhip_chain_t *c, char *out, unsigned long cap, bool wait)
@@ -934,10 +987,27 @@ long lrhip_chain_push(lrhip_chain_t *c, const void *in_host, unsigned long n_in,
         unsigned long take = c->ring_chunk - c->fill;
         if (take > n_in) take = n_in;
         memcpy((char *)c->ring[c->head]->h_in.p + (size_t)c->fill * in_size, src, (size_t)take * in_size);
+        if (!c->fill && c->max_latency > 0.0) c->fill_t0 = monotonic_seconds();
         c->fill += take; src += (size_t)take * in_size; n_in -= take;
         if (c->fill == c->ring_chunk) {
             long rc = push_launch(c);
             if (rc < 0) return rc;
+        }
+    }
+    // latency bound (live sources): the oldest pushed sample has waited long enough - run the partial batch now and hand its output back
+    // from this call (a live flow graph is far from the GPU's throughput, so the wait costs a launch, not the stream rate)
+    if (c->fill && c->max_latency > 0.0 && monotonic_seconds() - c->fill_t0 >= c->max_latency) {
+        if (c->inflight == c->ring.size()) {
+            long got = push_collect(c, dst + (size_t)total * out_size, out_capacity - (unsigned long)total, true);
+            if (got < 0) return got;
+            total += got;
+        }
+        long rc = push_launch(c);
+        if (rc < 0) return rc;
+        while (c->inflight) {
+            long got = push_collect(c, dst + (size_t)total * out_size, out_capacity - (unsigned long)total, true);
+            if (got < 0) return got;
+            total += got;
         }
     }
     while (c->inflight) {                                    // whatever has finished meanwhile, in stream order, without waiting
@@ -1075,6 +1145,7 @@ int lrhip_chain_seek(lrhip_chain_t *c, unsigned long long n0)
     if (!c) return set_error("null chain");
     if (c->inflight || c->fill) return set_error("chain seek: chunks still in flight or pushed and not flushed");
     if (ctx().ready) LR_HIP(hipStreamSynchronize(ctx().stream));
+    c->discard_in = 0;
     unsigned long long n = n0;
     for (auto &o : c->ops) {
         unsigned long long nn = 0;
@@ -1118,6 +1189,20 @@ unsigned long lrhip_chain_shard_align(const lrhip_chain_t *c)
         num /= g; den /= g;
     }
     return (unsigned long)l;
+}
+
+int lrhip_chain_start_at(lrhip_chain_t *c, unsigned long long first_sample, unsigned long long *seek_sample)
+{
+    if (!c) return set_error("null chain");
+    const long halo = lrhip_chain_halo(c);
+    if (halo < 0) return -1;
+    const unsigned long long align = lrhip_chain_shard_align(c);
+    unsigned long long s = first_sample > (unsigned long long)halo ? first_sample - (unsigned long long)halo : 0ULL;
+    s -= s % (align ? align : 1ULL);
+    if (lrhip_chain_seek(c, s)) return -1;
+    c->discard_in = first_sample - s;
+    if (seek_sample) *seek_sample = s;
+    return 0;
 }
 
 // ---- interprocess memory / events / peer copies --------------------------------------------------------------------

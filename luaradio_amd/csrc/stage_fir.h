@@ -47,6 +47,7 @@ struct FirStage : lrhip_stage {
     // fix-up of the wave-first discriminator outputs (disc_epilogue): done by fir_disc_fixup_kernel, or - defer_fixup - left to the next
     // stage of the chain, a pair-mode window filter that patches the samples as it stages them (FwcParams::fix_edge): one launch less
     bool defer_fixup = false, fix_ready = false;
+    long fix_nunits = 0; int fix_unit = 0;  // the deferred fix-up as fir_disc_fixup_kernel would have been launched (consumer chunks that emit nothing)
     int fix_shift = 8;                     // log2 of the outputs per edge record pair
     const float2 *fix_prev_ptr = nullptr;
     FirStage *fix_src = nullptr;           // consumer side: the stage whose edge records are to be applied
@@ -194,6 +195,7 @@ struct FirStage : lrhip_stage {
                     // (the consumer patches at most 32 samples per half window: a record pair per >= 256 outputs)
                     if (defer_fixup && (FIX_UNIT & (FIX_UNIT - 1)) == 0 && FIX_UNIT >= 256) {
                         fix_ready = true;
+                        fix_nunits = nunits; fix_unit = FIX_UNIT;
                         fix_prev_ptr = (const float2 *)(dp + disc_cur);
                         fix_shift = 0;
                         while ((1 << fix_shift) < FIX_UNIT) fix_shift++;
@@ -606,6 +608,15 @@ struct FirStage : lrhip_stage {
         fix_ready = false;
         long n_out = (unsigned long)n > index ? (long)((n - index + D - 1) / D) : 0;
         if ((unsigned long)n_out > cap) return set_error("fir: output capacity %lu < %ld", cap, n_out);
+        if (fix_src && fix_src->fix_ready && n_out == 0) {
+            // the producer left its wave-first discriminator outputs to this stage's staging, but this chunk launches no window kernel
+            // (fewer inputs than the decimation index): patch them in place before they enter the history
+            hipLaunchKernelGGL(fir_disc_fixup_kernel, dim3((unsigned)((fix_src->fix_nunits + 255) / 256)), dim3(256), 0, ctx().stream,
+                               (const float2 *)fix_src->edge.p, fix_src->fix_nunits, fix_src->fix_unit, const_cast<float *>(x), n, fix_src->fix_prev_ptr,
+                               1.0 / fix_src->disc_gain);
+            LR_LAUNCH_CHECK();
+            fix_src->fix_ready = false;
+        }
         if (n_out > 0) {
             int rc = (decfft && ((uintptr_t)x & 7) == 0) ? launch_decfft(x, n, y, n_out)
                      : fft_arith ? launch_fft(x, n, y, n_out)
@@ -742,7 +753,8 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
         // automatic (3) keeps the direct form for decimating filters: on MI355X the Toeplitz MFMA kernel is the faster one there
         // (Tuner + discriminator, 2^26 samples: 0.155 ms against 0.165 ms, same box) and it is bit-exact
         want_decfft = use_fft == 2 && FirStage::decfft_supported(decim, (int)ntaps, input_complex ? 2 : 1);
-        if (!want_decfft && use_fft == 2) { set_error("fir: no overlap-save form for %u taps at decimation %u on this input type", ntaps, decim); return nullptr; }
+        // "fast" is an arithmetic preference, not a framing: where no polyphase-FFT kernel exists for (taps, decimation) the direct form runs -
+        // stand-alone exactly as lrhip_chain_create does when it fuses filter and downsampler (one behaviour for both front doors)
         use_fft = 0;
     }
     if (use_fft == 3) use_fft = (decim == 1 && !rot && ntaps >= 48 && ntaps <= 16 * FirStage::FFT_PART && (input_complex || !taps_complex)) ? 2 : 0;

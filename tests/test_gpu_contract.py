@@ -1,0 +1,209 @@
+"""Round-3 boundary features of the C ABI, on the GPU (all through liblrhip.so):
+
+  * lrhip_chain_create_ex flags - the numerical contract per chain (EXACT = what the blocks compute one by one, bit for bit);
+  * lrhip_chain_start_at - a time partition's replayed halo is dropped inside the library, whatever entry point feeds the chain;
+  * lrhip_chain_set_latency - live sources get their partial batches without an EOF flush;
+  * the deferred wave-boundary fix-up when the consumer's chunk emits nothing (stage_fir.h);
+  * "fast" arithmetic falls back to the direct form stand-alone exactly as inside a chain;
+  * push() keeps its samples when a launch fails.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+import luaradio_amd as lr
+from luaradio_amd import _lib, types
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FS = 1102500.0
+
+
+def fm_signal(n, seed=3):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / FS
+    m = 0.5 * np.sin(2 * np.pi * 1e3 * t) + 0.5 * np.sin(2 * np.pi * 5e3 * t)
+    ph = 2 * np.pi * 250e3 * t + 2 * np.pi * 75e3 / FS * np.cumsum(m)
+    return (np.exp(1j * ph) + 0.01 * (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n))).astype(np.complex64)
+
+
+def make(cls, args, dtype, rate):
+    blk = cls(*args)
+    blk.rate = rate
+    blk.differentiate([dtype])
+    blk.initialize()
+    return blk
+
+
+def receiver_blocks():
+    """examples/rtlsdr_wbfm_mono.lua:12-17 flattened: 7 blocks"""
+    c, f = types.ComplexFloat32, types.Float32
+    return [make(lr.FrequencyTranslatorBlock, [-250e3], c, FS), make(lr.LowpassFilterBlock, [128, 100e3], c, FS),
+            make(lr.DownsamplerBlock, [5], c, FS), make(lr.FrequencyDiscriminatorBlock, [1.25], c, FS / 5),
+            make(lr.LowpassFilterBlock, [128, 15e3], f, FS / 5), make(lr.FMDeemphasisFilterBlock, [75e-6], f, FS / 5),
+            make(lr.DownsamplerBlock, [5], f, FS / 5)]
+
+
+def run_chunked(proc, x, cuts):
+    parts, a = [], 0
+    for b in list(cuts) + [len(x)]:
+        parts.append(proc(x[a:b]))
+        a = b
+    return np.concatenate(parts)
+
+
+def test_exact_flag_gives_the_blocks_own_bits_for_any_chunking():
+    x = fm_signal(400000)
+    want = x
+    for b in receiver_blocks():
+        want = b.process(want)
+    exact = lr.Chain(receiver_blocks(), exact=True)
+    assert exact.flags == _lib.CHAIN_EXACT == 11
+    got = run_chunked(exact.process, x, [1, 7, 8192, 8193, 100000, 100001, 333333])
+    assert len(got) == len(want) and np.array_equal(got, want)
+    # the default contract: same values to the stated roundings, fewer launches
+    fast = lr.Chain(receiver_blocks())
+    got2 = fast.process(x)
+    assert len(got2) == len(want)
+    assert float(np.sqrt(np.mean((got2.astype(np.float64) - want) ** 2))) < 1e-6
+    exact.process(x)
+    assert fast.last_launches < exact.last_launches
+
+
+def test_no_fusion_flag_and_unknown_bits():
+    x = fm_signal(100000)
+    blocks = receiver_blocks()
+    plain = lr.Chain(blocks, exact=_lib.CHAIN_NO_FUSION)
+    got = plain.process(x)
+    assert plain.last_launches >= 7
+    want = x
+    for b in receiver_blocks():
+        want = b.process(want)
+    assert np.array_equal(got, want)
+    L = _lib.load()
+    arr = (C.c_void_p * 2)(blocks[0].stage_handle(), blocks[1].stage_handle())
+    assert not L.lrhip_chain_create_ex(arr, 2, 1 << 9)
+    assert b"unknown flag" in L.lrhip_strerror()
+
+
+@pytest.mark.parametrize("entry", ["execute", "push"])
+def test_start_at_drops_the_replayed_halo_inside_the_library(entry):
+    n = 1 << 20
+    x = fm_signal(n, seed=9)
+    whole = lr.Chain(receiver_blocks()).process(x)
+    chain = lr.Chain(receiver_blocks())
+    align = chain.shard_align()
+    first = 4 * align                                   # a partition boundary on the tile grid: bit-identical
+    s = chain.start_at(first)
+    assert s <= first - chain.halo() and s % align == 0 and first - s < chain.halo() + align
+    want = whole[first // 25:]
+    if entry == "execute":
+        got = chain.process(x[s:])                      # one call: the library splits it at `first`, which is on the tile grid
+        assert len(got) == len(want) and np.array_equal(got, want)
+        # cuts inside and across the replay, off the grid: same sample COUNT, values to Float32 rounding of the tuner outputs
+        assert chain.start_at(first) == s
+        got = run_chunked(chain.process, x[s:], [1000, first - s - 3, first - s + 5])
+        assert len(got) == len(want) and float(np.max(np.abs(got - want))) < 5e-5
+    else:
+        chain.set_ring(3, align)                        # batches on the tile grid
+        parts = [chain.push(x[k:k + 8192]) for k in range(s, n, 8192)]
+        parts.append(chain.flush())
+        got = np.concatenate(parts)
+        assert len(got) == len(want) and np.array_equal(got, want)
+    # an unaligned first sample: same values to Float32 rounding (documented), never duplicated or missing samples
+    chain2 = lr.Chain(receiver_blocks())
+    first2 = 3 * align + 12350                          # multiple of 25: the output grid of the single stream
+    s2 = chain2.start_at(first2)
+    got2 = chain2.process(x[s2:])
+    want2 = whole[first2 // 25:]
+    assert len(got2) == len(want2) and float(np.max(np.abs(got2 - want2))) < 5e-5
+    # chains with unbounded memory refuse
+    agc = lr.Chain([make(lr.AGCBlock, ["fast"], types.ComplexFloat32, FS)])
+    with pytest.raises(_lib.LrhipError):
+        agc.start_at(1000)
+
+
+def test_latency_bound_releases_partial_batches_without_a_flush():
+    x = fm_signal(1 << 18, seed=11)
+    want = lr.Chain(receiver_blocks()).process(x)
+    chain = lr.Chain(receiver_blocks())
+    chain.set_ring(3, 1 << 20)                          # DeviceChainBlock's batch: a second of RF at 1.1 MS/s
+    chain.set_latency(0.01)
+    parts, emitted_calls = [], 0
+    for k in range(0, len(x), 8192):
+        if k in (8 * 8192, 20 * 8192):
+            time.sleep(0.03)                            # a live source: the batch is far from full, the clock is not
+        out = chain.push(x[k:k + 8192])
+        emitted_calls += len(out) > 0
+        parts.append(out)
+    before_flush = sum(len(p) for p in parts)
+    parts.append(chain.flush())
+    got = np.concatenate(parts)
+    assert emitted_calls >= 2 and before_flush > 0      # without the bound nothing leaves a 2^20 batch before EOF
+    assert len(got) == len(want)
+    assert float(np.max(np.abs(got - want))) < 5e-5      # batches cut off the tile grid: Float32 rounding of the tuner outputs
+    quiet = lr.Chain(receiver_blocks())
+    quiet.set_ring(3, 1 << 20)
+    assert sum(len(quiet.push(x[k:k + 8192])) for k in range(0, len(x), 8192)) == 0
+    with pytest.raises(_lib.LrhipError):
+        quiet.set_latency(-1.0)
+
+
+def test_deferred_fixup_when_the_tail_emits_nothing():
+    """the tuner + discriminator leaves its wave-first outputs to the audio tail's staging; chunks so small that the tail launches no
+    kernel (fewer than 5 tuner outputs) must still patch them before they enter the tail's history"""
+    x = fm_signal(60000, seed=13)
+    want = lr.Chain(receiver_blocks()).process(x)
+    chain = lr.Chain(receiver_blocks())
+    cuts = [5120 * 4, 5120 * 4 + 3, 5120 * 4 + 9, 5120 * 4 + 10, 5120 * 4 + 17, 40000, 40004, 40011]
+    got = run_chunked(chain.process, x, cuts)
+    assert len(got) == len(want)
+    assert float(np.max(np.abs(got - want))) < 5e-5
+    ora = O.wbfm_mono_chain(FS, -250e3, mode=O.MODE_LUA, rot_mode=O.MODE_F64).process(x)
+    assert float(np.sqrt(np.mean((got.astype(np.float64) - ora) ** 2))) <= 1e-5
+
+
+def test_fast_arithmetic_falls_back_to_the_direct_form_standalone_as_in_a_chain():
+    rng = np.random.default_rng(17)
+    x = (rng.uniform(-1, 1, 50000) + 1j * rng.uniform(-1, 1, 50000)).astype(np.complex64)
+    # 40 taps at decimation 7: no polyphase-FFT instantiation
+    fast = make(lr.DecimatorBlock, [7, {"num_taps": 40, "use_fft": "fast"}], types.ComplexFloat32, 2.0)
+    direct = make(lr.DecimatorBlock, [7, {"num_taps": 40, "use_fft": False}], types.ComplexFloat32, 2.0)
+    assert np.array_equal(fast.process(x), direct.process(x))
+    taps = np.asarray(lr.filter_utils.firwin_lowpass(40, 1 / 7), np.float32)
+    L = _lib.load()
+    st = L.lrhip_fir_create(taps.ctypes.data_as(C.POINTER(C.c_float)), 40, 0, 1, 7, 2)
+    assert st, L.lrhip_strerror()
+    L.lrhip_stage_destroy(st)
+
+
+def test_fir_mode_is_one_table_for_every_front_end():
+    from luaradio_amd import block
+    assert [block.fir_mode(v) for v in ("auto", "fast", True, False)] == [3, 2, 1, 0]
+    assert block.fir_mode(None) == 0                    # under the jig (tests/conftest.py), as firfilter.lua:57
+    saved, block.TESTS_JIGS_LOADED = block.TESTS_JIGS_LOADED, False
+    try:
+        assert block.fir_mode(None) == 3
+        blk = lr.LowpassFilterBlock(128, 0.2, 1.0)
+        assert blk.use_fft == 3
+    finally:
+        block.TESTS_JIGS_LOADED = saved
+
+
+def test_push_keeps_its_samples_when_the_launch_fails():
+    x = fm_signal(40000, seed=19)
+    chain = lr.Chain(receiver_blocks())
+    with pytest.raises(_lib.LrhipError, match="no ring"):
+        chain.push(x[:100])
+    with pytest.raises(_lib.LrhipError, match="no ring"):
+        chain.submit(x[:100])
+    assert len(chain.flush()) == 0                      # nothing is ever pending without a ring
+    chain.set_ring(2, 16384)
+    parts = [chain.push(x[k:k + 5000]) for k in range(0, len(x), 5000)]
+    parts.append(chain.flush())
+    got = np.concatenate(parts)
+    want = lr.Chain(receiver_blocks()).process(x)
+    assert len(got) == len(want) and float(np.max(np.abs(got - want))) < 5e-5

@@ -1597,7 +1597,7 @@ def test_ring_output_sized_for_chains_that_emit_more_than_they_take():
 def test_replay_of_devicechain_lua_call_sequence():
     """The exact C-ABI call sequence lua/radio/composites/devicechain.lua makes for examples/rtlsdr_wbfm_mono.lua after
     DeviceChainBlock.collapse(): lrhip_init, one create per member block in graph order with the arguments the Lua device variants
-    pass (use_fft nil -> mode 3), lrhip_chain_create, lrhip_chain_set_ring(depth 3, 2^20), then per process() call
+    pass (use_fft nil -> mode 3), lrhip_chain_create_ex(flags 0), lrhip_chain_set_ring(depth 3, 2^20), lrhip_chain_set_latency(20 ms), then per process() call
     lrhip_chain_push_bound + lrhip_chain_push with the file source's 8 192-sample chunks, lrhip_chain_flush in cleanup(),
     lrhip_chain_destroy / lrhip_stage_destroy from ffi.gc - raw ctypes, no Python block classes.  Audio against the oracle chain."""
     import ctypes as C
@@ -1623,9 +1623,10 @@ def test_replay_of_devicechain_lua_call_sequence():
               L.lrhip_downsampler_create(5, 4)]
     assert all(stages), L.lrhip_strerror()
     arr = (C.c_void_p * len(stages))(*stages)
-    chain = L.lrhip_chain_create(arr, len(stages))
+    chain = L.lrhip_chain_create_ex(arr, len(stages), 0)                            # DeviceChainBlock.exact = false
     assert chain, L.lrhip_strerror()
     assert L.lrhip_chain_set_ring(chain, 3, 1 << 20) == 0
+    assert L.lrhip_chain_set_latency(chain, 0.02) == 0                              # DeviceChainBlock.max_latency
     out = np.empty(0, np.float32)
     parts, calls_with_output = [], 0
     for k in range(0, n, 8192):
@@ -1651,7 +1652,9 @@ def test_replay_of_devicechain_lua_call_sequence():
     assert len(audio) == len(want)
     err = audio.astype(np.float64) - want.astype(np.float64)
     assert float(np.sqrt(np.mean(err ** 2))) <= 1e-5 and float(np.max(np.abs(err))) < 1e-4
-    assert calls_with_output <= 1          # 2^20 samples = one batch: everything comes out of the flush (or the 128th push)
+    # 2^20 samples = one batch: everything comes out of the flush or the 128th push - unless this loop was slower than the 20 ms latency
+    # bound (a cold box), in which case partial batches left earlier; the values above do not depend on it
+    assert calls_with_output <= 8
 
 
 def test_error_paths_report_through_strerror():
