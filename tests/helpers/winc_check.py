@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 import luaradio_amd as lr
+import tests  # noqa: F401  (the jig: use_fft = None means the direct form, as under tests.jigs in the reference)
 from luaradio_amd import types
 from oracle import oracle as O
 
