@@ -20,6 +20,7 @@
 #include "kernels_firwin.h"
 #include "kernels_firwin2.h"
 #include "kernels_interp.h"
+#include "kernels_rx.h"
 
 using namespace lrhip;
 
@@ -40,6 +41,7 @@ static int g_launches = 0;   // kernels enqueued since the counter was last clea
 #include "stage_elem2.h"
 #include "stage_resample.h"
 #include "stage_elem3.h"
+#include "stage_rx.h"
 #include "chain.h"
 
 // =====================================================================================================
@@ -726,6 +728,22 @@ lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, u
             prod->defer_fixup = true;
             cons->fix_src = prod;
         }
+    }
+    // ... and the two become ONE stage whose run() is a single launch (kernels_rx.h): the discriminator stream stays in LDS.  The stage keeps
+    // both FirStages and their state formats, so the two-launch form remains its fallback (and what LRHIP_CHAIN_NO_SINGLE_LAUNCH selects)
+    for (size_t k = 0; k + 1 < c->ops.size(); k++) {
+        FirStage *prod = c->ops[k].owned ? dynamic_cast<FirStage *>(c->ops[k].stage) : nullptr;
+        FirStage *cons = c->ops[k + 1].owned ? dynamic_cast<FirStage *>(c->ops[k + 1].stage) : nullptr;
+        if (!RxStage::shapes_ok(prod, cons)) continue;
+        std::unique_ptr<RxStage> rx(new (std::nothrow) RxStage());
+        if (!rx) { set_error("out of memory"); return nullptr; }
+        rx->A.reset(prod);
+        rx->B.reset(cons);
+        c->ops[k] = {nullptr, false};                        // ownership has moved: the unique_ptrs delete them
+        c->ops.erase(c->ops.begin() + (long)k + 1);
+        rx->single_launch = !(flags & LRHIP_CHAIN_NO_SINGLE_LAUNCH);
+        if (rx->prepare()) { c->ops.erase(c->ops.begin() + (long)k); return nullptr; }
+        c->ops[k] = {rx.release(), true};
     }
     for (size_t k = 0; k + 1 < c->ops.size(); k++) c->edges.emplace_back(new DeviceBuf());
     return c.release();

@@ -1,0 +1,119 @@
+// stage_rx.h - the FM receiver's device path as one stage: tuner + discriminator (FirStage A) and the polyphase audio tail (FirStage B)
+// run by ONE launch of rx_fused_kernel (kernels_rx.h), with the two-launch form of round 2 behind it for the chunks and settings the
+// single launch does not take (LRHIP_CHAIN_NO_SINGLE_LAUNCH, an unaligned source, chunks that emit no audio sample).
+// (part of liblrhip.so; included by lrhip.hip in this order, one translation unit)
+#pragma once
+
+struct RxStage : lrhip_stage {
+    std::unique_ptr<FirStage> A, B;       // state lives in the two stages, in their own formats: both forms can alternate chunk by chunk
+    DeviceBuf mid;                        // two-launch form: the discriminator stream between them
+    DeviceBuf d_ptab4;
+    int blocks_per_cu = 0;
+    bool single_launch = true;
+    int last_form = 0;                    // diagnostics: 1 = single launch, 2 = two launches (last run)
+
+    const char *kind() const override { return "fm-receiver"; }
+    unsigned long max_output(unsigned long n) const override { return B->max_output(A->max_output(n)); }
+    int reset() override { return (A->reset() || B->reset()) ? -1 : 0; }
+    int seek(unsigned long long n0, unsigned long long *n0_out) override
+    {
+        unsigned long long m = 0;
+        if (A->seek(n0, &m) || B->seek(m, n0_out)) return -1;
+        return 0;
+    }
+    long memory() const override
+    {
+        const long ma = A->memory(), mb = B->memory();
+        return (ma < 0 || mb < 0) ? -1 : ma + (long)A->D * mb;
+    }
+    void rate(unsigned long *num, unsigned long *den) const override { *num = (unsigned long)A->D * B->D; *den = 1; }
+    unsigned long align() const override
+    {
+        // tile grids of the two-launch form (which a partition may fall back to) and the batch grid of the single launch
+        auto gcd = [](unsigned long x, unsigned long y) { while (y) { unsigned long t = x % y; x = y; y = t; } return x; };
+        auto lcm = [&](unsigned long x, unsigned long y) { return x / gcd(x, y) * y; };
+        return lcm(lcm(A->align(), (unsigned long)A->D * B->align()), (unsigned long)RX_BATCH * RX_D);
+    }
+
+    static bool shapes_ok(const FirStage *a, const FirStage *b)
+    {
+        return a && b && a->S == 2 && !a->taps_complex && a->D == 5 && a->M == RX_M && a->ksteps == RX_KS && a->rot && a->rel_rot && a->post_disc &&
+               !a->decfft && !a->fft_arith && !a->use_fft && !a->win_cplx_ok() && b->S == 1 && b->M == RX_MT && b->D == 5 && b->ksteps == RX_KST && b->d_atab.p && b->iir_fused && b->win_pair_ok();
+    }
+
+    int prepare()
+    {
+        in_size = A->in_size;
+        out_size = B->out_size;
+        const double q = (double)B->iir_na1 + (double)B->iir_na1_lo;
+        std::vector<float> pt(64);
+        const double q4 = q * q * q * q;
+        double acc = 1.0;
+        for (int l = 0; l < 64; l++) { acc *= q4; pt[(size_t)l] = (float)acc; }      // q^(4 (l+1)): a lane owns four audio outputs
+        return upload(d_ptab4, pt.data(), pt.size() * sizeof(float));
+    }
+
+    long run_two(const void *in_dev, unsigned long n_in, void *out_dev, unsigned long cap)
+    {
+        const unsigned long need = A->max_output(n_in);
+        if (mid.reserve((size_t)need * sizeof(float) + 16)) return -1;
+        long m = A->run(in_dev, n_in, mid.p, need);
+        if (m < 0) return m;
+        last_form = 2;
+        return B->run(mid.p, (unsigned long)m, out_dev, cap);
+    }
+
+    long run(const void *in_dev, unsigned long n_in, void *out_dev, unsigned long cap) override
+    {
+        static const bool env_off = getenv("LRHIP_NO_SINGLE_LAUNCH") != nullptr;      // A/B knob
+        const long n = (long)n_in;
+        const long n_out_a = (unsigned long)n > A->index ? (long)((n - (long)A->index + RX_D - 1) / RX_D) : 0;
+        const long n_out_b = (unsigned long)n_out_a > B->index ? (long)((n_out_a - (long)B->index + RX_D - 1) / RX_D) : 0;
+        if (!single_launch || env_off || n_out_b < 1 || ((uintptr_t)in_dev % 8) != 0) return run_two(in_dev, n_in, out_dev, cap);
+        if ((unsigned long)n_out_b > cap) return set_error("fm-receiver: output capacity %lu < %ld", cap, n_out_b);
+        const float *x = (const float *)in_dev;
+        const size_t lds_bytes = (size_t)RX_LDS_FLOATS * sizeof(float);
+        if (!blocks_per_cu) {
+            LR_HIP(hipFuncSetAttribute((const void *)rx_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            int nb = 0;
+            LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rx_fused_kernel, 256, lds_bytes));
+            blocks_per_cu = nb < 1 ? 1 : nb;
+        }
+        RxParams pr;
+        memset(&pr, 0, sizeof(pr));
+        pr.hist = (const float *)A->hist[A->cur].p; pr.x = x; pr.n = n; pr.taps_pad = (const float *)A->d_atab.p;
+        pr.n_out_a = n_out_a; pr.first_a = (long)A->index;
+        const long v = (long)((uintptr_t)x / 8) + (long)A->index - (RX_M - 1);      // 16-B alignment of the staged window: slack of 0 or 1 sample
+        pr.e = (int)(((v % 2) + 2) % 2);
+        pr.ntiles = (n_out_a + RX_TILE - 1) / RX_TILE;
+        pr.rot_step_fx = A->rot_step; pr.rot_count0 = A->count;
+        float2 *dp = (float2 *)A->disc_prev.p;
+        pr.prev_in = dp + A->disc_cur; pr.prev_out = dp + (A->disc_cur ^ 1);
+        pr.inv_gain = 1.0 / A->disc_gain;
+        pr.hist_out = (float *)A->hist[A->cur ^ 1].p;
+        pr.g_pad = (const float *)B->d_atab.p;
+        pr.thist_in = (const float *)B->hist[B->cur].p; pr.thist_out = (float *)B->hist[B->cur ^ 1].p;
+        pr.first_b = (long)B->index; pr.n_out_b = n_out_b; pr.y = (float *)out_dev;
+        pr.b0 = B->iir_b0; pr.na1 = B->iir_na1; pr.na1_lo = B->iir_na1_lo; pr.ptab4 = (const float *)d_ptab4.p;
+        pr.state_in = (const float *)B->iir_state[B->iir_cur].p; pr.state_out = (float *)B->iir_state[B->iir_cur ^ 1].p;
+        pr.nbatches = (pr.ntiles + RX_TPB - 1) / RX_TPB;
+        // one round of workgroups: as many as fit the chip at once (fewer for short chunks: a run is at least one batch)
+        long wgs = (long)ctx().num_cus * blocks_per_cu;
+        if (getenv("LRHIP_RX_WGS_PER_CU")) wgs = (long)ctx().num_cus * atol(getenv("LRHIP_RX_WGS_PER_CU"));      // A/B knob
+        if (wgs < 1 || wgs > pr.nbatches) wgs = pr.nbatches;
+        pr.dbg = getenv("LRHIP_RX_DBG") ? atoi(getenv("LRHIP_RX_DBG")) : 0;      // ablation bits (wrong results)
+        const unsigned grid = (unsigned)wgs;
+        hipLaunchKernelGGL(rx_fused_kernel, dim3(grid), dim3(256), lds_bytes, ctx().stream, pr);
+        LR_LAUNCH_CHECK();
+        // what FirStage::core() does for each of the two stages
+        A->hist_in_kernel = true; A->fix_ready = false;
+        A->cur ^= 1; A->disc_cur ^= 1;
+        A->index = A->index + (unsigned long)n_out_a * RX_D - (unsigned long)n;
+        A->count += (uint64_t)n;
+        B->cur ^= 1; B->iir_cur ^= 1;
+        B->index = B->index + (unsigned long)n_out_b * RX_D - (unsigned long)n_out_a;
+        B->count += (uint64_t)n_out_a;
+        last_form = 1;
+        return n_out_b;
+    }
+};
