@@ -53,8 +53,8 @@ def main():
         whole = lr.wbfm_mono_receiver(FS, OFFSET).process(x)
         for parts in (2, 4, 8):
             got = np.concatenate([partition_audio(x, a, b, rx) for a, b in timeshard.bounds(n, parts, align)])
-            assert np.array_equal(got, whole), parts
-        print("selftest ok: halo %d samples, boundaries on multiples of %d, 2 / 4 / 8 partitions bit-equal to one stream (%d audio samples)"
+            assert len(got) == len(whole) and float(np.max(np.abs(got - whole))) < 1e-7, parts      # single-launch receiver: to its 1e-10 warm-up (bit for bit with Chain(..., CHAIN_NO_SINGLE_LAUNCH))
+        print("selftest ok: halo %d samples, boundaries on multiples of %d, 2 / 4 / 8 partitions equal one stream to 1e-7 (%d audio samples)"
               % (rx.halo(), align, len(whole)))
         return
     if not args.recording or not args.audio:

@@ -10,8 +10,8 @@
 //   * a workgroup owns a contiguous RUN of tuner tiles (512 discriminator samples each: one accumulator per wave).  Ten tiles are a BATCH:
 //     5 120 discriminator samples = 1 024 audio samples.  The discriminator epilogue (in registers, disc_epilogue of kernels_fir.h) writes its
 //     angles straight into the batch window P in LDS, in the padded-row layout of the Float32 Toeplitz product (FirMfmaGeom<1, 5>);
-//     the first output of every wave needs the previous wave's last filter output - the waves leave (first, last) in LDS and one lane per
-//     wave patches that sample after the tile's closing barrier.  No edge records in HBM, no fix-up launch, nothing for a next kernel to patch;
+//     the first output of every wave needs the previous wave's last filter output - the waves leave it in LDS in front of the barrier that
+//     frees the RF window, and lane 0 picks it up behind it, before the angles are computed.  No edge records in HBM, no fix-up launch, nothing for a next kernel to patch;
 //   * after the tenth tile the 136-tap decimating filter runs on P as ONE MORE Toeplitz product on the matrix cores (54 steps, an accumulator
 //     of 256 audio samples per wave; the same fmaf chain in ascending tap order as every direct-form filter of the library).  A first cut
 //     did this on the packed VALU, one output per lane and pair of batch halves: 544 B of LDS reads per audio sample made the pass
@@ -57,8 +57,8 @@ struct RxParams {
     const float *state_in;
     float *state_out;
     // ---- runs
-    long nbatches;               // batches in the chunk (dealt out evenly over the grid)
-    int dbg;                     // ablation bits (LRHIP_RX_DBG; wrong results): 1 no audio filter loop, 2 no discriminator arithmetic, 4 no MFMA loop
+    int min_tiles;               // (host) a run is at least this many tiles
+    int dbg;                     // ablation bits (LRHIP_RX_DBG; wrong results): 1 no audio product, 2 no discriminator arithmetic, 4 no tuner MFMA loop, 8 no HBM reads
 };
 
 constexpr int RX_D = 5, RX_KS = 51, RX_M = 128, RX_MT = 136;
@@ -76,7 +76,7 @@ constexpr int RX_PSPAN = FirMfmaGeom<1, RX_D>::span(1, RX_KST);       // 5 256 =
 constexpr int RX_PF = ((FirMfmaGeom<1, RX_D>::phys(RX_PSPAN) + FirMfmaGeom<1, RX_D>::PAD + 3) / 4) * 4;
 constexpr int RX_GZ = 4;                                              // extra leading zeros of the audio tap table: slack up to 4 (fir_taps_zl covers 3)
 constexpr int RX_GLEN = RX_GZ + fir_taps_len(RX_D, RX_KST);
-// LDS map (floats): [taps_pad TLEN | window XF (the audio pass reuses its head as the 1 024-float output row) | P | audio taps GLEN | ptab4 64 | xch 8 | eo 16 | prevabs 4]
+// LDS map (floats): [taps_pad TLEN | window XF (the audio pass reuses its head as the 1 024-float output row) | P | audio taps GLEN | ptab4 64 | xch 8 | eo 16 | 4]
 constexpr int RX_LDS_X = RX_TLEN;
 constexpr int RX_LDS_P = RX_LDS_X + ((RX_XF + 3) / 4) * 4;
 constexpr int RX_LDS_G = RX_LDS_P + RX_PF;
@@ -103,8 +103,7 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
     static_assert(2 * UX <= 64, "one lane per uniform phasor");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *ldsT = lds, *ldsX = lds + RX_LDS_X, *P = lds + RX_LDS_P, *ldsGT = lds + RX_LDS_G, *ldsPt = lds + RX_LDS_PT, *xch = lds + RX_LDS_XCH;
-    float2 *eo = reinterpret_cast<float2 *>(lds + RX_LDS_EO);         // eo[2 w] = first, eo[2 w + 1] = last filter output of wave w (tile basis)
-    float2 *prevabs = reinterpret_cast<float2 *>(lds + RX_LDS_PREV);  // the filter output before the current tile, absolute phase
+    float2 *eo = reinterpret_cast<float2 *>(lds + RX_LDS_EO);         // eo[4 (t & 1) + w] = last filter output of wave w in tile t (tile basis)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long n = pr.n;
     const float *__restrict__ x = pr.x;
@@ -122,21 +121,23 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
     __syncthreads();
 
     // ---- this workgroup's run
-    // the chunk's batches are dealt out as evenly as whole batches allow: the first (nbatches mod grid) workgroups take one more
-    const long bbase = pr.nbatches / gridDim.x, brem = pr.nbatches % gridDim.x;
-    const long bfirst = (long)blockIdx.x * bbase + ((long)blockIdx.x < brem ? (long)blockIdx.x : brem);
-    const long bend = bfirst + bbase + ((long)blockIdx.x < brem ? 1 : 0);
-    const long tend = bend * RX_TPB < pr.ntiles ? bend * RX_TPB : pr.ntiles;
-    const bool chunk_start = bfirst == 0;
-    long t = chunk_start ? 0 : bfirst * RX_TPB - 1;                   // the tile in front of the run: history + warm-up, output discarded
+    // the chunk's TILES are dealt out evenly (the first ntiles mod grid workgroups take one more); a run's batches count from its own first tile,
+    // so the audio outputs of a run are those whose window ends inside its tiles: m0 <= m < m1, and `phi` is the position of output m0's last
+    // sample in the run's first tile (0 .. 4)
+    const long tbase = pr.ntiles / gridDim.x, trem = pr.ntiles % gridDim.x;
+    const long t0 = (long)blockIdx.x * tbase + ((long)blockIdx.x < trem ? (long)blockIdx.x : trem);
+    const long tend = t0 + tbase + ((long)blockIdx.x < trem ? 1 : 0);
+    const long m0 = (t0 * RX_TILE - pr.first_b + 4) / 5, m1 = (tend * RX_TILE - pr.first_b + 4) / 5;
+    const int phi = (int)(pr.first_b + 5 * m0 - t0 * RX_TILE);
+    const bool chunk_start = t0 == 0;
+    long t = chunk_start ? 0 : t0 - 1;                                // the tile in front of the run: history + warm-up, output discarded
+    const long tfirst = t;
     float carry = 0.f;
     if (chunk_start) {
         if (tid < RX_TH) P[rx_pos(tid - RX_TH)] = pr.thist_in[tid];
         carry = pr.state_in[0];
-        if (tid == 0) *prevabs = *pr.prev_in;
-    } else if (tid == 0) {
-        *prevabs = make_float2(0.f, 0.f);
     }
+    const cf tileR = phasor_poly(pr.rot_step_fx * (uint64_t)(RX_TILE * RX_D));      // phase basis of tile t+1 over that of tile t
 
     auto xlo_of = [&](long tt) { return pr.first_a + tt * (long)RX_TILE * D - pr.e - (M - 1); };
     auto interior = [&](long tt) { const long lo = xlo_of(tt); return tt < tend && lo >= 0 && lo + RX_SPAN <= n; };
@@ -155,7 +156,10 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
     bool have = false;
     auto prefetch = [&](long tt) {
         have = interior(tt);
-        if (have) {
+        if (have && (pr.dbg & 8)) {                                   // ablation: no HBM reads
+#pragma unroll
+            for (int u = 0; u < UX; u++) pre[u] = make_float4(0.5f, 0.25f, -0.5f, 0.125f);
+        } else if (have) {
             const float4 *src = reinterpret_cast<const float4 *>(x + xlo_of(tt) * S);
 #pragma unroll
             for (int u = 0; u < UX; u++) {
@@ -167,9 +171,9 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
     prefetch(t);
 
     for (; t < tend; t++) {
-        const int tau = (int)(t % RX_TPB);                            // place of the tile in its batch (the warm-up tile is the last of its batch)
-        const long bidx = t / RX_TPB;
-        const bool warm = t < bfirst * RX_TPB;
+        const bool warm = t < t0;
+        const int tau = warm ? RX_TPB - 1 : (int)((t - t0) % RX_TPB);  // place of the tile in its batch (the warm-up tile: the last of the batch in front)
+        const long bidx = warm ? 0 : (t - t0) / RX_TPB;               // batch of the run
         const long tile_k0 = t * (long)RX_TILE;
         // ---- stage the RF window, rotated relative to its first sample
         if (have) {
@@ -190,7 +194,11 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
         if (pr.dbg & 4) acc[0][0] = (f32x4){ldsX[tid], ldsX[tid + 256], ldsX[tid + 512], ldsX[tid + 768]};
         else mfma_tile<S, D, 1, RX_KS, 1>(ldsT, RX_TLEN, pr.e, ldsX, RX_KS, acc);
 
-        // ---- discriminator on the accumulators -> P
+        // ---- discriminator on the accumulators -> P.  After the re/im exchange a lane owns two consecutive filter outputs; the one in front of them is
+        // one shuffle away - except for lane 0, whose predecessor is the previous wave's last output (through LDS, after the barrier that also
+        // frees the window) or, for wave 0, the previous TILE's last output, which lives in that tile's phase basis: bases of consecutive tiles
+        // differ by the constant phasor R = exp(j omega TILE D), so lane 0 takes prev * conj(R).  Only a run's very first sample meets a
+        // predecessor in absolute phase (the carried one) and pays for the tile's own phasor.
         {
             const int col = lane & 15, kq = lane >> 4;
             const bool odd = col & 1;
@@ -200,43 +208,36 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
             const float recv1 = __shfl_xor(odd ? a1 : a3, 1);
             const float2 o0 = odd ? make_float2(recv0, a2) : make_float2(a0, recv0);
             const float2 o1 = odd ? make_float2(recv1, a3) : make_float2(a1, recv1);
-            const float2 p = make_float2(__shfl(o1.x, src), __shfl(o1.y, src));            // lane 0: not its predecessor - patched below
-            const float2 d = (pr.dbg & 2) ? make_float2(o0.x + p.x, o1.y) : make_float2(discriminate(o0, p, pr.inv_gain), discriminate(o1, o0, pr.inv_gain));
+            float2 p = make_float2(__shfl(o1.x, src), __shfl(o1.y, src));
+            float2 *eo_t = eo + 4 * (int)(t & 1), *eo_p = eo + 4 * (int)((t & 1) ^ 1);     // last outputs of the four waves: this tile's, the previous tile's
+            if (lane == 63) eo_t[wave] = o1;
+            __syncthreads();                                          // (B) window free; the waves' last outputs are visible
+            // (+ 0: a silent stretch gives exactly +0 filter outputs, but +0 times a phasor with negative parts is -0, and the angle of a zero product
+            // is decided by the signs of the zeros - frequencydiscriminator.lua:74 via discriminate(): keep what the reference's own operands would be)
+            if (lane == 0) p = wave ? eo_t[wave - 1] : cf_to(cmulc(cf_from(eo_p[3]), tileR) + cf{0.f, 0.f});
+            float2 d = (pr.dbg & 2) ? make_float2(o0.x + p.x, o1.y) : make_float2(discriminate(o0, p, pr.inv_gain), discriminate(o1, o0, pr.inv_gain));
             const int lk = wave * 128 + 16 * (col >> 1) + 4 * kq + (odd ? 2 : 0);          // tile-local index of o0
+            const long k = tile_k0 + lk;
+            if (t == tfirst && tid == 0) {
+                // the run's first sample: the carried output is in absolute phase (zero in front of a warm-up tile, whose first angle is never used)
+                const cf pt = phasor_poly(pr.rot_step_fx * (pr.rot_count0 + (uint64_t)xlo_of(t)));
+                d.x = discriminate(cf_to(cmul(cf_from(o0), pt) + cf{0.f, 0.f}), chunk_start ? *pr.prev_in : make_float2(0.f, 0.f), pr.inv_gain);
+            }
             const int b = tau * RX_TILE + lk;
             P[rx_pos(b)] = d.x;
             P[rx_pos(b + 1)] = d.y;
-            if (lane == 0) eo[2 * wave] = o0;
-            if (lane == 63) eo[2 * wave + 1] = o1;
             // the chunk's last tuner output, in absolute phase, for the next chunk
-            const long k = tile_k0 + lk;
             if (k == pr.n_out_a - 1 || k + 1 == pr.n_out_a - 1) {
                 const cf pt = phasor_poly(pr.rot_step_fx * (pr.rot_count0 + (uint64_t)xlo_of(t)));
-                *pr.prev_out = cf_to(cmul(cf_from(k == pr.n_out_a - 1 ? o0 : o1), pt));
+                *pr.prev_out = cf_to(cmul(cf_from(k == pr.n_out_a - 1 ? o0 : o1), pt) + cf{0.f, 0.f});
             }
-        }
-        __syncthreads();                                              // (B) window free; P and eo complete
-        if (lane == 0) {
-            // first output of this wave's range: its predecessor is the previous wave's last output (same tile basis), or - wave 0 - the
-            // previous tile's, which lives in absolute phase
-            const float2 of = eo[2 * wave];
-            float dv;
-            if (wave) {
-                dv = discriminate(of, eo[2 * wave - 1], pr.inv_gain);
-            } else {
-                const cf pt = phasor_poly(pr.rot_step_fx * (pr.rot_count0 + (uint64_t)xlo_of(t)));
-                dv = discriminate(cf_to(cmul(cf_from(of), pt)), *prevabs, pr.inv_gain);
-                *prevabs = cf_to(cmul(cf_from(eo[7]), pt));
-            }
-            P[rx_pos(tau * RX_TILE + wave * 128)] = dv;
         }
 
         const bool last_tile = t == pr.ntiles - 1;
-        if (tau == RX_TPB - 1 || last_tile) {
-            __syncthreads();                                          // (P) patches visible
+        if (tau == RX_TPB - 1 || t == tend - 1) {
+            __syncthreads();                                          // (P) the batch's angles are all in P
             // ---- audio: the 136-tap decimating filter as a Toeplitz product on P (slack = the tail's carried downsampler index), 256 outputs per wave.
             // In front of a run only the last tile of the batch is real: its 75 whole windows are all in wave 3's accumulator
-            const int phi = (int)pr.first_b;
             f32x4 acct[1][1];
             acct[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (!(pr.dbg & 1) && (!warm || wave == 3)) mfma_tile<1, D, 1, RX_KST, 1>(ldsGT + RX_GZ, RX_GLEN - RX_GZ, phi, P, RX_KST, acct);
@@ -276,18 +277,19 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
             if (lane == 0) st = Cw;
             const float y0 = stepq(st, u0), y1 = stepq(y0, u1), y2 = stepq(y1, u2), y3 = stepq(y2, u3);
             if (!warm) {
-                const long m = bidx * RX_AUDIO + 4 * tid;
-                if (m + 3 < pr.n_out_b && (reinterpret_cast<uintptr_t>(pr.y) & 15) == 0) {
+                const long m = m0 + bidx * RX_AUDIO + 4 * tid;
+                const long mend = m1 < pr.n_out_b ? m1 : pr.n_out_b;  // outputs past the run's last tile belong to the next run
+                if (m + 3 < mend && (reinterpret_cast<uintptr_t>(pr.y + m) & 15) == 0) {
                     *reinterpret_cast<float4 *>(pr.y + m) = make_float4(y0, y1, y2, y3);
                 } else {
-                    if (m < pr.n_out_b) pr.y[m] = y0;
-                    if (m + 1 < pr.n_out_b) pr.y[m + 1] = y1;
-                    if (m + 2 < pr.n_out_b) pr.y[m + 2] = y2;
-                    if (m + 3 < pr.n_out_b) pr.y[m + 3] = y3;
+                    if (m < mend) pr.y[m] = y0;
+                    if (m + 1 < mend) pr.y[m + 1] = y1;
+                    if (m + 2 < mend) pr.y[m + 2] = y2;
+                    if (m + 3 < mend) pr.y[m + 3] = y3;
                 }
                 // the carried state: a chunk that ends inside the batch hands over the value at its last output; one that ends WITH the batch
                 // the scanned end state C - what the next batch of an uninterrupted run is given (fir_win_cplx_kernel's rule)
-                const bool ends_with_batch = pr.n_out_b == (bidx + 1) * RX_AUDIO;
+                const bool ends_with_batch = pr.n_out_b == m0 + (bidx + 1) * RX_AUDIO;
                 const long last = pr.n_out_b - 1 - m;
                 if (!ends_with_batch && last >= 0 && last < 4) pr.state_out[0] = last == 0 ? y0 : last == 1 ? y1 : last == 2 ? y2 : y3;
                 if (ends_with_batch && tid == 0) pr.state_out[0] = C;
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
             __syncthreads();                                          // (Q) every wave is done reading P
             if (last_tile) {
                 // the chunk's last 135 discriminator samples for the next chunk
-                const int ev = (int)(pr.n_out_a - bidx * RX_BATCH);   // valid samples of this batch, 1 .. 5120
+                const int ev = (int)(pr.n_out_a - (t0 * RX_TILE + bidx * RX_BATCH));   // valid samples of this batch, 1 .. 5120
                 if (tid < RX_TH) pr.thist_out[tid] = P[rx_pos(ev - RX_TH + tid)];
             } else if (tid < RX_TH) {
                 P[rx_pos(tid - RX_TH)] = P[rx_pos(RX_BATCH - RX_TH + tid)];      // history of the next batch = the end of this one (visible after barrier A)

@@ -96,11 +96,11 @@ struct RxStage : lrhip_stage {
         pr.first_b = (long)B->index; pr.n_out_b = n_out_b; pr.y = (float *)out_dev;
         pr.b0 = B->iir_b0; pr.na1 = B->iir_na1; pr.na1_lo = B->iir_na1_lo; pr.ptab4 = (const float *)d_ptab4.p;
         pr.state_in = (const float *)B->iir_state[B->iir_cur].p; pr.state_out = (float *)B->iir_state[B->iir_cur ^ 1].p;
-        pr.nbatches = (pr.ntiles + RX_TPB - 1) / RX_TPB;
-        // one round of workgroups: as many as fit the chip at once (fewer for short chunks: a run is at least one batch)
+        // one round of workgroups: as many as fit the chip at once; a run costs one extra tile, so short chunks take fewer, longer runs
         long wgs = (long)ctx().num_cus * blocks_per_cu;
         if (getenv("LRHIP_RX_WGS_PER_CU")) wgs = (long)ctx().num_cus * atol(getenv("LRHIP_RX_WGS_PER_CU"));      // A/B knob
-        if (wgs < 1 || wgs > pr.nbatches) wgs = pr.nbatches;
+        const long most = (pr.ntiles + 7) / 8;
+        if (wgs < 1 || wgs > most) wgs = most;
         pr.dbg = getenv("LRHIP_RX_DBG") ? atoi(getenv("LRHIP_RX_DBG")) : 0;      // ablation bits (wrong results)
         const unsigned grid = (unsigned)wgs;
         hipLaunchKernelGGL(rx_fused_kernel, dim3(grid), dim3(256), lds_bytes, ctx().stream, pr);

@@ -107,8 +107,9 @@ def test_no_fusion_flag_and_unknown_bits():
 def test_start_at_drops_the_replayed_halo_inside_the_library(entry):
     n = 1 << 20
     x = fm_signal(n, seed=9)
-    whole = lr.Chain(receiver_blocks()).process(x)
-    chain = lr.Chain(receiver_blocks())
+    # the two-launch form: partitions on the tile grid are bit-identical (the single launch agrees to its recurrence warm-up, tests/test_gpu_rx.py)
+    whole = lr.Chain(receiver_blocks(), _lib.CHAIN_NO_SINGLE_LAUNCH).process(x)
+    chain = lr.Chain(receiver_blocks(), _lib.CHAIN_NO_SINGLE_LAUNCH)
     align = chain.shard_align()
     first = 4 * align                                   # a partition boundary on the tile grid: bit-identical
     s = chain.start_at(first)
@@ -128,7 +129,7 @@ def test_start_at_drops_the_replayed_halo_inside_the_library(entry):
         got = np.concatenate(parts)
         assert len(got) == len(want) and np.array_equal(got, want)
     # an unaligned first sample: same values to Float32 rounding (documented), never duplicated or missing samples
-    chain2 = lr.Chain(receiver_blocks())
+    chain2 = lr.Chain(receiver_blocks(), _lib.CHAIN_NO_SINGLE_LAUNCH)
     first2 = 3 * align + 12350                          # multiple of 25: the output grid of the single stream
     s2 = chain2.start_at(first2)
     got2 = chain2.process(x[s2:])

@@ -93,16 +93,21 @@ def test_fir_iir_fused_many_tiles_many_workgroups():
         assert G.max_abs_err(g, want[:len(g)]) < 1e-6, s0
 
 
-def test_wbfm_receiver_is_two_launches():
-    """tuner + discriminator (Toeplitz MFMA) and the audio tail (pair-mode window kernel, which also applies the tuner's wave-boundary fix-up while
-    it stages its window); ragged chunks exercise the patched history and edge tiles, against the oracle chain"""
+@pytest.mark.parametrize("two_launch", [True, False])
+def test_wbfm_receiver_launch_forms(two_launch):
+    """round 3: ONE launch (kernels_rx.h) by default; LRHIP_CHAIN_NO_SINGLE_LAUNCH keeps the round-2 form - tuner + discriminator (Toeplitz MFMA)
+    and the audio tail (pair-mode window kernel, which also applies the tuner's wave-boundary fix-up while it stages its window).  Ragged chunks
+    exercise the carried state and edge tiles of both, against the oracle chain"""
+    from luaradio_amd import _lib
     fs = 1102500.0
     rx = lr.wbfm_mono_receiver(fs, -250e3)
+    if two_launch:
+        rx._chain = lr.Chain(rx._blocks, _lib.CHAIN_NO_SINGLE_LAUNCH)
     rng = np.random.default_rng(9)
     n = 1 << 19
     x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
     got = chunked(rx, x, [1, 2, 1281, 70001, 70002, 300000])
-    assert rx.chain.last_launches == 2
+    assert rx.chain.last_launches == (2 if two_launch else 1)
     want = O.wbfm_mono_chain(fs, -250e3, mode=O.MODE_LUA, rot_mode=O.MODE_F64).process(x)
     assert len(got) == len(want)
     err = got.astype(np.float64) - want.astype(np.float64)

@@ -1,0 +1,115 @@
+"""The FM receiver as ONE launch (luaradio_amd/csrc/kernels_rx.h; examples/rtlsdr_wbfm_mono.lua:12-17 after DeviceChainBlock.collapse).
+
+No chain-level vector exists in the reference (unpinned), so the bar is the composition of the per-block-pinned oracle
+restatements (RMS <= 1e-5, north_star) plus the properties the single launch must keep: it carries exactly the state of the two-launch
+form (the two may alternate chunk by chunk), any chunking gives the same audio to Float32 rounding, a run boundary between workgroups
+leaves no seam, and the sample count never depends on how the stream was cut."""
+import numpy as np
+import pytest
+
+import luaradio_amd as lr
+from luaradio_amd import _lib
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+FS = 1102500.0
+
+
+def fm(n, seed=3, noise=0.01):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / FS
+    m = 0.5 * np.sin(2 * np.pi * 1e3 * t) + 0.5 * np.sin(2 * np.pi * 5e3 * t)
+    ph = 2 * np.pi * 250e3 * t + 2 * np.pi * 75e3 / FS * np.cumsum(m)
+    return (np.exp(1j * ph) + noise * (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n))).astype(np.complex64)
+
+
+def receiver(flags=0):
+    rx = lr.wbfm_mono_receiver(FS, -250e3)
+    if flags:
+        rx._chain = lr.Chain(rx._blocks, flags)
+    return rx
+
+
+def chunked(rx, x, cuts):
+    parts, a = [], 0
+    for b in list(cuts) + [len(x)]:
+        parts.append(rx.process(x[a:b]))
+        a = b
+    return np.concatenate(parts)
+
+
+def test_single_launch_vs_oracle_and_two_launch_form():
+    n = 2500000                                          # 245 tiles: 31 runs of 8 tiles - run boundaries, partial batches, a partial last tile
+    x = fm(n)
+    one, two = receiver(), receiver(_lib.CHAIN_NO_SINGLE_LAUNCH)
+    a, b = one.process(x), two.process(x)
+    assert one.chain.last_launches == 1 and two.chain.last_launches == 2
+    assert len(a) == len(b) == (n + 24) // 25
+    assert float(np.max(np.abs(a - b))) < 2e-7           # same arithmetic up to the recurrence's scan order and the audio filter's block placement
+    want = O.wbfm_mono_chain(FS, -250e3, mode=O.MODE_LUA, rot_mode=O.MODE_F64).process(x[:1000000])
+    k = len(want) - 8
+    err = a[:k].astype(np.float64) - want[:k]
+    assert float(np.sqrt(np.mean(err ** 2))) <= 1e-5 and float(np.max(np.abs(err))) < 1e-6
+    # no seam where one workgroup's run ends and the next begins: the error against the two-launch form is flat over the whole vector
+    d = np.abs(a.astype(np.float64) - b)
+    assert float(d[len(d) // 2:].max()) < 2e-7 and float(d.max()) < 2e-7
+
+
+@pytest.mark.parametrize("cuts", [[1], [5], [24, 25, 26], [8192, 8193, 500000], [12800 * 7, 12800 * 7 + 3, 12800 * 7 + 9, 1500000],
+                                  list(range(100000, 2000000, 333337)), list(range(8192, 400000, 8192))])
+def test_chunking_changes_nothing_but_float32_rounding(cuts):
+    x = fm(2000000, seed=5)
+    whole = receiver().process(x)
+    got = chunked(receiver(), x, cuts)
+    assert len(got) == len(whole)
+    assert float(np.max(np.abs(got - whole))) < 2e-7
+
+
+def test_forms_alternate_chunk_by_chunk_on_the_same_state():
+    """the single launch reads and writes the two stages' own state buffers, so a chain may take either form from one chunk to the next
+    (what happens when a chunk is too short to emit an audio sample, or its device pointer is not 8-byte aligned)"""
+    x = fm(1500000, seed=7)
+    whole = receiver().process(x)
+    rx = receiver()
+    # 3-sample and 20-sample chunks emit no audio sample on their own -> two-launch form; the long ones take the single launch
+    cuts = [400000, 400003, 400023, 900000, 900001, 900002, 900020]
+    forms, parts, a = [], [], 0
+    for b in cuts + [len(x)]:
+        parts.append(rx.process(x[a:b]))
+        forms.append(rx.chain.last_launches)
+        a = b
+    got = np.concatenate(parts)
+    assert 1 in forms and max(forms) >= 2
+    assert len(got) == len(whole) and float(np.max(np.abs(got - whole))) < 2e-7
+
+
+def test_weak_and_silent_input_stays_finite():
+    """zeros and denormal-level input: angles of zero products follow the reference's sign rule; nothing in the window may turn into NaN
+    through the Toeplitz product's zero taps"""
+    n = 600000
+    x = np.zeros(n, np.complex64)
+    x[200000:400000] = fm(200000, seed=9, noise=0.0) * np.float32(1e-30)
+    got = receiver().process(x)
+    want = O.wbfm_mono_chain(FS, -250e3, mode=O.MODE_LUA, rot_mode=O.MODE_F64).process(x)
+    assert len(got) == len(want) and np.all(np.isfinite(got))
+    # silent stretches: exactly the reference's zeros (a -0 in a filter output would turn one angle per tile into pi)
+    lead = 200000 // 25 - 8
+    assert float(np.max(np.abs(got[:lead]))) == 0.0 and float(np.max(np.abs(want[:lead]))) == 0.0
+    # the weak stretch: products of 1e-30-level outputs underflow, the angles are ill-conditioned - finite and bounded is all that can be asked
+    assert float(np.max(np.abs(got))) < 1.0
+    # the tail after the weak stretch decays back to silence like the oracle's
+    assert float(np.max(np.abs(got[-2000:] - want[-2000:]))) < 1e-6
+
+
+def test_time_partitions_of_the_single_launch_receiver():
+    """lrhip_chain_start_at on the single-launch form: the partition's audio equals the single stream's to the warm-up's 1e-9 (run boundaries
+    fall differently in a partition, so this form is not bit-identical there; LRHIP_CHAIN_NO_SINGLE_LAUNCH is)"""
+    n = 1 << 21
+    x = fm(n, seed=11)
+    whole = receiver().process(x)
+    for first in (128000 * 3, 128000 * 9 + 12825):
+        rx = receiver()
+        s = rx.chain.start_at(first)
+        got = rx.process(x[s:])
+        want = whole[(first + 24) // 25:]
+        assert len(got) == len(want) and float(np.max(np.abs(got - want))) < 5e-5

@@ -136,6 +136,7 @@ def _chains():
         "lowpass": lambda: init([lr.LowpassFilterBlock(128, 50e3)]),
         "translate+downsample": lambda: init([lr.FrequencyTranslatorBlock(-1e5), lr.DownsamplerBlock(7)]),
         "wbfm": lambda: lr.wbfm_mono_receiver(rate, -250e3),
+        "wbfm-two-launch": lambda: lr.Chain(lr.wbfm_mono_receiver(rate, -250e3)._blocks, lr._lib.CHAIN_NO_SINGLE_LAUNCH),
         "deemphasis": lambda: init([lr.ComplexToRealBlock(), lr.FMDeemphasisFilterBlock(75e-6)]),
         "disc+lowpass+deemphasis": lambda: init([lr.FrequencyDiscriminatorBlock(1.25), lr.FIRFilterBlock(O_taps(), "fast"), lr.FMDeemphasisFilterBlock(75e-6)]),
     }
@@ -147,7 +148,7 @@ def O_taps():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["tuner", "tuner+disc", "lowpass", "translate+downsample", "wbfm", "deemphasis", "disc+lowpass+deemphasis"])
+@pytest.mark.parametrize("name", ["tuner", "tuner+disc", "lowpass", "translate+downsample", "wbfm", "wbfm-two-launch", "deemphasis", "disc+lowpass+deemphasis"])
 def test_virtual_partitions_on_one_device_bit_equal_to_the_single_stream(name):
     """G in {2, 4, 8} partitions of one stream, each started with lrhip_chain_seek + the chain's halo, concatenated ==
     the uninterrupted run, bit for bit (boundaries on multiples of the chain's shard_align())"""
@@ -161,12 +162,18 @@ def test_virtual_partitions_on_one_device_bit_equal_to_the_single_stream(name):
         assert 0 < h < 200000 or name == "translate+downsample"
         align = chain.shard_align()
         # tuner + discriminator: the tile grid of the window-relative rotator staging (1024 outputs x 5); the WBFM receiver = lcm with its tail's 64000
-        assert align == {"tuner+disc": 5120, "wbfm": 128000, "deemphasis": 4096, "disc+lowpass+deemphasis": 4096 * 7}.get(name, 1)
+        assert align == {"tuner+disc": 5120, "wbfm": 128000, "wbfm-two-launch": 128000, "deemphasis": 4096, "disc+lowpass+deemphasis": 4096 * 7}.get(name, 1)
         got = np.concatenate([timeshard.run_partition(chain, x, a, b) for a, b in timeshard.bounds(n, parts, 4096 * align if align == 1 else align)])
         assert len(got) == len(whole), (name, parts)
         if name == "disc+lowpass+deemphasis":
             # overlap-save arithmetic: the first block of a chunk takes its history from the carried buffer instead of the stream, which
             # rounds differently - same values to Float32 rounding (the block's own parity bar is 1e-6)
+            assert float(np.max(np.abs(got - whole))) < 1e-7, (name, parts)
+        elif name == "wbfm":
+            # the single-launch receiver (kernels_rx.h) deals its tiles out over one round of workgroups, and a run that does not start the
+            # chunk warms its recurrence up from zero over 75 audio samples (q^75 = 1.4e-10) instead of carrying state between workgroups:
+            # where the runs fall depends on the chunk length, so a partition agrees with the single stream to that warm-up, not bit for
+            # bit (tuner, discriminator and audio filter do - their tiles are pure functions of their windows); the two-launch form below does
             assert float(np.max(np.abs(got - whole))) < 1e-7, (name, parts)
         else:
             assert np.array_equal(got, whole), (name, parts, float(np.max(np.abs(got - whole))))
@@ -219,4 +226,5 @@ def test_example_timeshard_wbfm_selftest_and_file_mode(tmp_path):
     r = subprocess.run([sys.executable, ex, str(rec), str(out), "--parts", "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     want = lr.wbfm_mono_receiver(1102500.0, -250e3).process(x)
-    assert np.array_equal(np.fromfile(out, np.float32), want)
+    got = np.fromfile(out, np.float32)
+    assert len(got) == len(want) and float(np.max(np.abs(got - want))) < 1e-7      # single-launch receiver: equal to its recurrence warm-up (1e-10)
