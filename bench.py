@@ -40,8 +40,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fir", choices=["fir", "wbfm", "fanout"])
-    ap.add_argument("--log2-samples", type=int, default=None, help="per-GPU samples per step (default 28 fir, 26 wbfm/fanout)")
+    ap.add_argument("--workload", default="fir", choices=["fir", "wbfm", "fanout", "timeshard"])
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and, for fanout, the RCCL broadcast) even with one rank: "
+                                                              "exercises the N > 1 code path on a single GPU")
+    ap.add_argument("--log2-samples", type=int, default=None, help="per-GPU samples per step (default 28 fir, 26 wbfm/fanout); timeshard: the WHOLE recording (default 28)")
     ap.add_argument("--fir-mode", default="auto", choices=["auto", "direct", "fft"],
                     help="fir workload arithmetic: direct = Toeplitz MFMA (bit-exact fmaf chain); fft = fused overlap-save kernel; "
                          "auto = fft (the faster one; both are parity-tested)")
@@ -162,10 +164,12 @@ def wbfm_chain_report(lr, L, torch, dev, with_cpu):
         for _ in range(4):
             rx.process_device(x.data_ptr(), n, y.data_ptr(), cap)
         torch.cuda.synchronize()
+    rx.reset()                                    # the timed steps then start at absolute sample 0: the last one can be checked against the oracle
     tm = L.lrhip_timer_create()
     L.lrhip_timer_start(tm)
+    got_n = 0
     for _ in range(steps):
-        rx.process_device(x.data_ptr(), n, y.data_ptr(), cap)
+        got_n = rx.process_device(x.data_ptr(), n, y.data_ptr(), cap)
     L.lrhip_timer_stop(tm)
     torch.cuda.synchronize()
     ms = L.lrhip_timer_elapsed_ms(tm) / steps
@@ -173,47 +177,54 @@ def wbfm_chain_report(lr, L, torch, dev, with_cpu):
     rep = {"workload": "configs[2]: Tuner(-250e3, 200e3, 5) -> FrequencyDiscriminator(1.25) -> Lowpass(128, 15e3) -> FMDeemphasis(75e-6) -> "
                        "Downsampler(5), 2^26 RF samples per step, device-resident",
            "value": round(n / ms / 1e3, 1), "unit": "MSamples/s (RF samples in)", "ms_per_step": round(ms, 4), "launches": rx.chain.last_launches,
+           "kernel": "rx_fused_kernel (kernels_rx.h): tuner tiles -> discriminator -> batch window in LDS -> audio filter + recurrence, one launch",
            "algorithmic_GB/s": round(8.16 * n / ms / 1e6, 1)}
     rep["roofline_frac"] = round(8.16 * n / ms / 1e6 / HBM_PEAK_GBS, 4)
     if with_cpu:
-        rep.update(verify_wbfm_chain(lr, torch, x, n, fs, -250e3))
+        rep.update(verify_wbfm_chain(torch, x, y, got_n, n, (steps - 1) * n, fs, -250e3))
     return rep
 
 
-def verify_wbfm_chain(lr, torch, x, n, fs, offset, nslabs=8, slab_rf=262150, warm_rf=100000):
-    """The device chain's audio for the WHOLE 2^26-sample vector against the oracle chain (composition of the pinned per-block
-    restatements) on `nslabs` slabs spread from the first to the last sample.  A slab away from the start runs the oracle
-    from zero state `warm_rf` RF samples early (a multiple of 25 = both decimations; the de-emphasis pole 0.941^4000 and the
-    FIR transients are long gone) and compares the following slab_rf / 25 audio samples.  Also times the oracle (1 core)."""
+def verify_wbfm_chain(torch, x, y, got_n, n, base, fs, offset, nslabs=8, slab_rf=262150, warm_rf=100000):
+    """The audio the LAST TIMED STEP wrote (y, got_n samples) for the whole 2^26-sample vector against the oracle chain (composition of the
+    pinned per-block restatements) on `nslabs` slabs spread from the first to the last sample.  Every step runs the same vector with the
+    state carried from the step before, so the last step covers absolute samples base .. base + n and the samples in front of x[0] are the
+    tail of x.  A slab runs the oracle from zero state about `warm_rf` RF samples early - at an absolute sample that is a multiple of 25,
+    both decimations (the de-emphasis pole 0.941^4000 and the FIR transients are long gone; the discriminator does not see the constant
+    phase the oracle's rotator is off by) - and compares the following slab_rf / 25 audio samples.  Also times the oracle (1 core)."""
     import numpy as np
     from oracle import oracle as O
-    rx = lr.wbfm_mono_receiver(fs, offset)
-    cap = rx.max_output(n)
-    y = torch.empty(cap + 16, dtype=torch.float32, device=x.device)
-    got_n = rx.process_device(x.data_ptr(), n, y.data_ptr(), cap)
-    torch.cuda.synchronize()
-    starts = [0] + [int((n - slab_rf) * k / (nslabs - 1)) // 25 * 25 for k in range(1, nslabs)]
+    first_audio = (base + 24) // 25                          # absolute index of the step's first audio sample
+    starts = [0] + [int((n - slab_rf) * k / (nslabs - 1)) for k in range(1, nslabs)]
     se, cnt, worst, cpu_s, cpu_n = 0.0, 0, 0.0, 0.0, 0
     for s0 in starts:
-        lo = max(0, s0 - warm_rf)
-        xs = x[2 * lo:2 * (s0 + slab_rf)].cpu().numpy().view(np.complex64)
+        lo = s0 - warm_rf
+        if base + lo < 0:
+            lo = -base                                       # the stream starts here: zero state is the true state
+        lo -= (base + lo) % 25                               # oracle output i is absolute audio sample (base + lo) / 25 + i
+        hi = min(n, s0 + slab_rf)
+        if lo < 0:
+            xs = torch.cat([x[2 * (n + lo):], x[:2 * hi]]).cpu().numpy().view(np.complex64)
+        else:
+            xs = x[2 * lo:2 * hi].cpu().numpy().view(np.complex64)
         ch = O.wbfm_mono_chain(fs, offset, mode=O.MODE_LUA, rot_mode=O.MODE_F64)
         t0 = time.perf_counter()
         want = ch.process(xs)
         cpu_s += time.perf_counter() - t0
         cpu_n += len(xs)
-        want = want[(s0 - lo) // 25:]
-        a0 = s0 // 25
-        got = y[a0:a0 + len(want)].cpu().numpy()
+        skip = (base + s0 + 24) // 25 - (base + lo) // 25    # oracle samples in front of the slab
+        want = want[skip:]
+        a0 = (base + s0 + 24) // 25 - first_audio
+        got = y[a0:min(got_n, a0 + len(want))].cpu().numpy()
         m = min(len(got), len(want))
         err = got[:m].astype(np.float64) - want[:m].astype(np.float64)
         se += float(np.sum(err ** 2))
         cnt += m
         worst = max(worst, float(np.max(np.abs(err))))
     rms = (se / max(cnt, 1)) ** 0.5
-    return {"rms_err_vs_oracle": rms, "max_err_vs_oracle": worst, "verified": bool(rms <= 1e-5 and got_n > 0),
-            "verify": "device audio of the full 2^26-sample vector vs the oracle chain on %d slabs of %d RF samples from the first to the last "
-                      "sample (%d audio samples compared), bar: RMS <= 1e-5" % (len(starts), slab_rf, cnt),
+    return {"rms_err_vs_oracle": rms, "max_err_vs_oracle": worst, "verified": bool(rms <= 1e-5 and got_n > 0 and cnt > 60000),
+            "verify": "audio written by the LAST timed step (state carried through all %d steps) vs the oracle chain on %d slabs of %d RF samples from the "
+                      "first to the last sample (%d audio samples compared), bar: RMS <= 1e-5" % (base // n + 1, len(starts), slab_rf, cnt),
             "cpu_baseline": {"value": round(cpu_n / cpu_s / 1e6, 2), "unit": "MSamples/s", "cores": 1, "kind": "port",
                              "sample": "oracle chain (per-block restatement of the reference's Lua arithmetic) on the %d verification slabs, %d RF samples" % (len(starts), cpu_n)}}
 
@@ -251,23 +262,93 @@ def channelizer_report(lr, L, torch, dev, with_cpu):
                         "flops_per_sample": 8 * M, "mfma_busy_counter": "profiles/ (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES)"}}
     if with_cpu:
         from oracle import oracle as O
-        ns = K * 96
-        ch2 = lr.PolyphaseChannelizerBlock(K)
-        ch2.rate = 1102500.0
-        ch2.differentiate([types.ComplexFloat32])
-        ch2.initialize()
-        xs = x[:2 * ns].cpu().numpy().view(np.complex64)
-        got = ch2.process(xs)
-        taps = ch2.taps
+        # the output of the LAST timed step (every step starts from the state the previous one left: the 1023 samples in front of x[0] are the
+        # tail of x), 96 frames each at the start, in the middle and at the end of the 2^24-sample vector, channels 0, 7, .., 63
+        taps = ch.taps
+        frames, pre = 96, ((M - 1 + K - 1) // K) * K
         se, cnt, worst = 0.0, 0, 0.0
-        for c in range(0, K, 7):
-            want = O.Chain([O.Rotator(-2 * np.pi * c / K, O.MODE_F64), O.FIR(taps, True, O.MODE_F64), O.Downsampler(K, True)]).process(xs)
-            e = np.abs(got[:, c].astype(np.complex128) - want.astype(np.complex128))
-            se += float(np.sum(e ** 2)); cnt += len(e); worst = max(worst, float(e.max()))
+        nfr = n // K
+        for f0 in (0, nfr // 2 - frames // 2, nfr - frames):
+            lo = f0 * K - pre
+            if lo < 0:
+                xs = torch.cat([x[2 * (n + lo):], x[:2 * (f0 + frames) * K]]).cpu().numpy().view(np.complex64)
+            else:
+                xs = x[2 * lo:2 * (f0 + frames) * K].cpu().numpy().view(np.complex64)
+            got = y[2 * f0 * K:2 * (f0 + frames) * K].cpu().numpy().view(np.complex64).reshape(frames, K)
+            for c in range(0, K, 7):
+                # the oracle's rotator starts at phase 0 on sample lo; the block's at the absolute sample index: e^{-j 2 pi c lo / K} = 1 (lo is a multiple of K)
+                want = O.Chain([O.Rotator(-2 * np.pi * c / K, O.MODE_F64), O.FIR(taps, True, O.MODE_F64), O.Downsampler(K, True)]).process(xs)[pre // K:]
+                e = np.abs(got[:, c].astype(np.complex128) - want[:frames].astype(np.complex128))
+                se += float(np.sum(e ** 2)); cnt += len(e); worst = max(worst, float(e.max()))
         rep.update({"rms_err_vs_oracle_chains": (se / cnt) ** 0.5, "max_err_vs_oracle_chains": worst, "verified": bool(worst < 2e-6),
-                    "verify": "first %d samples, channels 0,7,..,63 vs oracle chains FrequencyTranslator(-c/K) -> FIRFilter(h) -> Downsampler(K) in f64 "
-                              "(no reference block exists: parity unpinned, SURVEY.md 8c-ii)" % ns})
+                    "verify": "output of the last timed step: %d frames each at the start, the middle and the end of the 2^24-sample vector, channels 0,7,..,63 vs oracle "
+                              "chains FrequencyTranslator(-c/K) -> FIRFilter(h) -> Downsampler(K) in f64 (no reference block exists: parity unpinned, SURVEY.md 8c-ii)" % frames})
     return rep
+
+
+def verify_tuner_branch(torch, tun, run, x, n, fs, offset, bandwidth, decim, slab=1 << 17, warm=2000):
+    """One fan-out branch against the oracle Tuner (radio/composites/tuner.lua:32-48 restated): the branch is reset, run() pushes the slab once
+    more, and its ComplexFloat32 output is compared on three slabs (first / middle / last samples).  The oracle's rotator starts at phase 0 on
+    the first sample it is given, the block's at the absolute sample index: the oracle's output is turned by exp(j omega lo) - the filter is linear."""
+    import numpy as np
+    from oracle import oracle as O
+    tun.reset()
+    out = run()
+    torch.cuda.synchronize()
+    worst, cnt = 0.0, 0
+    for s0 in (0, (n // 2) // decim * decim, (n - slab) // decim * decim):
+        lo = max(0, s0 - warm) // decim * decim
+        xs = x[2 * lo:2 * (s0 + slab)].cpu().numpy().view(np.complex64)
+        want = O.tuner(offset, bandwidth, decim, fs, mode=O.MODE_F64, rot_mode=O.MODE_F64).process(xs)[(s0 - lo) // decim:]
+        turn = (offset / fs * lo) % 1.0
+        want = want.astype(np.complex128) * np.exp(2j * np.pi * turn)
+        got = out[2 * (s0 // decim):2 * (s0 // decim + len(want))].cpu().numpy().view(np.complex64)
+        m = min(len(got), len(want))
+        worst = max(worst, float(np.max(np.abs(got[:m].astype(np.complex128) - want[:m]))))
+        cnt += m
+    return {"verified": bool(worst <= 2e-6 and cnt > 3 * slab // decim - 16), "max_err_vs_oracle": worst,
+            "verify": "branch output (after a reset, one more push of the slab) vs the oracle Tuner in f64 on 3 slabs of 2^17 RF samples (first / middle / last), %d outputs, bar 2e-6" % cnt}
+
+
+def fm_recording(torch, dev, a, b, fs=1102500.0, block=1 << 22):
+    """samples [a, b) of ONE long synthetic FM recording (SURVEY.md 8d C3 recipe), the same values whichever rank / partition asks: the phase is the
+    closed-form integral of the two-tone message, the noise comes from one generator per block of 2^22 samples (seed = block index)"""
+    import numpy as np
+    i = torch.arange(a, b, dtype=torch.float64, device=dev)
+    t = i / fs
+    integ = -0.5 * torch.cos(2 * np.pi * 1e3 * t) / (2 * np.pi * 1e3) - 0.5 * torch.cos(2 * np.pi * 5e3 * t) / (2 * np.pi * 5e3)
+    ph = 2 * np.pi * ((250e3 * t) % 1.0) + 2 * np.pi * 75e3 * integ
+    x = torch.stack([torch.cos(ph).float(), torch.sin(ph).float()], 1).reshape(-1)
+    del i, t, integ, ph
+    for blk in range(a // block, (b + block - 1) // block):
+        g = torch.Generator(device=dev).manual_seed(100000 + blk)
+        nz = torch.rand(2 * block, dtype=torch.float32, device=dev, generator=g) * 2 - 1
+        lo, hi = max(a, blk * block), min(b, (blk + 1) * block)
+        x[2 * (lo - a):2 * (hi - a)] += 0.01 * nz[2 * (lo - blk * block):2 * (hi - blk * block)]
+    return x
+
+
+def verify_partition(torch, dev, y, got_n, a, b, fs, offset, slab_rf=131075, warm_rf=100000):
+    """time partition [a, b) of the recording: its first and its last audio samples against the oracle chain run on the SAME recording from zero
+    state `warm_rf` samples early (so the oracle crosses the partition boundary, which the partition itself only saw through its replayed halo)"""
+    import numpy as np
+    from oracle import oracle as O
+    worst, se, cnt = 0.0, 0.0, 0
+    first_audio = (a + 24) // 25
+    for s0 in (a, max(a, b - slab_rf)):
+        lo = max(0, s0 - warm_rf)
+        lo -= lo % 25
+        hi = min(b, s0 + slab_rf)
+        xs = fm_recording(torch, dev, lo, hi, fs).cpu().numpy().view(np.complex64)
+        want = O.wbfm_mono_chain(fs, offset, mode=O.MODE_LUA, rot_mode=O.MODE_F64).process(xs)[(s0 + 24) // 25 - lo // 25:]
+        a0 = (s0 + 24) // 25 - first_audio
+        got = y[a0:min(got_n, a0 + len(want))].cpu().numpy()
+        m = min(len(got), len(want))
+        err = got[:m].astype(np.float64) - want[:m].astype(np.float64)
+        se += float(np.sum(err ** 2)); cnt += m
+        worst = max(worst, float(np.max(np.abs(err))))
+    rms = (se / max(cnt, 1)) ** 0.5
+    return bool(rms <= 1e-5 and cnt > 2 * (slab_rf // 25) - 64), rms, worst
 
 
 def fanout_report(lr, L, torch, dev):
@@ -292,8 +373,9 @@ def fanout_report(lr, L, torch, dev):
     torch.cuda.synchronize()
     ms = L.lrhip_timer_elapsed_ms(tm) / steps
     L.lrhip_timer_destroy(tm)
+    ver = verify_tuner_branch(torch, tun, lambda: fo.push(x)[0], x, n, fs, fanout.branch_offsets(8)[0], 100e3, 5)
     return {"workload": "configs[3] at N = 1: one fan-out branch Tuner(-350e3, 100e3, 5) on a 2^26-sample slab (no broadcast with one GPU)",
-            "value": round(n / ms / 1e3, 1), "unit": "MSamples/s (branch input)", "ms_per_step": round(ms, 4),
+            "value": round(n / ms / 1e3, 1), "unit": "MSamples/s (branch input)", "ms_per_step": round(ms, 4), **ver,
             "algorithmic_GB/s": round(9.6 * n / ms / 1e6, 1), "roofline_frac": round(9.6 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
             "xgmi_link_bound_MSps": 19125.0,
             "note": "for N > 1 every receiving GPU is bounded by one xGMI link: 153 GB/s / 8 B = 19.1 GS/s of ComplexFloat32, far below this branch rate"}
@@ -315,8 +397,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -385,6 +472,36 @@ def main():
                               "FMDeemphasis -> Downsampler) on 2^%d synthetic FM IQ samples @ 1.1025 MS/s, device-resident" % log2n,
                   "samples_per_step_per_gpu": n, "counted": "RF input samples", "parallelism": "independent streams x%d" % world}
         dominant = "fir_mfma_persistent_kernel<2,5,2,true,51,1,true>"
+    elif args.workload == "timeshard":
+        # ONE recording of 2^log2n samples cut into `world` time partitions (second mode): rank r runs the receiver on its own
+        # partition - lrhip_chain_start_at: seek to the aligned sample in front of (a - halo), replay, drop the replayed output - with no
+        # exchange between the ranks.  Total work is fixed: "scaling": "strong".  One step = the whole job once.
+        from luaradio_amd import timeshard
+        fs = 1102500.0
+        log2n = args.log2_samples or 28
+        n_total = 1 << log2n
+        rx = lr.wbfm_mono_receiver(fs, -250e3)
+        align, halo = rx.shard_align(), rx.halo()
+        pa, pb = timeshard.bounds(n_total, world, align)[rank]
+        ps = timeshard.replay_start(pa, halo, align)
+        x = fm_recording(torch, dev, ps, pb, fs)
+        n = pb - ps
+        cap = rx.max_output(n) + 16
+        y = torch.empty(cap, dtype=torch.float32, device=dev)
+        produced = []
+
+        def step():
+            assert rx.chain.start_at(pa) == ps
+            produced.append(rx.process_device(x.data_ptr(), n, y.data_ptr(), cap))
+
+        out_per_step = n_total / world      # the job is the recording, whatever the number of ranks
+        alg_bytes = 8.16 * (pb - pa)
+        flops = 167.0 * (pb - pa)
+        config = {"workload": "configs[2] chain on ONE synthetic FM recording of 2^%d samples cut into %d time partitions (lrhip_chain_start_at: halo %d samples "
+                              "replayed per partition, boundaries on multiples of %d), one partition per GPU, no exchange" % (log2n, world, halo, align),
+                  "samples_total": n_total, "counted": "RF input samples of the recording", "parallelism": "time partitions x%d" % world,
+                  "partition_of_rank0": [pa, pb], "replayed_samples_rank0": pa - ps}
+        dominant = "rx_fused_kernel"
     else:
         # fan-out: rank 0 owns the IQ slab; every step it is broadcast over RCCL/xGMI and each rank runs its own
         # Tuner branch (offsets -350 kHz .. +350 kHz step 100 kHz)
@@ -402,7 +519,7 @@ def main():
             tun.differentiate([types.ComplexFloat32])
             tun.initialize()
             mine[b] = fanout.DeviceBranch(tun, n)
-        fo = fanout.FanOut(dist, rank, world, nbranches, mine, src=0, device="cuda")
+        fo = fanout.FanOut(dist, rank, world, nbranches, mine, src=0, device="cuda", always_broadcast=args.force_dist)
         # double-buffered: the broadcast of slab k+1 (communication stream) overlaps the branch kernels on slab k (FanOut.stream)
         import itertools
         slab_iter = fo.stream(itertools.repeat(x), 2 * n)
@@ -426,7 +543,7 @@ def main():
 
     # clock ramp: a GPU that has been idle runs its first ~100 ms of work well below the sustained clocks (measured on the gpurun
     # pool: 1.02 ms for the first timed FIR passes of a process, 0.85 ms from then on) - untimed, before the W warm-up steps
-    if args.workload == "fanout" and world > 1:
+    if args.workload == "fanout" and (world > 1 or args.force_dist):
         for _ in range(8):            # a step holds a collective: every rank must run the SAME number of them (no time-based loop here)
             step()
         torch.cuda.synchronize()
@@ -457,6 +574,22 @@ def main():
         dist.all_gather(allw, mine_t)
         per_rank_wall = [float(w.item()) for w in allw]
         wall = max(per_rank_wall)
+
+    rank_verified = None
+    if args.workload == "timeshard" and not args.no_verify:
+        ok, rms, worst = verify_partition(torch, dev, y, produced[-1], pa, pb, fs, -250e3)
+        rank_verified = {"verified": ok, "rms_err_vs_oracle": rms, "max_err_vs_oracle": worst, "partition": [pa, pb]}
+    elif args.workload == "fanout" and not args.no_verify:
+        b0 = sorted(mine)[0]
+        # one more (plain, in-place) broadcast leaves the slab in x on every rank; every rank checks its own branch against the oracle Tuner
+        rv = verify_tuner_branch(torch, mine[b0].block, lambda: fo.push(x)[b0], x, n, fs, offs[b0 % len(offs)], 100e3, 5)
+        rank_verified = {"verified": rv["verified"], "max_err_vs_oracle": rv["max_err_vs_oracle"], "branch": b0}
+    if rank_verified is not None and dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_verified)
+        rank_verified = gathered
+    elif rank_verified is not None:
+        rank_verified = [rank_verified]
 
     verification = None
     if rank == 0 and world == 1 and args.workload == "fir" and not args.no_verify:
@@ -504,6 +637,14 @@ def main():
                          "fp32_tflops": round(flops / launch_s / 1e12, 2), "fp32_peak_tflops": FP32_PEAK_TFLOPS,
                          "fp32_frac": round(flops / launch_s / 1e12 / FP32_PEAK_TFLOPS, 4)},
         }
+        if args.workload == "timeshard":
+            res["scaling"] = "strong"
+        if rank_verified is not None:
+            res["nranks"] = world
+            res["verified"] = all(r["verified"] for r in rank_verified)
+            res["per_rank_verified"] = rank_verified
+        if dist is not None:
+            res["dist_backend"] = args.dist_backend
         if args.workload == "fanout":
             # every receiving GPU takes the whole slab over ONE xGMI link from the source (point-to-point links, 7 x ~153 GB/s per GPU):
             # 8 B per ComplexFloat32 sample -> at most ~19.1 GS/s per receiver, far below what a branch filters (the fanout leg of the N = 1 line)

@@ -63,8 +63,9 @@ class FanOut:
               .process(slab_tensor)
     """
 
-    def __init__(self, dist, rank, world_size, num_branches, branches, src=0, device=None):
+    def __init__(self, dist, rank, world_size, num_branches, branches, src=0, device=None, always_broadcast=False):
         self.dist, self.rank, self.world, self.src = dist, rank, world_size, src
+        self.always_broadcast = always_broadcast      # issue the collective even in a group of one rank (exercises RCCL + the communication stream on one GPU)
         self.device = device          # "cuda" / "cpu" for stream()'s slab buffers; None = cuda with RCCL or a single GPU process, cpu otherwise
         self.num_branches = num_branches
         mine = local_branches(num_branches, world_size, rank)
@@ -76,7 +77,7 @@ class FanOut:
     def push(self, slab):
         """Broadcast one slab from the source rank (in place into `slab` on the others) and run the local branches.
         Returns {branch_index: output}."""
-        if self.dist is not None and self.world > 1:
+        if self.dist is not None and (self.world > 1 or self.always_broadcast):
             self.dist.broadcast(slab, src=self.src)
         self.slabs += 1
         return {b: ex.process(slab) for b, ex in self.branches.items()}
@@ -89,7 +90,7 @@ class FanOut:
         an output view is valid until the next slab is requested.  With CPU tensors (gloo, tests) the same bookkeeping runs with
         asynchronous broadcast handles instead of streams."""
         import torch
-        multi = self.dist is not None and self.world > 1
+        multi = self.dist is not None and (self.world > 1 or self.always_broadcast)
         if self.device is not None:
             cuda = self.device == "cuda"
         else:

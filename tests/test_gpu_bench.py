@@ -1,0 +1,72 @@
+"""bench.py's multi-rank code paths on ONE GPU (the driver's SCALE run is their first contact with 2 / 4 / 8 GPUs) and the configs[3]
+branch settings against the oracle."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import luaradio_amd as lr
+from luaradio_amd import fanout, types
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_fanout_workload_runs_end_to_end_on_rccl_with_one_rank():
+    """`bench.py --workload fanout` as the driver launches it, except that the process group has one rank: backend "nccl" (= RCCL) is
+    initialised on the device, every slab goes through dist.broadcast on the communication stream of FanOut.stream, the branch output is
+    checked against the oracle Tuner on every rank and gathered"""
+    d = _bench("--gpus", "1", "--workload", "fanout", "--force-dist", "--steps", "3", "--warmup", "1", "--log2-samples", "22", "--no-cpu-baseline")
+    assert d["dist_backend"] == "nccl" and d["nranks"] == 1 and d["n_gpus"] == 1
+    assert d["verified"] is True and d["per_rank_verified"][0]["max_err_vs_oracle"] < 2e-6
+    assert d["fanout_links"]["double_buffered"] is True and d["value"] > 0
+
+
+def test_timeshard_workload_verifies_its_partition_seams():
+    d = _bench("--gpus", "1", "--workload", "timeshard", "--force-dist", "--steps", "2", "--warmup", "1", "--log2-samples", "24", "--no-cpu-baseline")
+    assert d["scaling"] == "strong" and d["config"]["samples_total"] == 1 << 24
+    assert d["verified"] is True and d["per_rank_verified"][0]["rms_err_vs_oracle"] <= 1e-5
+
+
+@pytest.mark.parametrize("branch", range(8))
+def test_configs3_branch_settings_vs_oracle(branch):
+    """BASELINE.json configs[3]: Tuner(offset_b, 100e3, 5), offsets -350 kHz .. +350 kHz, on 2^22 U(-1, 1) samples against the oracle Tuner
+    (rotator in closed form, filter in f64) - the device branch executor of bench.py, not a stand-in"""
+    import torch
+    n, fs = 1 << 22, 1102500.0
+    off = fanout.branch_offsets(8)[branch]
+    assert off == -350e3 + 100e3 * branch
+    rng = np.random.default_rng(40 + branch)
+    xh = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+    x = torch.from_numpy(xh.view(np.float32)).cuda()
+    tun = lr.TunerBlock(off, 100e3, 5)
+    tun.rate = fs
+    tun.differentiate([types.ComplexFloat32])
+    tun.initialize()
+    br = fanout.DeviceBranch(tun, n)
+    got = br.process(x).cpu().numpy().view(np.complex64)
+    want = O.tuner(off, 100e3, 5, fs, mode=O.MODE_F64, rot_mode=O.MODE_F64).process(xh)
+    assert len(got) == len(want) == (n + 4) // 5
+    assert float(np.max(np.abs(got.astype(np.complex128) - want))) < 2e-6
+    # and bit for bit against the fmaf-chain mode with the closed-form rotator rounded to Float32 as the block does: the device Tuner equals its own unfused blocks
+    parts = [lr.FrequencyTranslatorBlock(off), lr.LowpassFilterBlock(128, 50e3), lr.DownsamplerBlock(5)]
+    v, rate = xh, fs
+    for b in parts:
+        b.rate = rate
+        b.differentiate([types.ComplexFloat32])
+        b.initialize()
+        v, rate = b.process(v), b.get_rate()
+    assert np.array_equal(got, v)
