@@ -636,7 +636,10 @@ __global__ __launch_bounds__(256) void fir_resample_kernel(const float *__restri
 
 // ---- generic kernel: run-time number of MFMA steps, one tile per workgroup ----------------------------------------
 // NOUT = 2 (S = 1 geometry over the interleaved float stream, two Toeplitz tables): complex taps.
-template <int S, int D, int NACC, bool ROT, int NOUT>
+// HILB (S = 1, D = 1, real taps): HilbertTransformBlock in one launch (radio/blocks/signal/hilberttransform.lua:107-124: one loop writes the delayed
+// input as the real part and the filtered input as the imaginary part): the output is ComplexFloat32, out[k] = (s[(M-1)/2 + k], fir[k]) with
+// s = [M-1 history | chunk] - the delayed sample is already in the tile's staged window, (M-1)/2 + slack floats behind the output's first tap.
+template <int S, int D, int NACC, bool ROT, int NOUT, bool HILB = false>
 __global__ __launch_bounds__(256) void fir_mfma_kernel(
     const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_pad, float *__restrict__ y,
     int M, long n, long n_out, long first, int e, int ksteps, int out_aligned,
@@ -682,7 +685,30 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
     __syncthreads();
     f32x4 acc[NOUT][NACC];
     mfma_tile<S, D, NACC, 0, NOUT>(ldsT, tlen, e, ldsX, ksteps, acc);
-    store_tile<S, D, NACC, NOUT>(y, tile_k0, n_out, out_aligned, acc);
+    if constexpr (HILB) {
+        static_assert(S == 1 && D == 1 && NOUT == 1 && !ROT, "Hilbert epilogue: Float32 stream, real taps");
+        const int lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+        const int half = (M - 1) / 2;
+#pragma unroll
+        for (int a = 0; a < NACC; a++) {
+            const int l = 16 * ((wave * NACC + a) * G::BPA + col) + 4 * kq;      // tile-local index of the lane's first output
+            const long k = tile_k0 + l;
+            float dl[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) dl[i] = ldsX[G::phys(half + e + l + i)];
+            float *o = y + 2 * k;
+            if (out_aligned && k + 3 < n_out) {
+                *reinterpret_cast<float4 *>(o) = make_float4(dl[0], acc[0][a][0], dl[1], acc[0][a][1]);
+                *reinterpret_cast<float4 *>(o + 4) = make_float4(dl[2], acc[0][a][2], dl[3], acc[0][a][3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (k + i < n_out) *reinterpret_cast<float2 *>(o + 2 * i) = make_float2(dl[i], acc[0][a][i]);
+            }
+        }
+    } else {
+        store_tile<S, D, NACC, NOUT>(y, tile_k0, n_out, out_aligned, acc);
+    }
 }
 
 // ---- persistent kernel: compile-time number of MFMA steps KS -----------------------------------------------------------

@@ -535,7 +535,8 @@ lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, u
             if (mc && mc->mode <= 1) k++; else mc = nullptr;
             UpsamplerStage *up = k < nstages ? dynamic_cast<UpsamplerStage *>(stages[k]) : nullptr;
             FirStage *rf = (up && k + 1 < nstages) ? dynamic_cast<FirStage *>(stages[k + 1]) : nullptr;
-            if (!no_resample_fusion && up && rf && !rf->taps_complex && !rf->use_fft && !rf->fft_arith && rf->D == 1 && !rf->rot && !rf->pre_disc) {
+            // (a filter whose arithmetic was left to the library - use_fft nil, mode 3 - may have picked overlap-save for itself: the polyphase form wins)
+            if (!no_resample_fusion && up && rf && !rf->taps_complex && !rf->use_fft && (!rf->fft_arith || rf->mode_req == 3) && rf->D == 1 && !rf->rot && !rf->pre_disc) {
                 DownsamplerStage *rd = k + 2 < nstages ? dynamic_cast<DownsamplerStage *>(stages[k + 2]) : nullptr;
                 unsigned long D = rd ? rd->factor : 1;
                 int L = (int)up->factor;
@@ -550,7 +551,7 @@ lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, u
                     for (int t = 0; t < rf->M; t++) taps[t] = rf->taps_rev[rf->M - 1 - t];
                     if (upload(q->d_taps, taps.data(), taps.size() * sizeof(float)) || q->reset()) return nullptr;
                     static const bool no_interp_win = getenv("LRHIP_NO_INTERP_WIN") != nullptr;      // A/B knob: one output per thread (fir_resample_kernel)
-                    if (!no_interp_win && q->S == 2 && D == 1 && q->M == 128 && L >= 2 && L <= 5) {
+                    if (!no_interp_win && q->S == 2 && q->M == 128 && ((D == 1 && L >= 2 && L <= 5) || ResampleStage::rational_supported(L, D))) {
                         // tap table of fir_interp_kernel: ttab[s * LP + p] = h[p + (J - 1 - s) L], step 0 = the oldest sample
                         const int J = (q->M + L - 1) / L, LP = (L + 3) & ~3;
                         std::vector<float> tt((size_t)J * LP, 0.f);

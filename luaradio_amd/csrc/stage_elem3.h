@@ -67,6 +67,12 @@ struct HilbertStage : lrhip_stage {
     {
         if (n > cap) return set_error("hilbert: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
+        static const bool two_pass = getenv("LRHIP_HILBERT_TWO_PASS") != nullptr;      // A/B knob: filter, then combine (round 2)
+        if (!two_pass && fir->hilbert_ok() && ((uintptr_t)in_dev % 4) == 0) {
+            // one launch: the filter's epilogue writes (delayed input, filtered input) pairs (hilberttransform.lua:107-124 is one loop as well)
+            if (fir->launch_hilbert((const float *)in_dev, (long)n, (float *)out_dev)) return -1;
+            return (long)n;
+        }
         if (tmp.reserve(n * sizeof(float))) return -1;
         long got = fir->core((const float *)in_dev, (long)n, (float *)tmp.p, n);
         if (got < 0) return got;

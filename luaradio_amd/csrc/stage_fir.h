@@ -229,6 +229,36 @@ struct FirStage : lrhip_stage {
         return 0;
     }
 
+    // HilbertTransformBlock in one launch: the generic Float32 Toeplitz kernel with the pair epilogue (kernels_fir.h, HILB).  y2 receives n
+    // ComplexFloat32 samples (delayed input, filtered input); history / index bookkeeping is core()'s (D = 1: index stays 0)
+    bool hilbert_ok() const { return S == 1 && !taps_complex && D == 1 && ksteps > 0 && !rot && !fft_arith && !use_fft && !pre_disc && !post_disc; }
+    int launch_hilbert(const float *x, long n, float *y2)
+    {
+        constexpr int NACC = 4;
+        using G = FirMfmaGeom<1, 1>;
+        constexpr int TILE_OUT = G::tile_out(NACC);
+        if (((uintptr_t)x % 4) != 0) return set_error("hilbert: unaligned input pointer");
+        const long v = (long)((uintptr_t)x / 4) + (long)index - (M - 1);
+        const int e = (int)(((v % 4) + 4) % 4);
+        const int span = G::span(NACC, ksteps);
+        const size_t lds_bytes = ((size_t)fir_taps_len(1, ksteps) + (size_t)G::phys(span) + G::PAD + 8) * sizeof(float);
+        const long ntiles = (n + TILE_OUT - 1) / TILE_OUT;
+        auto kern = fir_mfma_kernel<1, 1, NACC, false, 1, true>;
+        if (prepare_kernel(kern, lds_bytes, nullptr)) return -1;
+        hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (const float *)d_atab.p, y2, M, n, n,
+                           (long)index, e, ksteps, (int)(((uintptr_t)y2 % 16) == 0), (uint64_t)0, (uint64_t)0);
+        LR_LAUNCH_CHECK();
+        // history carry, as core() does for kernels that do not write it themselves
+        if (M > 1) {
+            unsigned grid = grid_for((unsigned long)(M - 1), 256);
+            hipLaunchKernelGGL(fir_history_kernel<1>, dim3(grid), dim3(256), 0, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (float *)hist[cur ^ 1].p + hist_pad, M, n);
+            LR_LAUNCH_CHECK();
+            cur ^= 1;
+        }
+        count += (uint64_t)n;
+        return 0;
+    }
+
     // complex taps: two real Toeplitz filters (re / im) of 2M taps over the interleaved float stream, decimation 2D,
     // sharing every B fragment.  Stream position of output k in float units is 2*q_k + 1 once the float stream is
     // given one leading pad float (so the history is the 2M-1 floats the S = 1 kernel expects).

@@ -13,6 +13,9 @@ struct ResampleStage : lrhip_stage {
     int cur = 0;
     uint64_t Q0 = 0, m0 = 0;          // absolute input samples consumed / outputs emitted so far
     int interp_J = 0;                 // > 0: the register-window interpolator kernel applies (kernels_interp.h), taps per phase
+    int rat_blocks_per_cu = 0;
+    // (L, D) pairs with a kept-phases instantiation (fir_rational_kernel): 128 taps, ComplexFloat32, gcd(L, D) = 1
+    static bool rational_supported(int L, unsigned long D) { return (L == 3 && D == 2) || (L == 2 && D == 3) || (L == 4 && D == 3) || (L == 3 && D == 4) || (L == 5 && D == 4) || (L == 4 && D == 5); }
     int interp_blocks_per_cu = 0;     // its resident workgroups per CU (occupancy query, cached)
     static constexpr int SPAN_MAX = 6144;
     const char *kind() const override { return "resample"; }
@@ -44,7 +47,7 @@ struct ResampleStage : lrhip_stage {
         if ((unsigned long)n_out > cap) return set_error("resample: output capacity %lu < %ld", cap, n_out);
         const float *h = (const float *)hist[cur].p;
         float *ho = (float *)hist[cur ^ 1].p;
-        if (interp_J > 0 && ((uintptr_t)in_dev & 7) == 0 && ((uintptr_t)out_dev & 7) == 0) {
+        if (interp_J > 0 && D == 1 && ((uintptr_t)in_dev & 7) == 0 && ((uintptr_t)out_dev & 7) == 0) {
             // ComplexFloat32 Interpolator(L), 128 taps: a lane owns 5 input positions and all L phases (fir_interp_kernel)
             auto gi = [&](auto kern, size_t lds_bytes, int tq) -> int {
                 if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -61,6 +64,34 @@ struct ResampleStage : lrhip_stage {
 #define LR_INTERP(LL, JJ) gi(fir_interp_kernel<LL, JJ>, (size_t)FipGeom<LL, JJ>::LDS_FLOATS * sizeof(float), FipGeom<LL, JJ>::TQ)
             int rc = L == 2 ? LR_INTERP(2, 64) : L == 3 ? LR_INTERP(3, 43) : L == 4 ? LR_INTERP(4, 32) : LR_INTERP(5, 26);
 #undef LR_INTERP
+            if (rc) return rc;
+            LR_LAUNCH_CHECK();
+            cur ^= 1;
+            Q0 += n;
+            m0 = m_end;
+            return n_out;
+        }
+        static const bool no_rational = getenv("LRHIP_NO_RATIONAL_WIN") != nullptr;      // A/B knob: one output per thread (fir_resample_kernel)
+        if (!no_rational && interp_J > 0 && D > 1 && ((uintptr_t)in_dev & 7) == 0 && ((uintptr_t)out_dev & 7) == 0) {
+            // ComplexFloat32 RationalResampler(L, D), 128 taps: only the kept (position, phase) pairs, register window (fir_rational_kernel)
+            auto gr = [&](auto kern, size_t lds_bytes, int tq) -> int {
+                if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                if (!rat_blocks_per_cu) {
+                    int nb = 0;
+                    LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds_bytes));
+                    rat_blocks_per_cu = nb < 1 ? 1 : nb;
+                }
+                const long ntiles = ((long)n + (long)(Q0 % D) + tq - 1) / tq, slots = (long)ctx().num_cus * rat_blocks_per_cu;
+                hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < slots ? ntiles : slots)), dim3(256), lds_bytes, ctx().stream, h, (const float *)in_dev, (const float *)d_ttab.p,
+                                   (float *)out_dev, (long)n, n_out, m0, Q0, HQ, c, ho);
+                return 0;
+            };
+#define LR_RAT(LL, DD, JJ, RR) gr(fir_rational_kernel<LL, DD, JJ, RR>, (size_t)FrrGeom<LL, DD, JJ, RR>::LDS_FLOATS * sizeof(float), FrrGeom<LL, DD, JJ, RR>::TQ)
+            // positions per lane (R) by measurement on MI355X, 2^26 input samples: (3,4) R = 4 / 8 / 12 -> 0.33 / 0.70 / 0.49 ms, (5,4) R = 4 / 8 -> 0.86 / 0.24,
+            // (4,5) R = 5 / 10 -> 0.80 / 0.19: the shapes are sensitive to it in a way the instruction counts do not explain (same FMAs per input)
+            int rc = (L == 3 && D == 2) ? LR_RAT(3, 2, 43, 6) : (L == 2 && D == 3) ? LR_RAT(2, 3, 64, 6) : (L == 4 && D == 3) ? LR_RAT(4, 3, 32, 6)
+                   : (L == 3 && D == 4) ? LR_RAT(3, 4, 43, 4) : (L == 5 && D == 4) ? LR_RAT(5, 4, 26, 8) : LR_RAT(4, 5, 32, 10);
+#undef LR_RAT
             if (rc) return rc;
             LR_LAUNCH_CHECK();
             cur ^= 1;

@@ -672,7 +672,7 @@ def test_iir_single_launch_and_three_pass_paths_vs_oracle():
     assert G.max_abs_err(chunked(blk, xc, [7, 4096, 50000]), want) < 2e-6
 
 
-@pytest.mark.parametrize("L,D", [(5, 1), (2, 1), (3, 1), (4, 1), (3, 2), (2, 5), (7, 3), (4, 25), (25, 4)])
+@pytest.mark.parametrize("L,D", [(5, 1), (2, 1), (3, 1), (4, 1), (3, 2), (2, 3), (4, 3), (3, 4), (5, 4), (4, 5), (2, 5), (7, 3), (4, 25), (25, 4)])
 @pytest.mark.parametrize("cplx", [True, False])
 def test_polyphase_resampler_fusion_bit_equal_to_zero_stuffed_chain(L, D, cplx):
     """[MultiplyConstant] -> Upsampler(L) -> Lowpass -> [Downsampler(D)] in a chain is one polyphase launch that visits only the
@@ -696,6 +696,9 @@ def test_polyphase_resampler_fusion_bit_equal_to_zero_stuffed_chain(L, D, cplx):
         want = b.process(want)
     assert len(got) == len(want) == (n * L + D - 1) // D
     assert np.array_equal(got, want)
+    # one long chunk (interior tiles of the register-window kernels: fir_interp_kernel, fir_rational_kernel) equals the ragged run
+    whole = lr.Chain(blocks()).process(x)
+    assert np.array_equal(whole, want)
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -16,7 +16,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2-samples", type=int, default=26)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--only", default="", help="comma-separated substrings: run only the rows whose name contains one of them")
     args = ap.parse_args()
+    only = [t for t in args.only.split(",") if t]
     import numpy as np
     import torch
     import luaradio_amd as lr
@@ -53,6 +55,9 @@ def main():
     rows = []
 
     def run(name, blk, cplx, alg_bytes_per_sample, flops=0.0):
+        if only and not any(t in name for t in only):
+            return
+        blk = blk()
         x = xc if cplx else xr
         cap = blk.max_output(n)
         dst = out if cap * (2 if cplx else 1) <= out.numel() else torch.empty(cap * 2 + 64, device="cuda")
@@ -63,25 +68,40 @@ def main():
 
     taps128 = lr.filter_utils.firwin_lowpass(128, 15e3 / 110250)
     # yardstick: the cheapest streaming kernel (one multiply per scalar), 8 B in + 8 B out per sample
-    run("MultiplyConstant(1.0) cf32 (streaming yardstick)", mk(lr.MultiplyConstantBlock, [1.0], True), True, 16)
-    run("FIRFilter 128 real taps, cf32", mk(lr.FIRFilterBlock, [taps128], True), True, 16, 512)
-    run("FIRFilter 128 real taps, cf32, overlap-save (use_fft=fast)", mk(lr.FIRFilterBlock, [taps128, "fast"], True), True, 16, 125)
-    run("FIRFilter 128 real taps, f32", mk(lr.FIRFilterBlock, [taps128], False), False, 8, 256)
-    run("FIRFilter 128 real taps, f32, overlap-save (use_fft=fast)", mk(lr.FIRFilterBlock, [taps128, "fast"], False), False, 8, 63)
-    run("FIRFilter 16 real taps, cf32", mk(lr.FIRFilterBlock, [taps128[:16]], True), True, 16, 64)
-    run("FIRFilter 128 complex taps, cf32", mk(lr.FIRFilterBlock, [np.asarray(taps128, np.complex64) * (1 + 0.5j)], True), True, 16, 1024)
-    run("FIRFilter 128 complex taps, cf32, overlap-save (use_fft=fast)", mk(lr.FIRFilterBlock, [np.asarray(taps128, np.complex64) * (1 + 0.5j), "fast"], True), True, 16, 125)
-    run("FrequencyTranslator", mk(lr.FrequencyTranslatorBlock, [-250e3], True), True, 16)
-    run("FrequencyDiscriminator", mk(lr.FrequencyDiscriminatorBlock, [1.25], True), True, 12)
-    run("Downsampler(5) cf32", mk(lr.DownsamplerBlock, [5], True), True, 8 + 8 / 5)
-    run("Downsampler(5) f32", mk(lr.DownsamplerBlock, [5], False), False, 4 + 4 / 5)
-    run("FMDeemphasis f32", mk(lr.FMDeemphasisFilterBlock, [75e-6], False, 220500.0), False, 8)
-    run("Decimator(5) cf32 (fused FIR+downsample)", mk(lr.DecimatorBlock, [5], True), True, 8 + 8 / 5, 4 * 128 / 5)
-    run("Tuner(-250k,200k,5) (fused rot+FIR+downsample)", mk(lr.TunerBlock, [-250e3, 200e3, 5], True), True, 8 + 8 / 5, 4 * 128 / 5 + 6)
-    run("Decimator(5) cf32, polyphase FFT overlap-save", mk(lr.DecimatorBlock, [5, {"use_fft": "fast"}], True), True, 8 + 8 / 5, 62)
-    run("Tuner(-250k,200k,5), polyphase FFT overlap-save", mk(lr.TunerBlock, [-250e3, 200e3, 5, {"use_fft": "fast"}], True), True, 8 + 8 / 5, 62)
-    run("Interpolator(5) cf32 (polyphase, input samples)", mk(lr.InterpolatorBlock, [5], True), True, 8 + 8 * 5, 4 * 128)
-    run("RationalResampler(3, 2) cf32 (polyphase, input samples)", mk(lr.RationalResamplerBlock, [3, 2], True), True, 8 + 8 * 1.5, 4 * 128 * 1.5 / 3)
+    run("MultiplyConstant(1.0) cf32 (streaming yardstick)", lambda: mk(lr.MultiplyConstantBlock, [1.0], True), True, 16)
+    run("FIRFilter 128 real taps, cf32", lambda: mk(lr.FIRFilterBlock, [taps128], True), True, 16, 512)
+    run("FIRFilter 128 real taps, cf32, overlap-save (use_fft=fast)", lambda: mk(lr.FIRFilterBlock, [taps128, "fast"], True), True, 16, 125)
+    run("FIRFilter 128 real taps, f32", lambda: mk(lr.FIRFilterBlock, [taps128], False), False, 8, 256)
+    run("FIRFilter 128 real taps, f32, overlap-save (use_fft=fast)", lambda: mk(lr.FIRFilterBlock, [taps128, "fast"], False), False, 8, 63)
+    run("FIRFilter 16 real taps, cf32", lambda: mk(lr.FIRFilterBlock, [taps128[:16]], True), True, 16, 64)
+    run("FIRFilter 128 complex taps, cf32", lambda: mk(lr.FIRFilterBlock, [np.asarray(taps128, np.complex64) * (1 + 0.5j)], True), True, 16, 1024)
+    run("FIRFilter 128 complex taps, cf32, overlap-save (use_fft=fast)", lambda: mk(lr.FIRFilterBlock, [np.asarray(taps128, np.complex64) * (1 + 0.5j), "fast"], True), True, 16, 125)
+    run("FrequencyTranslator", lambda: mk(lr.FrequencyTranslatorBlock, [-250e3], True), True, 16)
+    run("FrequencyDiscriminator", lambda: mk(lr.FrequencyDiscriminatorBlock, [1.25], True), True, 12)
+    run("Downsampler(5) cf32", lambda: mk(lr.DownsamplerBlock, [5], True), True, 8 + 8 / 5)
+    run("Downsampler(5) f32", lambda: mk(lr.DownsamplerBlock, [5], False), False, 4 + 4 / 5)
+    run("FMDeemphasis f32", lambda: mk(lr.FMDeemphasisFilterBlock, [75e-6], False, 220500.0), False, 8)
+    run("Decimator(5) cf32 (fused FIR+downsample)", lambda: mk(lr.DecimatorBlock, [5], True), True, 8 + 8 / 5, 4 * 128 / 5)
+    run("Tuner(-250k,200k,5) (fused rot+FIR+downsample)", lambda: mk(lr.TunerBlock, [-250e3, 200e3, 5], True), True, 8 + 8 / 5, 4 * 128 / 5 + 6)
+    run("Decimator(5) cf32, polyphase FFT overlap-save", lambda: mk(lr.DecimatorBlock, [5, {"use_fft": "fast"}], True), True, 8 + 8 / 5, 62)
+    run("Tuner(-250k,200k,5), polyphase FFT overlap-save", lambda: mk(lr.TunerBlock, [-250e3, 200e3, 5, {"use_fft": "fast"}], True), True, 8 + 8 / 5, 62)
+    run("Interpolator(5) cf32 (polyphase, input samples)", lambda: mk(lr.InterpolatorBlock, [5], True), True, 8 + 8 * 5, 4 * 128)
+    run("RationalResampler(3, 2) cf32 (polyphase, input samples)", lambda: mk(lr.RationalResamplerBlock, [3, 2], True), True, 8 + 8 * 1.5, 4 * 128 * 1.5 / 3)
+    run("RationalResampler(2, 3) cf32 (polyphase, input samples)", lambda: mk(lr.RationalResamplerBlock, [2, 3], True), True, 8 + 8 * 2 / 3, 4 * 128 * (2 / 3) / 2)
+    run("RationalResampler(4, 3) cf32 (polyphase, input samples)", lambda: mk(lr.RationalResamplerBlock, [4, 3], True), True, 8 + 8 * 4 / 3, 4 * 128 * (4 / 3) / 4)
+    run("RationalResampler(5, 4) cf32 (polyphase, input samples)", lambda: mk(lr.RationalResamplerBlock, [5, 4], True), True, 8 + 8 * 5 / 4, 4 * 128 * (5 / 4) / 5)
+    run("RationalResampler(3, 4) cf32 (polyphase, input samples)", lambda: mk(lr.RationalResamplerBlock, [3, 4], True), True, 8 + 8 * 3 / 4, 4 * 128 * (3 / 4) / 3)
+    run("RationalResampler(4, 5) cf32 (polyphase, input samples)", lambda: mk(lr.RationalResamplerBlock, [4, 5], True), True, 8 + 8 * 4 / 5, 4 * 128 * (4 / 5) / 4)
+    run("HilbertTransform(65) f32 -> cf32", lambda: mk(lr.HilbertTransformBlock, [65], False), False, 12, 2 * 65)
+    # the reference suite's IIR entry (benchmarks/luaradio_benchmark.lua: 5 feed-forward, 3 feedback taps), a stable filter
+    b_iir, a_iir = [0.0976, 0.1953, 0.0976, 0.05, 0.02], [1.0, -0.9428, 0.3333]
+    run("IIRFilter 5 ff / 3 fb cf32", lambda: mk(lr.IIRFilterBlock, [b_iir, a_iir], True), True, 16)
+    run("IIRFilter 5 ff / 3 fb f32", lambda: mk(lr.IIRFilterBlock, [b_iir, a_iir], False), False, 8)
+    run("IIRFilter 3 ff / 3 fb (biquad) cf32", lambda: mk(lr.IIRFilterBlock, [b_iir[:3], a_iir], True), True, 16)
+    if only and not any(t in "WBFM PSD Channelizer" for t in only):
+        for r in rows:
+            print(json.dumps(r))
+        return
     rx0 = lr.wbfm_mono_receiver(1102500.0, -250e3, use_fft=False)
     cap = rx0.max_output(n)
     ms = timeit(lambda: rx0.process_device(xc.data_ptr(), n, out.data_ptr(), cap))
