@@ -48,6 +48,13 @@
 #define LRHIP_FFT_PREFETCH 0
 #endif
 
+// blocks per wave and iteration (round 3 A/B): 2 = two independent 1024-point pipelines interleaved stage by stage in one wave, each with its own
+// exchange buffer, so that the LDS exchanges and global loads of one block can overlap the butterflies of the other ("dependent phases" hypothesis); needs
+// LRHIP_FFT_WPB = 8 (one 512-thread workgroup = 8 waves per CU: 8 x 2 x 8.7 KB of exchange buffers + 17 KB of tables)
+#ifndef LRHIP_FFT_NB
+#define LRHIP_FFT_NB 1
+#endif
+
 namespace lrhip {
 
 constexpr int FFTN = 1024;
@@ -55,9 +62,10 @@ constexpr int FFT_E1_ROW = 68;
 constexpr int FFT_E2_ROW = 68;
 constexpr int FFT_EX_ELEMS = LRHIP_FFT_SPLIT ? 16 * FFT_E2_ROW / 2 : 16 * FFT_E2_ROW;   // per-wave exchange buffer (float2 units)
 constexpr int FFT_WPB = LRHIP_FFT_WPB;
-constexpr int FFT_WAVES_PER_SIMD = FFT_WPB == 16 ? 4 : LRHIP_FFT_SPLIT ? 4 : 3;
-// LDS map (float2 units): [FFT_WPB waves x FFT_EX_ELEMS | tw1 16x64 | H 16x64 | tw2 64]
-constexpr int FFT_LDS_TW1 = FFT_WPB * FFT_EX_ELEMS;
+constexpr int FFT_NB = LRHIP_FFT_NB;
+constexpr int FFT_WAVES_PER_SIMD = FFT_NB == 2 ? 2 : FFT_WPB == 16 ? 4 : LRHIP_FFT_SPLIT ? 4 : 3;
+// LDS map (float2 units): [FFT_WPB waves x FFT_NB x FFT_EX_ELEMS | tw1 16x64 | H 16x64 | tw2 64]
+constexpr int FFT_LDS_TW1 = FFT_WPB * FFT_NB * FFT_EX_ELEMS;
 constexpr int FFT_LDS_H = FFT_LDS_TW1 + 16 * 64;
 constexpr int FFT_LDS_TW2 = FFT_LDS_H + 16 * 64;
 constexpr int FFT_LDS_ELEMS = FFT_LDS_TW2 + 64;
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
                                                           const float2 *__restrict__ tables, float *__restrict__ y,
                                                           int M, long n, long n_out, long nblocks,
                                                           double inv_gain, const float2 *__restrict__ disc_prev, float *__restrict__ hist_out,
-                                                          int Mh, long delay, int accumulate, int rounds)
+                                                          int Mh, long delay, int accumulate, int rounds, int n_full, int taper)
 {
     // Long filters are PARTITIONED: this launch applies taps [delay, delay + M) of an Mh-tap filter - the M-tap overlap-save
     // on the stream delayed by `delay` samples (history = Mh - 1 samples) - and adds to y when accumulate != 0.
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
     if (PRE == 0 && hist_out && blockIdx.x == 0)
         for (int i = tid; i < (Mh - 1) * S; i += 64 * FFT_WPB) hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, Mh, n);
     cf *flc = reinterpret_cast<cf *>(fl);
-    cf *ex = flc + wave * FFT_EX_ELEMS;
+    cf *ex0 = flc + wave * FFT_NB * FFT_EX_ELEMS;
     const cf *tw1 = flc + FFT_LDS_TW1, *Hp = flc + FFT_LDS_H, *tw2 = flc + FFT_LDS_TW2;
 
     for (int i = tid; i < FFT_TABLE_ELEMS; i += 64 * FFT_WPB) fl[FFT_LDS_TW1 + i] = tables[i];
@@ -215,9 +223,21 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #define LRHIP_FFT_XCD_MAP 0
 #endif
     const long bid = (LRHIP_FFT_XCD_MAP && (gridDim.x & 7) == 0) ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+    // One-shot order with a TAPERED tail (taper > 0): the first n_full workgroups own `rounds` batches each, then `taper` workgroups (one per resident
+    // slot) own rounds / 2 each, the next `taper` rounds / 4, the rest rounds / 8 (at least one) - the dispatcher hands workgroups out in order, so the
+    // launch ends with short workgroups instead of a last wave of long ones finishing at different times (a 2^28-sample launch is 12 waves of 69 us
+    // workgroups: its fixed cost of ~60 us, read off the size sweep 2^24 .. 2^28, is mostly that tail).
+    long b0 = bid * rounds, bn = rounds;
+    if (rounds > 0 && taper > 0 && bid >= n_full) {
+        const long r1 = rounds / 2 > 0 ? rounds / 2 : 1, r2 = rounds / 4 > 0 ? rounds / 4 : 1, r3 = rounds / 8 > 0 ? rounds / 8 : 1;
+        const long k = bid - n_full, base = (long)n_full * rounds;
+        if (k < taper) { bn = r1; b0 = base + k * r1; }
+        else if (k < 2L * taper) { bn = r2; b0 = base + taper * r1 + (k - taper) * r2; }
+        else { bn = r3; b0 = base + taper * (r1 + r2) + (k - 2L * taper) * r3; }
+    }
     const long fstep = rounds > 0 ? FFT_WPB : (long)gridDim.x * FFT_WPB;
-    const long ffirst = (rounds > 0 ? bid * rounds : bid) * FFT_WPB + wave;
-    const long fend = rounds > 0 ? (bid + 1) * rounds * FFT_WPB : (nblocks + 1);
+    const long ffirst = (rounds > 0 ? b0 : bid) * FFT_WPB + wave;
+    const long fend = rounds > 0 ? (b0 + bn) * FFT_WPB : (nblocks + 1);
 #if LRHIP_FFT_PREFETCH
     cf pre[16];
     bool have = false;
@@ -232,15 +252,15 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
     };
     prefetch(ffirst);
 #endif
-    for (long fb = ffirst; fb * BPW < nblocks && fb < fend; fb += fstep) {
-        cf v[16];
+    // NB blocks per iteration (LRHIP_FFT_NB): block b of an iteration is transform fbase + b * fstep
+    auto load_block = [&](long fb, cf (&v)[16], [[maybe_unused]] int b) {
         // ---- load: window position 64*i + lane  (stream = [M-1 history | chunk])
         // (measured and dropped: 16-B accesses through an LDS transpose - no gain)
         if (S == 2) {
             const long xlo = fb * L - V - delay;          // x index of window position 0
             const long p0 = xlo + (Mh - 1);               // the same in stream coordinates
 #if LRHIP_FFT_PREFETCH
-            if (have) {
+            if (have && b == 0) {
 #pragma unroll
                 for (int i = 0; i < 16; i++) v[i] = pre[i];
             } else
@@ -283,45 +303,8 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             }
         }
 
-        // ---- forward stage 1: radix-16 over n1, twiddle W_1024^(t*k1)
-        dft16<1>(v);
-#if LRHIP_FFT_PREFETCH
-        if (S == 2) prefetch(fb + fstep);
-#endif
-#pragma unroll
-        for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw1[k * 64 + lane]);
-        // E1: write (k1, t), read (k1 = k1s, 4*t1 + t2), t2 = sub
-        exchange(ex, v, [&](int k) { return k * FFT_E1_ROW + lane; }, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; });
-        // ---- forward stage 2: radix-16 over t1, twiddle W_64^(t2*k2)
-        dft16<1>(v);
-#pragma unroll
-        for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw2[k * 4 + sub]);
-        // E2: write (k1 = k1s, k2, t2 = sub), read (k1 = k1s, k2 = 4j + q, t2 = 0..3), q = sub; register 4j + t2
-        exchange(ex, v, [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; },
-                 [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; });       // r = 4j + t2
-        // ---- forward stage 3: radix-4 over t2 -> k3; multiply by H; inverse stage 3: radix-4 over k3 -> t2
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            radix4<1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-#pragma unroll
-            for (int k3 = 0; k3 < 4; k3++) v[4 * j + k3] = cmul(v[4 * j + k3], Hp[(4 * j + k3) * 64 + lane]);
-            radix4<-1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-            // conj twiddle W_64^(-t2*k2), k2 = 4j + q
-#pragma unroll
-            for (int t2 = 1; t2 < 4; t2++) v[4 * j + t2] = cmulc(v[4 * j + t2], tw2[(4 * j + sub) * 4 + t2]);
-        }
-        // E2 back: write (k1, k2 = 4j + q, t2), read (k1 = k1s, k2 = 0..15, t2 = sub)
-        exchange(ex, v, [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; },
-                 [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; });
-        // ---- inverse stage 2: radix-16 over k2 -> t1
-        dft16<-1>(v);
-        // E1 back: write (k1 = k1s, 4*t1 + t2), read (k1, t = lane)
-        exchange(ex, v, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; }, [&](int k) { return k * FFT_E1_ROW + lane; });
-        // ---- inverse stage 1: conj twiddle, radix-16 over k1 -> n1
-#pragma unroll
-        for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], tw1[k * 64 + lane]);
-        dft16<-1>(v);
-
+    };
+    auto store_block = [&](long fb, cf (&v)[16]) {
         // ---- store: window positions V .. N-1 are this block's L outputs (positions < M-1 are the circular wrap,
         // firfilter.lua:379 copies output_block[M-1 ..]; we drop up to 63 more so the rows stay aligned)
         if (S == 2) {
@@ -366,6 +349,82 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
                 }
             }
         }
+    };
+    for (long fbase = ffirst; fbase * BPW < nblocks && fbase < fend; fbase += FFT_NB * fstep) {
+        cf v[FFT_NB][16];
+        bool live[FFT_NB];
+#pragma unroll
+        for (int b = 0; b < FFT_NB; b++) {
+            const long fb = fbase + b * fstep;
+            live[b] = fb * BPW < nblocks && fb < fend;      // wave-uniform
+            if (live[b]) load_block(fb, v[b], b);
+            else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[b][i] = cf{0.f, 0.f};
+            }
+        }
+        // ---- forward stage 1: radix-16 over n1, twiddle W_1024^(t*k1)
+#pragma unroll
+        for (int b = 0; b < FFT_NB; b++) {
+            dft16<1>(v[b]);
+#if LRHIP_FFT_PREFETCH
+            if (S == 2 && b == 0) prefetch(fbase + FFT_NB * fstep);
+#endif
+#pragma unroll
+            for (int k = 1; k < 16; k++) v[b][k] = cmul(v[b][k], tw1[k * 64 + lane]);
+        }
+        // E1: write (k1, t), read (k1 = k1s, 4*t1 + t2), t2 = sub
+#pragma unroll
+        for (int b = 0; b < FFT_NB; b++)
+            exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int k) { return k * FFT_E1_ROW + lane; }, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; });
+        // ---- forward stage 2: radix-16 over t1, twiddle W_64^(t2*k2)
+#pragma unroll
+        for (int b = 0; b < FFT_NB; b++) {
+            dft16<1>(v[b]);
+#pragma unroll
+            for (int k = 1; k < 16; k++) v[b][k] = cmul(v[b][k], tw2[k * 4 + sub]);
+        }
+        // E2: write (k1 = k1s, k2, t2 = sub), read (k1 = k1s, k2 = 4j + q, t2 = 0..3), q = sub; register 4j + t2
+#pragma unroll
+        for (int b = 0; b < FFT_NB; b++)
+            exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; },
+                     [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; });       // r = 4j + t2
+        // ---- forward stage 3: radix-4 over t2 -> k3; multiply by H; inverse stage 3: radix-4 over k3 -> t2
+#pragma unroll
+        for (int b = 0; b < FFT_NB; b++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                radix4<1>(v[b][4 * j], v[b][4 * j + 1], v[b][4 * j + 2], v[b][4 * j + 3]);
+#pragma unroll
+                for (int k3 = 0; k3 < 4; k3++) v[b][4 * j + k3] = cmul(v[b][4 * j + k3], Hp[(4 * j + k3) * 64 + lane]);
+                radix4<-1>(v[b][4 * j], v[b][4 * j + 1], v[b][4 * j + 2], v[b][4 * j + 3]);
+                // conj twiddle W_64^(-t2*k2), k2 = 4j + q
+#pragma unroll
+                for (int t2 = 1; t2 < 4; t2++) v[b][4 * j + t2] = cmulc(v[b][4 * j + t2], tw2[(4 * j + sub) * 4 + t2]);
+            }
+        }
+        // E2 back: write (k1, k2 = 4j + q, t2), read (k1 = k1s, k2 = 0..15, t2 = sub)
+#pragma unroll
+        for (int b = 0; b < FFT_NB; b++)
+            exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; },
+                     [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; });
+        // ---- inverse stage 2: radix-16 over k2 -> t1
+#pragma unroll
+        for (int b = 0; b < FFT_NB; b++) dft16<-1>(v[b]);
+        // E1 back: write (k1 = k1s, 4*t1 + t2), read (k1, t = lane)
+#pragma unroll
+        for (int b = 0; b < FFT_NB; b++)
+            exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; }, [&](int k) { return k * FFT_E1_ROW + lane; });
+        // ---- inverse stage 1: conj twiddle, radix-16 over k1 -> n1
+#pragma unroll
+        for (int b = 0; b < FFT_NB; b++) {
+#pragma unroll
+            for (int k = 1; k < 16; k++) v[b][k] = cmulc(v[b][k], tw1[k * 64 + lane]);
+            dft16<-1>(v[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < FFT_NB; b++)
+            if (live[b]) store_block(fbase + b * fstep, v[b]);
     }
 }
 

@@ -301,6 +301,8 @@ struct FirStage : lrhip_stage {
     int launch_fft(const float *x, long n, float *y, long n_out)
     {
         size_t lds_bytes = (size_t)FFT_LDS_ELEMS * sizeof(float2);
+        static const long lds_pad = getenv("LRHIP_FFT_LDS_PAD") ? atol(getenv("LRHIP_FFT_LDS_PAD")) : 0;      // A/B knob: unused LDS per workgroup -> fewer resident workgroups per CU
+        lds_bytes += (size_t)lds_pad;
         const float *h = (const float *)hist[cur].p + hist_pad;
         hist_in_kernel = false;
         // one launch per partition of at most FFT_PART taps (a plain filter has one); partitions after the first accumulate
@@ -323,10 +325,28 @@ struct FirStage : lrhip_stage {
                 int rounds = rounds_env >= 0 ? rounds_env : (want >= 8 * slots ? 8 : 0);
                 if (want <= slots) rounds = 0;
                 unsigned grid = rounds > 0 ? (unsigned)((want + rounds - 1) / rounds) : (unsigned)(want < slots ? want : slots);
+                // tapered tail of the one-shot order (kernels_firfft.h): the last three "waves" of workgroups own rounds/2, rounds/4, rounds/8 batches
+                // (measured equal on 2^28 samples, same box: 0.865-0.878 ms with, 0.860-0.867 without - the ~45 us fixed cost the size sweep shows is not
+                // the tail of long workgroups; opt-in, LRHIP_FFT_TAPER=1)
+                static const bool use_taper = getenv("LRHIP_FFT_TAPER") != nullptr && atoi(getenv("LRHIP_FFT_TAPER")) > 0;      // A/B knob
+                int n_full = 0, taper = 0;
+                if (rounds >= 2 && use_taper) {
+                    const long r1 = rounds / 2, r2 = rounds / 4 > 0 ? rounds / 4 : 1, r3 = rounds / 8 > 0 ? rounds / 8 : 1;
+                    const long tail_b = slots * (r1 + r2 + r3);
+                    if (want > 2 * tail_b) {
+                        taper = (int)slots;
+                        n_full = (int)((want - tail_b) / rounds);
+                        long rem = want - (long)n_full * rounds;                         // >= tail_b
+                        long k1 = slots, k2 = slots;
+                        rem -= k1 * r1 + k2 * r2;
+                        long k3 = rem > 0 ? (rem + r3 - 1) / r3 : 0;
+                        grid = (unsigned)(n_full + k1 + k2 + k3);
+                    }
+                }
                 const float2 *dp = pre_disc ? (const float2 *)disc_prev.p + disc_cur : nullptr;
                 float *ho = (!pre_disc && M > 1 && part == 0) ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FFT_WPB), lds_bytes, ctx().stream, h, x, tables, y, Mp, n, n_out, nblocks,
-                                   1.0 / disc_gain, dp, ho, M, (long)part * FFT_PART, part > 0 ? 1 : 0, rounds);
+                                   1.0 / disc_gain, dp, ho, M, (long)part * FFT_PART, part > 0 ? 1 : 0, rounds, n_full, taper);
                 if (ho) hist_in_kernel = true;
                 return 0;
             };
