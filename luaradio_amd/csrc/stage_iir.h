@@ -92,7 +92,13 @@ struct IirStage : lrhip_stage {
     {
         // the feed-forward loop is unrolled to NBT taps (terms beyond nb are predicated off, not free): 2 = single-pole filters, 4 = biquads and the
         // reference suite's 4-ff-tap entry, 16 = the rest
-        return nb <= 2 ? run_scan_nb<SS, PP, 2>(x, y, n) : nb <= 4 ? run_scan_nb<SS, PP, 4>(x, y, n) : run_scan_nb<SS, PP, 16>(x, y, n);
+        // (8 = the reference suite's "5 ff 3 fb" entry on orders up to 4: 0.373 -> measured below with half the predicated terms and 8 fewer staged samples)
+        if (nb <= 2) return run_scan_nb<SS, PP, 2>(x, y, n);
+        if (nb <= 4) return run_scan_nb<SS, PP, 4>(x, y, n);
+        if constexpr (PP <= 4) {
+            if (nb <= 8) return run_scan_nb<SS, PP, 8>(x, y, n);
+        }
+        return run_scan_nb<SS, PP, 16>(x, y, n);
     }
     long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
     {

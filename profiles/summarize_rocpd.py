@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 rocpd (.db) outputs into small text tables that can be committed under profiles/.
 
-usage: summarize_rocpd.py <dir-with-subdirs-of-*_results.db> [kernel-substring]
-  kernel trace dbs  -> per-kernel calls / avg / min / max duration (us), like `--stats`
+usage: summarize_rocpd.py <dir-with-subdirs-of-*_results.db> [kernel-substring] [--last N]
+  kernel trace dbs  -> per-kernel calls / avg / min / max duration (us), like `--stats`, plus the MEDIAN and - with --last N - the
+                       average and minimum over each kernel's LAST N dispatches: bench.py runs an untimed clock-ramp period and W warm-up
+                       steps before its K timed steps, so "last K" is the timed region and is what ms_per_step has to be held against
+                       (the all-dispatch average mixes the cold-clock calls in and comes out above the driver-timed step)
   pmc dbs           -> per-kernel per-counter average value per dispatch
 """
 import glob
@@ -17,8 +20,14 @@ def short(name, n=70):
 
 
 def main():
-    root = sys.argv[1]
-    filt = sys.argv[2] if len(sys.argv) > 2 else ""
+    argv = list(sys.argv[1:])
+    last = 0
+    if "--last" in argv:
+        i = argv.index("--last")
+        last = int(argv[i + 1])
+        del argv[i:i + 2]
+    root = argv[0]
+    filt = argv[1] if len(argv) > 1 else ""
     for db_path in sorted(glob.glob(os.path.join(root, "*", "*_results.db"))):
         db = sqlite3.connect(db_path)
         cur = db.cursor()
@@ -31,11 +40,24 @@ def main():
                 if filt in k:
                     print("%-28s %-72s %6d %16.1f %16.1f %16.1f" % (c, short(k), n, a, lo, hi))
         else:
-            print("%-72s %6s %12s %12s %12s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
-            tot = cur.execute("select sum(duration) from kernels").fetchone()[0] or 1
-            for k, n, a, lo, hi, s in cur.execute("select name, count(*), avg(duration), min(duration), max(duration), sum(duration) "
-                                                  "from kernels group by name order by sum(duration) desc limit 30"):
-                print("%-72s %6d %12.2f %12.2f %12.2f %6.1f%%" % (short(k), n, a / 1e3, lo / 1e3, hi / 1e3, 100.0 * s / tot))
+            cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+            order = "start" if "start" in cols else "rowid"
+            per = {}
+            for k, d in cur.execute("select name, duration from kernels order by %s" % order):
+                per.setdefault(k, []).append(d)
+            tot = sum(sum(v) for v in per.values()) or 1
+            hdr = "%-72s %6s %12s %12s %12s %12s %7s" % ("kernel", "calls", "avg_us", "median_us", "min_us", "max_us", "pct")
+            if last:
+                hdr += " %14s %14s" % ("avg_last%d_us" % last, "min_last%d_us" % last)
+            print(hdr)
+            for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))[:30]:
+                sv = sorted(v)
+                med = sv[len(sv) // 2] if len(sv) % 2 else 0.5 * (sv[len(sv) // 2 - 1] + sv[len(sv) // 2])
+                line = "%-72s %6d %12.2f %12.2f %12.2f %12.2f %6.1f%%" % (short(k), len(v), sum(v) / len(v) / 1e3, med / 1e3, sv[0] / 1e3, sv[-1] / 1e3, 100.0 * sum(v) / tot)
+                if last:
+                    tail = v[-last:]
+                    line += " %14.2f %14.2f" % (sum(tail) / len(tail) / 1e3, min(tail) / 1e3)
+                print(line)
         print()
 
 

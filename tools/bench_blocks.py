@@ -69,20 +69,20 @@ def main():
     taps128 = lr.filter_utils.firwin_lowpass(128, 15e3 / 110250)
     # yardstick: the cheapest streaming kernel (one multiply per scalar), 8 B in + 8 B out per sample
     run("MultiplyConstant(1.0) cf32 (streaming yardstick)", lambda: mk(lr.MultiplyConstantBlock, [1.0], True), True, 16)
-    run("FIRFilter 128 real taps, cf32", lambda: mk(lr.FIRFilterBlock, [taps128], True), True, 16, 512)
+    run("FIRFilter 128 real taps, cf32, direct form (use_fft=False)", lambda: mk(lr.FIRFilterBlock, [taps128, False], True), True, 16, 512)
     run("FIRFilter 128 real taps, cf32, overlap-save (use_fft=fast)", lambda: mk(lr.FIRFilterBlock, [taps128, "fast"], True), True, 16, 125)
-    run("FIRFilter 128 real taps, f32", lambda: mk(lr.FIRFilterBlock, [taps128], False), False, 8, 256)
+    run("FIRFilter 128 real taps, f32, direct form (use_fft=False)", lambda: mk(lr.FIRFilterBlock, [taps128, False], False), False, 8, 256)
     run("FIRFilter 128 real taps, f32, overlap-save (use_fft=fast)", lambda: mk(lr.FIRFilterBlock, [taps128, "fast"], False), False, 8, 63)
-    run("FIRFilter 16 real taps, cf32", lambda: mk(lr.FIRFilterBlock, [taps128[:16]], True), True, 16, 64)
-    run("FIRFilter 128 complex taps, cf32", lambda: mk(lr.FIRFilterBlock, [np.asarray(taps128, np.complex64) * (1 + 0.5j)], True), True, 16, 1024)
+    run("FIRFilter 16 real taps, cf32", lambda: mk(lr.FIRFilterBlock, [taps128[:16], False], True), True, 16, 64)
+    run("FIRFilter 128 complex taps, cf32, direct form (use_fft=False)", lambda: mk(lr.FIRFilterBlock, [np.asarray(taps128, np.complex64) * (1 + 0.5j), False], True), True, 16, 1024)
     run("FIRFilter 128 complex taps, cf32, overlap-save (use_fft=fast)", lambda: mk(lr.FIRFilterBlock, [np.asarray(taps128, np.complex64) * (1 + 0.5j), "fast"], True), True, 16, 125)
     run("FrequencyTranslator", lambda: mk(lr.FrequencyTranslatorBlock, [-250e3], True), True, 16)
     run("FrequencyDiscriminator", lambda: mk(lr.FrequencyDiscriminatorBlock, [1.25], True), True, 12)
     run("Downsampler(5) cf32", lambda: mk(lr.DownsamplerBlock, [5], True), True, 8 + 8 / 5)
     run("Downsampler(5) f32", lambda: mk(lr.DownsamplerBlock, [5], False), False, 4 + 4 / 5)
     run("FMDeemphasis f32", lambda: mk(lr.FMDeemphasisFilterBlock, [75e-6], False, 220500.0), False, 8)
-    run("Decimator(5) cf32 (fused FIR+downsample)", lambda: mk(lr.DecimatorBlock, [5], True), True, 8 + 8 / 5, 4 * 128 / 5)
-    run("Tuner(-250k,200k,5) (fused rot+FIR+downsample)", lambda: mk(lr.TunerBlock, [-250e3, 200e3, 5], True), True, 8 + 8 / 5, 4 * 128 / 5 + 6)
+    run("Decimator(5) cf32 (fused FIR+downsample)", lambda: mk(lr.DecimatorBlock, [5, {"use_fft": False}], True), True, 8 + 8 / 5, 4 * 128 / 5)
+    run("Tuner(-250k,200k,5) (fused rot+FIR+downsample)", lambda: mk(lr.TunerBlock, [-250e3, 200e3, 5, {"use_fft": False}], True), True, 8 + 8 / 5, 4 * 128 / 5 + 6)
     run("Decimator(5) cf32, polyphase FFT overlap-save", lambda: mk(lr.DecimatorBlock, [5, {"use_fft": "fast"}], True), True, 8 + 8 / 5, 62)
     run("Tuner(-250k,200k,5), polyphase FFT overlap-save", lambda: mk(lr.TunerBlock, [-250e3, 200e3, 5, {"use_fft": "fast"}], True), True, 8 + 8 / 5, 62)
     run("Interpolator(5) cf32 (polyphase, input samples)", lambda: mk(lr.InterpolatorBlock, [5], True), True, 8 + 8 * 5, 4 * 128)

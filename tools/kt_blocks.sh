@@ -1,13 +1,13 @@
 #!/bin/bash
-# rocprofv3 kernel traces of tools/bench_blocks.py and tools/bench_reference_suite.py -> gpurun_out/kt_blocks/summary.txt
+# rocprofv3 kernel trace of tools/bench_blocks.py only -> gpurun_out/prof_<tag>/summary_blocks_kernel_trace.txt (tools/profile_round.sh does the same as its last step)
+TAG=${1:-r}
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/kt_blocks
-mkdir -p "$OUT"
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"; rm -rf "$OUT/kt_blocks"
 export TMPDIR=/tmp
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/blocks" -o b -- python $ROOT/tools/bench_blocks.py > "$OUT/blocks.log" 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/suite" -o s -- python $ROOT/tools/bench_reference_suite.py > "$OUT/suite.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt_blocks/blocks" -o b -- python $ROOT/tools/bench_blocks.py --reps 10 > "$OUT/blocks.log" 2>&1
 cd "$ROOT"
-python profiles/summarize_rocpd.py "$OUT" > "$OUT/summary.txt" 2>&1
-find "$OUT" -name "*.db" -delete
-grep -c lrhip "$OUT/summary.txt"
+python profiles/summarize_rocpd.py "$OUT/kt_blocks" --last 10 > "$OUT/summary_blocks_kernel_trace.txt" 2>&1
+grep block "$OUT/blocks.log" > "$OUT/blocks_table.jsonl"
+grep -c lrhip "$OUT/summary_blocks_kernel_trace.txt"

@@ -2,25 +2,28 @@
 # Profiling recipe for one round (run on the GPU box through gpurun, from the repo root):
 #   tools/profile_round.sh <tag>      -> gpurun_out/prof_<tag>/{kt,pmc*}/... + gpurun_out/prof_<tag>/summary_*.txt
 # rocprofv3 is run from /tmp with TMPDIR=/tmp; --pmc passes never carry a trace option.  The kernel traces use the bench's own default
-# steps / warm-up (20 / 3) so that the per-kernel average can be held against the bench line's ms_per_step.
+# steps / warm-up (20 / 3); summarize_rocpd.py --last 20 reports each kernel's last 20 dispatches = the timed region, which is what the
+# bench line's ms_per_step has to be held against.  The (small) kernel-trace databases are kept next to the summaries.
 set -u
 TAG=${1:-r}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 B="python $ROOT/bench.py --no-cpu-baseline --no-verify --headline-only"
 run() { timeout 240 rocprofv3 "$@" > /dev/null 2>&1 || echo "rocprofv3 $* failed rc=$?"; }
-# kernel traces (durations): headline FFT form, bit-exact direct form, WBFM chain
+# kernel traces (durations): headline FFT form, bit-exact direct form, WBFM chain, channelizer
 run --kernel-trace --stats -d "$OUT/kt/fft" -o fft -- $B --steps 20 --warmup 3
 run --kernel-trace --stats -d "$OUT/kt/direct" -o direct -- $B --steps 20 --warmup 3 --fir-mode direct
 run --kernel-trace --stats -d "$OUT/kt/wbfm" -o wbfm -- $B --steps 20 --warmup 3 --workload wbfm
+run --kernel-trace --stats -d "$OUT/kt/chan" -o chan -- python $ROOT/tools/run_channelizer.py 20
 # counters, one small group per pass
 P="$B --steps 3 --warmup 1"
 D="$P --fir-mode direct"
 W="$P --workload wbfm"
-for spec in "fir:$P" "direct:$D" "wbfm:$W"; do
+C="python $ROOT/tools/run_channelizer.py 3"
+for spec in "fir:$P" "direct:$D" "wbfm:$W" "chan:$C"; do
     name=${spec%%:*}; cmd=${spec#*:}
     run --pmc FETCH_SIZE -d "$OUT/pmc_$name/fetch" -o p -- $cmd
     run --pmc WRITE_SIZE -d "$OUT/pmc_$name/write" -o p -- $cmd
@@ -30,11 +33,17 @@ for spec in "fir:$P" "direct:$D" "wbfm:$W"; do
     run --pmc GRBM_GUI_ACTIVE -d "$OUT/pmc_$name/grbm" -o p -- $cmd
 done
 run --pmc TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ -d "$OUT/pmc_fir/tcp" -o p -- $P
+# per-block table under the tracer (tools/bench_blocks.py, 2^26 samples)
+run --kernel-trace --stats -d "$OUT/kt_blocks/blocks" -o b -- python $ROOT/tools/bench_blocks.py --reps 10
 cd "$ROOT"
-python profiles/summarize_rocpd.py "$OUT/kt" > "$OUT/summary_kernel_trace.txt" 2>&1
+python profiles/summarize_rocpd.py "$OUT/kt" --last 20 > "$OUT/summary_kernel_trace.txt" 2>&1
+python profiles/summarize_rocpd.py "$OUT/kt_blocks" --last 10 > "$OUT/summary_blocks_kernel_trace.txt" 2>&1
 python profiles/summarize_rocpd.py "$OUT/pmc_fir" fir_ > "$OUT/summary_pmc_fir.txt" 2>&1
 python profiles/summarize_rocpd.py "$OUT/pmc_direct" fir_ > "$OUT/summary_pmc_direct.txt" 2>&1
 python profiles/summarize_rocpd.py "$OUT/pmc_wbfm" lrhip > "$OUT/summary_pmc_wbfm.txt" 2>&1
-# the rocpd databases are large (gpurun copies at most 64 MiB back): keep the summaries only
-find "$OUT" -name "*.db" -delete
-tail -n 45 "$OUT/summary_kernel_trace.txt"
+python profiles/summarize_rocpd.py "$OUT/pmc_chan" channelizer > "$OUT/summary_pmc_chan.txt" 2>&1
+# keep the kernel-trace databases (small); the counter databases are large (gpurun copies at most 64 MiB back)
+find "$OUT" -path "*pmc_*" -name "*.db" -delete
+find "$OUT" -name "*.db" -size +6M -delete
+du -sh "$OUT"
+tail -n 30 "$OUT/summary_kernel_trace.txt"
