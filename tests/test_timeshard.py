@@ -199,6 +199,39 @@ def test_unaligned_partition_boundaries_same_values():
 
 
 @pytest.mark.gpu
+def test_unaligned_partition_boundaries_on_an_fm_signal_are_tight():
+    """the same cuts on what the receiver is for - an FM signal, |tuner output| ~ 1: the window-relative rotator staging then moves the angles by
+    Float32 rounding of well-conditioned filter outputs, and the bounds are 2e-6 (tuner + discriminator) and 2e-7 (receiver audio); the U(-1, 1)
+    noise input of the test above is the documented worst case (small filter outputs, ill-conditioned angles)"""
+    n = 1 << 20
+    fs = 1102500.0
+    rng = np.random.default_rng(23)
+    t = np.arange(n) / fs
+    m = 0.5 * np.sin(2 * np.pi * 1e3 * t) + 0.5 * np.sin(2 * np.pi * 5e3 * t)
+    x = (np.exp(1j * (2 * np.pi * 250e3 * t + 2 * np.pi * 75e3 / fs * np.cumsum(m))) + 0.01 * (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n))).astype(np.complex64)
+    import luaradio_amd as lr
+    from luaradio_amd import types
+
+    def tuner_disc():
+        blocks = [lr.FrequencyTranslatorBlock(-250e3), lr.LowpassFilterBlock(128, 100e3), lr.DownsamplerBlock(5), lr.FrequencyDiscriminatorBlock(1.25)]
+        r, ty = fs, types.ComplexFloat32
+        for b in blocks:
+            b.rate = r
+            b.differentiate([ty])
+            b.initialize()
+            r, ty = b.get_rate(), b.get_output_type()
+        return lr.Chain(blocks)
+
+    for name, build, tol in (("tuner+disc", tuner_disc, 2e-6), ("wbfm", lambda: lr.wbfm_mono_receiver(fs, -250e3), 2e-7)):
+        whole = build().process(x)
+        chain = build()
+        cuts = [0, 100001, 333333, 700007, n]
+        got = np.concatenate([timeshard.run_partition(chain, x, a, b) for a, b in zip(cuts, cuts[1:])])
+        assert len(got) == len(whole)
+        assert float(np.max(np.abs(got - whole))) <= tol, (name, float(np.max(np.abs(got - whole))))
+
+
+@pytest.mark.gpu
 def test_halo_refuses_chains_with_unbounded_memory():
     import luaradio_amd as lr
     from luaradio_amd import types
