@@ -60,13 +60,13 @@ static long host_execute(PinnedBuf &h_in, PinnedBuf &h_out, DeviceBuf &d_in, Dev
     if (h_in.reserve(in_bytes ? in_bytes : 16) || d_in.reserve(in_bytes ? in_bytes : 16)) return -1;
     if (h_out.reserve((size_t)cap * out_size + 16) || d_out.reserve((size_t)cap * out_size + 16)) return -1;
     if (in_bytes) {
-        memcpy(h_in.p, in_host, in_bytes);
+        host_copy(h_in.p, in_host, in_bytes);
         LR_HIP(hipMemcpyAsync(d_in.p, h_in.p, in_bytes, hipMemcpyHostToDevice, ctx().stream));
     }
     long n_out = run(d_in.p, n_in, d_out.p, cap);
     if (n_out < 0) return n_out;
     if (n_out) LR_HIP(hipMemcpyAsync(h_out.p, d_out.p, (size_t)n_out * out_size, hipMemcpyDeviceToHost, ctx().stream));
     LR_HIP(hipStreamSynchronize(ctx().stream));
-    if (n_out) memcpy(out_host, h_out.p, (size_t)n_out * out_size);
+    if (n_out) host_copy(out_host, h_out.p, (size_t)n_out * out_size);
     return n_out;
 }

@@ -2,11 +2,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <unistd.h>
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 namespace lrhip {
@@ -139,6 +143,95 @@ struct PinnedBuf {
     }
     ~PinnedBuf() { release(); }
 };
+
+// ---- host-side copies into / out of the pinned slots --------------------------------------------------------------------------
+// A LuaRadio process() hands the library a pageable vector (radio/core/vector.lua:19-37); the copy into the pinned ring slot ran on ONE
+// host thread in round 2 and was the whole host-path bound (~10 GB/s: 1.3 GS/s of ComplexFloat32 at the pipe's 131 072-sample chunks,
+// DESIGN.md section 7).  Copies of half a megabyte and more are split over a small pool of helper threads (LRHIP_COPY_THREADS, default 8
+// including the caller, at most half the hardware threads; 1 = off).  The pool is created lazily in the process that uses it (a forked block process builds its own: the
+// parent's threads do not exist in the child) and never touches HIP.
+struct CopyPool {
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_work;
+    long pid = 0;
+    int nthreads = 1;
+    // one job at a time (the caller blocks until it is done)
+    char *dst = nullptr;
+    const char *src = nullptr;
+    size_t bytes = 0, part = 0;
+    std::atomic<size_t> next{0};
+    std::atomic<int> generation{0}, running{0};
+    bool stop = false;
+
+    void work()
+    {
+        for (;;) {
+            const size_t off = next.fetch_add(part);
+            if (off >= bytes) break;
+            const size_t len = off + part <= bytes ? part : bytes - off;
+            memcpy(dst + off, src + off, len);
+        }
+    }
+    void loop()
+    {
+        int seen = 0;
+        for (;;) {
+            // a megabyte copies in ~25 us on four threads - less than a condition-variable wake-up: spin for a while first (chunks arrive back to
+            // back while a stream runs), sleep when the stream pauses
+            int spins = 0;
+            while (generation.load(std::memory_order_acquire) == seen && spins < 20000) {
+                __builtin_ia32_pause();
+                spins++;
+            }
+            if (generation.load(std::memory_order_acquire) == seen) {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return stop || generation.load(std::memory_order_acquire) != seen; });
+                if (stop) return;
+            }
+            seen = generation.load(std::memory_order_acquire);
+            work();
+            running.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    void start()
+    {
+        const char *e = getenv("LRHIP_COPY_THREADS");
+        int n = e ? atoi(e) : 8;
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && (unsigned)n > (hw + 1) / 2) n = (int)((hw + 1) / 2);
+        nthreads = n < 1 ? 1 : n > 16 ? 16 : n;
+        pid = (long)getpid();
+        for (int i = 1; i < nthreads; i++) workers.emplace_back([this] { loop(); });
+        for (auto &t : workers) t.detach();        // they live as long as the process (no join at exit: the library never unloads cleanly under LuaJIT)
+    }
+    void copy(void *d, const void *s_, size_t n)
+    {
+        dst = (char *)d; src = (const char *)s_; bytes = n;
+        part = ((n / (size_t)(4 * nthreads)) + 4095) & ~(size_t)4095;      // a few parts per thread, page multiples
+        if (part < 65536) part = 65536;
+        next.store(0);
+        running.store(nthreads - 1, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            generation.fetch_add(1, std::memory_order_release);
+        }
+        cv_work.notify_all();
+        work();
+        while (running.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+    }
+};
+inline void host_copy(void *dst, const void *src, size_t bytes)
+{
+    static CopyPool *pool = nullptr;
+    if (bytes < (512u << 10)) { memcpy(dst, src, bytes); return; }
+    if (!pool || pool->pid != (long)getpid()) {
+        pool = new (std::nothrow) CopyPool();      // after a fork the parent's pool object is abandoned (its threads do not exist here)
+        if (pool) pool->start();
+    }
+    if (!pool || pool->nthreads <= 1) { memcpy(dst, src, bytes); return; }
+    pool->copy(dst, src, bytes);
+}
 
 // Streaming kernels are launched ONE-SHOT: a workgroup per 256 work items, every thread one item (the grid-stride loops in
 // the kernels then run once and only guard grids clipped at 2^31-1).  Measured on MI355X (tools/mb_stream.hip, 2 GiB in +

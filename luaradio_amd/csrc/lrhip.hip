@@ -901,7 +901,7 @@ long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_i
     size_t bytes = (size_t)n_in * in_size;
     // the slot was collected (ev_out waited) before it can be reused, so its buffers are free on host and device
     if (bytes) {
-        if (in_host != sl.h_in.p) memcpy(sl.h_in.p, in_host, bytes);      // lrhip_chain_ring_input(): the caller filled the slot itself
+        if (in_host != sl.h_in.p) host_copy(sl.h_in.p, in_host, bytes);      // lrhip_chain_ring_input(): the caller filled the slot itself
         LR_HIP(hipMemcpyAsync(sl.d_in.p, sl.h_in.p, bytes, hipMemcpyHostToDevice, c->s_in));
     }
     LR_HIP(hipEventRecord(sl.ev_in, c->s_in));
@@ -937,7 +937,7 @@ long lrhip_chain_collect(lrhip_chain_t *c, void *out_host, unsigned long out_cap
     if ((unsigned long)sl.n_out > out_capacity) return set_error("output capacity %lu < %ld", out_capacity, sl.n_out);
     if (sl.n_out && !out_host) return set_error("null output buffer");
     LR_HIP(hipEventSynchronize(sl.ev_out));
-    if (sl.n_out) memcpy(out_host, sl.h_out.p, (size_t)sl.n_out * c->ops.back().stage->out_size);
+    if (sl.n_out) host_copy(out_host, sl.h_out.p, (size_t)sl.n_out * c->ops.back().stage->out_size);
     c->inflight--;
     return sl.n_out;
 }
@@ -1005,7 +1005,7 @@ long lrhip_chain_push(lrhip_chain_t *c, const void *in_host, unsigned long n_in,
         }
         unsigned long take = c->ring_chunk - c->fill;
         if (take > n_in) take = n_in;
-        memcpy((char *)c->ring[c->head]->h_in.p + (size_t)c->fill * in_size, src, (size_t)take * in_size);
+        host_copy((char *)c->ring[c->head]->h_in.p + (size_t)c->fill * in_size, src, (size_t)take * in_size);
         if (!c->fill && c->max_latency > 0.0) c->fill_t0 = monotonic_seconds();
         c->fill += take; src += (size_t)take * in_size; n_in -= take;
         if (c->fill == c->ring_chunk) {
