@@ -204,7 +204,11 @@ __host__ __device__ constexpr int fir_taps_len(int D, int ksteps) { return ((fir
 // A fragment of step s: lane (m = lane&15, kq = lane>>4) reads taps_pad[ZL + 4s + kq - e - m*D] (a broadcast-friendly
 // LDS read; equal addresses across lanes are free).  NOUT = 2: two tap arrays (ldsT, ldsT + tlen) applied to the same B
 // fragments -> two accumulator sets (the re and im outputs of a complex-taps filter over the interleaved float stream).
-template <int S, int D, int NACC, int KS, int NOUT>
+// TQS > 0: the tap array is kept in FOUR copies, TQS floats apart, and lane group kq reads copy kq.  At D = 5 the A-fragment address is
+// kq - 5 col + const: the 32 lanes of a half-wave (kq in {0, 1} or {2, 3}) then hit 16 + 16 banks that overlap in three places (5 (c' - c) = 1
+// mod 32 at c' = c + 13), a 2-way conflict on every tap read (SQ_LDS_BANK_CONFLICT: 14 M of 48 M LDS cycles of the receiver kernel).  With
+// TQS = 15 mod 32 the second lane group of a half lands 16 banks away from the first - the complement of {-5 c mod 32} - and the read is conflict-free.
+template <int S, int D, int NACC, int KS, int NOUT, int TQS = 0>
 __device__ __forceinline__ void mfma_tile(const float *ldsT, int tlen, int e, const float *ldsX, int ksteps, f32x4 (&acc)[NOUT][NACC])
 {
     using G = FirMfmaGeom<S, D>;
@@ -214,7 +218,7 @@ __device__ __forceinline__ void mfma_tile(const float *ldsT, int tlen, int e, co
     const int comp = S == 2 ? (col & 1) : 0;
     constexpr int ACC_STRIDE = (G::ROW + G::PAD) * G::BPA;    // floats between consecutive accumulators' blocks
     const float *bptr = ldsX + (G::ROW + G::PAD) * ((wave * NACC) * G::BPA + blk_in_acc) + S * kq + comp;
-    const float *aptr = ldsT + fir_taps_zl(D) + kq - e - col * D;      // row m of the Toeplitz block = lane & 15
+    const float *aptr = ldsT + kq * TQS + fir_taps_zl(D) + kq - e - col * D;      // row m of the Toeplitz block = lane & 15
 #pragma unroll
     for (int o = 0; o < NOUT; o++)
 #pragma unroll

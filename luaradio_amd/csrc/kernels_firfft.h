@@ -203,9 +203,6 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
     cf *ex0 = flc + wave * FFT_NB * FFT_EX_ELEMS;
     const cf *tw1 = flc + FFT_LDS_TW1, *Hp = flc + FFT_LDS_H, *tw2 = flc + FFT_LDS_TW2;
 
-    for (int i = tid; i < FFT_TABLE_ELEMS; i += 64 * FFT_WPB) fl[FFT_LDS_TW1 + i] = tables[i];
-    __syncthreads();
-
     // block advance: the overlap is rounded up to a multiple of 64 samples (V >= M-1) so that every block's load window
     // AND its stored rows start on 512-B boundaries relative to x / y (L = 897 would misalign every row)
     const int V = ((M - 1 + 63) / 64) * 64;
@@ -350,6 +347,18 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             }
         }
     };
+    // Start-up: the one-shot block order pays it once per WORKGROUP, and a 2^28-sample launch is 12 rounds of workgroups per resident slot (the ~45 us
+    // per launch that do not scale with n, profiles/r03_fir_fft_ab_counters.txt): the first block's 16 loads are issued BEFORE the 17 KB of tables are
+    // staged, so the two latencies overlap instead of adding (LRHIP_FFT_EARLY = 0: tables first, as in round 2)
+#ifndef LRHIP_FFT_EARLY
+#define LRHIP_FFT_EARLY 1
+#endif
+    cf v_first[16];
+    const bool early = LRHIP_FFT_EARLY && FFT_NB == 1 && !LRHIP_FFT_PREFETCH && ffirst * BPW < nblocks && ffirst < fend;
+    if (early) load_block(ffirst, v_first, 0);
+    for (int i = tid; i < FFT_TABLE_ELEMS; i += 64 * FFT_WPB) fl[FFT_LDS_TW1 + i] = tables[i];
+    __syncthreads();
+
     for (long fbase = ffirst; fbase * BPW < nblocks && fbase < fend; fbase += FFT_NB * fstep) {
         cf v[FFT_NB][16];
         bool live[FFT_NB];
@@ -357,7 +366,10 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
         for (int b = 0; b < FFT_NB; b++) {
             const long fb = fbase + b * fstep;
             live[b] = fb * BPW < nblocks && fb < fend;      // wave-uniform
-            if (live[b]) load_block(fb, v[b], b);
+            if (live[b] && early && b == 0 && fbase == ffirst) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) v[b][i] = v_first[i];
+            } else if (live[b]) load_block(fb, v[b], b);
             else {
 #pragma unroll
                 for (int i = 0; i < 16; i++) v[b][i] = cf{0.f, 0.f};

@@ -70,6 +70,11 @@ constexpr int RX_AUDIO = RX_BATCH / 5;                                // 1 024 a
 constexpr int RX_TH = RX_MT - 1;                                      // 135 samples of tail history
 constexpr int RX_SPAN = FirMfmaGeom<2, RX_D>::span(1, RX_KS);
 constexpr int RX_TLEN = fir_taps_len(RX_D, RX_KS);
+#ifndef LRHIP_RX_TAP_COPIES
+#define LRHIP_RX_TAP_COPIES 0      /* 1: four copies of the tuner tap array, 303 floats apart (conflict-free A-fragment reads, mfma_tile TQS) - measured equal on the receiver (0.1515 against 0.1518 ms, same box): the conflicts are not on its critical path; 0: one copy */
+#endif
+constexpr int RX_TQS = LRHIP_RX_TAP_COPIES ? 303 : 0;                 // 303 = 15 mod 32, >= TLEN
+constexpr int RX_TFLOATS = LRHIP_RX_TAP_COPIES ? ((3 * RX_TQS + RX_TLEN + 3) / 4) * 4 : RX_TLEN;
 constexpr int RX_XF = FirMfmaGeom<2, RX_D>::phys(2 * RX_SPAN) + FirMfmaGeom<2, RX_D>::PAD + 8;
 // audio window: logical float a = (discriminator sample of the batch) + 135, padded rows of the Float32 Toeplitz product
 constexpr int RX_PSPAN = FirMfmaGeom<1, RX_D>::span(1, RX_KST);       // 5 256 = 5 120 + 135 + 1
@@ -77,7 +82,7 @@ constexpr int RX_PF = ((FirMfmaGeom<1, RX_D>::phys(RX_PSPAN) + FirMfmaGeom<1, RX
 constexpr int RX_GZ = 4;                                              // extra leading zeros of the audio tap table: slack up to 4 (fir_taps_zl covers 3)
 constexpr int RX_GLEN = RX_GZ + fir_taps_len(RX_D, RX_KST);
 // LDS map (floats): [taps_pad TLEN | window XF (the audio pass reuses its head as the 1 024-float output row) | P | audio taps GLEN | ptab4 64 | xch 8 | eo 16 | 4]
-constexpr int RX_LDS_X = RX_TLEN;
+constexpr int RX_LDS_X = RX_TFLOATS;
 constexpr int RX_LDS_P = RX_LDS_X + ((RX_XF + 3) / 4) * 4;
 constexpr int RX_LDS_G = RX_LDS_P + RX_PF;
 constexpr int RX_LDS_PT = RX_LDS_G + RX_GLEN;
@@ -85,6 +90,7 @@ constexpr int RX_LDS_XCH = RX_LDS_PT + 64;
 constexpr int RX_LDS_EO = RX_LDS_XCH + 8;
 constexpr int RX_LDS_PREV = RX_LDS_EO + 16;
 constexpr int RX_LDS_FLOATS = RX_LDS_PREV + 4;
+static_assert(RX_TQS == 0 || (RX_TQS >= RX_TLEN && RX_TQS % 32 == 15), "tap copies: 16 banks apart");
 static_assert(RX_TILE == 512 && RX_AUDIO == 1024 && RX_TLEN % 4 == 0 && RX_GLEN % 4 == 0 && RX_PSPAN == RX_BATCH + RX_TH + 1, "receiver geometry");
 static_assert(RX_XF >= RX_AUDIO, "the audio output row lives in the RF window area");
 
@@ -112,7 +118,11 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
     // raw tuner history for the next chunk (the other ping-pong buffer)
     if (pr.hist_out && blockIdx.x == 0)
         for (int i = tid; i < (M - 1) * S; i += NT) pr.hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
-    for (int i = tid; i < RX_TLEN; i += NT) ldsT[i] = pr.taps_pad[i];
+    for (int i = tid; i < RX_TLEN; i += NT) {
+        const float v = pr.taps_pad[i];
+        ldsT[i] = v;
+        if (RX_TQS) { ldsT[RX_TQS + i] = v; ldsT[2 * RX_TQS + i] = v; ldsT[3 * RX_TQS + i] = v; }
+    }
     for (int i = tid; i < RX_GLEN; i += NT) ldsGT[i] = i < RX_GZ ? 0.f : pr.g_pad[i - RX_GZ];
     if (tid < 64) ldsPt[tid] = pr.ptab4[tid];
     // Every float of the audio window meets taps in the Toeplitz product - zero taps outside an output's own 136 - so what a run has not
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
         // ---- filter: banded-Toeplitz product on the f32 matrix cores, one accumulator (128 outputs) per wave
         f32x4 acc[1][1];
         if (pr.dbg & 4) acc[0][0] = (f32x4){ldsX[tid], ldsX[tid + 256], ldsX[tid + 512], ldsX[tid + 768]};
-        else mfma_tile<S, D, 1, RX_KS, 1>(ldsT, RX_TLEN, pr.e, ldsX, RX_KS, acc);
+        else mfma_tile<S, D, 1, RX_KS, 1, RX_TQS>(ldsT, RX_TLEN, pr.e, ldsX, RX_KS, acc);
 
         // ---- discriminator on the accumulators -> P.  After the re/im exchange a lane owns two consecutive filter outputs; the one in front of them is
         // one shuffle away - except for lane 0, whose predecessor is the previous wave's last output (through LDS, after the barrier that also
