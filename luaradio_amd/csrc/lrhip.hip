@@ -174,6 +174,8 @@ lrhip_stage_t *lrhip_iir_create(const float *b, unsigned nb, const float *a, uns
         } else if (P == 1 && p16 == 0.0) {
             q->warm_chunks = 1;
         }
+        // (orders 2-4 were given the same one-shot launch in round 3 - 4 chunks of warm-up instead of a whole tile per 8 - and lost: 0.417 against 0.372 ms
+        // for the suite's 3-feedback-tap entry on ComplexFloat32, same box: every workgroup then runs the 18-barrier block scan twice per emitted tile)
         if (P == 1) {                                               // p^(16 (l + 1)), l < 64: the per-lane powers of the single-launch kernel's wave scan
             double acc = 1.0;
             for (int l = 0; l < 64; l++) { acc *= p16; tpow.push_back((float)acc); }
