@@ -64,9 +64,13 @@ struct RxParams {
 constexpr int RX_D = 5, RX_KS = 51, RX_M = 128, RX_MT = 136;
 constexpr int RX_KST = 54;                                            // audio filter: slack (0..4) + 15 x 5 + 136 <= 4 x 54
 constexpr int RX_TILE = FirMfmaGeom<2, RX_D>::tile_out(1);            // 512 tuner outputs per tile
-constexpr int RX_TPB = 10;                                            // tiles per batch
+#ifndef LRHIP_RX_TPB
+#define LRHIP_RX_TPB 10      /* tiles per batch: 10 = 1 024 audio outputs, an accumulator for each of the four waves, 46 KB of LDS (3 workgroups per CU); 5 = 512 audio outputs on waves 0-1, 36 KB (4 per CU) */
+#endif
+constexpr int RX_TPB = LRHIP_RX_TPB;                                  // tiles per batch
 constexpr int RX_BATCH = RX_TILE * RX_TPB;                            // 5 120 discriminator samples
 constexpr int RX_AUDIO = RX_BATCH / 5;                                // 1 024 audio outputs per batch: one accumulator (256) per wave
+constexpr int RX_AW = RX_AUDIO / 256;                                 // waves that run the audio product
 constexpr int RX_TH = RX_MT - 1;                                      // 135 samples of tail history
 constexpr int RX_SPAN = FirMfmaGeom<2, RX_D>::span(1, RX_KS);
 constexpr int RX_TLEN = fir_taps_len(RX_D, RX_KS);
@@ -77,7 +81,7 @@ constexpr int RX_TQS = LRHIP_RX_TAP_COPIES ? 303 : 0;                 // 303 = 1
 constexpr int RX_TFLOATS = LRHIP_RX_TAP_COPIES ? ((3 * RX_TQS + RX_TLEN + 3) / 4) * 4 : RX_TLEN;
 constexpr int RX_XF = FirMfmaGeom<2, RX_D>::phys(2 * RX_SPAN) + FirMfmaGeom<2, RX_D>::PAD + 8;
 // audio window: logical float a = (discriminator sample of the batch) + 135, padded rows of the Float32 Toeplitz product
-constexpr int RX_PSPAN = FirMfmaGeom<1, RX_D>::span(1, RX_KST);       // 5 256 = 5 120 + 135 + 1
+constexpr int RX_PSPAN = FirMfmaGeom<1, RX_D>::span(1, RX_KST, RX_AW);       // 5 256 = 5 120 + 135 + 1
 constexpr int RX_PF = ((FirMfmaGeom<1, RX_D>::phys(RX_PSPAN) + FirMfmaGeom<1, RX_D>::PAD + 3) / 4) * 4;
 constexpr int RX_GZ = 4;                                              // extra leading zeros of the audio tap table: slack up to 4 (fir_taps_zl covers 3)
 constexpr int RX_GLEN = RX_GZ + fir_taps_len(RX_D, RX_KST);
@@ -91,11 +95,11 @@ constexpr int RX_LDS_EO = RX_LDS_XCH + 8;
 constexpr int RX_LDS_PREV = RX_LDS_EO + 16;
 constexpr int RX_LDS_FLOATS = RX_LDS_PREV + 4;
 static_assert(RX_TQS == 0 || (RX_TQS >= RX_TLEN && RX_TQS % 32 == 15), "tap copies: 16 banks apart");
-static_assert(RX_TILE == 512 && RX_AUDIO == 1024 && RX_TLEN % 4 == 0 && RX_GLEN % 4 == 0 && RX_PSPAN == RX_BATCH + RX_TH + 1, "receiver geometry");
+static_assert(RX_TILE == 512 && (RX_TPB == 10 || RX_TPB == 5) && RX_AUDIO == 256 * RX_AW && RX_TLEN % 4 == 0 && RX_GLEN % 4 == 0 && RX_PSPAN == RX_BATCH + RX_TH + 1, "receiver geometry");
 static_assert(RX_XF >= RX_AUDIO, "the audio output row lives in the RF window area");
 
 #ifndef LRHIP_RX_WAVES_PER_SIMD
-#define LRHIP_RX_WAVES_PER_SIMD 3
+#define LRHIP_RX_WAVES_PER_SIMD (LRHIP_RX_TPB == 5 ? 4 : 3)
 #endif
 
 // discriminator sample b of the batch (-135 .. 5119: negative = the history in front of it) -> its float in the padded audio window
@@ -250,14 +254,15 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
             // In front of a run only the last tile of the batch is real: its 75 whole windows are all in wave 3's accumulator
             f32x4 acct[1][1];
             acct[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (!(pr.dbg & 1) && (!warm || wave == 3)) mfma_tile<1, D, 1, RX_KST, 1>(ldsGT + RX_GZ, RX_GLEN - RX_GZ, phi, P, RX_KST, acct);
+            if (!(pr.dbg & 1) && wave < RX_AW && (!warm || wave == RX_AW - 1)) mfma_tile<1, D, 1, RX_KST, 1>(ldsGT + RX_GZ, RX_GLEN - RX_GZ, phi, P, RX_KST, acct);
             float *vrow = ldsX;                                       // the RF window is free between barrier (B) and the next staging
             {
                 const int col = lane & 15, kq = lane >> 4;
-                *reinterpret_cast<float4 *>(vrow + 16 * (wave * 16 + col) + 4 * kq) = make_float4(acct[0][0][0], acct[0][0][1], acct[0][0][2], acct[0][0][3]);
+                if (wave < RX_AW) *reinterpret_cast<float4 *>(vrow + 16 * (wave * 16 + col) + 4 * kq) = make_float4(acct[0][0][0], acct[0][0][1], acct[0][0][2], acct[0][0][3]);
             }
             __syncthreads();
-            float4 v4 = *reinterpret_cast<const float4 *>(vrow + 4 * tid);
+            const bool scan_lane = tid < 64 * RX_AW;                  // the lanes that own four audio outputs of this batch
+            float4 v4 = scan_lane ? *reinterpret_cast<const float4 *>(vrow + 4 * tid) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (warm) {
                 // the first window that lies inside the tile in front of the run (its first sample, whose own predecessor was not computed, excluded)
                 const int kmin = (RX_TH + (RX_TPB - 1) * RX_TILE + 1 - phi + 4) / 5;
@@ -273,12 +278,12 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
                 const float prev = __shfl_up(z, 1 << l);
                 if (lane >= (1 << l)) z = z + fmaf(ldsPt[(1 << l) - 1], prev, 0.f);
             }
-            if (lane == 63) xch[wave] = z;
+            if (lane == 63 && scan_lane) xch[wave] = z;
             __syncthreads();
             const float pw256 = ldsPt[63];
             float C = carry, Cw = carry;
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
+            for (int w = 0; w < RX_AW; w++) {
                 if (w == wave) Cw = C;
                 C = xch[w] + fmaf(pw256, C, 0.f);
             }
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
             float st = __shfl_up(Sx, 1);
             if (lane == 0) st = Cw;
             const float y0 = stepq(st, u0), y1 = stepq(y0, u1), y2 = stepq(y1, u2), y3 = stepq(y2, u3);
-            if (!warm) {
+            if (!warm && scan_lane) {
                 const long m = m0 + bidx * RX_AUDIO + 4 * tid;
                 const long mend = m1 < pr.n_out_b ? m1 : pr.n_out_b;  // outputs past the run's last tile belong to the next run
                 if (m + 3 < mend && (reinterpret_cast<uintptr_t>(pr.y + m) & 15) == 0) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of the single-launch FM receiver (kernels_rx.h): build variants (LRHIP_LIB_PATH), ablation bits, the two-launch form
+# same-box A/B of the single-launch FM receiver (kernels_rx.h): build variants (LRHIP_LIB_PATH), the two-launch form
 ROOT=$(pwd)
 for r in 1 2; do
   TAG=full python tools/time_wbfm.py 2
