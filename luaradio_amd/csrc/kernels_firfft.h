@@ -458,7 +458,7 @@ enum { SPEC_FWD_COMPLEX = 0, SPEC_FWD_PSD = 1, SPEC_FWD_PSD_LOG = 2, SPEC_INV_CO
 template <bool IN_REAL>
 __global__ __launch_bounds__(256, 3) void spectrum1024_kernel(const float *__restrict__ x, float *__restrict__ y, long nframes,
                                                                const float2 *__restrict__ tables, const float *__restrict__ window,
-                                                               int mode, float out_scale, int shift)
+                                                               int mode, float out_scale, int shift, int rounds)
 {
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -470,7 +470,12 @@ __global__ __launch_bounds__(256, 3) void spectrum1024_kernel(const float *__res
     __syncthreads();
     const int sub = lane & 3, k1s = lane >> 2;
 
-    for (long f = (long)blockIdx.x * 4 + wave; f < nframes; f += (long)gridDim.x * 4) {
+    // rounds > 0: one-shot order - workgroup g owns the `rounds` consecutive batches of four frames from g * rounds on and the dispatcher hands workgroups out in
+    // address order (what took the overlap-save filter kernel from 263-314 to 316 GS/s); 0: persistent stride
+    const long fstep = rounds > 0 ? 4 : (long)gridDim.x * 4;
+    const long ffirst = (rounds > 0 ? (long)blockIdx.x * rounds : (long)blockIdx.x) * 4 + wave;
+    const long fend = rounds > 0 ? ((long)blockIdx.x + 1) * rounds * 4 : nframes;
+    for (long f = ffirst; f < nframes && f < fend; f += fstep) {
         cf v[16];
         if (mode <= SPEC_FWD_PSD_LOG) {
             // ---- forward

@@ -35,9 +35,12 @@ struct FftStage : lrhip_stage {
                     spec_blocks_per_cu = nb < 1 ? 1 : nb;
                 }
                 long slots = (long)ctx().num_cus * spec_blocks_per_cu, want = (nframes + 3) / 4;
-                unsigned g = (unsigned)(want < slots ? want : slots);
+                static const int rounds_env = getenv("LRHIP_SPEC_ROUNDS") ? atoi(getenv("LRHIP_SPEC_ROUNDS")) : -1;      // A/B knob
+                int rounds = rounds_env >= 0 ? rounds_env : 0;      // measured, 2^26 samples, same box: persistent 0.1572 ms, one-shot with 4 / 8 / 16 batches per workgroup 0.1628 / 0.159 / 0.1694
+                if (want <= slots) rounds = 0;
+                unsigned g = rounds > 0 ? (unsigned)((want + rounds - 1) / rounds) : (unsigned)(want < slots ? want : slots);
                 hipLaunchKernelGGL(kern, dim3(g), dim3(256), lds_bytes, ctx().stream, (const float *)in_dev, (float *)out_dev, nframes,
-                                   (const float2 *)spec_tables.p, wp, mode, out_scale, shift);
+                                   (const float2 *)spec_tables.p, wp, mode, out_scale, shift, rounds);
                 return 0;
             };
             int rc = in_real ? go(spectrum1024_kernel<true>) : go(spectrum1024_kernel<false>);
