@@ -113,3 +113,64 @@ def test_time_partitions_of_the_single_launch_receiver():
         got = rx.process(x[s:])
         want = whole[(first + 24) // 25:]
         assert len(got) == len(want) and float(np.max(np.abs(got - want))) < 5e-5
+
+
+# ---- the other round-3 kernels at size (properties that need no oracle run over millions of samples) --------------------------------------------
+def test_hilbert_single_launch_properties_at_size():
+    """HilbertTransformBlock in one launch (kernels_fir.h HILB epilogue), 2^22 samples in ragged chunks: the real part IS the input delayed by (M - 1) / 2
+    samples (bit for bit: it is a copy out of the staged window), the imaginary part has the bits of the same taps run as a plain direct-form
+    FIRFilterBlock (hilberttransform.lua:107-124 computes both in one loop)"""
+    from luaradio_amd import types
+    n, M = 1 << 22, 65
+    rng = np.random.default_rng(31)
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    hb = lr.HilbertTransformBlock(M)
+    hb.rate = 2.0
+    hb.differentiate([types.Float32])
+    hb.initialize()
+    cuts = [1, 2, 33, 64, 65, 8191, 8192, 1000003, 3000001]
+    parts, a = [], 0
+    for b in cuts + [n]:
+        parts.append(hb.process(x[a:b]))
+        a = b
+    got = np.concatenate(parts)
+    assert got.dtype == np.complex64 and len(got) == n
+    half = (M - 1) // 2
+    assert np.array_equal(got.real[half:], x[:n - half]) and not got.real[:half].any()
+    fir = lr.FIRFilterBlock(np.asarray(hb.hilbert_taps if hasattr(hb, "hilbert_taps") else hb.taps, np.float32), False)
+    fir.rate = 2.0
+    fir.differentiate([types.Float32])
+    fir.initialize()
+    assert np.array_equal(got.imag, fir.process(x))
+
+
+@pytest.mark.parametrize("L,D", [(3, 2), (2, 3), (4, 3), (3, 4), (5, 4), (4, 5)])
+def test_rational_resampler_kept_phases_kernel_at_size(L, D):
+    """fir_rational_kernel on 2^21 samples in two unequal chunks (second one starts at an absolute input position that is not a multiple of D):
+    the bits of the unfused device blocks MultiplyConstant -> Upsampler -> Lowpass -> Downsampler, and linearity in the input"""
+    from luaradio_amd import types
+    n = (1 << 21) + 1237
+    rng = np.random.default_rng(50 + 10 * L + D)
+    x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+
+    def resampler():
+        r = lr.RationalResamplerBlock(L, D)
+        r.rate = 2.0
+        r.differentiate([types.ComplexFloat32])
+        r.initialize()
+        return r
+
+    rs = resampler()
+    cut = 700001
+    got = np.concatenate([rs.process(x[:cut]), rs.process(x[cut:])])
+    assert rs.chain.last_launches == 1
+    want, rate = x, 2.0
+    for b in (lr.MultiplyConstantBlock(float(L)), lr.UpsamplerBlock(L), lr.LowpassFilterBlock(128, min(1 / L, 1 / D), 1.0), lr.DownsamplerBlock(D)):
+        b.rate = rate
+        b.differentiate([types.ComplexFloat32])
+        b.initialize()
+        want, rate = b.process(want), b.get_rate()
+    assert len(got) == len(want) == (n * L + D - 1) // D
+    assert np.array_equal(got, want)
+    # linearity (exact for a power-of-two scale)
+    assert np.array_equal(resampler().process(x * np.float32(0.5)), (want * np.float32(0.5)).astype(np.complex64))

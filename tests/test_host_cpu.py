@@ -180,3 +180,40 @@ def test_composite_checks_its_own_type_signatures():
     t.rate = 1e6
     with pytest.raises(TypeError, match="No compatible type signatures"):
         t.differentiate([types.Float32])
+
+
+def test_bench_recording_is_the_same_whichever_partition_asks():
+    """bench.py --workload timeshard: every rank generates only its own partition (+ halo) of ONE synthetic FM recording - closed-form phase, noise from
+    one generator per block of 2^22 samples - so the partitions must tile the recording exactly, wherever they are cut"""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    blk = 1 << 12
+    a, b = 3 * blk - 100, 6 * blk + 77
+    whole = bench.fm_recording(torch, "cpu", a, b, block=blk)
+    cuts = [a, a + 1, 4 * blk, 4 * blk + 5, 5 * blk - 1, b]
+    parts = torch.cat([bench.fm_recording(torch, "cpu", lo, hi, block=blk) for lo, hi in zip(cuts, cuts[1:])])
+    assert whole.shape == (2 * (b - a),) and torch.equal(whole, parts)
+    z = whole.view(-1, 2)
+    mag = torch.sqrt(z[:, 0] ** 2 + z[:, 1] ** 2)
+    assert float(mag.min()) > 0.97 and float(mag.max()) < 1.03          # unit carrier + 1 % noise
+
+
+def test_fir_mode_table_matches_the_lua_glue():
+    """one use_fft table for every front end: luaradio_amd/block.py fir_mode == lrhip.fir_mode in lua/radio/core/lrhip.lua"""
+    import re
+    from luaradio_amd import block
+    lua = open(os.path.join(ROOT, "lua", "radio", "core", "lrhip.lua")).read()
+    body = lua[lua.index("function M.fir_mode(use_fft)"):]
+    body = body[:body.index("\nend\n")]
+    assert re.search(r"package\.loaded\['tests\.jigs'\]\s*then\s*return 0", body) and re.search(r"use_fft == nil.*?return 3", body, re.S)
+    assert 'use_fft == "auto" then return 3' in body and 'use_fft == "fast" then return 2' in body and "return use_fft and 1 or 0" in body
+    saved, block.TESTS_JIGS_LOADED = block.TESTS_JIGS_LOADED, False
+    try:
+        assert [block.fir_mode(v) for v in (None, "auto", "fast", True, False)] == [3, 3, 2, 1, 0]
+        block.TESTS_JIGS_LOADED = True
+        assert block.fir_mode(None) == 0
+    finally:
+        block.TESTS_JIGS_LOADED = saved
