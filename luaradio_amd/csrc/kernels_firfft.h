@@ -232,9 +232,18 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
         else if (k < 2L * taper) { bn = r2; b0 = base + taper * r1 + (k - taper) * r2; }
         else { bn = r3; b0 = base + taper * (r1 + r2) + (k - 2L * taper) * r3; }
     }
-    const long fstep = rounds > 0 ? FFT_WPB : (long)gridDim.x * FFT_WPB;
-    const long ffirst = (rounds > 0 ? b0 : bid) * FFT_WPB + wave;
-    const long fend = rounds > 0 ? (b0 + bn) * FFT_WPB : (nblocks + 1);
+    // LRHIP_FFT_CARRY (A/B, round 3): in the one-shot order a wave takes `bn` ADJACENT blocks instead of every FFT_WPB-th one, and keeps the last V = 128
+    // samples of a block's window (two of its sixteen rows, raw) in registers as the first two rows of the next: 14 loads per block instead of 16 - the
+    // 12.5 % overlap is then not even re-read from L2
+#ifndef LRHIP_FFT_CARRY
+#define LRHIP_FFT_CARRY 0
+#endif
+    const bool wave_major = LRHIP_FFT_CARRY && S == 2 && PRE == 0 && FFT_NB == 1 && rounds > 0 && V == 128 && delay == 0;
+    const long fstep = wave_major ? 1 : rounds > 0 ? FFT_WPB : (long)gridDim.x * FFT_WPB;
+    const long ffirst = wave_major ? b0 * FFT_WPB + (long)wave * bn : (rounds > 0 ? b0 : bid) * FFT_WPB + wave;
+    const long fend = wave_major ? ffirst + bn : rounds > 0 ? (b0 + bn) * FFT_WPB : (nblocks + 1);
+    cf keep0 = cf{0.f, 0.f}, keep1 = cf{0.f, 0.f};
+    bool kept = false;
 #if LRHIP_FFT_PREFETCH
     cf pre[16];
     bool have = false;
@@ -264,13 +273,21 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #endif
             if (xlo >= 0 && xlo + FFTN <= n) {
                 const cf *src = reinterpret_cast<const cf *>(x) + xlo + lane;
+                if (wave_major && kept) {
+                    v[0] = keep0; v[1] = keep1;
+#pragma unroll
+                    for (int i = 2; i < 16; i++) v[i] = src[64 * i];
+                } else {
 #pragma unroll
 #if LRHIP_FFT_NT >= 2
-                for (int i = 0; i < 16; i++) v[i] = __builtin_nontemporal_load(src + 64 * i);
+                    for (int i = 0; i < 16; i++) v[i] = __builtin_nontemporal_load(src + 64 * i);
 #else
-                for (int i = 0; i < 16; i++) v[i] = src[64 * i];
+                    for (int i = 0; i < 16; i++) v[i] = src[64 * i];
 #endif
+                }
+                if (wave_major) { keep0 = v[14]; keep1 = v[15]; kept = true; }
             } else {
+                kept = false;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     long p = p0 + 64 * i + lane;
