@@ -268,12 +268,21 @@ template <int S, int P, int NBT>
 __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict__ x, float *__restrict__ y, long n,
                                                          const float *__restrict__ xhist, const float *__restrict__ state_in,
                                                          float *__restrict__ state_out, long dec, long dfirst, int run, int warm, int warm_chunks, IirCoeffs co,
-                                                         float *__restrict__ xhist_out, const typename IirScanT<P>::T *__restrict__ tpow)
+                                                         float *__restrict__ xhist_out, const typename IirScanT<P>::T *__restrict__ tpow, int no_coal)
 {
     using ST = typename IirScanT<P>::T;
     constexpr int LC = IIR_LC, TILE = IIR_TILE, PV = NBT - 1;
-    __shared__ ST sst[S][256][P];
+    // orders 1-4 scan inside the waves (shuffles): LDS only holds the four wave totals and, in the last row, the tile end state
+    constexpr int NS = P <= 4 ? 8 : 256, LAST = NS - 1;
+    __shared__ ST sst[S][NS][P];
     __shared__ ST carry[S][P];
+    // Coalesced tile I/O (round 3).  A thread's zero-state run wants LC = 16 CONSECUTIVE samples - 64 B (Float32) or 128 B (ComplexFloat32) per thread - but
+    // a load instruction whose 64 lanes are 64 / 128 B apart moves 4.1 / 2.2 TB/s where consecutive lanes on consecutive 16 B move 5.3-6.2 (tools/mb_chunk.hip,
+    // 512 MiB in + out): that mapping, not the scan, was what held the recurrences at 38-53 % of the roof.  Whole tiles inside the chunk are now loaded and
+    // stored lane-contiguously and transposed through LDS: linear float4 i of the tile lives at i + i / F4 (one float4 of padding per thread chunk: the chunk
+    // stride F4 + 1 is odd in 16-byte units, both directions conflict-free).  Edge tiles and partial warm-up tiles keep the per-thread path; same arithmetic.
+    constexpr int F4 = IIR_LC * S / 4;
+    __shared__ float4 tr[256 * (F4 + 1)];
     const int tid = threadIdx.x;
     const int nb = co.nb;
     // carried feed-forward history (iir_state_kernel's job): the last nb-1 inputs
@@ -303,7 +312,26 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
         // ---- load (as iir_scan_kernel)
         float xs[S][PV + LC];
         const bool vec = (c0 + LC <= n) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-        if (skip) {
+        // workgroup-uniform: the whole tile lies inside the chunk, 16-byte aligned, and nobody skips its chunk
+        const bool coal = !no_coal && (tt + 1) * TILE <= n && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && !(!emit && !from_true_state && warm_chunks > 0);
+        if (coal) {
+            const float4 *src = reinterpret_cast<const float4 *>(x + tt * (long)TILE * S);
+#pragma unroll
+            for (int j = 0; j < F4; j++) {
+                const int idx = 256 * j + tid;
+                tr[idx + idx / F4] = src[idx];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < F4; q++) {
+                const float4 v = tr[tid * (F4 + 1) + q];
+                if (S == 1) {
+                    xs[0][PV + 4 * q] = v.x; xs[0][PV + 4 * q + 1] = v.y; xs[0][PV + 4 * q + 2] = v.z; xs[0][PV + 4 * q + 3] = v.w;
+                } else {
+                    xs[0][PV + 2 * q] = v.x; xs[S - 1][PV + 2 * q] = v.y; xs[0][PV + 2 * q + 1] = v.z; xs[S - 1][PV + 2 * q + 1] = v.w;
+                }
+            }
+        } else if (skip) {
 #pragma unroll
             for (int i = 0; i < PV + LC; i++)
 #pragma unroll
@@ -325,26 +353,51 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
 #pragma unroll
                 for (int c = 0; c < S; c++) xs[c][PV + i] = (c0 + i < n) ? x[(c0 + i) * S + c] : 0.f;
         }
+        if (coal && tid > 0) {
+            // the previous thread's chunk is in LDS: its last PV samples are the tail of chunk tid - 1 (PV < LC), read as whole 16-byte words
+            constexpr int NQ = (PV * S + 3) / 4;
 #pragma unroll
-        for (int j = 1; j <= PV; j++)
+            for (int q = F4 - NQ; q < F4; q++) {
+                const float4 v = tr[(tid - 1) * (F4 + 1) + q];
+                const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int c = 0; c < S; c++) {
-                long g = c0 - j;
-                float v = 0.f;
-                if (j < nb && c0 < n && !skip) v = g >= 0 ? x[g * S + c] : xhist[(g + (nb - 1)) * S + c];
-                xs[c][PV - j] = v;
+                for (int r = 0; r < 4; r++) {
+                    const int f = 4 * q + r, i = f / S, c = f % S, j = LC - i;      // float f of the chunk = sample i, component c = j samples back
+                    if (j >= 1 && j <= PV) xs[c][PV - j] = e[r];
+                }
             }
+        } else {
+#pragma unroll
+            for (int j = 1; j <= PV; j++)
+#pragma unroll
+                for (int c = 0; c < S; c++) {
+                    long g = c0 - j;
+                    float v = 0.f;
+                    if (j < nb && c0 < n && !skip) v = g >= 0 ? x[g * S + c] : xhist[(g + (nb - 1)) * S + c];
+                    xs[c][PV - j] = v;
+                }
+        }
         float u[S][LC];
+        // feed-forward part, with the tap count a compile-time constant where that is cheap (nb in (NBT - 4, NBT]: the predicated form below costs a
+        // v_cndmask per term, 262 of the 815 vector instructions of this section for the suite's 5-tap entry); same terms, same order
+        auto ff = [&](auto nbc) {
+            constexpr int NB = decltype(nbc)::value;
 #pragma unroll
-        for (int c = 0; c < S; c++)
+            for (int c = 0; c < S; c++)
 #pragma unroll
-            for (int i = 0; i < LC; i++) {
-                float acc = 0.f;
+                for (int i = 0; i < LC; i++) {
+                    float acc = 0.f;
 #pragma unroll
-                for (int j = 0; j < NBT; j++)
-                    if (j < nb) acc = fmaf(co.b[j], xs[c][PV + i - j], acc);
-                u[c][i] = acc;
-            }
+                    for (int j = 0; j < NBT; j++)
+                        if (NB ? j < NB : j < nb) acc = fmaf(co.b[j], xs[c][PV + i - j], acc);
+                    u[c][i] = acc;
+                }
+        };
+        if (nb == NBT) ff(std::integral_constant<int, NBT>());
+        else if (NBT > 1 && nb == NBT - 1) ff(std::integral_constant<int, (NBT > 1 ? NBT - 1 : 0)>());
+        else if (NBT > 2 && NBT <= 8 && nb == NBT - 2) ff(std::integral_constant<int, (NBT > 2 ? NBT - 2 : 0)>());
+        else if (NBT > 3 && NBT <= 8 && nb == NBT - 3) ff(std::integral_constant<int, (NBT > 3 ? NBT - 3 : 0)>());
+        else ff(std::integral_constant<int, 0>());
         // ---- zero-state run, scan of the chunk end states seeded with the carried tile start state
         float st[S][P];
 #pragma unroll
@@ -396,7 +449,72 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
             __syncthreads();                                                // the wave totals are read: the next tile may overwrite them
             if (tid == 255)
 #pragma unroll
-                for (int c = 0; c < S; c++) sst[c][255][0] = creg[c];       // read below (by this thread) when the chunk ends with this tile
+                for (int c = 0; c < S; c++) sst[c][LAST][0] = creg[c];       // read below (by this thread) when the chunk ends with this tile
+        } else if constexpr (P <= 4) {
+            // orders 2-4 (round 3): the same two-barrier wave scan on P-vectors.  tpow + l P^2 = A^(16 * 2^l) (l <= 8), tpow + (9 + l) P^2 = A^(16 (l + 1))
+            // (l < 64), host, from double.  The LDS Kogge-Stone below (16 barriers and 8 x 3 P S LDS words per thread and tile) is left to orders 5-8.
+            const int lane = tid & 63, wave = tid >> 6;
+            ST zs[S][P], tmp[P];
+#pragma unroll
+            for (int c = 0; c < S; c++) {
+#pragma unroll
+                for (int k = 0; k < P; k++) zs[c][k] = (ST)st[c][k];
+                if (tid == 0) {
+                    ST ts[P];
+#pragma unroll
+                    for (int k = 0; k < P; k++) ts[k] = carry[c][k];
+                    mat_apply<P, ST>(tpow, ts, tmp);
+#pragma unroll
+                    for (int k = 0; k < P; k++) zs[c][k] += tmp[k];
+                }
+#pragma unroll
+                for (int l = 0; l < 6; l++) {
+                    ST prev[P];
+#pragma unroll
+                    for (int k = 0; k < P; k++) prev[k] = __shfl_up(zs[c][k], 1 << l);
+                    mat_apply<P, ST>(tpow + l * P * P, prev, tmp);
+                    if (lane >= (1 << l))
+#pragma unroll
+                        for (int k = 0; k < P; k++) zs[c][k] += tmp[k];
+                }
+                if (lane == 63)
+#pragma unroll
+                    for (int k = 0; k < P; k++) sst[c][wave][k] = zs[c][k];
+            }
+            __syncthreads();
+            ST Mp[P * P];                                                   // A^(16 (lane + 1))
+#pragma unroll
+            for (int i = 0; i < P * P; i++) Mp[i] = tpow[(9 + lane) * P * P + i];
+#pragma unroll
+            for (int c = 0; c < S; c++) {
+                ST E[P], Ew[P], Sx[P];
+#pragma unroll
+                for (int k = 0; k < P; k++) E[k] = Ew[k] = 0;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    if (w == wave)
+#pragma unroll
+                        for (int k = 0; k < P; k++) Ew[k] = E[k];
+                    mat_apply<P, ST>(tpow + 6 * P * P, E, tmp);
+#pragma unroll
+                    for (int k = 0; k < P; k++) E[k] = sst[c][w][k] + tmp[k];
+                }
+                mat_apply<P, ST>(Mp, Ew, tmp);
+#pragma unroll
+                for (int k = 0; k < P; k++) {
+                    Sx[k] = zs[c][k] + tmp[k];                              // true end state of this chunk
+                    const ST up = __shfl_up(Sx[k], 1);
+                    st[c][k] = (float)(tid == 0 ? carry[c][k] : lane ? up : Ew[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < P; k++) zs[c][k] = E[k];                // state at the end of the tile
+            }
+            __syncthreads();                                                // wave totals and carry are read
+            if (tid == 255)
+#pragma unroll
+                for (int c = 0; c < S; c++)
+#pragma unroll
+                    for (int k = 0; k < P; k++) { carry[c][k] = zs[c][k]; sst[c][LAST][k] = zs[c][k]; }
         } else {
 #pragma unroll
         for (int c = 0; c < S; c++) {
@@ -440,21 +558,41 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
                     for (int k = P - 1; k > 0; k--) st[c][k] = st[c][k - 1];
                     st[c][0] = v;
                     u[c][i] = v;
-                    long g = c0 + i;
-                    // (a chunk that ends WITH this tile hands over the scanned tile end state instead - below - which is what the next tile
-                    // of an uninterrupted run is given: the scan and the re-run round differently, and time partitions must not see that)
-                    if (g < n && g >= n - P && n != (tt + 1) * TILE) state_out[c * P + (int)(n - 1 - g)] = v;
                 }
+            // carried state = the chunk's last P outputs: only the tile(s) holding them look for them
+            // (a chunk that ends WITH this tile hands over the scanned tile end state instead - below - which is what the next tile
+            // of an uninterrupted run is given: the scan and the re-run round differently, and time partitions must not see that)
+            if ((tt + 1) * TILE + P > n && n != (tt + 1) * TILE)
+#pragma unroll
+                for (int c = 0; c < S; c++)
+#pragma unroll
+                    for (int i = 0; i < LC; i++) {
+                        const long g = c0 + i;
+                        if (g < n && g >= n - P) state_out[c * P + (int)(n - 1 - g)] = u[c][i];
+                    }
             if (tid == 255 && n == (tt + 1) * TILE)
 #pragma unroll
                 for (int c = 0; c < S; c++)
 #pragma unroll
-                    for (int k = 0; k < P; k++) state_out[c * P + k] = (float)sst[c][255][k];
+                    for (int k = 0; k < P; k++) state_out[c * P + k] = (float)sst[c][LAST][k];
             if (tt == 0 && tid == 0 && n < P)
 #pragma unroll
                 for (int c = 0; c < S; c++)
                     for (int k = (int)n; k < P; k++) state_out[c * P + k] = state_in[c * P + k - (int)n];
-            if (dec == 1) {
+            if (dec == 1 && coal && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+                // (every thread read its inputs out of `tr` before the scan's barriers: the buffer is free)
+#pragma unroll
+                for (int q = 0; q < F4; q++)
+                    tr[tid * (F4 + 1) + q] = S == 1 ? make_float4(u[0][4 * q], u[0][4 * q + 1], u[0][4 * q + 2], u[0][4 * q + 3])
+                                                    : make_float4(u[0][2 * q], u[S - 1][2 * q], u[0][2 * q + 1], u[S - 1][2 * q + 1]);
+                __syncthreads();
+                float4 *dst = reinterpret_cast<float4 *>(y + tt * (long)TILE * S);
+#pragma unroll
+                for (int j = 0; j < F4; j++) {
+                    const int idx = 256 * j + tid;
+                    dst[idx] = tr[idx + idx / F4];
+                }
+            } else if (dec == 1) {
                 if (vec && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
                     float4 *dst = reinterpret_cast<float4 *>(y + c0 * S);
 #pragma unroll

@@ -176,9 +176,26 @@ lrhip_stage_t *lrhip_iir_create(const float *b, unsigned nb, const float *a, uns
         }
         // (orders 2-4 were given the same one-shot launch in round 3 - 4 chunks of warm-up instead of a whole tile per 8 - and lost: 0.417 against 0.372 ms
         // for the suite's 3-feedback-tap entry on ComplexFloat32, same box: every workgroup then runs the 18-barrier block scan twice per emitted tile)
+        // Round 3, on top of the two-barrier wave scan: a workgroup per tile still loses (0.267 against 0.232 ms), but the partial warm-up tile itself pays
+        // at the old 8 tiles per workgroup - 0.213 (stage_iir.h has the table).
+        if (P >= 2 && P <= 4) {
+            std::vector<double> A16(tpow64.begin(), tpow64.begin() + P * P), M = A16;
+            for (int wc = 1; wc <= 128 && !q->warm_chunks; wc++) {
+                double mx = 0.0;
+                for (double v : M) mx = std::fabs(v) > mx ? std::fabs(v) : mx;
+                if (std::isfinite(mx) && mx < 1e-12) q->warm_chunks = wc;
+                matmul(M, A16, M, P);
+            }
+        }
         if (P == 1) {                                               // p^(16 (l + 1)), l < 64: the per-lane powers of the single-launch kernel's wave scan
             double acc = 1.0;
             for (int l = 0; l < 64; l++) { acc *= p16; tpow.push_back((float)acc); }
+        } else if (P <= 4) {                                        // the same for orders 2-4: the matrices A^(16 (l + 1))
+            std::vector<double> A16(tpow64.begin(), tpow64.begin() + P * P), M = A16;
+            for (int l = 0; l < 64; l++) {
+                for (int i = 0; i < P * P; i++) tpow.push_back((float)M[i]);
+                matmul(M, A16, M, P);
+            }
         }
         if (P > 4 ? upload(q->d_tpow, tpow64.data(), tpow64.size() * sizeof(double)) : upload(q->d_tpow, tpow.data(), tpow.size() * sizeof(float))) return nullptr;
         if (upload(q->d_ttile, q->Ttile.data(), q->Ttile.size() * sizeof(double))) return nullptr;

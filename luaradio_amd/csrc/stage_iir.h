@@ -55,11 +55,20 @@ struct IirStage : lrhip_stage {
             run = run < 1 ? 1 : run > 8 ? 8 : run;
             if (run < 2 * warm_tiles && ntiles > 4 * warm_tiles) run = 2 * warm_tiles;      // bound the re-read overhead
             int wc = 0;
-            static const bool no_oneshot = getenv("LRHIP_IIR_NO_ONESHOT") != nullptr;      // A/B knob
-            if (warm_chunks > 0 && !no_oneshot) { run = 1; wc = warm_chunks; }             // one-shot: a workgroup per tile, partial warm-up tile
+            static const bool no_oneshot = getenv("LRHIP_IIR_NO_ONESHOT") != nullptr;      // A/B knob: whole warm-up tiles (round 2)
+            static const bool no_coal = getenv("LRHIP_IIR_NO_COAL") != nullptr;            // A/B knob: per-thread chunk loads / stores (round 2)
+            static const int run_knob = getenv("LRHIP_IIR_RUN") ? atoi(getenv("LRHIP_IIR_RUN")) : 0;       // A/B knob: tiles per workgroup
+            if (warm_chunks > 0 && !no_oneshot) {
+                // partial warm-up tile: only its last warm_chunks chunks are read.  Tiles per workgroup by measurement (2^26 samples, one box, ms):
+                //   first order Float32        1: 0.104   2: 0.098   4: 0.109   8: 0.112
+                //   2 poles, 5 taps, Complex   1: 0.267   2: 0.226   4: 0.219   8: 0.213   16: 0.247      (whole warm-up tile, 8: 0.232)
+                wc = warm_chunks;
+                if (PP == 1) run = ntiles >= 8L * ctx().num_cus ? 2 : 1;
+                if (run_knob > 0) run = run_knob;
+            }
             unsigned grid = (unsigned)((ntiles + run - 1) / run);
             hipLaunchKernelGGL((iir_stream_kernel<SS, PP, NBT>), dim3(grid), dim3(256), 0, ctx().stream, x, y, n, xh, st, st_out, (long)D, (long)index, run,
-                               wc ? 1 : warm_tiles, wc, co, (float *)xhist[cur ^ 1].p, tp);
+                               wc ? 1 : warm_tiles, wc, co, (float *)xhist[cur ^ 1].p, tp, no_coal ? 1 : 0);
             LR_LAUNCH_CHECK();
             cur ^= 1;
             return 0;
