@@ -5,7 +5,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -o mb_chunk tools/mb_chunk.hip ; run: ./mb_chunk
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#pragma clang diagnostic ignored "-Wunused-result"
+#pragma clang diagnostic ignored "-Wunused-value"
 template <int CH, bool CHUNKED>
 __global__ __launch_bounds__(256) void k(const float4 *__restrict__ x, float4 *__restrict__ y, long n4)
 {
@@ -21,6 +21,66 @@ __global__ __launch_bounds__(256) void k(const float4 *__restrict__ x, float4 *_
         const long i = CHUNKED ? base + (long)threadIdx.x * CH + j : base + 256L * j + threadIdx.x;
         if (i < n4) y[i] = make_float4(v[j].x * 1.5f, v[j].y, v[j].z, v[j].w);
     }
+}
+// (c) the overlap-save FIR's traffic with no arithmetic: a wave per 1024-sample window at a hop of 896 (16 loads of 64 lanes x 8 B, 14 stores), windows dealt to
+//     waves one-shot (a wave per window, address order) or to a persistent grid (PERSIST workgroups per CU, stride = the grid)
+__global__ __launch_bounds__(256) void k_os(const float2 *__restrict__ x, float2 *__restrict__ y, long n, long nblocks, int persist)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long first = (long)blockIdx.x * 4 + wave, step = persist ? (long)gridDim.x * 4 : nblocks;
+    for (long fb = first; fb < nblocks; fb += step) {
+        const long p0 = fb * 896;
+        float2 v[16];
+        if (p0 + 1024 <= n) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = x[p0 + 64 * i + lane];
+#pragma unroll
+            for (int i = 2; i < 16; i++) y[p0 + 64 * i + lane] = make_float2(v[i].x * 1.5f + v[i & 1].y, v[i].y);
+        }
+    }
+}
+// the same with 16-byte accesses (8 loads of 64 lanes x 16 B) and / or without the overlap (hop 1024): what each ingredient of the pattern costs
+template <int HOP>
+__global__ __launch_bounds__(256) void k_os4(const float4 *__restrict__ x, float4 *__restrict__ y, long n, long nblocks)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long fb = (long)blockIdx.x * 4 + wave;
+    if (fb >= nblocks) return;
+    const long p0 = fb * (HOP / 2);      // in float4 = two samples
+    float4 v[8];
+    if (2 * p0 + 1024 <= n) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = x[p0 + 64 * i + lane];
+#pragma unroll
+        for (int i = (1024 - HOP) / 128; i < 8; i++) y[p0 + 64 * i + lane] = make_float4(v[i].x * 1.5f + v[i & 1].y, v[i].y, v[i].z, v[i].w);
+    }
+}
+template <int HOP>
+static void run_os4(const char *name, const float4 *x, float4 *y, long n)
+{
+    const long nblocks = n / HOP;
+    const unsigned grid = (unsigned)((nblocks + 3) / 4);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 5; i++) hipLaunchKernelGGL(k_os4<HOP>, dim3(grid), dim3(256), 0, 0, x, y, n, nblocks);
+    hipEventRecord(a);
+    for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_os4<HOP>, dim3(grid), dim3(256), 0, 0, x, y, n, nblocks);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); ms /= 20;
+    printf("%-44s %8.4f ms  %7.1f GB/s (16 B per sample)\n", name, ms, 16.0 * n / ms / 1e6);
+}
+static void run_os(const char *name, const float2 *x, float2 *y, long n, int wgs_per_cu)
+{
+    const long nblocks = n / 896;
+    const unsigned grid = wgs_per_cu ? 256u * wgs_per_cu : (unsigned)((nblocks + 3) / 4);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 5; i++) hipLaunchKernelGGL(k_os, dim3(grid), dim3(256), 0, 0, x, y, n, nblocks, wgs_per_cu);
+    hipEventRecord(a);
+    for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_os, dim3(grid), dim3(256), 0, 0, x, y, n, nblocks, wgs_per_cu);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); ms /= 20;
+    printf("%-44s %8.4f ms  %7.1f GB/s (16 B per sample)\n", name, ms, 16.0 * n / ms / 1e6);
 }
 template <int CH, bool CHUNKED>
 static void run(const char *name, const float4 *x, float4 *y, long n4)
@@ -47,6 +107,15 @@ int main()
         run<8, false>("coalesced, 8 float4 per thread", x, y, n4);
         run<4, true>("chunked, 4 float4 (64 B) per thread", x, y, n4);
         run<8, true>("chunked, 8 float4 (128 B) per thread", x, y, n4);
+    }
+    const long n = n4 * 2;      // ComplexFloat32 samples in the same buffers
+    for (int r = 0; r < 2; r++) {
+        run_os("overlap-save traffic, wave per window", (const float2 *)x, (float2 *)y, n, 0);
+        run_os("overlap-save traffic, persistent 2 WG / CU", (const float2 *)x, (float2 *)y, n, 2);
+        run_os("overlap-save traffic, persistent 4 WG / CU", (const float2 *)x, (float2 *)y, n, 4);
+        run_os("overlap-save traffic, persistent 8 WG / CU", (const float2 *)x, (float2 *)y, n, 8);
+        run_os4<896>("overlap-save traffic, 16-B accesses", x, y, n);
+        run_os4<1024>("same windows without overlap, 16-B accesses", x, y, n);
     }
     return 0;
 }
