@@ -340,4 +340,130 @@ __global__ __launch_bounds__(256) void fir_short_real_kernel(const float *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// HilbertTransformBlock (radio/blocks/signal/hilberttransform.lua:107-124: out[i] = {delayed input, dot(state[i ..], reversed taps)}) on the window
+// engine, for the tap counts the reference uses (65: its benchmark suite, 129: its examples).  A Hilbert transformer's taps at even distance from the
+// centre are exactly zero (filter_utils.fir_hilbert_transform), so
+//   * only the (M - 1) / 2 steps of one parity run - half the packed FMAs of the plain filter, and none of the Toeplitz product's structural zeros
+//     (the matrix-core form of round 3, 0.21 ms for 2^26 samples, spent 3 of every 4 products on zeros);
+//   * all operand pairs have the same parity, so ONE staged copy of the tile serves (C[i] = s[i + 1]);
+//   * the lane's 16 outputs become (re, im) pairs = 128 consecutive bytes per lane, the mapping tools/mb_chunk.hip prices at 2.2 TB/s: the imaginary
+//     parts go through an LDS out-area instead (lane stride 20 dwords, conflict-free both ways) and leave as lane-contiguous 16-byte stores, the
+//     real parts are read back from the staged tile at the centre-tap offset.
+// The chain is the oracle's fmaf chain without its zero-tap terms (those add +-0: equal bits for finite input).  The host checks the zero pattern.
+// ------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int fwh_ophys(int o) { return o + 4 * (o >> 4); }
+
+template <int M>
+struct FwhGeom {
+    static_assert(M % 4 == 1, "centre tap at an even index: the non-zero reversed taps are the odd ones");
+    static constexpr int HALO = M - 1, SPAN = FWR_TILE + HALO, NF4 = SPAN / 4, NPRE = (NF4 + 255) / 256;
+    static constexpr int NZ = (M - 1) / 2;                          // non-zero taps: reversed index 2 k + 1
+    static constexpr int CEN = (M - 1) / 2 - 1;                     // C index of output o's delayed input sample is o + CEN
+    static constexpr int LDSC = fwr_phys(SPAN) + 16;
+    static constexpr int LDSO = fwh_ophys(FWR_TILE);
+    static constexpr int LDS_FLOATS = LDSC + LDSO + NZ;
+};
+
+template <int M>
+__global__ __launch_bounds__(256, 4) void hilbert_win_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_rev,
+                                                             float *__restrict__ y, long n, long run, float *__restrict__ hist_out)
+{
+    using G = FwhGeom<M>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *ldsC = lds, *ldsOut = lds + G::LDSC, *ldsT = ldsOut + G::LDSO;
+    const unsigned tid = threadIdx.x;
+    if (hist_out && blockIdx.x == 0)
+        for (int i = tid; i < M - 1; i += 256) hist_out[i] = stream_at<1>(hist, x, n + i, 0, M, n);
+    for (int i = tid; i < G::NZ; i += 256) ldsT[i] = taps_rev[2 * i + 1];
+
+    const long ntiles = (n + FWR_TILE - 1) / FWR_TILE;
+    const long first_tile = (long)blockIdx.x * run;
+    const long t_end = first_tile + run < ntiles ? first_tile + run : ntiles;
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0, yal = (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    auto interior = [&](long tt) { const long lo = tt * FWR_TILE - G::HALO; return aligned && lo >= 0 && lo + G::SPAN <= n; };
+    // every address below is one per-lane base plus a compile-time constant (LDS: immediate offsets; global: a wave-uniform pointer plus the lane's
+    // 32-bit offset), so no address lives in a vector register across the tap loop: with an address pair per access the kernel spilled (72 bytes of
+    // scratch, 17 reloads per tile) at the 128 registers four workgroups per CU leave it
+    constexpr int NFULL = G::NF4 / 256, NTAIL = G::NF4 - 256 * NFULL;       // full rounds of 256 16-byte loads, and the lanes of the last one
+    static_assert(NTAIL > 0 && NTAIL < 256 && G::NPRE == NFULL + 1, "tile geometry");
+    float4 pre[G::NPRE];
+    bool have = false;
+    auto prefetch = [&](long tt) {
+        have = interior(tt);
+        if (have) {
+            const float4 *src = reinterpret_cast<const float4 *>(x + (tt * FWR_TILE - G::HALO));      // wave-uniform
+#pragma unroll
+            for (int u = 0; u < NFULL; u++) pre[u] = (src + 256 * u)[tid];
+            if (tid < NTAIL) pre[NFULL] = (src + 256 * NFULL)[tid];
+        }
+    };
+    float *const stC = ldsC + fwr_phys(4 * (int)tid), *const stC1 = ldsC + fwr_phys(4 * (int)tid - 1);      // staging: coordinates 4 tid (+ 1024 u) and the one before
+    auto stage = [&](int u, float4 v) {
+        constexpr int K = 1024 + 128;                                   // fwr_phys(a + 1024 u) = fwr_phys(a) + 1152 u
+        if (u || tid) stC1[K * u] = v.x;
+        *reinterpret_cast<float2 *>(stC + K * u) = make_float2(v.y, v.z);
+        stC[K * u + 2] = v.w;
+    };
+    const float *const re0 = ldsC + fwr_phys(2 * (int)tid + G::CEN), *const re1 = ldsC + fwr_phys(2 * (int)tid + 1 + G::CEN);
+    const float *const imp = ldsOut + fwh_ophys(2 * (int)tid);
+    if (first_tile < t_end) prefetch(first_tile);
+    for (long tt = first_tile; tt < t_end; tt++) {
+        if (have) {
+#pragma unroll
+            for (int u = 0; u < NFULL; u++) stage(u, pre[u]);
+            if (tid < NTAIL) stage(NFULL, pre[NFULL]);
+        } else {
+            const long p0 = tt * FWR_TILE - G::HALO + (M - 1);          // stream position of tile coordinate 0
+            for (int c = tid + 1; c < G::SPAN; c += 256) ldsC[fwr_phys(c - 1)] = stream_at<1>(hist, x, p0 + c, 0, M, n);
+        }
+        __syncthreads();
+
+        // ---- the tap loop of fwr_taps over the odd steps: step j = 2 k + 1 reads pair index m = i + k of the copy
+        cf acc[8];
+        {
+            constexpr int R = 8, LA = 2, NS = R + LA;
+            const float *base = ldsC + 18 * tid;
+            cf W[NS];
+            float4 T[2];
+            auto ld = [&](int m) { return *reinterpret_cast<const cf *>(base + 2 * m + 2 * (m >> 3)); };
+#pragma unroll
+            for (int i = 0; i < R; i++) acc[i] = cf{0.f, 0.f};
+            static_for<R - 1 + LA>([&](auto I) { constexpr int i = decltype(I)::value; W[i % NS] = ld(i); });
+            T[0] = *reinterpret_cast<const float4 *>(ldsT);
+            static_for<G::NZ>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                if constexpr ((k & 3) == 0 && k + 4 < G::NZ) T[((k >> 2) + 1) & 1] = *reinterpret_cast<const float4 *>(ldsT + k + 4);
+                if constexpr (k + LA < G::NZ) W[(R - 1 + k + LA) % NS] = ld(R - 1 + k + LA);
+                const float4 tq = T[(k >> 2) & 1];
+                const cf tp = (k & 2) ? cf{tq.z, tq.w} : cf{tq.x, tq.y};
+                fw_step8<(k & 1)>(acc, tp, W[(0 + k) % NS], W[(1 + k) % NS], W[(2 + k) % NS], W[(3 + k) % NS], W[(4 + k) % NS], W[(5 + k) % NS],
+                                  W[(6 + k) % NS], W[(7 + k) % NS]);
+            });
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            *reinterpret_cast<float4 *>(ldsOut + 20 * tid + 4 * q) = make_float4(acc[2 * q].x, acc[2 * q].y, acc[2 * q + 1].x, acc[2 * q + 1].y);
+        // the next tile's loads fly during the store phase only, not across the tap loop (20 registers)
+        if (tt + 1 < t_end) prefetch(tt + 1);
+        else have = false;
+        __syncthreads();
+        const long ob = tt * FWR_TILE;
+        if (ob + FWR_TILE <= n && yal) {
+            f32x4 *dst = reinterpret_cast<f32x4 *>(y + 2 * ob);         // wave-uniform
+#pragma unroll
+            for (int u = 0; u < FWR_TILE / 512; u++) {
+                // outputs o = 2 tid + 512 u, o + 1:  fwr_phys(o + c) = fwr_phys(2 tid + c) + 576 u, fwh_ophys(o) = fwh_ophys(2 tid) + 640 u
+                const float2 im = *reinterpret_cast<const float2 *>(imp + 640 * u);
+                const f32x4 v = {re0[576 * u], im.x, re1[576 * u], im.y};
+                __builtin_nontemporal_store(v, (dst + 256 * u) + tid);
+            }
+        } else {
+            for (int o = tid; o < FWR_TILE && ob + o < n; o += 256)
+                *reinterpret_cast<float2 *>(y + 2 * (ob + o)) = make_float2(ldsC[fwr_phys(o + G::CEN)], ldsOut[fwh_ophys(o)]);
+        }
+        __syncthreads();                                                // the tile and the out-area are read: the next tile may be staged
+    }
+}
+
 }  // namespace lrhip

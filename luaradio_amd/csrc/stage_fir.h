@@ -232,8 +232,41 @@ struct FirStage : lrhip_stage {
     // HilbertTransformBlock in one launch: the generic Float32 Toeplitz kernel with the pair epilogue (kernels_fir.h, HILB).  y2 receives n
     // ComplexFloat32 samples (delayed input, filtered input); history / index bookkeeping is core()'s (D = 1: index stays 0)
     bool hilbert_ok() const { return S == 1 && !taps_complex && D == 1 && ksteps > 0 && !rot && !fft_arith && !use_fft && !pre_disc && !post_disc; }
+    // the window form (kernels_firwin.h hilbert_win_kernel): the reference's tap counts, taps at even distance from the centre exactly zero
+    int hilb_sparse = -1, hilb_blocks = 0;
+    template <int MM>
+    int launch_hilbert_win(const float *x, long n, float *y2)
+    {
+        using G = FwhGeom<MM>;
+        const size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
+        auto kern = hilbert_win_kernel<MM>;
+        if (!hilb_blocks) {
+            if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            int nb_ = 0;
+            LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, kern, 256, lds_bytes));
+            hilb_blocks = nb_ < 1 ? 1 : nb_;
+        }
+        static const int run_knob = getenv("LRHIP_HILBERT_RUN") ? atoi(getenv("LRHIP_HILBERT_RUN")) : 0;      // A/B knob: tiles per workgroup
+        const long ntiles = (n + FWR_TILE - 1) / FWR_TILE, slots = (long)ctx().num_cus * hilb_blocks;
+        long run = (ntiles + 4 * slots - 1) / (4 * slots);
+        if (run_knob > 0) run = run_knob;
+        const unsigned grid = (unsigned)((ntiles + run - 1) / run);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (const float *)d_taps.p, y2, n, run,
+                           (float *)hist[cur ^ 1].p + hist_pad);
+        LR_LAUNCH_CHECK();
+        cur ^= 1;
+        count += (uint64_t)n;
+        return 0;
+    }
     int launch_hilbert(const float *x, long n, float *y2)
     {
+        if (hilb_sparse < 0) {
+            hilb_sparse = (M == 65 || M == 129) ? 1 : 0;
+            for (int j = 0; j < M && hilb_sparse; j += 2)
+                if (taps_rev[(size_t)j] != 0.0f) hilb_sparse = 0;
+        }
+        static const bool no_win = getenv("LRHIP_HILBERT_MFMA") != nullptr;      // A/B knob: the matrix-core pair epilogue of round 3
+        if (hilb_sparse && !no_win && index == 0) return M == 65 ? launch_hilbert_win<65>(x, n, y2) : launch_hilbert_win<129>(x, n, y2);
         constexpr int NACC = 4;
         using G = FirMfmaGeom<1, 1>;
         constexpr int TILE_OUT = G::tile_out(NACC);

@@ -93,6 +93,7 @@ def main():
     run("RationalResampler(3, 4) cf32 (polyphase, input samples)", lambda: mk(lr.RationalResamplerBlock, [3, 4], True), True, 8 + 8 * 3 / 4, 4 * 128 * (3 / 4) / 3)
     run("RationalResampler(4, 5) cf32 (polyphase, input samples)", lambda: mk(lr.RationalResamplerBlock, [4, 5], True), True, 8 + 8 * 4 / 5, 4 * 128 * (4 / 5) / 4)
     run("HilbertTransform(65) f32 -> cf32", lambda: mk(lr.HilbertTransformBlock, [65], False), False, 12, 2 * 65)
+    run("HilbertTransform(129) f32 -> cf32", lambda: mk(lr.HilbertTransformBlock, [129], False), False, 12, 2 * 129)
     # the reference suite's IIR entry (benchmarks/luaradio_benchmark.lua: 5 feed-forward, 3 feedback taps), a stable filter
     b_iir, a_iir = [0.0976, 0.1953, 0.0976, 0.05, 0.02], [1.0, -0.9428, 0.3333]
     run("IIRFilter 5 ff / 3 fb cf32", lambda: mk(lr.IIRFilterBlock, [b_iir, a_iir], True), True, 16)

@@ -22,6 +22,41 @@ __global__ __launch_bounds__(256) void k(const float4 *__restrict__ x, float4 *_
         if (i < n4) y[i] = make_float4(v[j].x * 1.5f, v[j].y, v[j].z, v[j].w);
     }
 }
+// (d) read : write ratios other than 1 : 1, ideal mapping (one 16-byte access per lane and instruction, one-shot grid): RD float4 loads and WR float4 stores per thread
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int RD, int WR, bool NT = false>
+__global__ __launch_bounds__(256) void k_rw(const float4 *__restrict__ x, float4 *__restrict__ y, long nthreads)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nthreads) return;
+    float4 a = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < RD; j++) {
+        const float4 v = x[((long)blockIdx.x * RD + j) * 256 + threadIdx.x];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < WR; j++) {
+        float4 *d = y + ((long)blockIdx.x * WR + j) * 256 + threadIdx.x;
+        if (NT) { const f32x4 v = {a.x + j, a.y, a.z, a.w}; __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(d)); }
+        else *d = make_float4(a.x + j, a.y, a.z, a.w);
+    }
+    if (WR == 0 && a.x == 12345.678f) y[t] = a;
+}
+template <int RD, int WR, bool NT = false>
+static void run_rw(const char *name, const float4 *x, float4 *y, long n4)
+{
+    const long nthreads = n4 / (RD > WR ? RD : WR);
+    const unsigned grid = (unsigned)(nthreads / 256);
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 5; i++) hipLaunchKernelGGL((k_rw<RD, WR, NT>), dim3(grid), dim3(256), 0, 0, x, y, nthreads);
+    hipEventRecord(a);
+    for (int i = 0; i < 20; i++) hipLaunchKernelGGL((k_rw<RD, WR, NT>), dim3(grid), dim3(256), 0, 0, x, y, nthreads);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); ms /= 20;
+    printf("%-44s %8.4f ms  %7.1f GB/s (%d read + %d written float4 per thread)\n", name, ms, 16.0 * (RD + WR) * nthreads / ms / 1e6, RD, WR);
+}
 // (c) the overlap-save FIR's traffic with no arithmetic: a wave per 1024-sample window at a hop of 896 (16 loads of 64 lanes x 8 B, 14 stores), windows dealt to
 //     waves one-shot (a wave per window, address order) or to a persistent grid (PERSIST workgroups per CU, stride = the grid)
 __global__ __launch_bounds__(256) void k_os(const float2 *__restrict__ x, float2 *__restrict__ y, long n, long nblocks, int persist)
@@ -114,6 +149,18 @@ int main()
         run_os("overlap-save traffic, persistent 2 WG / CU", (const float2 *)x, (float2 *)y, n, 2);
         run_os("overlap-save traffic, persistent 4 WG / CU", (const float2 *)x, (float2 *)y, n, 4);
         run_os("overlap-save traffic, persistent 8 WG / CU", (const float2 *)x, (float2 *)y, n, 8);
+        run_rw<1, 0>("read only", x, y, n4);
+        run_rw<0, 1>("write only", x, y, n4);
+        run_rw<1, 1>("1 : 1", x, y, n4);
+        run_rw<2, 1>("2 : 1 (discriminator, PSD)", x, y, n4);
+        run_rw<5, 1>("5 : 1 (decimator)", x, y, n4);
+        run_rw<1, 2>("1 : 2 (Hilbert)", x, y, n4);
+        run_rw<1, 5>("1 : 5 (interpolator)", x, y, n4);
+        run_rw<0, 1, true>("write only, non-temporal stores", x, y, n4);
+        run_rw<1, 1, true>("1 : 1, non-temporal stores", x, y, n4);
+        run_rw<2, 1, true>("2 : 1, non-temporal stores", x, y, n4);
+        run_rw<1, 2, true>("1 : 2, non-temporal stores", x, y, n4);
+        run_rw<1, 5, true>("1 : 5, non-temporal stores", x, y, n4);
         run_os4<896>("overlap-save traffic, 16-B accesses", x, y, n);
         run_os4<1024>("same windows without overlap, 16-B accesses", x, y, n);
     }
