@@ -15,6 +15,18 @@
 
 namespace lrhip {
 
+// A 16-byte store that tells the caches the line will not be read again by this launch.  tools/mb_chunk.hip, 2^26 ComplexFloat32 samples: a 1 : 1 stream moves
+// 6.27 -> 6.44 TB/s with it, one read per two writes 5.95 -> 8.07, one per five 5.48 -> 6.88: the more of a kernel's traffic is output, the more it matters.
+#ifdef __HIPCC__
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store(float4 *dst, float4 v)
+{
+    const nt_f32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_f32x4 *>(dst));
+}
+#endif
+
+
 // ---- error channel: nothing in the library throws, aborts or prints (include/lrhip.h) -----------------
 inline char *err_buf()
 {

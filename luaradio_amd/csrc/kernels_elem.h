@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void rotator_kernel(const float2 *__restrict__
         for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += 2 * stride) {
             const unsigned long j = i + stride;
             const float4 a = x4[i], b = j < n2 ? x4[j] : a;
-            y4[i] = rotate_pair(a, step_fx, count0 + 2 * i, tab);
-            if (j < n2) y4[j] = rotate_pair(b, step_fx, count0 + 2 * j, tab);
+            nt_store(y4 + i, rotate_pair(a, step_fx, count0 + 2 * i, tab));
+            if (j < n2) nt_store(y4 + j, rotate_pair(b, step_fx, count0 + 2 * j, tab));
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = rotate_sample(x[n - 1], step_fx, count0 + n - 1);
     } else {
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(256) void fmdiscrim_vec4_kernel(const float2 *__res
         const float4 v0 = reinterpret_cast<const float4 *>(x)[2 * i], v1 = reinterpret_cast<const float4 *>(x)[2 * i + 1];
         const float2 p = i ? x[4 * i - 1] : *prev_in;
         const float2 a = make_float2(v0.x, v0.y), b = make_float2(v0.z, v0.w), c = make_float2(v1.x, v1.y), d = make_float2(v1.z, v1.w);
-        reinterpret_cast<float4 *>(y)[i] = make_float4(discriminate(a, p, inv_gain), discriminate(b, a, inv_gain), discriminate(c, b, inv_gain),
-                                                       discriminate(d, c, inv_gain));
+        nt_store(reinterpret_cast<float4 *>(y) + i, make_float4(discriminate(a, p, inv_gain), discriminate(b, a, inv_gain), discriminate(c, b, inv_gain),
+                                                                discriminate(d, c, inv_gain)));
         if (4 * i + 4 == n) *prev_out = d;
     }
     if (i == n4 && (n & 3)) {        // tail samples
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void binary_vec4_kernel(const float *__restric
         } else if (OP == BIN_ADD) o = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
         else if (OP == BIN_SUBTRACT) o = make_float4(p.x - q.x, p.y - q.y, p.z - q.z, p.w - q.w);
         else o = make_float4(p.x * q.x, p.y * q.y, p.z * q.z, p.w * q.w);
-        reinterpret_cast<float4 *>(y)[i] = o;
+        nt_store(reinterpret_cast<float4 *>(y) + i, o);
     }
 }
 
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void multiply_constant_vec4_kernel(const float
             const double c = cr, d = ci, ar = v.x, ai = v.y, br = v.z, bi = v.w;
             o = make_float4((float)(ar * c - ai * d), (float)(ar * d + ai * c), (float)(br * c - bi * d), (float)(br * d + bi * c));
         }
-        reinterpret_cast<float4 *>(y)[i] = o;
+        nt_store(reinterpret_cast<float4 *>(y) + i, o);
     }
 }
 
@@ -417,23 +417,119 @@ enum { UN_CMAG = 0, UN_CPHASE = 1, UN_CREAL = 2, UN_CIMAG = 3, UN_CCONJ = 4, UN_
        UN_ADDC_REAL = 7, UN_ADDC_CPLX_BY_REAL = 8, UN_ADDC_CPLX = 9 };
 
 template <int OP>
+__device__ __forceinline__ void unary_sample(const float *__restrict__ x, float *__restrict__ y, unsigned long i, float cr, float ci)
+{
+    const float2 *xc = reinterpret_cast<const float2 *>(x);
+    float2 *yc = reinterpret_cast<float2 *>(y);
+    if (OP == UN_CMAG) { float2 v = xc[i]; y[i] = sqrtf((float)((double)v.x * v.x + (double)v.y * v.y)); }   // complexfloat32.lua:163-165
+    else if (OP == UN_CPHASE) { float2 v = xc[i]; y[i] = atan2f(v.y, v.x); }                                   // :152-154
+    else if (OP == UN_CREAL) y[i] = xc[i].x;
+    else if (OP == UN_CIMAG) y[i] = xc[i].y;
+    else if (OP == UN_CCONJ) { float2 v = xc[i]; yc[i] = make_float2(v.x, -v.y); }
+    else if (OP == UN_R2C) yc[i] = make_float2(x[i], 0.f);
+    else if (OP == UN_ABS) y[i] = fabsf(x[i]);
+    else if (OP == UN_ADDC_REAL) y[i] = x[i] + cr;
+    else if (OP == UN_ADDC_CPLX_BY_REAL) { float2 v = xc[i]; yc[i] = make_float2(v.x + cr, v.y); }             // addconstant.lua:66-72
+    else { float2 v = xc[i]; yc[i] = make_float2(v.x + cr, v.y + ci); }
+}
+template <int OP>
 __global__ __launch_bounds__(256) void unary_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned long n, float cr, float ci)
 {
     unsigned long stride = (unsigned long)gridDim.x * blockDim.x;
-    const float2 *xc = reinterpret_cast<const float2 *>(x);
-    float2 *yc = reinterpret_cast<float2 *>(y);
-    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if (OP == UN_CMAG) { float2 v = xc[i]; y[i] = sqrtf((float)((double)v.x * v.x + (double)v.y * v.y)); }   // complexfloat32.lua:163-165
-        else if (OP == UN_CPHASE) { float2 v = xc[i]; y[i] = atan2f(v.y, v.x); }                                   // :152-154
-        else if (OP == UN_CREAL) y[i] = xc[i].x;
-        else if (OP == UN_CIMAG) y[i] = xc[i].y;
-        else if (OP == UN_CCONJ) { float2 v = xc[i]; yc[i] = make_float2(v.x, -v.y); }
-        else if (OP == UN_R2C) yc[i] = make_float2(x[i], 0.f);
-        else if (OP == UN_ABS) y[i] = fabsf(x[i]);
-        else if (OP == UN_ADDC_REAL) y[i] = x[i] + cr;
-        else if (OP == UN_ADDC_CPLX_BY_REAL) { float2 v = xc[i]; yc[i] = make_float2(v.x + cr, v.y); }             // addconstant.lua:66-72
-        else { float2 v = xc[i]; yc[i] = make_float2(v.x + cr, v.y + ci); }
+    for (unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) unary_sample<OP>(x, y, i, cr, ci);
+}
+
+// The same operations with 16-byte accesses on the wider side (round 3: the one-sample-per-thread form above ran the reference suite's entries at
+// 3.7-5.7 TB/s where the 16-byte kernels stream at 6.1-6.4).  One thread = one float4 of output for the ComplexFloat32 -> Float32 operations (four
+// samples, two 16-byte loads), one float4 in and out for the same-type operations, two samples (an 8-byte load, one 16-byte store) for RealToComplex.
+// `nitems` = number of such threads; thread `nitems` (the grid has one to spare) takes the up to three samples behind them.  Pointers 16-byte aligned.
+// samples one unary_vec_kernel thread covers
+__host__ __device__ constexpr int unary_vec_samples(int op)
+{
+    return (op == UN_CMAG || op == UN_CPHASE || op == UN_CREAL || op == UN_CIMAG || op == UN_ABS || op == UN_ADDC_REAL) ? 4 : 2;
+}
+template <int OP>
+__device__ __forceinline__ float unary_c2r(float re, float im)
+{
+    if (OP == UN_CMAG) return sqrtf((float)((double)re * re + (double)im * im));
+    if (OP == UN_CPHASE) return atan2f(im, re);
+    return OP == UN_CREAL ? re : im;
+}
+template <int OP>
+__global__ __launch_bounds__(256) void unary_vec_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned long nitems, unsigned long n, float cr, float ci)
+{
+    const unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == nitems)
+        for (unsigned long k = nitems * unary_vec_samples(OP); k < n; k++) unary_sample<OP>(x, y, k, cr, ci);
+    if (i >= nitems) return;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    float4 *y4 = reinterpret_cast<float4 *>(y);
+    if (OP == UN_CMAG || OP == UN_CPHASE || OP == UN_CREAL || OP == UN_CIMAG) {
+        const float4 a = x4[2 * i], b = x4[2 * i + 1];
+        nt_store(y4 + i, make_float4(unary_c2r<OP>(a.x, a.y), unary_c2r<OP>(a.z, a.w), unary_c2r<OP>(b.x, b.y), unary_c2r<OP>(b.z, b.w)));
+    } else if (OP == UN_R2C) {
+        const float2 v = reinterpret_cast<const float2 *>(x)[i];
+        nt_store(y4 + i, make_float4(v.x, 0.f, v.y, 0.f));
+    } else {
+        const float4 v = x4[i];
+        float4 o;
+        if (OP == UN_CCONJ) o = make_float4(v.x, -v.y, v.z, -v.w);
+        else if (OP == UN_ABS) o = make_float4(fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w));
+        else if (OP == UN_ADDC_REAL) o = make_float4(v.x + cr, v.y + cr, v.z + cr, v.w + cr);
+        else if (OP == UN_ADDC_CPLX_BY_REAL) o = make_float4(v.x + cr, v.y, v.z + cr, v.w);
+        else o = make_float4(v.x + cr, v.y + ci, v.z + cr, v.w + ci);
+        nt_store(y4 + i, o);
     }
+}
+
+// UpsamplerBlock, one 16-byte store per thread (PER = samples per store: 2 ComplexFloat32 or 4 Float32): one division per thread, then the
+// position inside the zero-stuffing period is carried along.  y 16-byte aligned; `nitems` stores, thread `nitems` takes the tail.
+template <typename T, int PER>
+__global__ __launch_bounds__(256) void upsample_vec_kernel(const T *__restrict__ x, float4 *__restrict__ y, unsigned long nitems, unsigned long factor, unsigned long n_out)
+{
+    const unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == nitems)                                   // the grid's spare thread: the samples behind the last whole store
+        for (unsigned long o = nitems * PER; o < n_out; o++) {
+            T v = {};
+            if (o % factor == 0) v = x[o / factor];
+            reinterpret_cast<T *>(y)[o] = v;
+        }
+    if (i >= nitems) return;
+    const unsigned long o = i * PER;
+    unsigned long q = o / factor, r = o - q * factor;
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        if (r == 0) {
+            const T v = x[q];
+            __builtin_memcpy(&w[k * (4 / PER)], &v, sizeof(T));
+        }
+        if (++r == factor) { r = 0; q++; }
+    }
+    nt_store(y + i, make_float4(w[0], w[1], w[2], w[3]));
+}
+
+// FloatToComplexBlock, two samples per thread: 8-byte loads, one 16-byte store.  Pointers 8- / 16-byte aligned, `nitems` = n / 2 (+ a spare thread for an odd n).
+__global__ __launch_bounds__(256) void float_to_complex_vec_kernel(const float2 *__restrict__ a, const float2 *__restrict__ b, float4 *__restrict__ y,
+                                                                   unsigned long nitems, unsigned long n)
+{
+    const unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == nitems && 2 * nitems < n)
+        reinterpret_cast<float2 *>(y)[n - 1] = make_float2(reinterpret_cast<const float *>(a)[n - 1], reinterpret_cast<const float *>(b)[n - 1]);
+    if (i >= nitems) return;
+    const float2 p = a[i], q = b[i];
+    nt_store(y + i, make_float4(p.x, q.x, p.y, q.y));
+}
+
+// DelayBlock on 16-byte words: D, n and the pointers all whole multiples of 16 bytes (D4, n4 in such words)
+__global__ __launch_bounds__(256) void delay_vec_kernel(const float4 *__restrict__ state_in, const float4 *__restrict__ x, float4 *__restrict__ y,
+                                                        float4 *__restrict__ state_out, unsigned long n4, unsigned long D4)
+{
+    const unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4 + D4) return;
+    const float4 v = i < D4 ? state_in[i] : x[i - D4];
+    if (i < n4) nt_store(y + i, v);
+    else state_out[i - n4] = v;
 }
 
 // ------------------------------------------------------------------------------------------------

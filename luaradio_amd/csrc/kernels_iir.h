@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
 #pragma unroll
                 for (int j = 0; j < F4; j++) {
                     const int idx = 256 * j + tid;
-                    dst[idx] = tr[idx + idx / F4];
+                    nt_store(dst + idx, tr[idx + idx / F4]);
                 }
             } else if (dec == 1) {
                 if (vec && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {

@@ -95,7 +95,10 @@ struct BinaryStage : lrhip_stage {
         if (n > cap) return set_error("binary: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
         if (op == BIN_F2C) {
-            hipLaunchKernelGGL(float_to_complex_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx().stream, (const float *)a, (const float *)b, (float2 *)y, n);
+            if (((uintptr_t)a % 8) == 0 && ((uintptr_t)b % 8) == 0 && ((uintptr_t)y % 16) == 0)
+                hipLaunchKernelGGL(float_to_complex_vec_kernel, dim3(grid_for(n / 2 + 1, 256)), dim3(256), 0, ctx().stream, (const float2 *)a, (const float2 *)b, (float4 *)y, n / 2, n);
+            else
+                hipLaunchKernelGGL(float_to_complex_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ctx().stream, (const float *)a, (const float *)b, (float2 *)y, n);
             LR_LAUNCH_CHECK();
             return (long)n;
         }
@@ -195,6 +198,17 @@ struct UpsamplerStage : lrhip_stage {
         unsigned long n_out = n * factor;                 // upsampler.lua:46
         if (n_out > cap) return set_error("upsampler: output capacity %lu < %lu", cap, n_out);
         if (!n_out) return 0;
+        static const bool no_vec = getenv("LRHIP_ELEM_SCALAR") != nullptr;      // A/B knob: one output sample per thread (round 2)
+        const unsigned long per = 16 / in_size;
+        if (!no_vec && ((uintptr_t)out_dev % 16) == 0) {
+            const unsigned long items = n_out / per;
+            if (in_size == 8)
+                hipLaunchKernelGGL((upsample_vec_kernel<float2, 2>), dim3(grid_for(items + 1, 256)), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float4 *)out_dev, items, factor, n_out);
+            else
+                hipLaunchKernelGGL((upsample_vec_kernel<float, 4>), dim3(grid_for(items + 1, 256)), dim3(256), 0, ctx().stream, (const float *)in_dev, (float4 *)out_dev, items, factor, n_out);
+            LR_LAUNCH_CHECK();
+            return (long)n_out;
+        }
         unsigned grid = grid_for(n_out, 256);
         if (in_size == 8)
             hipLaunchKernelGGL(upsample_kernel<float2>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float2 *)out_dev, n_out, factor);

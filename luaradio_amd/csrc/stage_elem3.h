@@ -14,9 +14,28 @@ struct UnaryStage : lrhip_stage {
     {
         if (n > cap) return set_error("unary: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
-        unsigned grid = grid_for(n, 256);
         const float *x = (const float *)in_dev;
         float *y = (float *)out_dev;
+        // 16-byte accesses (the one-sample kernel when a pointer is not 16-byte aligned)
+        static const bool no_vec = getenv("LRHIP_ELEM_SCALAR") != nullptr;      // A/B knob: one sample per thread (round 2)
+        if (!no_vec && ((uintptr_t)in_dev % 16) == 0 && ((uintptr_t)out_dev % 16) == 0) {
+            const unsigned long per = (unsigned long)unary_vec_samples(op), items = n / per;
+            const unsigned vg = grid_for(items + 1, 256);
+#define LR_UNV(OP) case OP: hipLaunchKernelGGL(unary_vec_kernel<OP>, dim3(vg), dim3(256), 0, ctx().stream, x, y, items, n, cr, ci); break
+            switch (op) {
+                LR_UNV(UN_CMAG); LR_UNV(UN_CPHASE); LR_UNV(UN_CREAL); LR_UNV(UN_CIMAG); LR_UNV(UN_CCONJ); LR_UNV(UN_R2C); LR_UNV(UN_ABS);
+                LR_UNV(UN_ADDC_REAL); LR_UNV(UN_ADDC_CPLX_BY_REAL); LR_UNV(UN_ADDC_CPLX);
+                default: return set_error("unary: bad op");
+            }
+#undef LR_UNV
+            LR_LAUNCH_CHECK();
+            return (long)n;
+        }
+        return run_scalar(x, y, n);
+    }
+    long run_scalar(const float *x, float *y, unsigned long n)
+    {
+        unsigned grid = grid_for(n, 256);
 #define LR_UN(OP) case OP: hipLaunchKernelGGL(unary_kernel<OP>, dim3(grid), dim3(256), 0, ctx().stream, x, y, n, cr, ci); break
         switch (op) {
             LR_UN(UN_CMAG); LR_UN(UN_CPHASE); LR_UN(UN_CREAL); LR_UN(UN_CIMAG); LR_UN(UN_CCONJ); LR_UN(UN_R2C); LR_UN(UN_ABS);
@@ -44,6 +63,15 @@ struct DelayStage : lrhip_stage {
     {
         if (n > cap) return set_error("delay: output capacity %lu < %lu", cap, n);
         if (!n) return 0;
+        static const bool no_vec = getenv("LRHIP_ELEM_SCALAR") != nullptr;
+        if (!no_vec && (D * in_size) % 16 == 0 && (n * in_size) % 16 == 0 && ((uintptr_t)in_dev % 16) == 0 && ((uintptr_t)out_dev % 16) == 0) {
+            const unsigned long n4 = n * in_size / 16, D4 = D * in_size / 16;
+            hipLaunchKernelGGL(delay_vec_kernel, dim3(grid_for(n4 + D4, 256)), dim3(256), 0, ctx().stream, (const float4 *)state[cur].p, (const float4 *)in_dev,
+                               (float4 *)out_dev, (float4 *)state[cur ^ 1].p, n4, D4);
+            LR_LAUNCH_CHECK();
+            cur ^= 1;
+            return (long)n;
+        }
         unsigned grid = grid_for(n + D, 256);
         if (in_size == 8)
             hipLaunchKernelGGL(delay_kernel<float2>, dim3(grid), dim3(256), 0, ctx().stream, (const float2 *)state[cur].p, (const float2 *)in_dev,

@@ -62,7 +62,7 @@ def main():
 
     rows = []
 
-    def run(name, published, blk, cplx):
+    def run(name, published, blk, cplx, third=False):
         if args.trials > 0:
             from luaradio_amd import meters
             src = lr.ZeroSource(types.ComplexFloat32 if cplx else types.Float32, 1.0, n)
@@ -83,9 +83,10 @@ def main():
                          "ratio": round(r["samples_per_second"] / 1e6 / published, 1) if published else None})
             return
         x = xc if cplx else xr
-        cap = blk.max_output(n)
-        ms = timeit(lambda: blk.process_device(x.data_ptr(), n, out.data_ptr(), cap))
-        got = n / ms / 1e3                     # MS/s of input; the reference counts output samples
+        nin = n // 3 if third else n           # (an upsampler's output has to fit the output vector)
+        cap = blk.max_output(nin)
+        ms = timeit(lambda: blk.process_device(x.data_ptr(), nin, out.data_ptr(), cap))
+        got = nin / ms / 1e3                   # MS/s of input; the reference counts output samples
         rows.append({"benchmark": name, "MS/s": round(got, 1), "reference_i5_MS/s": published,
                      "ratio": round(got / published, 1) if published else None, "ms": round(ms, 4)})
 
@@ -113,9 +114,43 @@ def main():
     run("Downsampler (M = 5), Complex input", 144.11, mk(lr.DownsamplerBlock, [5], True), True)
     run("Downsampler (M = 5), Real input", 253.07, mk(lr.DownsamplerBlock, [5], False), False)
     run("Frequency Translator", 396.69, mk(lr.FrequencyTranslatorBlock, [0.2], True), True)
-    run("Hilbert Transform (65 taps)", None, mk(lr.HilbertTransformBlock, [65], False), False)
-    run("AGC (fast), Complex input", None, mk(lr.AGCBlock, ["fast"], True, 1e6), True)
+    run("Upsampler (L = 3), Complex input", 702.62, mk(lr.UpsamplerBlock, [3], True), True, third=True)
+    run("Upsampler (L = 3), Real input", 1259.63, mk(lr.UpsamplerBlock, [3], False), False, third=True)
+    run("Hilbert Transform (65 taps)", 67.66, mk(lr.HilbertTransformBlock, [65], False), False)
+    run("Hilbert Transform (129 taps)", 47.47, mk(lr.HilbertTransformBlock, [129], False), False)
     run("Frequency Discriminator", 111.61, mk(lr.FrequencyDiscriminatorBlock, [1.25], True), True)
+
+    # the element-wise entries (luaradio_benchmark.lua:422-625): the reference feeds both inputs of a two-input block from one source
+    def mk2(cls, cplx):
+        b = cls()
+        b.rate = 1.0
+        t = types.ComplexFloat32 if cplx else types.Float32
+        b.differentiate([t, t])
+        b.initialize()
+        return b
+
+    def run2(name, published, blk, cplx):
+        x = xc if cplx else xr
+        ms = timeit(lambda: lr._lib.check(L.lrhip_stage_execute2_device(blk.stage_handle(), x.data_ptr(), x.data_ptr(), n, out.data_ptr(), n), name))
+        rows.append({"benchmark": name, "MS/s": round(n / ms / 1e3, 1), "reference_i5_MS/s": published, "ratio": round(n / ms / 1e3 / published, 1), "ms": round(ms, 4)})
+
+    if args.trials == 0:
+        run2("Add (Complex)", 226.38, mk2(lr.AddBlock, True), True)
+        run2("Subtract (Complex)", 224.0, mk2(lr.SubtractBlock, True), True)
+        run2("Multiply (Complex)", 280.61, mk2(lr.MultiplyBlock, True), True)
+        run2("Multiply (Real)", 608.55, mk2(lr.MultiplyBlock, False), False)
+        run2("Multiply Conjugate", 291.61, mk2(lr.MultiplyConjugateBlock, True), True)
+        run2("Float to Complex", 397.66, mk2(lr.FloatToComplexBlock, False), False)
+    run("Multiply Constant (Real constant, Complex input)", 308.63, mk(lr.MultiplyConstantBlock, [5.0], True), True)
+    run("Multiply Constant (Complex constant, Complex input)", 254.46, mk(lr.MultiplyConstantBlock, [complex(3.0, 2.0)], True), True)
+    run("Multiply Constant (Real constant, Real input)", 570.66, mk(lr.MultiplyConstantBlock, [5.0], False), False)
+    run("Absolute Value", 647.47, mk(lr.AbsoluteValueBlock, [], False), False)
+    run("Complex Conjugate", 383.44, mk(lr.ComplexConjugateBlock, [], True), True)
+    run("Complex Magnitude", 297.39, mk(lr.ComplexMagnitudeBlock, [], True), True)
+    run("Complex Phase", 130.04, mk(lr.ComplexPhaseBlock, [], True), True)
+    run("Delay (N = 3000, Complex input)", 473.35, mk(lr.DelayBlock, [3000], True), True)
+    run("Complex to Real", 554.76, mk(lr.ComplexToRealBlock, [], True), True)
+    run("Complex to Imaginary", 555.63, mk(lr.ComplexToImagBlock, [], True), True)
     for r in rows:
         print(json.dumps(r))
 
