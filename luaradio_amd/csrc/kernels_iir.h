@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
         float xs[S][PV + LC];
         const bool vec = (c0 + LC <= n) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
         // workgroup-uniform: the whole tile lies inside the chunk, 16-byte aligned, and nobody skips its chunk
-        const bool coal = !no_coal && (tt + 1) * TILE <= n && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && !(!emit && !from_true_state && warm_chunks > 0);
+        const bool coal = !(no_coal & 1) && (tt + 1) * TILE <= n && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && !(!emit && !from_true_state && warm_chunks > 0);
         if (coal) {
             const float4 *src = reinterpret_cast<const float4 *>(x + tt * (long)TILE * S);
 #pragma unroll
@@ -590,7 +590,8 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
 #pragma unroll
                 for (int j = 0; j < F4; j++) {
                     const int idx = 256 * j + tid;
-                    nt_store(dst + idx, tr[idx + idx / F4]);
+                    if (no_coal & 2) dst[idx] = tr[idx + idx / F4];
+                    else nt_store(dst + idx, tr[idx + idx / F4]);
                 }
             } else if (dec == 1) {
                 if (vec && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {

@@ -57,6 +57,9 @@ struct IirStage : lrhip_stage {
             int wc = 0;
             static const bool no_oneshot = getenv("LRHIP_IIR_NO_ONESHOT") != nullptr;      // A/B knob: whole warm-up tiles (round 2)
             static const bool no_coal = getenv("LRHIP_IIR_NO_COAL") != nullptr;            // A/B knob: per-thread chunk loads / stores (round 2)
+            // A/B knob: ordinary stores instead of non-temporal ones (measured, 2^26 samples: Float32 first order 0.100 -> 0.082 ms and two poles 0.117 -> 0.091 with
+            // them; the ComplexFloat32 kernels do not move - 155 registers = 3 workgroups per CU hold them at 4.8 TB/s; forcing 4 spills 80 bytes and loses 40 %)
+            static const bool plain_st = getenv("LRHIP_IIR_PLAIN_STORES") != nullptr;
             static const int run_knob = getenv("LRHIP_IIR_RUN") ? atoi(getenv("LRHIP_IIR_RUN")) : 0;       // A/B knob: tiles per workgroup
             if (warm_chunks > 0 && !no_oneshot) {
                 // partial warm-up tile: only its last warm_chunks chunks are read.  Tiles per workgroup by measurement (2^26 samples, one box, ms):
@@ -68,7 +71,7 @@ struct IirStage : lrhip_stage {
             }
             unsigned grid = (unsigned)((ntiles + run - 1) / run);
             hipLaunchKernelGGL((iir_stream_kernel<SS, PP, NBT>), dim3(grid), dim3(256), 0, ctx().stream, x, y, n, xh, st, st_out, (long)D, (long)index, run,
-                               wc ? 1 : warm_tiles, wc, co, (float *)xhist[cur ^ 1].p, tp, no_coal ? 1 : 0);
+                               wc ? 1 : warm_tiles, wc, co, (float *)xhist[cur ^ 1].p, tp, (no_coal ? 1 : 0) | (plain_st ? 2 : 0));
             LR_LAUNCH_CHECK();
             cur ^= 1;
             return 0;
