@@ -60,6 +60,30 @@ long FormatStage::run(const void *in_dev, unsigned long n, void *out_dev, unsign
         LR_LAUNCH_CHECK();
         return (long)n;
     }
+    static const bool no_vec = getenv("LRHIP_ELEM_SCALAR") != nullptr;      // A/B knob: one scalar per thread (round 2)
+    const size_t in_align = (size_t)(f.bytes >= 8 ? 16 : 4 * f.bytes);
+    if (!no_vec && ((uintptr_t)in_dev % in_align) == 0 && ((uintptr_t)out_dev % 16) == 0) {
+        const unsigned long items = ns / 4;
+        const unsigned vg = grid_for(items + 1, 256);
+#define LR_FMTV(RAW, VAL)                                                                                                  \
+    do {                                                                                                                   \
+        if (f.swap) hipLaunchKernelGGL((format_convert_vec_kernel<RAW, VAL, true>), dim3(vg), dim3(256), 0, ctx().stream, (const RAW *)in_dev, out, items, ns, f.offset, f.scale); \
+        else hipLaunchKernelGGL((format_convert_vec_kernel<RAW, VAL, false>), dim3(vg), dim3(256), 0, ctx().stream, (const RAW *)in_dev, out, items, ns, f.offset, f.scale);      \
+    } while (0)
+        switch (f.cls) {
+            case 0: LR_FMTV(uint8_t, uint8_t); break;
+            case 1: LR_FMTV(uint8_t, int8_t); break;
+            case 2: LR_FMTV(uint16_t, uint16_t); break;
+            case 3: LR_FMTV(uint16_t, int16_t); break;
+            case 4: LR_FMTV(uint32_t, uint32_t); break;
+            case 5: LR_FMTV(uint32_t, int32_t); break;
+            case 6: LR_FMTV(uint32_t, float); break;
+            default: LR_FMTV(uint64_t, double); break;
+        }
+#undef LR_FMTV
+        LR_LAUNCH_CHECK();
+        return (long)n;
+    }
 #define LR_FMT(RAW, VAL)                                                                                                   \
     do {                                                                                                                   \
         if (f.swap) hipLaunchKernelGGL((format_convert_kernel<RAW, VAL, true>), dim3(grid), dim3(256), 0, ctx().stream, (const RAW *)in_dev, out, ns, f.offset, f.scale); \

@@ -92,6 +92,21 @@ def main():
     run("RationalResampler(5, 4) cf32 (polyphase, input samples)", lambda: mk(lr.RationalResamplerBlock, [5, 4], True), True, 8 + 8 * 5 / 4, 4 * 128 * (5 / 4) / 5)
     run("RationalResampler(3, 4) cf32 (polyphase, input samples)", lambda: mk(lr.RationalResamplerBlock, [3, 4], True), True, 8 + 8 * 3 / 4, 4 * 128 * (3 / 4) / 3)
     run("RationalResampler(4, 5) cf32 (polyphase, input samples)", lambda: mk(lr.RationalResamplerBlock, [4, 5], True), True, 8 + 8 * 4 / 5, 4 * 128 * (4 / 5) / 4)
+    # IQFileSource's sample formats converted on the device (iqfile.lua:82-116, format_utils.lua:82-97): raw records in, ComplexFloat32 out
+    class _Fmt:
+        def __init__(self, fmt):
+            self.q = L.lrhip_format_convert_create(fmt.encode(), 1)
+            assert self.q, lr._lib.last_error()
+
+        def max_output(self, n_):
+            return n_
+
+        def process_device(self, xp, n_, yp, cap):
+            return lr._lib.check(L.lrhip_stage_execute_device(self.q, xp, n_, yp, cap), "format")
+
+    run("IQ records u8 -> cf32 (device)", lambda: _Fmt("u8"), True, 2 + 8)
+    run("IQ records s16le -> cf32 (device)", lambda: _Fmt("s16le"), True, 4 + 8)
+    run("IQ records f32be -> cf32 (device)", lambda: _Fmt("f32be"), True, 8 + 8)
     run("HilbertTransform(65) f32 -> cf32", lambda: mk(lr.HilbertTransformBlock, [65], False), False, 12, 2 * 65)
     run("HilbertTransform(129) f32 -> cf32", lambda: mk(lr.HilbertTransformBlock, [129], False), False, 12, 2 * 129)
     # the reference suite's IIR entry (benchmarks/luaradio_benchmark.lua: 5 feed-forward, 3 feedback taps), a stable filter
