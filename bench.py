@@ -471,7 +471,7 @@ def main():
         config = {"workload": "configs[2]: examples/rtlsdr_wbfm_mono.lua chain (Tuner -> FrequencyDiscriminator -> Lowpass -> "
                               "FMDeemphasis -> Downsampler) on 2^%d synthetic FM IQ samples @ 1.1025 MS/s, device-resident" % log2n,
                   "samples_per_step_per_gpu": n, "counted": "RF input samples", "parallelism": "independent streams x%d" % world}
-        dominant = "fir_mfma_persistent_kernel<2,5,2,true,51,1,true>"
+        dominant = "rx_fused_kernel (the whole receiver, one launch)"
     elif args.workload == "timeshard":
         # ONE recording of 2^log2n samples cut into `world` time partitions (second mode): rank r runs the receiver on its own
         # partition - lrhip_chain_start_at: seek to the aligned sample in front of (a - halo), replay, drop the replayed output - with no

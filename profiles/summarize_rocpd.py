@@ -50,7 +50,7 @@ def main():
             if last:
                 hdr += " %14s %14s" % ("avg_last%d_us" % last, "min_last%d_us" % last)
             print(hdr)
-            for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))[:30]:
+            for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))[:60]:
                 sv = sorted(v)
                 med = sv[len(sv) // 2] if len(sv) % 2 else 0.5 * (sv[len(sv) // 2 - 1] + sv[len(sv) // 2])
                 line = "%-72s %6d %12.2f %12.2f %12.2f %12.2f %6.1f%%" % (short(k), len(v), sum(v) / len(v) / 1e3, med / 1e3, sv[0] / 1e3, sv[-1] / 1e3, 100.0 * sum(v) / tot)

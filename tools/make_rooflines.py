@@ -64,7 +64,11 @@ def main():
         ("RationalResampler(3, 4) cf32", blocks, ("fir_rational_kernel<3, 4",), 14, n26, 0),
         ("RationalResampler(5, 4) cf32", blocks, ("fir_rational_kernel<5, 4",), 18, n26, 0),
         ("RationalResampler(4, 5) cf32", blocks, ("fir_rational_kernel<4, 5",), 14.4, n26, 0),
-        ("HilbertTransform(65) f32 -> cf32, one launch", blocks, ("fir_mfma_kernel<1, 1, 4, false, 1, true>",), 12, n26, 130),
+        ("HilbertTransform(65) f32 -> cf32 (window kernel, zero taps skipped)", blocks, ("hilbert_win_kernel<65>",), 12, n26, 64),
+        ("HilbertTransform(129) f32 -> cf32", blocks, ("hilbert_win_kernel<129>",), 12, n26, 128),
+        ("IQ records u8 -> cf32", blocks, ("format_convert_vec_kernel<unsigned char, unsigned char",), 10, n26, 0),
+        ("IQ records s16le -> cf32", blocks, ("format_convert_vec_kernel<unsigned short, short",), 12, n26, 0),
+        ("IQ records f32be -> cf32", blocks, ("format_convert_vec_kernel<unsigned int, float, true",), 16, n26, 0),
         ("PSD N=1024 hamming log fftshift", blocks, ("spectrum1024_kernel",), 12, n26, 58),
         ("WBFM mono receiver (bench_blocks: U(-1,1) noise input)", blocks, ("rx_fused_kernel",), 8.16, n26, 167),
     ]
