@@ -193,7 +193,9 @@ lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages);
  *                                  (block-of-8 staging): fused == unfused and chunked == unchunked bit for bit, at 0.19 instead of
  *                                  0.16 ms per 2^26 samples of the WBFM receiver;
  *   LRHIP_CHAIN_NO_POLYPHASE_TAIL  FIR -> single-pole IIR -> downsampler keeps the blocks' own arithmetic (filter at the high rate,
- *                                  recurrence, gather) instead of ONE decimating filter with the recurrence at the low rate;
+ *                                  recurrence, gather) instead of ONE decimating filter with the recurrence at the low rate; and
+ *                                  consecutive overlap-save filters on a ComplexFloat32 stream stay separate filters instead of ONE
+ *                                  filter with the convolved taps (up to 1 281 taps, one 4096-point launch);
  *   LRHIP_CHAIN_NO_FUSION          every stage runs its own kernels (edges still device-resident);
  *   LRHIP_CHAIN_NO_SINGLE_LAUNCH   the FM receivers keep tuner + discriminator and audio tail as two launches (the round-2 form).
  * LRHIP_CHAIN_EXACT = EXACT_ROTATOR | NO_POLYPHASE_TAIL | NO_SINGLE_LAUNCH: the chain computes what its blocks compute one by one (bit for bit

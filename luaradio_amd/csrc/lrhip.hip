@@ -19,6 +19,7 @@
 #include "kernels_agc.h"
 #include "kernels_firwin.h"
 #include "kernels_firwin2.h"
+#include "kernels_firfft4k.h"
 #include "kernels_interp.h"
 #include "kernels_rx.h"
 
@@ -545,6 +546,61 @@ lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, u
             c->ops.push_back({stages[i], false});
             i++;
             continue;
+        }
+        // fusion: fir fir ... (ComplexFloat32 stream, every one of them on the overlap-save arithmetic: "fast", or left to the library)  ->  ONE filter with the convolved taps
+        // while they fit the 4096-point kernel (kernels_firfft4k.h: 1 281 taps).  A chain of filters is a filter; overlap-save promises 1e-6 of the exact
+        // result, not the bits of a particular block size, and the merged filter rounds once where the chain rounds per stage.  The reference suite's first
+        // entry (five 256-tap filters back to back, luaradio_benchmark.lua:17-37) = 1 276 taps = one launch instead of five.
+        {
+            static const bool no_cascade = getenv("LRHIP_NO_FIR_CASCADE") != nullptr;      // A/B knob
+            auto mergeable = [](lrhip_stage_t *st) -> FirStage * {
+                FirStage *f = dynamic_cast<FirStage *>(st);
+                return (f && f->S == 2 && f->D == 1 && !f->rot && !f->pre_disc && !f->post_disc && !f->use_fft && f->fft_arith && (f->mode_req == 2 || f->mode_req == 3)) ? f : nullptr;
+            };
+            // (LRHIP_CHAIN_NO_POLYPHASE_TAIL = "keep every block's own arithmetic": the same kind of identity, the same switch)
+            FirStage *f0 = (no_cascade || (flags & LRHIP_CHAIN_NO_POLYPHASE_TAIL)) ? nullptr : mergeable(stages[i]);
+            if (f0 && i + 1 < nstages && mergeable(stages[i + 1])) {
+                // taps in natural order, double, complex (real taps: zero imaginary parts)
+                auto natural = [](const FirStage *f) {
+                    const int ts = f->taps_complex ? 2 : 1;
+                    std::vector<double> h((size_t)2 * f->M, 0.0);
+                    for (int t = 0; t < f->M; t++) {
+                        h[2 * t] = f->taps_rev[(size_t)(f->M - 1 - t) * ts];
+                        if (ts == 2) h[2 * t + 1] = f->taps_rev[(size_t)(f->M - 1 - t) * ts + 1];
+                    }
+                    return h;
+                };
+                std::vector<double> acc = natural(f0);
+                bool cplx = f0->taps_complex;
+                unsigned k = i + 1;
+                while (k < nstages) {
+                    FirStage *fk = mergeable(stages[k]);
+                    if (!fk || acc.size() / 2 + (size_t)fk->M - 1 > 1281) break;
+                    const std::vector<double> h = natural(fk);
+                    std::vector<double> out(acc.size() + h.size() - 2, 0.0);
+                    for (size_t a = 0; a < acc.size() / 2; a++)
+                        for (size_t b = 0; b < h.size() / 2; b++) {
+                            out[2 * (a + b)] += acc[2 * a] * h[2 * b] - acc[2 * a + 1] * h[2 * b + 1];
+                            out[2 * (a + b) + 1] += acc[2 * a] * h[2 * b + 1] + acc[2 * a + 1] * h[2 * b];
+                        }
+                    acc.swap(out);
+                    cplx = cplx || fk->taps_complex;
+                    k++;
+                }
+                if (k > i + 1) {
+                    const unsigned Mm = (unsigned)(acc.size() / 2);
+                    std::vector<float> taps((size_t)Mm * (cplx ? 2 : 1));
+                    for (unsigned t = 0; t < Mm; t++) {
+                        if (cplx) { taps[2 * t] = (float)acc[2 * t]; taps[2 * t + 1] = (float)acc[2 * t + 1]; }
+                        else taps[t] = (float)acc[2 * t];
+                    }
+                    FirStage *merged = fir_build(taps.data(), Mm, cplx ? 1 : 0, 1, 1, 2, false, 0.0);
+                    if (!merged) return nullptr;
+                    c->ops.push_back({merged, true});
+                    i = k;
+                    continue;
+                }
+            }
         }
         // fusion: [multiplyconstant(real)] upsampler fir(real taps, plain) [downsampler]  ->  one polyphase resampling launch
         {

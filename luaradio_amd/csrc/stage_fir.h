@@ -30,6 +30,8 @@ struct FirStage : lrhip_stage {
     static constexpr int FFT_PART = 512;   // taps per overlap-save partition (V = 512, L = 512 of the 1024-point block)
     bool fft_arith = false;
     DeviceBuf d_fft_tables;
+    DeviceBuf d_fft4k_tables;             // 513 .. 1281 taps on a ComplexFloat32 stream: the 4096-point kernel (kernels_firfft4k.h)
+    int fft4k_V = 0, fft4k_blocks = 0;    // its overlap (768 / 1024 / 1280; 0 = not built)
     int fft_blocks_per_cu = 0;
     // decimating polyphase-FFT form (kernels_firdecfft.h): ComplexFloat32 stream, D >= 2, ceil(M / D) <= 32
     bool decfft = false;
@@ -331,8 +333,31 @@ struct FirStage : lrhip_stage {
         }
     }
 
+    template <int VV>
+    int launch_fft4k(const float *x, long n, float *y, long n_out)
+    {
+        constexpr long Lf = F4K_N - VV;
+        const size_t lds_bytes = (size_t)F4K_LDS_ELEMS * sizeof(float2);
+        auto kern = fir_fft4k_kernel<VV>;
+        if (!fft4k_blocks && prepare_kernel(kern, lds_bytes, &fft4k_blocks, 256)) return -1;
+        const long nblocks = (n_out + Lf - 1) / Lf, slots = (long)ctx().num_cus * fft4k_blocks;
+        const unsigned grid = (unsigned)(nblocks < slots ? nblocks : slots);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (const float2 *)d_fft4k_tables.p, y, M, n,
+                           n_out, nblocks, M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : (float *)nullptr);
+        LR_LAUNCH_CHECK();
+        hist_in_kernel = true;
+        return 0;
+    }
     int launch_fft(const float *x, long n, float *y, long n_out)
     {
+        static const bool no_4k = getenv("LRHIP_FFT_NO_4K") != nullptr;      // A/B knob: partitions of the 1024-point kernel (round 2)
+        if (fft4k_V && !no_4k && !pre_disc && !post_disc) {
+            switch (fft4k_V) {
+                case 768: return launch_fft4k<768>(x, n, y, n_out);
+                case 1024: return launch_fft4k<1024>(x, n, y, n_out);
+                default: return launch_fft4k<1280>(x, n, y, n_out);
+            }
+        }
         size_t lds_bytes = (size_t)FFT_LDS_ELEMS * sizeof(float2);
         static const long lds_pad = getenv("LRHIP_FFT_LDS_PAD") ? atol(getenv("LRHIP_FFT_LDS_PAD")) : 0;      // A/B knob: unused LDS per workgroup -> fewer resident workgroups per CU
         lds_bytes += (size_t)lds_pad;
@@ -955,6 +980,44 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
         }
         if (upload(q->d_fft_tables, tab.data(), tab.size() * sizeof(float))) return nullptr;
         q->fft_arith = true;
+        if (input_complex && (int)ntaps > FirStage::FFT_PART && ntaps <= 1281) {
+            // tables of the 4096-point kernel (kernels_firfft4k.h): tw1 | tw2 | c[w][i] = W_64^(i w) | b[w][t] = W_4096^(t w) | H[w][16 x 64] of the bins w + 4 k'
+            std::vector<float> t4((size_t)F4K_TABLE_ELEMS * 2);
+            auto put = [&](size_t o, double a) { t4[2 * o] = (float)std::cos(a); t4[2 * o + 1] = (float)std::sin(a); };
+            for (int k1 = 0; k1 < 16; k1++)
+                for (int t = 0; t < 64; t++) put((size_t)k1 * 64 + t, -PI2 * (double)((k1 * t) % FFTN) / FFTN);
+            for (int k2 = 0; k2 < 16; k2++)
+                for (int t2 = 0; t2 < 4; t2++) put((size_t)16 * 64 + k2 * 4 + t2, -PI2 * (double)((k2 * t2) % 64) / 64.0);
+            for (int w = 0; w < 4; w++) {
+                for (int i = 0; i < 16; i++) put((size_t)16 * 64 + 64 + w * 16 + i, -PI2 * (double)((i * w) % 64) / 64.0);
+                for (int t = 0; t < 64; t++) put((size_t)F4K_TAB_B + w * 64 + t, -PI2 * (double)(t * w) / F4K_N);
+            }
+            std::vector<double> cs(F4K_N), sn(F4K_N), Hr(F4K_N), Hi(F4K_N);
+            for (int k = 0; k < F4K_N; k++) { cs[k] = std::cos(-PI2 * k / F4K_N); sn[k] = std::sin(-PI2 * k / F4K_N); }
+            for (int k = 0; k < F4K_N; k++) {
+                double sr = 0, si = 0;
+                for (unsigned m = 0; m < ntaps; m++) {
+                    const int a = (int)(((long)k * m) % F4K_N);
+                    const double hr = taps_complex ? taps[2 * m] : taps[m], hi = taps_complex ? taps[2 * m + 1] : 0.0;
+                    sr += hr * cs[a] - hi * sn[a];
+                    si += hr * sn[a] + hi * cs[a];
+                }
+                Hr[k] = sr / F4K_N;
+                Hi[k] = si / F4K_N;
+            }
+            for (int w = 0; w < 4; w++)
+                for (int j = 0; j < 4; j++)
+                    for (int k3 = 0; k3 < 4; k3++)
+                        for (int lane = 0; lane < 64; lane++) {
+                            const int qq = lane & 3, k1 = lane >> 2, kp = k1 + 16 * (4 * j + qq) + 256 * k3, k = w + 4 * kp;
+                            const size_t o = (size_t)F4K_TAB_H + (size_t)w * 1024 + (size_t)(4 * j + k3) * 64 + lane;
+                            t4[2 * o] = (float)Hr[k];
+                            t4[2 * o + 1] = (float)Hi[k];
+                        }
+            if (upload(q->d_fft4k_tables, t4.data(), t4.size() * sizeof(float))) return nullptr;
+            q->fft4k_V = (int)((ntaps - 1 + 255) / 256) * 256;
+            if (q->fft4k_V < 768) q->fft4k_V = 768;
+        }
     }
     if (q->use_fft) {
         long N = 1L << (long)std::floor(std::log(8.0 * ntaps) / std::log(2.0));   // firfilter.lua:329

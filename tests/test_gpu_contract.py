@@ -222,3 +222,37 @@ def test_push_keeps_its_samples_when_the_launch_fails():
     got = np.concatenate(parts)
     want = lr.Chain(receiver_blocks()).process(x)
     assert len(got) == len(want) and float(np.max(np.abs(got - want))) < 5e-5
+
+
+def test_cascaded_overlap_save_filters_run_as_one_filter():
+    """benchmarks/luaradio_benchmark.lua:17-37, the suite's first entry: five 256-tap FIRFilterBlocks back to back.  A chain of filters is a filter
+    (1 276 taps); filters that asked for the overlap-save arithmetic are merged into ONE launch of the 4096-point kernel, and the merged
+    filter is held to the f64 oracle CHAIN (five stages, each rounded to Float32 like the reference's vectors between blocks)."""
+    rng = np.random.default_rng(21)
+    c = types.ComplexFloat32
+    taps = [(rng.uniform(0, 1, 256) / 128).astype(np.float32) for _ in range(5)]
+    n = 300001
+    x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+    want = x
+    for t in taps:
+        want = O.FIR(t, True, O.MODE_F64).process(want)
+    scale = float(np.max(np.abs(want)))
+    cuts = [1, 4095, 4096, 100000, 100001]
+    merged = lr.Chain([make(lr.FIRFilterBlock, [t, "fast"], c, FS) for t in taps])
+    got = run_chunked(merged.process, x, cuts)
+    assert merged.last_launches == 1
+    assert len(got) == n and float(np.max(np.abs(got - want))) <= 2e-6 * max(scale, 1.0)
+    # LRHIP_CHAIN_EXACT keeps every block's own arithmetic: five filters, five launches, the same values to the same bar
+    apart = lr.Chain([make(lr.FIRFilterBlock, [t, "fast"], c, FS) for t in taps], exact=True)
+    got5 = run_chunked(apart.process, x, cuts)
+    assert apart.last_launches == 5
+    assert float(np.max(np.abs(got5 - want))) <= 5e-6 * max(scale, 1.0)
+    assert float(np.max(np.abs(got5 - got))) <= 5e-6 * max(scale, 1.0)
+    # direct-form filters (bit-exact by contract) are never merged
+    direct = lr.Chain([make(lr.FIRFilterBlock, [t[:16], False], c, FS) for t in taps[:2]])
+    direct.process(x[:5000])
+    assert direct.last_launches == 2
+    # six filters = 1 531 taps do not fit one block: five are merged, the sixth stays
+    six = lr.Chain([make(lr.FIRFilterBlock, [t, "fast"], c, FS) for t in taps + taps[:1]])
+    six.process(x[:100000])
+    assert six.last_launches == 2

@@ -243,9 +243,10 @@ def test_fir_unaligned_host_and_device_views():
 
 
 @pytest.mark.parametrize("cplx_in,cplx_taps", [(True, False), (False, False), (True, True)])
-@pytest.mark.parametrize("ntaps", [32, 64, 128, 129, 300, 512, 513, 1024, 1300, 2049])
+@pytest.mark.parametrize("ntaps", [32, 64, 128, 129, 300, 512, 513, 769, 770, 1024, 1025, 1026, 1276, 1281, 1282, 1300, 2049])
 def test_fir_fft_arithmetic_fast_mode(cplx_in, cplx_taps, ntaps):
-    """use_fft="fast": fused overlap-save kernel (1024-point FFT), one output per input; filters above 512 taps run as
+    """use_fft="fast": fused overlap-save kernel (1024-point FFT), one output per input; 513 .. 1281 taps on a ComplexFloat32 stream run
+    on the 4096-point kernel (one block per workgroup, overlaps 768 / 1024 / 1280: kernels_firfft4k.h), everything else above 512 taps as
     partitions of 512 taps that accumulate into the output.  Held to the reference's 1e-6 against the f64 oracle; chunk
     boundaries move the FFT block grid but not the values."""
     rng = np.random.default_rng(ntaps + 7 * cplx_in + 13 * cplx_taps)

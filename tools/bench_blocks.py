@@ -73,6 +73,11 @@ def main():
     run("FIRFilter 128 real taps, cf32, overlap-save (use_fft=fast)", lambda: mk(lr.FIRFilterBlock, [taps128, "fast"], True), True, 16, 125)
     run("FIRFilter 128 real taps, f32, direct form (use_fft=False)", lambda: mk(lr.FIRFilterBlock, [taps128, False], False), False, 8, 256)
     run("FIRFilter 128 real taps, f32, overlap-save (use_fft=fast)", lambda: mk(lr.FIRFilterBlock, [taps128, "fast"], False), False, 8, 63)
+    taps1276 = np.convolve(np.convolve(np.convolve(np.convolve(lr.filter_utils.firwin_lowpass(256, 0.3), lr.filter_utils.firwin_lowpass(256, 0.35)),
+                                                   lr.filter_utils.firwin_lowpass(256, 0.4)), lr.filter_utils.firwin_lowpass(256, 0.45)),
+                           lr.filter_utils.firwin_lowpass(256, 0.5)).astype(np.float32)
+    run("FIRFilter 1276 real taps, cf32, overlap-save (4096-point blocks)", lambda: mk(lr.FIRFilterBlock, [taps1276, "fast"], True), True, 16, 180)
+    run("FIRFilter 768 real taps, cf32, overlap-save (4096-point blocks)", lambda: mk(lr.FIRFilterBlock, [taps1276[:768], "fast"], True), True, 16, 160)
     run("FIRFilter 16 real taps, cf32", lambda: mk(lr.FIRFilterBlock, [taps128[:16], False], True), True, 16, 64)
     run("FIRFilter 128 complex taps, cf32, direct form (use_fft=False)", lambda: mk(lr.FIRFilterBlock, [np.asarray(taps128, np.complex64) * (1 + 0.5j), False], True), True, 16, 1024)
     run("FIRFilter 128 complex taps, cf32, overlap-save (use_fft=fast)", lambda: mk(lr.FIRFilterBlock, [np.asarray(taps128, np.complex64) * (1 + 0.5j), "fast"], True), True, 16, 125)
