@@ -26,10 +26,9 @@ namespace lrhip {
 
 static_assert(LRHIP_FFT_SPLIT == 0, "the 4096-point kernel reuses the one-pass exchange buffers");
 constexpr int F4K_N = 4096;
-constexpr int F4K_LDS_TW1 = 4 * FFT_EX_ELEMS;                 // [cross-stage buffer (4096) = 4 per-wave exchange buffers | tw1 16x64 | tw2 64 | c 4x16]
-constexpr int F4K_LDS_TW2 = F4K_LDS_TW1 + 16 * 64;
-constexpr int F4K_LDS_C = F4K_LDS_TW2 + 64;
-constexpr int F4K_LDS_ELEMS = F4K_LDS_C + 64;
+// LDS (float2 units): [NG x (cross-stage buffer (4096) = 4 per-wave exchange buffers) | tw1 16x64 | tw2 64 | c 4x16], NG = blocks per workgroup (4 waves each)
+__host__ __device__ constexpr int f4k_lds_tw1(int ng) { return ng * 4 * FFT_EX_ELEMS; }
+__host__ __device__ constexpr int f4k_lds_elems(int ng) { return f4k_lds_tw1(ng) + 16 * 64 + 64 + 64; }
 static_assert(4 * FFT_EX_ELEMS >= F4K_N, "cross-stage buffer");
 // host tables (float2 units): tw1 16x64 | tw2 64 | c[w][i] = W_64^(i w) (4x16) | b[w][t] = W_4096^(t w) (4x64) | H[w][r * 64 + lane] (4x1024)
 constexpr int F4K_TAB_LDS = 16 * 64 + 64 + 64;
@@ -37,21 +36,25 @@ constexpr int F4K_TAB_B = F4K_TAB_LDS;
 constexpr int F4K_TAB_H = F4K_TAB_B + 4 * 64;
 constexpr int F4K_TABLE_ELEMS = F4K_TAB_H + F4K_N;
 
-template <int V>
-__global__ __launch_bounds__(256, 3) void fir_fft4k_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float2 *__restrict__ tables,
-                                                           float *__restrict__ y, int M, long n, long n_out, long nblocks, float *__restrict__ hist_out)
+// NG = 2: two blocks per 512-thread workgroup share the tables: 2 x 78 KB = 16 waves per CU instead of 3 x 44 KB = 12.  xcd_map: workgroup g (on XCD g % 8)
+// takes the blocks of the (g % 8)-th eighth of the stream, so that the 31 % window overlap of neighbouring blocks is an L2 hit instead of an HBM read.
+template <int V, int NG>
+__global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : 3) void fir_fft4k_kernel(const float *__restrict__ hist, const float *__restrict__ x,
+                                                                              const float2 *__restrict__ tables, float *__restrict__ y, int M, long n, long n_out,
+                                                                              long nblocks, float *__restrict__ hist_out, int xcd_map)
 {
+    constexpr int F4K_LDS_TW1 = f4k_lds_tw1(NG), F4K_LDS_TW2 = F4K_LDS_TW1 + 16 * 64, F4K_LDS_C = F4K_LDS_TW2 + 64;
     static_assert(V % 256 == 0 && V >= 256 && V < F4K_N, "the overlap is a whole number of 256-sample rows");
     constexpr int L = F4K_N - V, NJ = L / 256;
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63, tid = threadIdx.x & 255;      // tid: inside the block's four waves
+    const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3), grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
     if (hist_out && blockIdx.x == 0)
-        for (int i = tid; i < (M - 1) * 2; i += 256) hist_out[i] = stream_at<2>(hist, x, n + i / 2, i % 2, M, n);
+        for (int i = threadIdx.x; i < (M - 1) * 2; i += 256 * NG) hist_out[i] = stream_at<2>(hist, x, n + i / 2, i % 2, M, n);
     cf *flc = reinterpret_cast<cf *>(fl);
-    cf *xb = flc, *ex = flc + wave * FFT_EX_ELEMS;
+    cf *xb = flc + grp * 4 * FFT_EX_ELEMS, *ex = xb + wave * FFT_EX_ELEMS;
     const cf *tw1 = flc + F4K_LDS_TW1, *tw2 = flc + F4K_LDS_TW2, *ctab = flc + F4K_LDS_C + 16 * wave;
-    for (int i = tid; i < F4K_TAB_LDS; i += 256) fl[F4K_LDS_TW1 + i] = tables[i];
+    for (int i = threadIdx.x; i < F4K_TAB_LDS; i += 256 * NG) fl[F4K_LDS_TW1 + i] = tables[i];
     const cf *tb = reinterpret_cast<const cf *>(tables);
     const cf bw = tb[F4K_TAB_B + 64 * wave + lane];
     cf Hreg[16];
@@ -72,8 +75,20 @@ __global__ __launch_bounds__(256, 3) void fir_fft4k_kernel(const float *__restri
             for (int i = 0; i < 16; i++) pre[i] = src[64 * i];
         }
     };
-    prefetch(blockIdx.x);
-    for (long fb = blockIdx.x; fb < nblocks; fb += gridDim.x) {
+    // block order: slot = workgroup-major (plain) or XCD-major; a slot is NG adjacent blocks
+    const long nslots = (nblocks + NG - 1) / NG;
+    long slot0 = blockIdx.x, sstep = gridDim.x, send = nslots;
+    if (xcd_map && (gridDim.x & 7) == 0) {
+        const long per = (nslots + 7) / 8;
+        slot0 = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        sstep = gridDim.x >> 3;
+        send = (long)((blockIdx.x & 7) + 1) * per < nslots ? (long)((blockIdx.x & 7) + 1) * per : nslots;
+    }
+    prefetch(slot0 < send ? slot0 * NG + grp : nblocks);
+    // (every wave of the workgroup runs the same number of iterations - the barriers are workgroup-wide; a group without a block computes on zeros)
+    for (long slot = slot0; slot < send; slot += sstep) {
+        const long fb = slot * NG + grp;
+        const bool live = fb < nblocks;
         const long xlo = fb * L - V;                      // x index of window position 0
         cf v[16];
         // ---- this wave's quarter of the window: positions 1024 wave + 64 i + lane
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(256, 3) void fir_fft4k_kernel(const float *__restri
             for (int i = 0; i < 16; i++) v[i] = cmul(v[i], cmul(bw, ctab[i]));
         }
         __syncthreads();                                  // the window is read: its space becomes the four exchange buffers
-        if (LRHIP_F4K_PREFETCH) prefetch(fb + gridDim.x);
+        if (LRHIP_F4K_PREFETCH && slot + sstep < send) prefetch((slot + sstep) * NG + grp);
         else have = false;
         // ---- the 1024-point pipeline of fir_fft_kernel on y_w (lane t holds y_w[64 i + t])
         dft16<1>(v);
@@ -157,7 +172,7 @@ __global__ __launch_bounds__(256, 3) void fir_fft4k_kernel(const float *__restri
                 const cf e = cadd(z0, z2), d = cadd(z1, z3);
                 o = m == 0 ? cadd(e, d) : csub(e, d);
             }
-            if (ob + 256 * j < n_out) __builtin_nontemporal_store(o, reinterpret_cast<cf *>(y) + ob + 256 * j);
+            if (live && ob + 256 * j < n_out) __builtin_nontemporal_store(o, reinterpret_cast<cf *>(y) + ob + 256 * j);
         });
         __syncthreads();                                  // the outputs are read: the next window may be written
     }

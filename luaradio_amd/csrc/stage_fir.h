@@ -333,20 +333,32 @@ struct FirStage : lrhip_stage {
         }
     }
 
-    template <int VV>
-    int launch_fft4k(const float *x, long n, float *y, long n_out)
+    template <int VV, int NG>
+    int launch_fft4k_ng(const float *x, long n, float *y, long n_out, int *blocks_per_cu)
     {
         constexpr long Lf = F4K_N - VV;
-        const size_t lds_bytes = (size_t)F4K_LDS_ELEMS * sizeof(float2);
-        auto kern = fir_fft4k_kernel<VV>;
-        if (!fft4k_blocks && prepare_kernel(kern, lds_bytes, &fft4k_blocks, 256)) return -1;
-        const long nblocks = (n_out + Lf - 1) / Lf, slots = (long)ctx().num_cus * fft4k_blocks;
-        const unsigned grid = (unsigned)(nblocks < slots ? nblocks : slots);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (const float2 *)d_fft4k_tables.p, y, M, n,
-                           n_out, nblocks, M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : (float *)nullptr);
+        const size_t lds_bytes = (size_t)f4k_lds_elems(NG) * sizeof(float2);
+        auto kern = fir_fft4k_kernel<VV, NG>;
+        if (!*blocks_per_cu && prepare_kernel(kern, lds_bytes, blocks_per_cu, 256 * NG)) return -1;
+        // XCD-major block order (kernels_firfft4k.h), measured on 2^26 samples, same box: 1 276 taps 0.479 -> 0.448 ms (the 31 % overlap becomes L2 hits),
+        // 768 taps equal; LRHIP_F4K_XCD_MAP=0 is the plain order
+        static const int xcd_map = getenv("LRHIP_F4K_XCD_MAP") ? atoi(getenv("LRHIP_F4K_XCD_MAP")) : 1;
+        const long nblocks = (n_out + Lf - 1) / Lf, nslots = (nblocks + NG - 1) / NG, slots = (long)ctx().num_cus * *blocks_per_cu;
+        const unsigned grid = (unsigned)(nslots < slots ? nslots : slots);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * NG), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (const float2 *)d_fft4k_tables.p, y, M, n,
+                           n_out, nblocks, M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : (float *)nullptr, xcd_map);
         LR_LAUNCH_CHECK();
         hist_in_kernel = true;
         return 0;
+    }
+    int fft4k_blocks2 = 0;
+    template <int VV>
+    int launch_fft4k(const float *x, long n, float *y, long n_out)
+    {
+        // A/B knob: blocks per workgroup.  2 (512 threads, shared tables, 16 waves per CU instead of 12) measured SLOWER: 0.505 against 0.479 ms - the
+        // barriers then couple eight waves; the kernel is bound by its five workgroup barriers per block, not by occupancy (counters: VALU 27 %, LDS 42 % busy)
+        static const int ng = getenv("LRHIP_F4K_NG") ? atoi(getenv("LRHIP_F4K_NG")) : 1;
+        return ng == 2 ? launch_fft4k_ng<VV, 2>(x, n, y, n_out, &fft4k_blocks2) : launch_fft4k_ng<VV, 1>(x, n, y, n_out, &fft4k_blocks);
     }
     int launch_fft(const float *x, long n, float *y, long n_out)
     {
