@@ -116,12 +116,14 @@ def test_time_partitions_of_the_single_launch_receiver():
 
 
 # ---- the other round-3 kernels at size (properties that need no oracle run over millions of samples) --------------------------------------------
-def test_hilbert_single_launch_properties_at_size():
-    """HilbertTransformBlock in one launch (kernels_fir.h HILB epilogue), 2^22 samples in ragged chunks: the real part IS the input delayed by (M - 1) / 2
-    samples (bit for bit: it is a copy out of the staged window), the imaginary part has the bits of the same taps run as a plain direct-form
-    FIRFilterBlock (hilberttransform.lua:107-124 computes both in one loop)"""
+@pytest.mark.parametrize("M", [65, 129, 33])
+def test_hilbert_single_launch_properties_at_size(M):
+    """HilbertTransformBlock in one launch (65 / 129 taps: kernels_firwin.h hilbert_win_kernel, the zero taps skipped; other counts: kernels_fir.h HILB
+    epilogue), 2^22 samples in ragged chunks: the real part IS the input delayed by (M - 1) / 2 samples (bit for bit: it is a copy out of the staged
+    window), the imaginary part has the bits of the same taps run as a plain direct-form FIRFilterBlock - skipping a zero tap adds +-0 to a finite
+    sum (hilberttransform.lua:107-124 computes both in one loop)"""
     from luaradio_amd import types
-    n, M = 1 << 22, 65
+    n = 1 << 22
     rng = np.random.default_rng(31)
     x = rng.uniform(-1, 1, n).astype(np.float32)
     hb = lr.HilbertTransformBlock(M)
@@ -174,3 +176,84 @@ def test_rational_resampler_kept_phases_kernel_at_size(L, D):
     assert np.array_equal(got, want)
     # linearity (exact for a power-of-two scale)
     assert np.array_equal(resampler().process(x * np.float32(0.5)), (want * np.float32(0.5)).astype(np.complex64))
+
+
+# ---- element-wise blocks on 16-byte accesses (round 3): the vector kernels against the one-sample kernels they replaced -----------------------------
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 1023, 1024, 1025, 300003])
+def test_elementwise_vector_kernels_equal_the_scalar_ones(n):
+    """Every *_vec_kernel of kernels_elem.h (16-byte accesses, tail on a spare thread of the same launch) gives the bits of the one-sample kernel: the
+    library picks the vector form when the device pointers are 16-byte aligned, so the same block is run on an aligned and on a 4-byte-offset copy of
+    the same data.  The golden-vector tests pin the values; this pins the two code paths to each other for ragged lengths."""
+    import torch
+    from luaradio_amd import _lib, types
+    L = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(n)
+    pool = torch.rand(4 * n + 64, device="cuda", generator=g) * 2 - 1
+
+    def views(nfloats, off):
+        buf = torch.empty(nfloats + 16, device="cuda")
+        v = buf[off:off + nfloats]
+        v.copy_(pool[:nfloats])
+        return buf, v
+
+    def mk(cls, args, t):
+        b = cls(*args)
+        b.rate = 2.0
+        b.differentiate([t] if not isinstance(t, list) else t)
+        b.initialize()
+        return b
+
+    c, f = types.ComplexFloat32, types.Float32
+    cases = [(lr.ComplexMagnitudeBlock, [], c, 2, 1, 1), (lr.ComplexPhaseBlock, [], c, 2, 1, 1), (lr.ComplexToRealBlock, [], c, 2, 1, 1),
+             (lr.ComplexToImagBlock, [], c, 2, 1, 1), (lr.ComplexConjugateBlock, [], c, 2, 2, 1), (lr.RealToComplexBlock, [], f, 1, 2, 1),
+             (lr.AbsoluteValueBlock, [], f, 1, 1, 1), (lr.AddConstantBlock, [0.25], f, 1, 1, 1), (lr.AddConstantBlock, [complex(0.25, -1.5)], c, 2, 2, 1),
+             (lr.UpsamplerBlock, [3], c, 2, 2, 3), (lr.UpsamplerBlock, [5], f, 1, 1, 5), (lr.DelayBlock, [4], c, 2, 2, 1), (lr.DelayBlock, [3], f, 1, 1, 1),
+             (lr.MultiplyConstantBlock, [complex(0.5, 2.0)], c, 2, 2, 1)]
+    for cls, args, t, fin, fout, up in cases:
+        outs = []
+        for off in (4, 1):            # 16-byte aligned, 4-byte offset
+            blk = mk(cls, args, t)
+            _, xv = views(n * fin, off)
+            ybuf = torch.zeros(n * up * fout + 16, device="cuda")
+            yv = ybuf[off:off + n * up * fout]
+            got = blk.process_device(xv.data_ptr(), n, yv.data_ptr(), n * up)
+            assert got == n * up
+            # a second chunk through the same block (Delay carries state; the others must not care)
+            got = blk.process_device(xv.data_ptr(), n, yv.data_ptr(), n * up)
+            torch.cuda.synchronize()
+            outs.append(yv.cpu().numpy().copy())
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), (cls.__name__, args, n)
+    # two-input FloatToComplex
+    outs = []
+    for off in (4, 1):
+        blk = mk(lr.FloatToComplexBlock, [], [f, f])
+        _, av = views(n, off)
+        bbuf = torch.empty(n + 16, device="cuda")
+        bv = bbuf[off:off + n]
+        bv.copy_(pool[n:2 * n])
+        ybuf = torch.zeros(2 * n + 16, device="cuda")
+        yv = ybuf[off:off + 2 * n]
+        assert _lib.check(L.lrhip_stage_execute2_device(blk.stage_handle(), av.data_ptr(), bv.data_ptr(), n, yv.data_ptr(), n), "f2c") == n
+        torch.cuda.synchronize()
+        outs.append(yv.cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0][0::2], pool[:n].cpu().numpy()) and np.array_equal(outs[0][1::2], pool[n:2 * n].cpu().numpy())
+    # IQ file records: vector kernel (aligned) against the one-scalar kernel (1-byte offset), every format class
+    raw = (torch.rand(16 * n + 64, device="cuda", generator=g) * 256).to(torch.uint8)
+    for fmt, nbytes in (("u8", 1), ("s8", 1), ("u16le", 2), ("s16be", 2), ("u32le", 4), ("s32be", 4), ("f32le", 4), ("f32be", 4), ("f64le", 8)):
+        outs = []
+        for off in (16, 1):
+            q = L.lrhip_format_convert_create(fmt.encode(), 1)
+            assert q
+            rbuf = torch.empty(2 * n * nbytes + 64, dtype=torch.uint8, device="cuda")
+            rv = rbuf[off:off + 2 * n * nbytes]
+            rv.copy_(raw[:2 * n * nbytes])
+            if fmt.startswith("f"):          # keep the float formats finite: small integers in every 4 / 8-byte word
+                rv.copy_((raw[:2 * n * nbytes] & 0x3f))
+            ybuf = torch.zeros(2 * n + 16, device="cuda")
+            yv = ybuf[4:4 + 2 * n]
+            assert _lib.check(L.lrhip_stage_execute_device(q, rv.data_ptr(), n, yv.data_ptr(), n), fmt) == n
+            torch.cuda.synchronize()
+            outs.append(yv.cpu().numpy().copy())
+            L.lrhip_stage_destroy(q)
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), (fmt, n)
