@@ -105,6 +105,30 @@ static_assert(RX_XF >= RX_AUDIO, "the audio output row lives in the RF window ar
 // discriminator sample b of the batch (-135 .. 5119: negative = the history in front of it) -> its float in the padded audio window
 __device__ __forceinline__ int rx_pos(int b) { return FirMfmaGeom<1, RX_D>::phys(b + RX_TH); }
 
+// U8 (round 3): the RF input is the raw record stream of an RTL-SDR style IQ file - unsigned 8-bit (I, Q) pairs, 2 bytes per sample instead of 8 - and
+// IQFileSource's conversion (radio/blocks/sources/iqfile.lua:99-113, format_utils.lua:82: (raw - 127.5) / 127.5, evaluated in double, stored as
+// Float32) happens on the way into LDS.  x = raw - 127.5 is exact in Float32, and fma(x, RH, x * RL) with RH + RL = 1 / 127.5 to 48 bits gives the
+// bits of the double-precision expression for all 256 byte values (checked by tests/test_gpu_rx.py against the file-format kernel's table).
+__device__ __forceinline__ cf rx_u8_sample(unsigned i8, unsigned q8)
+{
+    constexpr float RH = (float)(1.0 / 127.5), RL = (float)(1.0 / 127.5 - (double)RH);
+    const cf x = cf{(float)i8, (float)q8} - cf{127.5f, 127.5f};
+    return __builtin_elementwise_fma(x, cf{RH, RH}, x * cf{RL, RL});
+}
+// stream = [127 ComplexFloat32 history samples | chunk], the chunk as ComplexFloat32 or as u8 records
+template <bool U8>
+__device__ __forceinline__ cf rx_stream_at(const float *__restrict__ hist, const float *__restrict__ x, long p, int M, long n)
+{
+    if (p < 0) return cf{0.f, 0.f};
+    if (p < M - 1) return cf{hist[2 * p], hist[2 * p + 1]};
+    const long xi = p - (M - 1);
+    if (xi >= n) return cf{0.f, 0.f};
+    if (!U8) return cf{x[2 * xi], x[2 * xi + 1]};
+    const uint8_t *b = reinterpret_cast<const uint8_t *>(x) + 2 * xi;
+    return rx_u8_sample(b[0], b[1]);
+}
+
+template <bool U8>
 __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(const RxParams pr)
 {
     constexpr int NT = 256, D = RX_D, S = 2, M = RX_M;
@@ -121,7 +145,11 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
 
     // raw tuner history for the next chunk (the other ping-pong buffer)
     if (pr.hist_out && blockIdx.x == 0)
-        for (int i = tid; i < (M - 1) * S; i += NT) pr.hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
+        for (int i = tid; i < M - 1; i += NT) {
+            const cf v = rx_stream_at<U8>(hist, x, n + i, M, n);
+            pr.hist_out[2 * i] = v.x;
+            pr.hist_out[2 * i + 1] = v.y;
+        }
     for (int i = tid; i < RX_TLEN; i += NT) {
         const float v = pr.taps_pad[i];
         ldsT[i] = v;
@@ -166,11 +194,21 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
             for (int j = 0; j < 2; j++) rel_w[u][j] = cmul(pt, cf{__shfl(pu.x, 2 * u + j), __shfl(pu.y, 2 * u + j)});
     }
 
-    float4 pre[UX];
+    float4 pre[U8 ? 1 : UX];
+    unsigned pre8[U8 ? UX : 1];                                      // u8 records: the same two samples per lane and load are 4 bytes
     bool have = false;
     auto prefetch = [&](long tt) {
         have = interior(tt);
-        if (have && (pr.dbg & 8)) {                                   // ablation: no HBM reads
+        if (U8) {
+            if (have) {
+                const unsigned *src = reinterpret_cast<const unsigned *>(reinterpret_cast<const uint8_t *>(x) + 2 * xlo_of(tt));
+#pragma unroll
+                for (int u = 0; u < UX; u++) {
+                    const int idx = tid + NT * u;
+                    pre8[u] = src[idx < NF4 ? idx : NF4 - 1];
+                }
+            }
+        } else if (have && (pr.dbg & 8)) {                            // ablation: no HBM reads
 #pragma unroll
             for (int u = 0; u < UX; u++) pre[u] = make_float4(0.5f, 0.25f, -0.5f, 0.125f);
         } else if (have) {
@@ -194,8 +232,27 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
 #pragma unroll
             for (int u = 0; u < UX; u++) {
                 const int i4 = tid + u * NT;
-                const cf a = cmul(cf{pre[u].x, pre[u].y}, rel_w[u][0]), b = cmul(cf{pre[u].z, pre[u].w}, rel_w[u][1]);
+                cf s0, s1;
+                if (U8) {
+                    const unsigned w = pre8[u];
+                    s0 = rx_u8_sample(w & 0xffu, (w >> 8) & 0xffu);
+                    s1 = rx_u8_sample((w >> 16) & 0xffu, w >> 24);
+                } else {
+                    s0 = cf{pre[U8 ? 0 : u].x, pre[U8 ? 0 : u].y};
+                    s1 = cf{pre[U8 ? 0 : u].z, pre[U8 ? 0 : u].w};
+                }
+                const cf a = cmul(s0, rel_w[u][0]), b = cmul(s1, rel_w[u][1]);
                 if (i4 < NF4) lds_put4<S, D>(ldsX, i4, make_float4(a.x, a.y, b.x, b.y));
+            }
+        } else if (U8) {
+            // stage_edge<S, D, true, true, NT> on the record stream
+            using GE = FirMfmaGeom<S, D>;
+            const long base = pr.first_a + tile_k0 * D - pr.e;
+            for (int r = tid; r < RX_SPAN; r += NT) {
+                const cf o = cmul(rx_stream_at<true>(hist, x, base + r, M, n), rel_window_phasor<NT>(pr.rot_step_fx, r));
+                const int pa = GE::phys(S * r);
+                ldsX[pa] = o.x;
+                ldsX[pa + 1] = o.y;
             }
         } else {
             stage_edge<S, D, true, true, NT>(ldsX, hist, x, pr.first_a + tile_k0 * D - pr.e, RX_SPAN, M, n, pr.rot_step_fx, pr.rot_count0);

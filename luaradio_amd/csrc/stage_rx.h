@@ -8,9 +8,14 @@ struct RxStage : lrhip_stage {
     std::unique_ptr<FirStage> A, B;       // state lives in the two stages, in their own formats: both forms can alternate chunk by chunk
     DeviceBuf mid;                        // two-launch form: the discriminator stream between them
     DeviceBuf d_ptab4;
-    int blocks_per_cu = 0;
+    int blocks_per_cu = 0, blocks_per_cu8 = 0;
+    // round 3: an IQFileSource format stage for unsigned 8-bit records directly in front of the receiver is folded into it (lrhip_chain_create): the single
+    // launch reads the 2-byte records and converts them on the way into LDS (kernels_rx.h, U8); the stage itself (not owned) serves the fall-back form
+    bool in_u8 = false;
+    lrhip_stage *fmt = nullptr;
+    DeviceBuf converted;
     bool single_launch = true;
-    int last_form = 0;                    // diagnostics: 1 = single launch, 2 = two launches (last run)
+    int last_form = 0;                    // diagnostics: 1 = single launch, 2 = two launches, 3 = single launch on u8 records (last run)
 
     const char *kind() const override { return "fm-receiver"; }
     unsigned long max_output(unsigned long n) const override { return B->max_output(A->max_output(n)); }
@@ -43,7 +48,7 @@ struct RxStage : lrhip_stage {
 
     int prepare()
     {
-        in_size = A->in_size;
+        in_size = in_u8 ? 2 : A->in_size;
         out_size = B->out_size;
         const double q = (double)B->iir_na1 + (double)B->iir_na1_lo;
         std::vector<float> pt(64);
@@ -66,24 +71,44 @@ struct RxStage : lrhip_stage {
     long run(const void *in_dev, unsigned long n_in, void *out_dev, unsigned long cap) override
     {
         static const bool env_off = getenv("LRHIP_NO_SINGLE_LAUNCH") != nullptr;      // A/B knob
+        static const bool no_u8 = getenv("LRHIP_RX_NO_U8") != nullptr;                // A/B knob: convert first (the file-format kernel), then the receiver
         const long n = (long)n_in;
         const long n_out_a = (unsigned long)n > A->index ? (long)((n - (long)A->index + RX_D - 1) / RX_D) : 0;
         const long n_out_b = (unsigned long)n_out_a > B->index ? (long)((n_out_a - (long)B->index + RX_D - 1) / RX_D) : 0;
-        if (!single_launch || env_off || n_out_b < 1 || ((uintptr_t)in_dev % 8) != 0) return run_two(in_dev, n_in, out_dev, cap);
+        const bool one = single_launch && !env_off && n_out_b >= 1;
+        if (in_u8 && (!one || no_u8 || ((uintptr_t)in_dev % 2) != 0)) {
+            // the forms that take ComplexFloat32: convert the records with the format stage's own kernel first
+            if (!n_in) return 0;
+            if (converted.reserve((size_t)n_in * 8 + 16)) return -1;
+            const long m = fmt->run(in_dev, n_in, converted.p, n_in);
+            if (m < 0) return m;
+            return run_cf32(converted.p, n_in, out_dev, cap, one, n_out_a, n_out_b, false);
+        }
+        return run_cf32(in_dev, n_in, out_dev, cap, one, n_out_a, n_out_b, in_u8);
+    }
+
+    long run_cf32(const void *in_dev, unsigned long n_in, void *out_dev, unsigned long cap, bool one, long n_out_a, long n_out_b, bool u8)
+    {
+        const long n = (long)n_in;
+        if (!one || (!u8 && ((uintptr_t)in_dev % 8) != 0)) return run_two(in_dev, n_in, out_dev, cap);
         if ((unsigned long)n_out_b > cap) return set_error("fm-receiver: output capacity %lu < %ld", cap, n_out_b);
         const float *x = (const float *)in_dev;
         const size_t lds_bytes = (size_t)RX_LDS_FLOATS * sizeof(float);
-        if (!blocks_per_cu) {
-            LR_HIP(hipFuncSetAttribute((const void *)rx_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        int &bpc = u8 ? blocks_per_cu8 : blocks_per_cu;
+        if (!bpc) {
+            const void *kf = u8 ? (const void *)rx_fused_kernel<true> : (const void *)rx_fused_kernel<false>;
+            LR_HIP(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             int nb = 0;
-            LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rx_fused_kernel, 256, lds_bytes));
-            blocks_per_cu = nb < 1 ? 1 : nb;
+            if (u8) LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rx_fused_kernel<true>, 256, lds_bytes));
+            else LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rx_fused_kernel<false>, 256, lds_bytes));
+            bpc = nb < 1 ? 1 : nb;
         }
         RxParams pr;
         memset(&pr, 0, sizeof(pr));
         pr.hist = (const float *)A->hist[A->cur].p; pr.x = x; pr.n = n; pr.taps_pad = (const float *)A->d_atab.p;
         pr.n_out_a = n_out_a; pr.first_a = (long)A->index;
-        const long v = (long)((uintptr_t)x / 8) + (long)A->index - (RX_M - 1);      // 16-B alignment of the staged window: slack of 0 or 1 sample
+        // alignment of the staged window (16-byte loads of ComplexFloat32 pairs, 4-byte loads of record pairs): slack of 0 or 1 sample
+        const long v = (long)((uintptr_t)x / (u8 ? 2 : 8)) + (long)A->index - (RX_M - 1);
         pr.e = (int)(((v % 2) + 2) % 2);
         pr.ntiles = (n_out_a + RX_TILE - 1) / RX_TILE;
         pr.rot_step_fx = A->rot_step; pr.rot_count0 = A->count;
@@ -97,13 +122,14 @@ struct RxStage : lrhip_stage {
         pr.b0 = B->iir_b0; pr.na1 = B->iir_na1; pr.na1_lo = B->iir_na1_lo; pr.ptab4 = (const float *)d_ptab4.p;
         pr.state_in = (const float *)B->iir_state[B->iir_cur].p; pr.state_out = (float *)B->iir_state[B->iir_cur ^ 1].p;
         // one round of workgroups: as many as fit the chip at once; a run costs one extra tile, so short chunks take fewer, longer runs
-        long wgs = (long)ctx().num_cus * blocks_per_cu;
+        long wgs = (long)ctx().num_cus * bpc;
         if (getenv("LRHIP_RX_WGS_PER_CU")) wgs = (long)ctx().num_cus * atol(getenv("LRHIP_RX_WGS_PER_CU"));      // A/B knob
         const long most = (pr.ntiles + 7) / 8;
         if (wgs < 1 || wgs > most) wgs = most;
         pr.dbg = getenv("LRHIP_RX_DBG") ? atoi(getenv("LRHIP_RX_DBG")) : 0;      // ablation bits (wrong results)
         const unsigned grid = (unsigned)wgs;
-        hipLaunchKernelGGL(rx_fused_kernel, dim3(grid), dim3(256), lds_bytes, ctx().stream, pr);
+        if (u8) hipLaunchKernelGGL(rx_fused_kernel<true>, dim3(grid), dim3(256), lds_bytes, ctx().stream, pr);
+        else hipLaunchKernelGGL(rx_fused_kernel<false>, dim3(grid), dim3(256), lds_bytes, ctx().stream, pr);
         LR_LAUNCH_CHECK();
         // what FirStage::core() does for each of the two stages
         A->hist_in_kernel = true; A->fix_ready = false;
@@ -113,7 +139,7 @@ struct RxStage : lrhip_stage {
         B->cur ^= 1; B->iir_cur ^= 1;
         B->index = B->index + (unsigned long)n_out_b * RX_D - (unsigned long)n_out_a;
         B->count += (uint64_t)n_out_a;
-        last_form = 1;
+        last_form = u8 ? 3 : 1;
         return n_out_b;
     }
 };

@@ -257,3 +257,57 @@ def test_elementwise_vector_kernels_equal_the_scalar_ones(n):
             outs.append(yv.cpu().numpy().copy())
             L.lrhip_stage_destroy(q)
         assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)), (fmt, n)
+
+
+# ---- the receiver on raw u8 IQ records (round 3: IQFileSource's format stage folded into the single launch) ---------------------------------------
+def test_u8_record_conversion_formula_is_the_reference_expression():
+    """kernels_rx.h rx_u8_sample: x = raw - 127.5 (exact), fma(x, RH, x * RL) with RH + RL = 1 / 127.5 - emulated here in double with one rounding per
+    Float32 operation - gives Float32((raw - 127.5) / 127.5 evaluated in double) (format_utils.lua:82, iqfile.lua:99-113) for every byte value"""
+    b = np.arange(256, dtype=np.float64)
+    want = ((b - 127.5) / 127.5).astype(np.float32)
+    rh = np.float32(1.0 / 127.5)
+    rl = np.float32(1.0 / 127.5 - np.float64(rh))
+    x = b - 127.5
+    t = np.float32(x * np.float64(rl))                               # x * RL, rounded to Float32
+    got = np.float32(x * np.float64(rh) + t.astype(np.float64))      # fma: one rounding (the sum is exact in double: 9 + 24 bits)
+    assert np.array_equal(got, want)
+
+
+def test_receiver_reads_u8_records_in_the_single_launch():
+    """[IQFileSource(u8) format stage, Translator, Lowpass, Downsampler, Discriminator, Lowpass, Deemphasis, Downsampler] is ONE launch on the 2-byte
+    records, and its audio has the bits of the same receiver fed the converted ComplexFloat32 samples (the conversion is the same Float32 values, the
+    arithmetic behind it the same kernel), for ragged chunks; LRHIP_CHAIN_NO_FUSION keeps the conversion launch"""
+    import importlib.util
+    import os
+    import torch
+    from luaradio_amd import _lib, types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("iqfile_wbfm_mono", os.path.join(root, "examples", "iqfile_wbfm_mono.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    raw = np.frombuffer(ex.synth_capture(1102500.0, -250e3, 1.2), np.uint8)
+    n = len(raw) // 2
+    _src, chain, _rate = ex.build_chain(bytes(16), "u8", 1102500.0, -250e3)
+    host = lr.IQFileSource(raw.tobytes(), "u8", 1102500.0)
+    host.initialize()
+    xc = host.read_all()
+    assert len(xc) == n
+    ref = lr.wbfm_mono_receiver(1102500.0, -250e3)
+    d_raw = torch.from_numpy(raw.copy()).cuda()
+    d_x = torch.from_numpy(xc.view(np.float32).copy()).cuda()
+    cap = chain.max_output(n) + 64
+    out8, outc = torch.zeros(cap, device="cuda"), torch.zeros(cap, device="cuda")
+    cuts = [0, 25, 1000000, 1000001, 1000002, 1100000, n]
+    got8, gotc = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        m8 = chain.process_device(d_raw.data_ptr() + 2 * a, b - a, out8.data_ptr(), cap)
+        if b - a > 1000:
+            assert chain.last_launches == 1
+        mc = ref.process_device(d_x.data_ptr() + 8 * a, b - a, outc.data_ptr(), cap)
+        assert m8 == mc
+        torch.cuda.synchronize()
+        got8.append(out8[:m8].cpu().numpy().copy())
+        gotc.append(outc[:mc].cpu().numpy().copy())
+    got8, gotc = np.concatenate(got8), np.concatenate(gotc)
+    assert len(got8) == (n + 24) // 25
+    assert np.array_equal(got8.view(np.uint32), gotc.view(np.uint32))

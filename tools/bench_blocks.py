@@ -133,6 +133,18 @@ def main():
     ms = timeit(lambda: rx.process_device(xc.data_ptr(), n, out.data_ptr(), cap))
     rows.append({"block": "WBFM mono chain (RF samples in)", "MS/s": round(n / ms / 1e3, 1), "alg_GB/s": round(8.16 * n / ms / 1e6, 1),
                  "frac_8TB/s": round(8.16 * n / ms / 1e6 / 8000, 4), "ms": round(ms, 4), "TFLOP/s": None, "launches": rx.chain.last_launches})
+    # the same receiver fed the raw unsigned 8-bit records of an RTL-SDR style IQ file (IQFileSource's format stage at the head of the chain): the single
+    # launch reads the records itself; LRHIP_RX_NO_U8_FOLD=1 = conversion launch + receiver
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("iqfile_wbfm_mono", os.path.join(ROOT, "examples", "iqfile_wbfm_mono.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    _src, ch8, _rate = ex.build_chain(bytes(16), "u8", 1102500.0, -250e3)
+    raw8 = (torch.rand(2 * n + 64, device="cuda") * 256).to(torch.uint8)
+    cap = ch8.max_output(n)
+    ms = timeit(lambda: ch8.process_device(raw8.data_ptr(), n, out.data_ptr(), cap))
+    rows.append({"block": "WBFM mono chain from u8 IQ records (RF samples in)", "MS/s": round(n / ms / 1e3, 1), "alg_GB/s": round(2.16 * n / ms / 1e6, 1),
+                 "frac_8TB/s": round(2.16 * n / ms / 1e6 / 8000, 4), "ms": round(ms, 4), "TFLOP/s": None, "launches": ch8.last_launches})
     # PSD: frames of 1024
     N = 1024
     frames = n // N
