@@ -182,7 +182,60 @@ def wbfm_chain_report(lr, L, torch, dev, with_cpu):
     rep["roofline_frac"] = round(8.16 * n / ms / 1e6 / HBM_PEAK_GBS, 4)
     if with_cpu:
         rep.update(verify_wbfm_chain(torch, x, y, got_n, n, (steps - 1) * n, fs, -250e3))
+    rep["from_u8_records"] = wbfm_u8_report(lr, L, torch, dev, x, n, fs, steps)
     return rep
+
+
+def wbfm_u8_report(lr, L, torch, dev, x, n, fs, steps):
+    """configs[2] says "fed from IQ file source": the same receiver behind IQFileSource's format stage for unsigned 8-bit records (RTL-SDR captures), the
+    records resident in HBM.  The single launch reads the 2-byte records itself (kernels_rx.h, U8).  Checked bit for bit against the ComplexFloat32
+    receiver (itself held to the oracle chain above) fed the same records converted by the stand-alone file-format kernel."""
+    import numpy as np
+    from luaradio_amd import _lib
+    raw = torch.clamp(torch.round(x * 0.5 * 127.5 + 127.5), 0, 255).to(torch.uint8)      # the test signal at half scale as u8 (I, Q) records
+    src = lr.IQFileSource(bytes(16), "u8", fs)
+    src.initialize()
+    blocks = [src, lr.FrequencyTranslatorBlock(-250e3), lr.LowpassFilterBlock(128, 100e3), lr.DownsamplerBlock(5), lr.FrequencyDiscriminatorBlock(1.25),
+              lr.LowpassFilterBlock(128, 15e3), lr.FMDeemphasisFilterBlock(75e-6), lr.DownsamplerBlock(5)]
+    r, t = src.get_rate(), src.get_output_type()
+    for b in blocks[1:]:
+        b.rate = r
+        b.differentiate([t])
+        b.initialize()
+        r, t = b.get_rate(), b.get_output_type()
+    chain = lr.Chain(blocks)
+    cap = chain.max_output(n)
+    y8 = torch.empty(cap + 16, dtype=torch.float32, device=dev)
+    for _ in range(3):
+        chain.process_device(raw.data_ptr(), n, y8.data_ptr(), cap)
+    torch.cuda.synchronize()
+    chain.reset()
+    tm = L.lrhip_timer_create()
+    L.lrhip_timer_start(tm)
+    got = 0
+    for _ in range(steps):
+        got = chain.process_device(raw.data_ptr(), n, y8.data_ptr(), cap)
+    L.lrhip_timer_stop(tm)
+    torch.cuda.synchronize()
+    ms = L.lrhip_timer_elapsed_ms(tm) / steps
+    L.lrhip_timer_destroy(tm)
+    launches = chain.last_launches
+    # the ComplexFloat32 receiver on the converted records, the same number of steps (state carried alike), compared on the whole last output
+    q = L.lrhip_format_convert_create(b"u8", 1)
+    xc = torch.empty(2 * n, dtype=torch.float32, device=dev)
+    _lib.check(L.lrhip_stage_execute_device(q, raw.data_ptr(), n, xc.data_ptr(), n), "format")
+    L.lrhip_stage_destroy(q)
+    ref = lr.wbfm_mono_receiver(fs, -250e3)
+    yc = torch.empty(cap + 16, dtype=torch.float32, device=dev)
+    gc = 0
+    for _ in range(steps):
+        gc = ref.process_device(xc.data_ptr(), n, yc.data_ptr(), cap)
+    torch.cuda.synchronize()
+    same = bool(got == gc and torch.equal(y8[:got].view(torch.int32), yc[:gc].view(torch.int32)))
+    return {"ms_per_step": round(ms, 4), "value": round(n / ms / 1e3, 1), "unit": "MSamples/s (RF records in)", "launches": launches,
+            "algorithmic_bytes_per_sample": 2.16, "algorithmic_GB/s": round(2.16 * n / ms / 1e6, 1),
+            "verified": same, "verify": "audio of the last of %d steps bit-equal to the ComplexFloat32 receiver fed the records converted by the file-format "
+                                        "kernel (%d audio samples)" % (steps, got)}
 
 
 def verify_wbfm_chain(torch, x, y, got_n, n, base, fs, offset, nslabs=8, slab_rf=262150, warm_rf=100000):
