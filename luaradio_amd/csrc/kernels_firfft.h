@@ -465,6 +465,9 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 // scattered store is still one full segment per instruction.  Inverse: gather-load in that layout, mirror stages,
 // natural-order store.  LDS: [4 waves x exchange | tw1 16x64 | tw2 64] float2.
 // ------------------------------------------------------------------------------------------------------------
+#ifndef LRHIP_PSD_SCALAR_STORES
+#define LRHIP_PSD_SCALAR_STORES 0      /* 1 = the round-2 stores, 4 bytes per lane (A/B) */
+#endif
 constexpr int SPEC_LDS_TW1 = 4 * FFT_EX_ELEMS;
 constexpr int SPEC_LDS_TW2 = SPEC_LDS_TW1 + 16 * 64;
 constexpr int SPEC_LDS_ELEMS = SPEC_LDS_TW2 + 64;
@@ -525,6 +528,25 @@ __global__ __launch_bounds__(256, 3) void spectrum1024_kernel(const float *__res
 #pragma unroll
             for (int j = 0; j < 4; j++) radix4<1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
             // ---- store bin k = k1 + 16*(4j + q) + 256*k3 at position (k + N/2) mod N when shifting
+            if (mode != SPEC_FWD_COMPLEX && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) && !LRHIP_PSD_SCALAR_STORES) {
+                // power spectra leave as 16-byte non-temporal stores (round 3): the 1024 values of the frame go through the wave's exchange buffer in
+                // natural order - 16 four-byte LDS writes, 4 sixteen-byte reads - instead of 16 stores of 4 bytes per lane
+                float *exf = reinterpret_cast<float *>(ex);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int k3 = 0; k3 < 4; k3++) {
+                        const int k = k1s + 16 * (4 * j + sub) + 256 * k3;
+                        const int pos = shift ? ((k + FFTN / 2) & (FFTN - 1)) : k;
+                        const cf X = v[4 * j + k3];
+                        const float p = fmaf(X.x, X.x, X.y * X.y) * out_scale;       // spectrum_utils.lua:631-638
+                        exf[pos] = mode == SPEC_FWD_PSD_LOG ? psd_db(p) : p;
+                    }
+                float4 *dst = reinterpret_cast<float4 *>(y + f * FFTN);
+#pragma unroll
+                for (int i = 0; i < 4; i++) nt_store(dst + 64 * i + lane, reinterpret_cast<const float4 *>(exf)[64 * i + lane]);
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
