@@ -311,3 +311,34 @@ def test_receiver_reads_u8_records_in_the_single_launch():
     got8, gotc = np.concatenate(got8), np.concatenate(gotc)
     assert len(got8) == (n + 24) // 25
     assert np.array_equal(got8.view(np.uint32), gotc.view(np.uint32))
+
+
+def test_u8_receiver_time_partitions_agree_with_the_single_stream():
+    """SURVEY.md 8e on the record stream: the chain that starts with IQFileSource's u8 format stage is cut into 2 and 4 time partitions (seek to the
+    aligned sample in front of a - halo, replay, keep [a, b)); like the ComplexFloat32 single-launch receiver the partitions agree with the single
+    stream to the 1e-7 of the run warm-up (tests/test_timeshard.py), the counts exactly"""
+    import importlib.util
+    import os
+    from luaradio_amd import timeshard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("iqfile_wbfm_mono", os.path.join(root, "examples", "iqfile_wbfm_mono.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    raw = np.frombuffer(ex.synth_capture(1102500.0, -250e3, 1.9), np.uint8)
+    n = len(raw) // 2
+    _src, chain, _rate = ex.build_chain(bytes(16), "u8", 1102500.0, -250e3)
+    whole = chain.process(raw)
+    assert len(whole) == (n + 24) // 25
+    h, align = chain.halo(), chain.shard_align()
+    assert 0 < h < 200000 and align == 128000
+    for parts in (2, 4):
+        got = []
+        for a, b in timeshard.bounds(n, parts, align):
+            s = timeshard.replay_start(a, h, align)
+            chain.seek(s)
+            if a > s:
+                chain.process(raw[2 * s:2 * a])
+            got.append(chain.process(raw[2 * a:2 * b]))
+        got = np.concatenate(got)
+        assert len(got) == len(whole)
+        assert float(np.max(np.abs(got - whole))) < 1e-7, parts
