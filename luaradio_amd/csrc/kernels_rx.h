@@ -105,32 +105,45 @@ static_assert(RX_XF >= RX_AUDIO, "the audio output row lives in the RF window ar
 // discriminator sample b of the batch (-135 .. 5119: negative = the history in front of it) -> its float in the padded audio window
 __device__ __forceinline__ int rx_pos(int b) { return FirMfmaGeom<1, RX_D>::phys(b + RX_TH); }
 
-// U8 (round 3): the RF input is the raw record stream of an RTL-SDR style IQ file - unsigned 8-bit (I, Q) pairs, 2 bytes per sample instead of 8 - and
-// IQFileSource's conversion (radio/blocks/sources/iqfile.lua:99-113, format_utils.lua:82: (raw - 127.5) / 127.5, evaluated in double, stored as
-// Float32) happens on the way into LDS.  x = raw - 127.5 is exact in Float32, and fma(x, RH, x * RL) with RH + RL = 1 / 127.5 to 48 bits gives the
-// bits of the double-precision expression for all 256 byte values (checked by tests/test_gpu_rx.py against the file-format kernel's table).
-__device__ __forceinline__ cf rx_u8_sample(unsigned i8, unsigned q8)
+// FMT > 0 (round 3): the RF input is the raw record stream of an IQ file - (I, Q) pairs of unsigned 8-bit (RTL-SDR), signed 8-bit (HackRF) or little-endian
+// signed 16-bit integers, 2 or 4 bytes per sample instead of 8 - and IQFileSource's conversion (radio/blocks/sources/iqfile.lua:99-113, format_utils.lua:82-88:
+// (raw - offset) / scale, evaluated in double, stored as Float32) happens on the way into LDS.  x = raw - offset is exact in Float32, and
+// fma(x, RH, x * RL) with RH + RL = 1 / scale to 48 bits gives the bits of the double-precision expression for every raw value of these formats
+// (tests/test_gpu_rx.py: emulated for all values, and the kernel against the file-format kernel).
+enum { RX_FMT_CF32 = 0, RX_FMT_U8 = 1, RX_FMT_S8 = 2, RX_FMT_S16LE = 3 };
+template <int FMT> __host__ __device__ constexpr int rx_raw_bytes() { return FMT == RX_FMT_S16LE ? 2 : 1; }      // per scalar
+template <int FMT>
+__device__ __forceinline__ cf rx_raw_sample(unsigned i_raw, unsigned q_raw)
 {
-    constexpr float RH = (float)(1.0 / 127.5), RL = (float)(1.0 / 127.5 - (double)RH);
-    const cf x = cf{(float)i8, (float)q8} - cf{127.5f, 127.5f};
+    constexpr double SC = FMT == RX_FMT_S16LE ? 32767.5 : 127.5;
+    constexpr float RH = (float)(1.0 / SC), RL = (float)(1.0 / SC - (double)RH);
+    cf x;
+    if (FMT == RX_FMT_U8) x = cf{(float)i_raw, (float)q_raw} - cf{127.5f, 127.5f};
+    else if (FMT == RX_FMT_S8) x = cf{(float)(int)(int8_t)i_raw, (float)(int)(int8_t)q_raw};
+    else x = cf{(float)(int)(int16_t)i_raw, (float)(int)(int16_t)q_raw};
     return __builtin_elementwise_fma(x, cf{RH, RH}, x * cf{RL, RL});
 }
-// stream = [127 ComplexFloat32 history samples | chunk], the chunk as ComplexFloat32 or as u8 records
-template <bool U8>
+// stream = [127 ComplexFloat32 history samples | chunk], the chunk as ComplexFloat32 or as raw records
+template <int FMT>
 __device__ __forceinline__ cf rx_stream_at(const float *__restrict__ hist, const float *__restrict__ x, long p, int M, long n)
 {
     if (p < 0) return cf{0.f, 0.f};
     if (p < M - 1) return cf{hist[2 * p], hist[2 * p + 1]};
     const long xi = p - (M - 1);
     if (xi >= n) return cf{0.f, 0.f};
-    if (!U8) return cf{x[2 * xi], x[2 * xi + 1]};
+    if (FMT == RX_FMT_CF32) return cf{x[2 * xi], x[2 * xi + 1]};
+    if (FMT == RX_FMT_S16LE) {
+        const uint16_t *b = reinterpret_cast<const uint16_t *>(x) + 2 * xi;
+        return rx_raw_sample<FMT>(b[0], b[1]);
+    }
     const uint8_t *b = reinterpret_cast<const uint8_t *>(x) + 2 * xi;
-    return rx_u8_sample(b[0], b[1]);
+    return rx_raw_sample<FMT>(b[0], b[1]);
 }
 
-template <bool U8>
+template <int FMT>
 __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(const RxParams pr)
 {
+    constexpr bool U8 = FMT != RX_FMT_CF32;      // raw records (the name of the first format folded in)
     constexpr int NT = 256, D = RX_D, S = 2, M = RX_M;
     constexpr int NF4 = RX_SPAN * S / 4;
     constexpr int UX = (NF4 + NT - 1) / NT;
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
     // raw tuner history for the next chunk (the other ping-pong buffer)
     if (pr.hist_out && blockIdx.x == 0)
         for (int i = tid; i < M - 1; i += NT) {
-            const cf v = rx_stream_at<U8>(hist, x, n + i, M, n);
+            const cf v = rx_stream_at<FMT>(hist, x, n + i, M, n);
             pr.hist_out[2 * i] = v.x;
             pr.hist_out[2 * i + 1] = v.y;
         }
@@ -195,17 +208,18 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
     }
 
     float4 pre[U8 ? 1 : UX];
-    unsigned pre8[U8 ? UX : 1];                                      // u8 records: the same two samples per lane and load are 4 bytes
+    uint2 pre8[U8 ? UX : 1];                                         // raw records: the same two samples per lane and load are 4 (.x) or 8 bytes
     bool have = false;
     auto prefetch = [&](long tt) {
         have = interior(tt);
         if (U8) {
             if (have) {
-                const unsigned *src = reinterpret_cast<const unsigned *>(reinterpret_cast<const uint8_t *>(x) + 2 * xlo_of(tt));
+                const uint8_t *src0 = reinterpret_cast<const uint8_t *>(x) + 2 * rx_raw_bytes<FMT>() * xlo_of(tt);
 #pragma unroll
                 for (int u = 0; u < UX; u++) {
-                    const int idx = tid + NT * u;
-                    pre8[u] = src[idx < NF4 ? idx : NF4 - 1];
+                    const int idx = tid + NT * u, ic = idx < NF4 ? idx : NF4 - 1;
+                    if (FMT == RX_FMT_S16LE) pre8[u] = reinterpret_cast<const uint2 *>(src0)[ic];
+                    else pre8[u].x = reinterpret_cast<const unsigned *>(src0)[ic];
                 }
             }
         } else if (have && (pr.dbg & 8)) {                            // ablation: no HBM reads
@@ -234,9 +248,14 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
                 const int i4 = tid + u * NT;
                 cf s0, s1;
                 if (U8) {
-                    const unsigned w = pre8[u];
-                    s0 = rx_u8_sample(w & 0xffu, (w >> 8) & 0xffu);
-                    s1 = rx_u8_sample((w >> 16) & 0xffu, w >> 24);
+                    if (FMT == RX_FMT_S16LE) {
+                        s0 = rx_raw_sample<FMT>(pre8[u].x & 0xffffu, pre8[u].x >> 16);
+                        s1 = rx_raw_sample<FMT>(pre8[u].y & 0xffffu, pre8[u].y >> 16);
+                    } else {
+                        const unsigned w = pre8[u].x;
+                        s0 = rx_raw_sample<FMT>(w & 0xffu, (w >> 8) & 0xffu);
+                        s1 = rx_raw_sample<FMT>((w >> 16) & 0xffu, w >> 24);
+                    }
                 } else {
                     s0 = cf{pre[U8 ? 0 : u].x, pre[U8 ? 0 : u].y};
                     s1 = cf{pre[U8 ? 0 : u].z, pre[U8 ? 0 : u].w};
@@ -249,7 +268,7 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
             using GE = FirMfmaGeom<S, D>;
             const long base = pr.first_a + tile_k0 * D - pr.e;
             for (int r = tid; r < RX_SPAN; r += NT) {
-                const cf o = cmul(rx_stream_at<true>(hist, x, base + r, M, n), rel_window_phasor<NT>(pr.rot_step_fx, r));
+                const cf o = cmul(rx_stream_at<FMT>(hist, x, base + r, M, n), rel_window_phasor<NT>(pr.rot_step_fx, r));
                 const int pa = GE::phys(S * r);
                 ldsX[pa] = o.x;
                 ldsX[pa + 1] = o.y;

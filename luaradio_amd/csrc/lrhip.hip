@@ -818,12 +818,13 @@ lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, u
         c->ops[k] = {nullptr, false};                        // ownership has moved: the unique_ptrs delete them
         c->ops.erase(c->ops.begin() + (long)k + 1);
         rx->single_launch = !(flags & LRHIP_CHAIN_NO_SINGLE_LAUNCH);
-        // IQFileSource's unsigned 8-bit records directly in front of it: the receiver reads them itself (2 bytes per RF sample instead of a 10-byte
+        // IQFileSource's u8 / s8 / s16le records directly in front of it: the receiver reads them itself (2 or 4 bytes per RF sample instead of a
         // conversion pass and an 8-byte read); every other format keeps its conversion launch
         static const bool no_u8_fold = getenv("LRHIP_RX_NO_U8_FOLD") != nullptr;      // A/B knob
         FormatStage *fs = (k > 0 && !no_u8_fold && !(flags & LRHIP_CHAIN_NO_FUSION)) ? dynamic_cast<FormatStage *>(c->ops[k - 1].stage) : nullptr;
-        const bool fold = fs && !fs->pack && fs->scalars == 2 && kFormats[fs->fmt].cls == 0 && !c->ops[k - 1].owned;
-        if (fold) { rx->in_u8 = true; rx->fmt = fs; }
+        const int fcls = fs ? kFormats[fs->fmt].cls : -1;
+        const bool fold = fs && !fs->pack && fs->scalars == 2 && !kFormats[fs->fmt].swap && (fcls == 0 || fcls == 1 || fcls == 3) && !c->ops[k - 1].owned;
+        if (fold) { rx->in_u8 = true; rx->fmt = fs; rx->in_fmt = fcls == 0 ? RX_FMT_U8 : fcls == 1 ? RX_FMT_S8 : RX_FMT_S16LE; }
         if (rx->prepare()) { c->ops.erase(c->ops.begin() + (long)k); return nullptr; }
         c->ops[k] = {rx.release(), true};
         if (fold) { c->ops.erase(c->ops.begin() + (long)k - 1); k--; }

@@ -9,6 +9,7 @@ struct RxStage : lrhip_stage {
     DeviceBuf mid;                        // two-launch form: the discriminator stream between them
     DeviceBuf d_ptab4;
     int blocks_per_cu = 0, blocks_per_cu8 = 0;
+    int in_fmt = RX_FMT_CF32;             // RX_FMT_* of the folded format stage
     // round 3: an IQFileSource format stage for unsigned 8-bit records directly in front of the receiver is folded into it (lrhip_chain_create): the single
     // launch reads the 2-byte records and converts them on the way into LDS (kernels_rx.h, U8); the stage itself (not owned) serves the fall-back form
     bool in_u8 = false;
@@ -48,7 +49,7 @@ struct RxStage : lrhip_stage {
 
     int prepare()
     {
-        in_size = in_u8 ? 2 : A->in_size;
+        in_size = in_u8 ? (in_fmt == RX_FMT_S16LE ? 4 : 2) : A->in_size;
         out_size = B->out_size;
         const double q = (double)B->iir_na1 + (double)B->iir_na1_lo;
         std::vector<float> pt(64);
@@ -76,7 +77,7 @@ struct RxStage : lrhip_stage {
         const long n_out_a = (unsigned long)n > A->index ? (long)((n - (long)A->index + RX_D - 1) / RX_D) : 0;
         const long n_out_b = (unsigned long)n_out_a > B->index ? (long)((n_out_a - (long)B->index + RX_D - 1) / RX_D) : 0;
         const bool one = single_launch && !env_off && n_out_b >= 1;
-        if (in_u8 && (!one || no_u8 || ((uintptr_t)in_dev % 2) != 0)) {
+        if (in_u8 && (!one || no_u8 || ((uintptr_t)in_dev % (in_fmt == RX_FMT_S16LE ? 4 : 2)) != 0)) {
             // the forms that take ComplexFloat32: convert the records with the format stage's own kernel first
             if (!n_in) return 0;
             if (converted.reserve((size_t)n_in * 8 + 16)) return -1;
@@ -95,20 +96,31 @@ struct RxStage : lrhip_stage {
         const float *x = (const float *)in_dev;
         const size_t lds_bytes = (size_t)RX_LDS_FLOATS * sizeof(float);
         int &bpc = u8 ? blocks_per_cu8 : blocks_per_cu;
+        const int fmt_k = u8 ? in_fmt : RX_FMT_CF32;
+        auto with_kernel = [&](auto fn) -> int {
+            switch (fmt_k) {
+                case RX_FMT_U8: return fn(rx_fused_kernel<RX_FMT_U8>);
+                case RX_FMT_S8: return fn(rx_fused_kernel<RX_FMT_S8>);
+                case RX_FMT_S16LE: return fn(rx_fused_kernel<RX_FMT_S16LE>);
+                default: return fn(rx_fused_kernel<RX_FMT_CF32>);
+            }
+        };
         if (!bpc) {
-            const void *kf = u8 ? (const void *)rx_fused_kernel<true> : (const void *)rx_fused_kernel<false>;
-            LR_HIP(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            int nb = 0;
-            if (u8) LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rx_fused_kernel<true>, 256, lds_bytes));
-            else LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rx_fused_kernel<false>, 256, lds_bytes));
-            bpc = nb < 1 ? 1 : nb;
+            const int rc0 = with_kernel([&](auto kern) -> int {
+                LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                int nb = 0;
+                LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds_bytes));
+                bpc = nb < 1 ? 1 : nb;
+                return 0;
+            });
+            if (rc0) return rc0;
         }
         RxParams pr;
         memset(&pr, 0, sizeof(pr));
         pr.hist = (const float *)A->hist[A->cur].p; pr.x = x; pr.n = n; pr.taps_pad = (const float *)A->d_atab.p;
         pr.n_out_a = n_out_a; pr.first_a = (long)A->index;
         // alignment of the staged window (16-byte loads of ComplexFloat32 pairs, 4-byte loads of record pairs): slack of 0 or 1 sample
-        const long v = (long)((uintptr_t)x / (u8 ? 2 : 8)) + (long)A->index - (RX_M - 1);
+        const long v = (long)((uintptr_t)x / (u8 ? (in_fmt == RX_FMT_S16LE ? 4 : 2) : 8)) + (long)A->index - (RX_M - 1);
         pr.e = (int)(((v % 2) + 2) % 2);
         pr.ntiles = (n_out_a + RX_TILE - 1) / RX_TILE;
         pr.rot_step_fx = A->rot_step; pr.rot_count0 = A->count;
@@ -128,8 +140,7 @@ struct RxStage : lrhip_stage {
         if (wgs < 1 || wgs > most) wgs = most;
         pr.dbg = getenv("LRHIP_RX_DBG") ? atoi(getenv("LRHIP_RX_DBG")) : 0;      // ablation bits (wrong results)
         const unsigned grid = (unsigned)wgs;
-        if (u8) hipLaunchKernelGGL(rx_fused_kernel<true>, dim3(grid), dim3(256), lds_bytes, ctx().stream, pr);
-        else hipLaunchKernelGGL(rx_fused_kernel<false>, dim3(grid), dim3(256), lds_bytes, ctx().stream, pr);
+        (void)with_kernel([&](auto kern) -> int { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, pr); return 0; });
         LR_LAUNCH_CHECK();
         // what FirStage::core() does for each of the two stages
         A->hist_in_kernel = true; A->fix_ready = false;

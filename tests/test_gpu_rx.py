@@ -260,6 +260,20 @@ def test_elementwise_vector_kernels_equal_the_scalar_ones(n):
 
 
 # ---- the receiver on raw u8 IQ records (round 3: IQFileSource's format stage folded into the single launch) ---------------------------------------
+def test_s8_s16_record_conversion_formula_is_the_reference_expression():
+    """the same for the other two folded formats: s8 (offset 0, scale 127.5) and s16 (offset 0, scale 32767.5), every raw value"""
+    for vals, scale in ((np.arange(-128, 128), 127.5), (np.arange(-32768, 32768), 32767.5)):
+        x = vals.astype(np.float64)
+        want = (x / scale).astype(np.float32)
+        rh = np.float32(1.0 / scale)
+        rl = np.float32(1.0 / scale - np.float64(rh))
+        t = np.float32(x * np.float64(rl))
+        # fma(x, RH, t) with one rounding: exact rational arithmetic on the three Float32 values
+        from fractions import Fraction
+        got = np.array([np.float32(Fraction(float(xv)) * Fraction(float(rh)) + Fraction(float(tv))) for xv, tv in zip(x, t)], np.float32)
+        assert np.array_equal(got, want), scale
+
+
 def test_u8_record_conversion_formula_is_the_reference_expression():
     """kernels_rx.h rx_u8_sample: x = raw - 127.5 (exact), fma(x, RH, x * RL) with RH + RL = 1 / 127.5 - emulated here in double with one rounding per
     Float32 operation - gives Float32((raw - 127.5) / 127.5 evaluated in double) (format_utils.lua:82, iqfile.lua:99-113) for every byte value"""
@@ -273,10 +287,11 @@ def test_u8_record_conversion_formula_is_the_reference_expression():
     assert np.array_equal(got, want)
 
 
-def test_receiver_reads_u8_records_in_the_single_launch():
-    """[IQFileSource(u8) format stage, Translator, Lowpass, Downsampler, Discriminator, Lowpass, Deemphasis, Downsampler] is ONE launch on the 2-byte
-    records, and its audio has the bits of the same receiver fed the converted ComplexFloat32 samples (the conversion is the same Float32 values, the
-    arithmetic behind it the same kernel), for ragged chunks; LRHIP_CHAIN_NO_FUSION keeps the conversion launch"""
+@pytest.mark.parametrize("fmt", ["u8", "s8", "s16le", "s16be"])
+def test_receiver_reads_u8_records_in_the_single_launch(fmt):
+    """[IQFileSource(u8 / s8 / s16le) format stage, Translator, Lowpass, Downsampler, Discriminator, Lowpass, Deemphasis, Downsampler] is ONE launch on the
+    2- or 4-byte records, and its audio has the bits of the same receiver fed the converted ComplexFloat32 samples (the conversion is the same Float32
+    values, the arithmetic behind it the same kernel), for ragged chunks; a big-endian format keeps its conversion launch (two launches, same bits)"""
     import importlib.util
     import os
     import torch
@@ -287,8 +302,15 @@ def test_receiver_reads_u8_records_in_the_single_launch():
     spec.loader.exec_module(ex)
     raw = np.frombuffer(ex.synth_capture(1102500.0, -250e3, 1.2), np.uint8)
     n = len(raw) // 2
-    _src, chain, _rate = ex.build_chain(bytes(16), "u8", 1102500.0, -250e3)
-    host = lr.IQFileSource(raw.tobytes(), "u8", 1102500.0)
+    rb = {"u8": 2, "s8": 2, "s16le": 4, "s16be": 4}[fmt]                  # bytes per record
+    if fmt == "s8":
+        raw = (raw.astype(np.int16) - 128).astype(np.int8).view(np.uint8)
+    elif fmt.startswith("s16"):
+        rng16 = np.random.default_rng(3)
+        v = ((raw.astype(np.int32) - 128) * 256 + rng16.integers(0, 256, len(raw))).astype(np.int16)      # every low byte occurs
+        raw = v.astype("<i2" if fmt == "s16le" else ">i2").view(np.uint8)
+    _src, chain, _rate = ex.build_chain(bytes(16), fmt, 1102500.0, -250e3)
+    host = lr.IQFileSource(raw.tobytes(), fmt, 1102500.0)
     host.initialize()
     xc = host.read_all()
     assert len(xc) == n
@@ -300,9 +322,9 @@ def test_receiver_reads_u8_records_in_the_single_launch():
     cuts = [0, 25, 1000000, 1000001, 1000002, 1100000, n]
     got8, gotc = [], []
     for a, b in zip(cuts[:-1], cuts[1:]):
-        m8 = chain.process_device(d_raw.data_ptr() + 2 * a, b - a, out8.data_ptr(), cap)
+        m8 = chain.process_device(d_raw.data_ptr() + rb * a, b - a, out8.data_ptr(), cap)
         if b - a > 1000:
-            assert chain.last_launches == 1
+            assert chain.last_launches == (2 if fmt == "s16be" else 1)
         mc = ref.process_device(d_x.data_ptr() + 8 * a, b - a, outc.data_ptr(), cap)
         assert m8 == mc
         torch.cuda.synchronize()
@@ -310,7 +332,12 @@ def test_receiver_reads_u8_records_in_the_single_launch():
         gotc.append(outc[:mc].cpu().numpy().copy())
     got8, gotc = np.concatenate(got8), np.concatenate(gotc)
     assert len(got8) == (n + 24) // 25
-    assert np.array_equal(got8.view(np.uint32), gotc.view(np.uint32))
+    if fmt == "s16be":
+        # (not folded: the receiver then reads the chain's own 16-byte aligned edge buffer where the stand-alone receiver reads the caller's pointer, and the
+        # window-relative rotator staging rounds with the alignment slack of the window, DESIGN.md 4.3a: same values to Float32 rounding)
+        assert float(np.max(np.abs(got8 - gotc))) < 1e-6
+    else:
+        assert np.array_equal(got8.view(np.uint32), gotc.view(np.uint32))
 
 
 def test_u8_receiver_time_partitions_agree_with_the_single_stream():

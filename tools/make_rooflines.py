@@ -38,7 +38,7 @@ def main():
         ("FIR 128 real taps cf32, overlap-save (headline, configs[1])", bench, ("fir_fft_kernel<2, 0>",), 16, n28, 125),
         ("FIR 128 real taps cf32, direct form (bit-exact)", bench, ("fir_mfma_persistent_kernel<2, 1, 8",), 16, n28, 512),
         ("streaming yardstick: MultiplyConstant cf32 on the headline buffers", bench, ("multiply_constant_vec4",), 16, n28, 0),
-        ("WBFM mono receiver, ONE launch (configs[2])", bench, ("rx_fused_kernel<false>",), 8.16, n26, 167),
+        ("WBFM mono receiver, ONE launch (configs[2])", bench, ("rx_fused_kernel<0>",), 8.16, n26, 167),
         ("PolyphaseChannelizer K=64, 1024 taps (configs[4])", bench, ("channelizer_kernel",), 16, n24, 8192),
         ("MultiplyConstant cf32 (2^26)", blocks, ("multiply_constant_vec4",), 16, n26, 0),
         ("FIR 128 real taps cf32, overlap-save (2^26)", blocks, ("fir_fft_kernel<2, 0>",), 16, n26, 125),
@@ -71,9 +71,9 @@ def main():
         ("IQ records f32be -> cf32", blocks, ("format_convert_vec_kernel<unsigned int, float, true",), 16, n26, 0),
         ("FIR 1276 real taps cf32, overlap-save, one 4096-point launch", blocks, ("fir_fft4k_kernel<1280",), 16, n26, 180),
         ("FIR 768 real taps cf32, overlap-save, one 4096-point launch", blocks, ("fir_fft4k_kernel<768",), 16, n26, 160),
-        ("WBFM mono receiver from u8 IQ records, ONE launch (bench_blocks: noise input)", blocks, ("rx_fused_kernel<true>",), 2.16, n26, 167),
+        ("WBFM mono receiver from u8 IQ records, ONE launch (bench_blocks: noise input)", blocks, ("rx_fused_kernel<1>",), 2.16, n26, 167),
         ("PSD N=1024 hamming log fftshift", blocks, ("spectrum1024_kernel",), 12, n26, 58),
-        ("WBFM mono receiver (bench_blocks: U(-1,1) noise input)", blocks, ("rx_fused_kernel<false>",), 8.16, n26, 167),
+        ("WBFM mono receiver (bench_blocks: U(-1,1) noise input)", blocks, ("rx_fused_kernel<0>",), 8.16, n26, 167),
     ]
     rows = []
     for name, src, subs, bps, n, flops in table:
