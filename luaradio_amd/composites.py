@@ -42,6 +42,10 @@ class Chain:
         except Exception:
             pass
 
+    def get_output_type(self):
+        """the last block's output type (what a block answers: a Chain can stand where a block stands, e.g. as a fan-out branch)"""
+        return self.out_type
+
     def max_output(self, n_in):
         return _lib.load().lrhip_chain_max_output(self._chain, n_in)
 

@@ -39,9 +39,13 @@ class DeviceBranch:
         self.out_floats = 2 if block.get_output_type().size == 8 else 1
         self.out = torch.empty(self.cap * self.out_floats + 16, dtype=torch.float32, device="cuda")
         self.produced = 0
+        # a chain that starts with IQFileSource's format stage takes the raw file records: the slab then carries bytes (2 per sample for u8 / s8
+        # instead of 8 - what crosses the xGMI link to every receiving GPU is a quarter, the link bound 76 GS/s instead of 19)
+        self.in_record = int(getattr(block, "in_record", 0) or 0)
 
     def process(self, slab):
-        """slab: 1-D float32 CUDA tensor of interleaved ComplexFloat32 samples.  The kernels are enqueued on torch's CURRENT stream
+        """slab: 1-D float32 CUDA tensor of interleaved ComplexFloat32 samples (or, for a chain with a file-format head, any 1-D CUDA tensor
+        holding whole raw records).  The kernels are enqueued on torch's CURRENT stream
         (lrhip_set_stream orders it behind whatever the library had queued before), so they follow the broadcast that filled the slab
         and precede any torch consumer of the returned view."""
         import torch
@@ -49,7 +53,7 @@ class DeviceBranch:
         if not slab.is_cuda:
             raise RuntimeError("DeviceBranch needs a CUDA tensor: there is no CPU path in luaradio_amd")
         _lib.adopt_torch_stream()
-        n = slab.numel() // 2
+        n = slab.numel() * slab.element_size() // self.in_record if self.in_record else slab.numel() // 2
         got = self.block.process_device(slab.data_ptr(), n, self.out.data_ptr(), self.cap)
         self.produced += got
         return self.out[:got * self.out_floats]

@@ -369,3 +369,26 @@ def test_u8_receiver_time_partitions_agree_with_the_single_stream():
         got = np.concatenate(got)
         assert len(got) == len(whole)
         assert float(np.max(np.abs(got - whole))) < 1e-7, parts
+
+
+def test_fanout_branch_on_raw_records():
+    """configs[3] fed from an IQ file: the slab that is broadcast holds the u8 records (a quarter of the bytes per sample on every xGMI link) and each
+    branch is a chain that starts with the format stage; DeviceBranch counts records, the branch output equals the chain run on its own"""
+    import importlib.util
+    import os
+    import torch
+    from luaradio_amd import fanout
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("iqfile_wbfm_mono", os.path.join(root, "examples", "iqfile_wbfm_mono.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    raw = np.frombuffer(ex.synth_capture(1102500.0, -250e3, 0.5), np.uint8)
+    n = len(raw) // 2
+    _src, chain, _rate = ex.build_chain(bytes(16), "u8", 1102500.0, -250e3)
+    want = chain.process(raw)
+    chain.reset()
+    fo = fanout.FanOut(None, 0, 1, 1, {0: fanout.DeviceBranch(chain, n)}, src=0)
+    slab = torch.from_numpy(raw.copy()).cuda()
+    got = fo.push(slab)[0]
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want)
