@@ -351,7 +351,23 @@ struct FirStage : lrhip_stage {
         hist_in_kernel = true;
         return 0;
     }
-    int fft4k_blocks2 = 0;
+    int fft4k_blocks2 = 0, fft4kw_blocks = 0;
+    template <int VV>
+    int launch_fft4kw(const float *x, long n, float *y, long n_out)
+    {
+        constexpr long Lf = F4K_N - VV;
+        const size_t lds_bytes = (size_t)F4W_LDS_ELEMS * sizeof(float2);
+        auto kern = fir_fft4kw_kernel<VV>;
+        if (!fft4kw_blocks && prepare_kernel(kern, lds_bytes, &fft4kw_blocks, 256)) return -1;
+        static const int xcd_map = getenv("LRHIP_F4K_XCD_MAP") ? atoi(getenv("LRHIP_F4K_XCD_MAP")) : 1;
+        const long nblocks = (n_out + Lf - 1) / Lf, nslots = (nblocks + 3) / 4, slots = (long)ctx().num_cus * fft4kw_blocks;
+        const unsigned grid = (unsigned)(nslots < slots ? nslots : slots);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (const float2 *)d_fft4k_tables.p, y, M, n,
+                           n_out, nblocks, M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : (float *)nullptr, xcd_map);
+        LR_LAUNCH_CHECK();
+        hist_in_kernel = true;
+        return 0;
+    }
     template <int VV>
     int launch_fft4k(const float *x, long n, float *y, long n_out)
     {
@@ -363,6 +379,19 @@ struct FirStage : lrhip_stage {
     int launch_fft(const float *x, long n, float *y, long n_out)
     {
         static const bool no_4k = getenv("LRHIP_FFT_NO_4K") != nullptr;      // A/B knob: partitions of the 1024-point kernel (round 2)
+        // one wave per 4096-point block (fir_fft4kw_kernel) once the launch has at least two rounds of four blocks per CU - measured 0-5 % (1 276 taps) and
+        // 8 % (768 taps) ahead of the workgroup-per-block form on 2^26 samples; smaller launches keep the form that spreads over more CUs.
+        // LRHIP_F4K_WAVE=1 / 0 forces one or the other (A/B)
+        static const int wave_knob = getenv("LRHIP_F4K_WAVE") ? atoi(getenv("LRHIP_F4K_WAVE")) : -1;
+        const long nblocks4k = fft4k_V ? (n_out + (F4K_N - fft4k_V) - 1) / (F4K_N - fft4k_V) : 0;
+        const bool wave4k = wave_knob >= 0 ? wave_knob != 0 : nblocks4k >= 8L * ctx().num_cus;
+        if (fft4k_V && !no_4k && !pre_disc && !post_disc && wave4k) {
+            switch (fft4k_V) {
+                case 768: return launch_fft4kw<768>(x, n, y, n_out);
+                case 1024: return launch_fft4kw<1024>(x, n, y, n_out);
+                default: return launch_fft4kw<1280>(x, n, y, n_out);
+            }
+        }
         if (fft4k_V && !no_4k && !pre_disc && !post_disc) {
             switch (fft4k_V) {
                 case 768: return launch_fft4k<768>(x, n, y, n_out);
