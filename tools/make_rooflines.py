@@ -69,8 +69,8 @@ def main():
         ("IQ records u8 -> cf32", blocks, ("format_convert_vec_kernel<unsigned char, unsigned char",), 10, n26, 0),
         ("IQ records s16le -> cf32", blocks, ("format_convert_vec_kernel<unsigned short, short",), 12, n26, 0),
         ("IQ records f32be -> cf32", blocks, ("format_convert_vec_kernel<unsigned int, float, true",), 16, n26, 0),
-        ("FIR 1276 real taps cf32, overlap-save, one 4096-point launch", blocks, ("fir_fft4k_kernel<1280",), 16, n26, 180),
-        ("FIR 768 real taps cf32, overlap-save, one 4096-point launch", blocks, ("fir_fft4k_kernel<768",), 16, n26, 160),
+        ("FIR 1276 real taps cf32, overlap-save, one 4096-point launch (a wave per block)", blocks, ("fir_fft4kw_kernel<1280",), 16, n26, 180),
+        ("FIR 768 real taps cf32, overlap-save, one 4096-point launch (a wave per block)", blocks, ("fir_fft4kw_kernel<768",), 16, n26, 160),
         ("WBFM mono receiver from u8 IQ records, ONE launch (bench_blocks: noise input)", blocks, ("rx_fused_kernel<1>",), 2.16, n26, 167),
         ("PSD N=1024 hamming log fftshift", blocks, ("spectrum1024_kernel",), 12, n26, 58),
         ("WBFM mono receiver (bench_blocks: U(-1,1) noise input)", blocks, ("rx_fused_kernel<0>",), 8.16, n26, 167),
