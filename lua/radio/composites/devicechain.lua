@@ -38,8 +38,9 @@ DeviceChainBlock.ring_depth = 3
 -- 1.1 MS/s sees ~22 000-sample batches every 20 ms instead of waiting a second for 2^20 samples, and an audio-rate chain does not
 -- sit on minutes of samples; file and benchmark sources deliver faster than real time and still fill whole batches.  0 = off.
 DeviceChainBlock.max_latency = 0.02
--- the chain's numerical contract (lrhip_chain_create_ex flags): false = fused kernels with the three stated roundings of
--- include/lrhip.h; true = lrhip.CHAIN_EXACT, what the member blocks compute one by one; or a flag number.
+-- the chain's numerical contract (lrhip_chain_create_ex flags): false = fused kernels with the stated roundings of
+-- include/lrhip.h (window-relative rotator staging, the polyphase audio tail, consecutive overlap-save filters merged into one
+-- filter, the single-launch FM receiver); true = lrhip.CHAIN_EXACT, what the member blocks compute one by one; or a flag number.
 -- Set on the class before top:run(), or per chain on the object collapse() returns.
 DeviceChainBlock.exact = false
 
