@@ -273,6 +273,7 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #endif
             if (xlo >= 0 && xlo + FFTN <= n) {
                 const cf *src = reinterpret_cast<const cf *>(x) + xlo + lane;
+                [[maybe_unused]] const cf *srcu = reinterpret_cast<const cf *>(x) + xlo;
                 if (wave_major && kept) {
                     v[0] = keep0; v[1] = keep1;
 #pragma unroll
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #if LRHIP_FFT_NT >= 2
                     for (int i = 0; i < 16; i++) v[i] = __builtin_nontemporal_load(src + 64 * i);
 #else
-                    for (int i = 0; i < 16; i++) v[i] = src[64 * i];
+                    for (int i = 0; i < 16; i++) v[i] = (srcu + 64 * i)[(unsigned)lane];      // wave-uniform row pointer + the lane's 32-bit index
 #endif
                 }
                 if (wave_major) { keep0 = v[14]; keep1 = v[15]; kept = true; }
@@ -324,12 +325,13 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
         if (S == 2) {
             const long o0 = fb * L - V;
             cf *dst = reinterpret_cast<cf *>(y) + o0 + lane;
+            [[maybe_unused]] cf *dstu = reinterpret_cast<cf *>(y) + o0;
             if (o0 + FFTN <= n_out) {
 #pragma unroll
                 for (int i = 0; i < 16; i++)
                     if (64 * i >= V) {                                                                // wave-uniform: whole rows only
 #if LRHIP_FFT_NT >= 1
-                        if (!accumulate) __builtin_nontemporal_store(v[i], dst + 64 * i);
+                        if (!accumulate) __builtin_nontemporal_store(v[i], (dstu + 64 * i) + (unsigned)lane);
                         else dst[64 * i] = dst[64 * i] + v[i];
 #else
                         dst[64 * i] = accumulate ? dst[64 * i] + v[i] : v[i];
