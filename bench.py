@@ -427,11 +427,62 @@ def fanout_report(lr, L, torch, dev):
     ms = L.lrhip_timer_elapsed_ms(tm) / steps
     L.lrhip_timer_destroy(tm)
     ver = verify_tuner_branch(torch, tun, lambda: fo.push(x)[0], x, n, fs, fanout.branch_offsets(8)[0], 100e3, 5)
-    return {"workload": "configs[3] at N = 1: one fan-out branch Tuner(-350e3, 100e3, 5) on a 2^26-sample slab (no broadcast with one GPU)",
+    rec = fanout_records_report(lr, L, torch, dev, x, n, fs, fanout.branch_offsets(8)[0])
+    return {"from_u8_records": rec,
+            "workload": "configs[3] at N = 1: one fan-out branch Tuner(-350e3, 100e3, 5) on a 2^26-sample slab (no broadcast with one GPU)",
             "value": round(n / ms / 1e3, 1), "unit": "MSamples/s (branch input)", "ms_per_step": round(ms, 4), **ver,
             "algorithmic_GB/s": round(9.6 * n / ms / 1e6, 1), "roofline_frac": round(9.6 * n / ms / 1e6 / HBM_PEAK_GBS, 4),
             "xgmi_link_bound_MSps": 19125.0,
             "note": "for N > 1 every receiving GPU is bounded by one xGMI link: 153 GB/s / 8 B = 19.1 GS/s of ComplexFloat32, far below this branch rate"}
+
+
+def fanout_records_report(lr, L, torch, dev, x, n, fs, offset):
+    """the same branch when the source is an IQ file: the slab that would be broadcast holds the raw u8 records (2 B per sample on every xGMI link
+    instead of 8) and the branch chain starts with IQFileSource's format stage, which lrhip_chain_create folds into the Tuner's launch.  Checked bit for bit
+    against the ComplexFloat32 Tuner (held to the oracle above) on the records converted by the file-format kernel."""
+    from luaradio_amd import _lib, fanout, types
+    raw = torch.clamp(torch.round(x * 127.5 + 127.5), 0, 255).to(torch.uint8)
+
+    def tuner(head):
+        blocks = head + [lr.FrequencyTranslatorBlock(offset), lr.LowpassFilterBlock(128, 100e3), lr.DownsamplerBlock(5)]
+        r, t = fs, types.ComplexFloat32
+        for b in blocks[len(head):]:
+            b.rate = r
+            b.differentiate([t])
+            b.initialize()
+            r, t = b.get_rate(), b.get_output_type()
+        return lr.Chain(blocks)
+
+    src = lr.IQFileSource(bytes(16), "u8", fs)
+    src.initialize()
+    chain = tuner([src])
+    br = fanout.DeviceBranch(chain, n)
+    fo = fanout.FanOut(None, 0, 1, 1, {0: br}, src=0)
+    fo.push(raw)
+    steps = 10
+    tm = L.lrhip_timer_create()
+    L.lrhip_timer_start(tm)
+    for _ in range(steps):
+        got = fo.push(raw)[0]
+    L.lrhip_timer_stop(tm)
+    torch.cuda.synchronize()
+    ms = L.lrhip_timer_elapsed_ms(tm) / steps
+    L.lrhip_timer_destroy(tm)
+    launches = chain.last_launches
+    q = L.lrhip_format_convert_create(b"u8", 1)
+    xc = torch.empty(2 * n, dtype=torch.float32, device=dev)
+    _lib.check(L.lrhip_stage_execute_device(q, raw.data_ptr(), n, xc.data_ptr(), n), "format")
+    L.lrhip_stage_destroy(q)
+    ref = fanout.DeviceBranch(tuner([]), n)
+    want = None
+    for _ in range(steps + 1):                     # the same number of pushes: the rotator phase and the filter history advance alike
+        want = ref.process(xc)
+    torch.cuda.synchronize()
+    same = bool(got.numel() == want.numel() and torch.equal(got.view(torch.int32), want.view(torch.int32)))
+    return {"ms_per_step": round(ms, 4), "value": round(n / ms / 1e3, 1), "unit": "MSamples/s (branch input records)", "launches": launches,
+            "xgmi_link_bound_MSps": 76500.0, "verified": same,
+            "verify": "branch output of the last push bit-equal to the ComplexFloat32 Tuner on the converted records (%d outputs)" % (got.numel() // 2),
+            "note": "2 B per sample on the link: 153 GB/s / 2 B = 76.5 GS/s per receiving GPU instead of 19.1"}
 
 
 def main():

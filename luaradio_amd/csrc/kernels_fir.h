@@ -57,6 +57,52 @@ __device__ __forceinline__ float stream_at(const float *__restrict__ hist, const
     return xi < n ? x[xi * S + c] : 0.0f;
 }
 
+// Raw IQ-file records as a kernel's input (round 3; FMT > 0): the input is the raw record stream of an IQ file - (I, Q) pairs of unsigned 8-bit (RTL-SDR), signed 8-bit (HackRF) or little-endian
+// signed 16-bit integers, 2 or 4 bytes per sample instead of 8 - and IQFileSource's conversion (radio/blocks/sources/iqfile.lua:99-113, format_utils.lua:82-88:
+// (raw - offset) / scale, evaluated in double, stored as Float32) happens on the way into LDS.  x = raw - offset is exact in Float32, and
+// fma(x, RH, x * RL) with RH + RL = 1 / scale to 48 bits gives the bits of the double-precision expression for every raw value of these formats
+// (tests/test_gpu_rx.py: emulated for all values, and the kernel against the file-format kernel).
+enum { RX_FMT_CF32 = 0, RX_FMT_U8 = 1, RX_FMT_S8 = 2, RX_FMT_S16LE = 3 };
+template <int FMT> __host__ __device__ constexpr int rx_raw_bytes() { return FMT == RX_FMT_S16LE ? 2 : 1; }      // per scalar
+template <int FMT>
+__device__ __forceinline__ cf rx_raw_sample(unsigned i_raw, unsigned q_raw)
+{
+    constexpr double SC = FMT == RX_FMT_S16LE ? 32767.5 : 127.5;
+    constexpr float RH = (float)(1.0 / SC), RL = (float)(1.0 / SC - (double)RH);
+    cf x;
+    if (FMT == RX_FMT_U8) x = cf{(float)i_raw, (float)q_raw} - cf{127.5f, 127.5f};
+    else if (FMT == RX_FMT_S8) x = cf{(float)(int)(int8_t)i_raw, (float)(int)(int8_t)q_raw};
+    else x = cf{(float)(int)(int16_t)i_raw, (float)(int)(int16_t)q_raw};
+    return __builtin_elementwise_fma(x, cf{RH, RH}, x * cf{RL, RL});
+}
+// two samples = one 4-byte (8-bit formats: .x) or 8-byte word of records -> (re0, im0, re1, im1)
+template <int FMT>
+__device__ __forceinline__ float4 rx_raw_pair(uint2 w)
+{
+    cf s0, s1;
+    if (FMT == RX_FMT_S16LE) {
+        s0 = rx_raw_sample<FMT>(w.x & 0xffffu, w.x >> 16);
+        s1 = rx_raw_sample<FMT>(w.y & 0xffffu, w.y >> 16);
+    } else {
+        s0 = rx_raw_sample<FMT>(w.x & 0xffu, (w.x >> 8) & 0xffu);
+        s1 = rx_raw_sample<FMT>((w.x >> 16) & 0xffu, w.x >> 24);
+    }
+    return make_float4(s0.x, s0.y, s1.x, s1.y);
+}
+// stream_at<2> on a stream whose chunk is raw records (the carried history stays ComplexFloat32)
+template <int FMT>
+__device__ __forceinline__ float stream_at_raw(const float *__restrict__ hist, const float *__restrict__ x, long p, int c, int M, long n)
+{
+    if (FMT == RX_FMT_CF32) return stream_at<2>(hist, x, p, c, M, n);
+    if (p < 0) return 0.0f;
+    if (p < M - 1) return hist[p * 2 + c];
+    const long xi = p - (M - 1);
+    if (xi >= n) return 0.0f;
+    const cf v = FMT == RX_FMT_S16LE ? rx_raw_sample<FMT>(reinterpret_cast<const uint16_t *>(x)[2 * xi], reinterpret_cast<const uint16_t *>(x)[2 * xi + 1])
+                                     : rx_raw_sample<FMT>(reinterpret_cast<const uint8_t *>(x)[2 * xi], reinterpret_cast<const uint8_t *>(x)[2 * xi + 1]);
+    return c ? v.y : v.x;
+}
+
 // ------------------------------------------------------------------------------------------------
 // history carry: hist_out[i] = s[n + i], i < M-1   (firfilter.lua:248 memmove of the last M-1 state samples)
 // ping-pong buffers, so it can run concurrently with nothing and after the filter kernel in stream order.
@@ -169,15 +215,16 @@ __device__ __forceinline__ cf rel_window_phasor(uint64_t step_fx, int k)
     return cmul(phasor_poly(step_fx * (uint64_t)(2 * (i4 % NT))), phasor_poly(step_fx * (uint64_t)(2 * NT * (i4 / NT) + (k & 1))));
 }
 
-template <int S, int D, bool ROT, bool REL = false, int NT = 256>
+template <int S, int D, bool ROT, bool REL = false, int NT = 256, int FMT = 0>
 __device__ __forceinline__ void stage_edge(float *ldsX, const float *__restrict__ hist, const float *__restrict__ x,
                                            long base, int span, int M, long n, uint64_t rot_step_fx, uint64_t rot_count0)
 {
     using G = FirMfmaGeom<S, D>;
+    static_assert(FMT == 0 || S == 2, "raw records are (I, Q) pairs");
     for (int r = threadIdx.x; r < span; r += NT) {
         long p = base + r;
-        float v0 = stream_at<S>(hist, x, p, 0, M, n);
-        float v1 = S == 2 ? stream_at<S>(hist, x, p, 1, M, n) : 0.f;
+        float v0 = FMT ? stream_at_raw<FMT>(hist, x, p, 0, M, n) : stream_at<S>(hist, x, p, 0, M, n);
+        float v1 = S == 2 ? (FMT ? stream_at_raw<FMT>(hist, x, p, 1, M, n) : stream_at<S>(hist, x, p, 1, M, n)) : 0.f;
         if (REL) {
             const cf o = cmul(cf{v0, v1}, rel_window_phasor<NT>(rot_step_fx, r));
             v0 = o.x;
@@ -722,7 +769,8 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
 // after the loop.  Edge tiles (first tile: history; last tiles: end of chunk) are staged synchronously.
 // EPI = 1 (S = 2, real taps): fused FrequencyDiscriminatorBlock BEHIND the filter (frequencydiscriminator.lua:68-88): the
 // ComplexFloat32 outputs never leave the registers, y receives arg(o[k] conj(o[k-1])) / gain as Float32 (disc_epilogue).
-template <int S, int D, int NACC, bool ROT, int KS, int EPI = 0, bool REL = false, int NW = 4>
+// FMT > 0 (round 3): x holds raw IQ-file records (u8 / s8 / s16le, RX_FMT_*) converted on the way into LDS - the plain Tuner (rotator, no discriminator) only
+template <int S, int D, int NACC, bool ROT, int KS, int EPI = 0, bool REL = false, int NW = 4, int FMT = 0>
 __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persistent_kernel(
     const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_pad, float *__restrict__ y,
     int M, long n, long n_out, long first, int e, long ntiles, int out_aligned,
@@ -735,9 +783,10 @@ __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_pe
     static_assert(NW == 4 || (NW == 1 && REL), "one-wave workgroups: relative rotator staging + discriminator epilogue only");
     constexpr int TILE_OUT = G::tile_out(NACC, NW);
     constexpr int SPAN = G::span(NACC, KS, NW);
+    static_assert(FMT == 0 || (S == 2 && ROT && !REL && EPI == 0 && NW == 4), "raw records: the plain Tuner instantiation");
     // history carry (fir_history_kernel's job, saved launch): the other ping-pong buffer, raw (unrotated) samples
     if (hist_out && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < (M - 1) * S; i += NT) hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
+        for (int i = threadIdx.x; i < (M - 1) * S; i += NT) hist_out[i] = FMT ? stream_at_raw<FMT>(hist, x, n + i / S, i % S, M, n) : stream_at<S>(hist, x, n + i / S, i % S, M, n);
     constexpr int NF4 = SPAN * S / 4;
     constexpr int UX = (NF4 + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -801,21 +850,32 @@ __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_pe
         const long tl = xj + k * xper;
         return tl < xt8 ? xbase + tl : ntiles;
     };
-    float4 pre[NPRE];
+    float4 pre[FMT ? 1 : NPRE];
+    uint2 praw[FMT ? NPRE : 1];                             // raw records: the same two samples per load are 4 (.x) or 8 bytes
     long tk = 0;
     long t = tile_of(0);
     bool have = false;
     auto prefetch = [&](long tt) {
         have = interior(tt);
-        if (have) {
+        if (have && FMT) {
+            const uint8_t *src0 = reinterpret_cast<const uint8_t *>(x) + 2 * rx_raw_bytes<FMT>() * xlo_of(tt);
+#pragma unroll
+            for (int u = 0; u < NPRE; u++) {
+                const int idx = i4_of(u), ic = idx < 0 ? 0 : idx < NF4 ? idx : NF4 - 1;
+                if (FMT == RX_FMT_S16LE) praw[FMT ? u : 0] = reinterpret_cast<const uint2 *>(src0)[ic];
+                else praw[FMT ? u : 0].x = reinterpret_cast<const unsigned *>(src0)[ic];
+            }
+        } else if (have) {
             const float4 *src = reinterpret_cast<const float4 *>(x + xlo_of(tt) * S);
 #pragma unroll
             for (int u = 0; u < NPRE; u++) {
                 int idx = i4_of(u);
-                pre[u] = src[idx < 0 ? 0 : idx < NF4 ? idx : NF4 - 1];        // clamped, unconditional: no branch between loads
+                pre[FMT ? 0 : u] = src[idx < 0 ? 0 : idx < NF4 ? idx : NF4 - 1];        // clamped, unconditional: no branch between loads
             }
         }
     };
+    // staged value u of the thread as ComplexFloat32 pairs
+    auto pre_of = [&](int u) -> float4 { if constexpr (FMT != 0) return rx_raw_pair<FMT>(praw[u]); else return pre[u]; };
     prefetch(t);
     for (; t < ntiles; t = tile_of(++tk)) {
         const long tile_k0 = t * (long)TILE_OUT;
@@ -836,13 +896,13 @@ __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_pe
 #pragma unroll
                         for (int j = 0; j < 4; j++)
                             if (i40 + j < NF4)
-                                lds_put4<S, D>(ldsX, i40 + j, rotate_pair(pre[4 * v + j], rot_step_fx, rot_count0 + (uint64_t)(xlo + 2 * (long)(i40 + j)), rot_t));
+                                lds_put4<S, D>(ldsX, i40 + j, rotate_pair(pre_of(4 * v + j), rot_step_fx, rot_count0 + (uint64_t)(xlo + 2 * (long)(i40 + j)), rot_t));
                     } else if (i40 + 3 >= 0 && i40 < NF4) {
                         const cf p = phasor_poly(rot_step_fx * (rot_count0 + (uint64_t)(xlo + 2 * (long)i40)));
-                        if (i40 >= 0) lds_put4<S, D>(ldsX, i40, rotate_in_block<0>(pre[4 * v], p, rot_t));
-                        if (i40 + 1 >= 0 && i40 + 1 < NF4) lds_put4<S, D>(ldsX, i40 + 1, rotate_in_block<1>(pre[4 * v + 1], p, rot_t));
-                        if (i40 + 2 >= 0 && i40 + 2 < NF4) lds_put4<S, D>(ldsX, i40 + 2, rotate_in_block<2>(pre[4 * v + 2], p, rot_t));
-                        if (i40 + 3 < NF4) lds_put4<S, D>(ldsX, i40 + 3, rotate_in_block<3>(pre[4 * v + 3], p, rot_t));
+                        if (i40 >= 0) lds_put4<S, D>(ldsX, i40, rotate_in_block<0>(pre_of(4 * v), p, rot_t));
+                        if (i40 + 1 >= 0 && i40 + 1 < NF4) lds_put4<S, D>(ldsX, i40 + 1, rotate_in_block<1>(pre_of(4 * v + 1), p, rot_t));
+                        if (i40 + 2 >= 0 && i40 + 2 < NF4) lds_put4<S, D>(ldsX, i40 + 2, rotate_in_block<2>(pre_of(4 * v + 2), p, rot_t));
+                        if (i40 + 3 < NF4) lds_put4<S, D>(ldsX, i40 + 3, rotate_in_block<3>(pre_of(4 * v + 3), p, rot_t));
                     }
                 }
             } else {
@@ -853,7 +913,7 @@ __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_pe
                 }
             }
         } else {
-            stage_edge<S, D, ROT, REL, NT>(ldsX, hist, x, first + tile_k0 * D - e, SPAN, M, n, rot_step_fx, rot_count0);
+            stage_edge<S, D, ROT, REL, NT, FMT>(ldsX, hist, x, first + tile_k0 * D - e, SPAN, M, n, rot_step_fx, rot_count0);
         }
         __syncthreads();
         // prefetch the next tile while this one is multiplied

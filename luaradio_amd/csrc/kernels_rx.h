@@ -105,24 +105,6 @@ static_assert(RX_XF >= RX_AUDIO, "the audio output row lives in the RF window ar
 // discriminator sample b of the batch (-135 .. 5119: negative = the history in front of it) -> its float in the padded audio window
 __device__ __forceinline__ int rx_pos(int b) { return FirMfmaGeom<1, RX_D>::phys(b + RX_TH); }
 
-// FMT > 0 (round 3): the RF input is the raw record stream of an IQ file - (I, Q) pairs of unsigned 8-bit (RTL-SDR), signed 8-bit (HackRF) or little-endian
-// signed 16-bit integers, 2 or 4 bytes per sample instead of 8 - and IQFileSource's conversion (radio/blocks/sources/iqfile.lua:99-113, format_utils.lua:82-88:
-// (raw - offset) / scale, evaluated in double, stored as Float32) happens on the way into LDS.  x = raw - offset is exact in Float32, and
-// fma(x, RH, x * RL) with RH + RL = 1 / scale to 48 bits gives the bits of the double-precision expression for every raw value of these formats
-// (tests/test_gpu_rx.py: emulated for all values, and the kernel against the file-format kernel).
-enum { RX_FMT_CF32 = 0, RX_FMT_U8 = 1, RX_FMT_S8 = 2, RX_FMT_S16LE = 3 };
-template <int FMT> __host__ __device__ constexpr int rx_raw_bytes() { return FMT == RX_FMT_S16LE ? 2 : 1; }      // per scalar
-template <int FMT>
-__device__ __forceinline__ cf rx_raw_sample(unsigned i_raw, unsigned q_raw)
-{
-    constexpr double SC = FMT == RX_FMT_S16LE ? 32767.5 : 127.5;
-    constexpr float RH = (float)(1.0 / SC), RL = (float)(1.0 / SC - (double)RH);
-    cf x;
-    if (FMT == RX_FMT_U8) x = cf{(float)i_raw, (float)q_raw} - cf{127.5f, 127.5f};
-    else if (FMT == RX_FMT_S8) x = cf{(float)(int)(int8_t)i_raw, (float)(int)(int8_t)q_raw};
-    else x = cf{(float)(int)(int16_t)i_raw, (float)(int)(int16_t)q_raw};
-    return __builtin_elementwise_fma(x, cf{RH, RH}, x * cf{RL, RL});
-}
 // stream = [127 ComplexFloat32 history samples | chunk], the chunk as ComplexFloat32 or as raw records
 template <int FMT>
 __device__ __forceinline__ cf rx_stream_at(const float *__restrict__ hist, const float *__restrict__ x, long p, int M, long n)

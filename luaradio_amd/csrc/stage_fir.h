@@ -29,6 +29,12 @@ struct FirStage : lrhip_stage {
     // overlap-save ARITHMETIC (fused 1024-point FFT kernel); independent of the emission framing
     static constexpr int FFT_PART = 512;   // taps per overlap-save partition (V = 512, L = 512 of the 1024-point block)
     bool fft_arith = false;
+    // round 3: IQFileSource's format stage (u8 / s8 / s16le records) in front of a fused Tuner is folded into it: the persistent kernel converts the records
+    // on the way into LDS (kernels_fir.h FMT); the stage itself (not owned) converts for every other launch form
+    int in_fmt = 0;                       // RX_FMT_*
+    lrhip_stage *fmt_stage = nullptr;
+    DeviceBuf converted;
+    bool raw_now = false;                 // set around core() while x holds raw records
     DeviceBuf d_fft_tables;
     DeviceBuf d_fft4k_tables;             // 513 .. 1281 taps on a ComplexFloat32 stream: the 4096-point kernel (kernels_firfft4k.h)
     int fft4k_V = 0, fft4k_blocks = 0;    // its overlap (768 / 1024 / 1280; 0 = not built)
@@ -152,12 +158,13 @@ struct FirStage : lrhip_stage {
             // tuner + discriminator with window-relative phasors: one-wave workgroups (every wave stages its own window, no barriers)
             if (rot && post_disc && rel_rot && rel_nw1) return launch_mfma_ks<SS, DD, NACC, KS, 1>(x, n, y, n_out);
         }
-        // alignment slack so that the tile's first staged sample is 16-B aligned in global memory
-        if (((uintptr_t)x % (4 * SS)) != 0) {
+        // alignment slack so that the tile's first staged sample is 16-B aligned in global memory (raw records: the 4- / 8-byte word of two samples)
+        const unsigned esz = raw_now ? (in_fmt == RX_FMT_S16LE ? 4u : 2u) : (unsigned)(4 * SS);
+        if (((uintptr_t)x % esz) != 0) {
             if (rot || post_disc) return set_error("fir: fused rotator / discriminator needs a sample-aligned input pointer");
             return launch_direct(x, n, y, n_out);
         }
-        long sample_addr = (long)((uintptr_t)x / (4 * SS));
+        long sample_addr = (long)((uintptr_t)x / esz);
         int q = 4 / SS;
         long v = sample_addr + (long)index - (M - 1);
         int e = (int)(((v % q) + q) % q);
@@ -211,6 +218,18 @@ struct FirStage : lrhip_stage {
                 }
             }
             if (post_disc) return set_error("internal: discriminator epilogue without a persistent kernel variant");
+            if constexpr (SS == 2 && DD == 5 && KS == 51 && NW == 4) {
+                if (raw_now) {
+                    if (!rot) return set_error("internal: raw records without the rotator instantiation");
+                    rc2 = in_fmt == RX_FMT_U8 ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 0, false, 4, RX_FMT_U8>)
+                        : in_fmt == RX_FMT_S8 ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 0, false, 4, RX_FMT_S8>)
+                                              : launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 0, false, 4, RX_FMT_S16LE>);
+                    if (rc2) return rc2;
+                    LR_LAUNCH_CHECK();
+                    return 0;
+                }
+            }
+            if (raw_now) return set_error("internal: raw records reached a kernel without a record instantiation");
             if constexpr (SS == 2) rc2 = rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS>);
             else rc2 = rot ? set_error("rotator fusion needs complex input") : launch(fir_mfma_persistent_kernel<1, DD, NACC, false, KS>);
             if (rc2) return rc2;
@@ -806,10 +825,32 @@ struct FirStage : lrhip_stage {
         return n_out;
     }
 
+    // does this chunk reach the persistent Tuner kernel, the one with a record instantiation?  (core()'s dispatch, the D = 5 / 128-tap shape)
+    bool raw_path_ok(const void *in_dev, unsigned long n_in) const
+    {
+        if (!in_fmt || !rot || post_disc || pre_disc || use_fft || decfft || fft_arith || taps_complex || S != 2 || D != 5 || ksteps != 51) return false;
+        if (win_cplx_ok() || win_pair_ok()) return false;
+        if (n_in <= index) return false;                                  // no output: nothing launches, the history kernel would read x
+        return ((uintptr_t)in_dev % (in_fmt == RX_FMT_S16LE ? 4u : 2u)) == 0;
+    }
     long run(const void *in_dev, unsigned long n_in, void *out_dev, unsigned long cap) override
     {
         const float *x = (const float *)in_dev;
         float *y = (float *)out_dev;
+        if (in_fmt) {
+            static const bool no_raw = getenv("LRHIP_TUNER_NO_RAW") != nullptr;      // A/B knob: conversion launch first
+            if (!n_in) return 0;
+            if (!no_raw && raw_path_ok(in_dev, n_in)) {
+                raw_now = true;
+                const long rc = core(x, (long)n_in, y, cap);
+                raw_now = false;
+                return rc;
+            }
+            if (converted.reserve((size_t)n_in * 8 + 16)) return -1;
+            const long m = fmt_stage->run(in_dev, n_in, converted.p, n_in);
+            if (m < 0) return m;
+            x = (const float *)converted.p;
+        }
         if (!use_fft) return core(x, (long)n_in, y, cap);
         // overlap-save framing: emit only whole L-blocks, keep the tail pending (firfilter.lua:451-485)
         long total = fill + (long)n_in, emit = (total / L) * L;

@@ -427,3 +427,54 @@ def test_fir_fft4k_kernel_at_size_against_the_f64_oracle():
         out = y[2 * o:2 * (o + ln)].cpu().numpy().view(np.complex64)
         assert len(ref) == ln
         assert float(np.max(np.abs(out - ref))) <= 1e-6 * max(1.0, float(np.max(np.abs(ref)))), o
+
+
+@pytest.mark.parametrize("fmt", ["u8", "s8", "s16le", "u16le"])
+def test_tuner_reads_raw_records_in_its_launch(fmt):
+    """[IQFileSource(u8 / s8 / s16le) format stage, FrequencyTranslator, Lowpass(128), Downsampler(5)] - a fan-out branch fed from an IQ file - is ONE
+    launch of the persistent Toeplitz kernel on the records, bit-equal to the same Tuner on the converted ComplexFloat32 samples (block-of-8 rotator
+    staging: the stand-alone translator's phasors whatever the alignment), ragged chunks incl. one that emits nothing; another format (u16le) keeps its
+    conversion launch and the same bits"""
+    import torch
+    from luaradio_amd import types
+    rng = np.random.default_rng(11)
+    n = 700003
+    rb = {"u8": 2, "s8": 2, "s16le": 4, "u16le": 4}[fmt]
+    raw = rng.integers(0, 256, n * rb, dtype=np.uint8)
+    fs = 1102500.0
+
+    def tuner(head):
+        blocks = head + [lr.FrequencyTranslatorBlock(-350e3), lr.LowpassFilterBlock(128, 100e3), lr.DownsamplerBlock(5)]
+        r, t = fs, types.ComplexFloat32
+        for b in blocks[len(head):]:
+            b.rate = r
+            b.differentiate([t])
+            b.initialize()
+            r, t = b.get_rate(), b.get_output_type()
+        return lr.Chain(blocks)
+
+    src = lr.IQFileSource(bytes(16), fmt, fs)
+    src.initialize()
+    chain = tuner([src])
+    host = lr.IQFileSource(raw.tobytes(), fmt, fs)
+    host.initialize()
+    xc = host.read_all()
+    ref = tuner([])
+    d_raw = torch.from_numpy(raw.copy()).cuda()
+    d_x = torch.from_numpy(xc.view(np.float32).copy()).cuda()
+    cap = chain.max_output(n) + 64
+    o1, o2 = torch.zeros(2 * cap, device="cuda"), torch.zeros(2 * cap, device="cuda")
+    cuts = [0, 3, 4, 100000, 100001, 400002, n]
+    g1, g2 = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        m1 = chain.process_device(d_raw.data_ptr() + rb * a, b - a, o1.data_ptr(), cap)
+        if b - a > 1000:
+            assert chain.last_launches == (2 if fmt == "u16le" else 1)
+        m2 = ref.process_device(d_x.data_ptr() + 8 * a, b - a, o2.data_ptr(), cap)
+        assert m1 == m2
+        torch.cuda.synchronize()
+        g1.append(o1[:2 * m1].cpu().numpy().copy())
+        g2.append(o2[:2 * m2].cpu().numpy().copy())
+    g1, g2 = np.concatenate(g1), np.concatenate(g2)
+    assert len(g1) == 2 * ((n + 4) // 5)
+    assert np.array_equal(g1.view(np.uint32), g2.view(np.uint32))

@@ -133,6 +133,26 @@ def main():
     ms = timeit(lambda: rx.process_device(xc.data_ptr(), n, out.data_ptr(), cap))
     rows.append({"block": "WBFM mono chain (RF samples in)", "MS/s": round(n / ms / 1e3, 1), "alg_GB/s": round(8.16 * n / ms / 1e6, 1),
                  "frac_8TB/s": round(8.16 * n / ms / 1e6 / 8000, 4), "ms": round(ms, 4), "TFLOP/s": None, "launches": rx.chain.last_launches})
+    # a fan-out branch fed from an IQ file: [format stage (u8 records), Tuner(-350e3, 100e3, 5)] - one launch of the persistent Toeplitz kernel on the records
+    def tuner_chain(head):
+        blocks = head + [lr.FrequencyTranslatorBlock(-350e3), lr.LowpassFilterBlock(128, 100e3), lr.DownsamplerBlock(5)]
+        r, t = 1102500.0, types.ComplexFloat32
+        for b in blocks[len(head):]:
+            b.rate = r
+            b.differentiate([t])
+            b.initialize()
+            r, t = b.get_rate(), b.get_output_type()
+        return lr.Chain(blocks)
+
+    if True:
+        src8 = lr.IQFileSource(bytes(16), "u8", 1102500.0)
+        src8.initialize()
+        tch = tuner_chain([src8])
+        raw8t = (torch.rand(2 * n + 64, device="cuda") * 256).to(torch.uint8)
+        capt = tch.max_output(n)
+        ms = timeit(lambda: tch.process_device(raw8t.data_ptr(), n, out.data_ptr(), capt))
+        rows.append({"block": "Tuner from u8 IQ records (fan-out branch fed from a file)", "MS/s": round(n / ms / 1e3, 1), "alg_GB/s": round(3.6 * n / ms / 1e6, 1),
+                     "frac_8TB/s": round(3.6 * n / ms / 1e6 / 8000, 4), "ms": round(ms, 4), "TFLOP/s": None, "launches": tch.last_launches})
     # the same receiver fed the raw unsigned 8-bit records of an RTL-SDR style IQ file (IQFileSource's format stage at the head of the chain): the single
     # launch reads the records itself; LRHIP_RX_NO_U8_FOLD=1 = conversion launch + receiver
     import importlib.util
