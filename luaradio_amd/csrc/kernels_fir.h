@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(
 // after the loop.  Edge tiles (first tile: history; last tiles: end of chunk) are staged synchronously.
 // EPI = 1 (S = 2, real taps): fused FrequencyDiscriminatorBlock BEHIND the filter (frequencydiscriminator.lua:68-88): the
 // ComplexFloat32 outputs never leave the registers, y receives arg(o[k] conj(o[k-1])) / gain as Float32 (disc_epilogue).
-// FMT > 0 (round 3): x holds raw IQ-file records (u8 / s8 / s16le, RX_FMT_*) converted on the way into LDS - the plain Tuner (rotator, no discriminator) only
+// FMT > 0 (round 3): x holds raw IQ-file records (u8 / s8 / s16le, RX_FMT_*) converted on the way into LDS - the plain Tuner / Decimator (no discriminator) only
 template <int S, int D, int NACC, bool ROT, int KS, int EPI = 0, bool REL = false, int NW = 4, int FMT = 0>
 __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persistent_kernel(
     const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_pad, float *__restrict__ y,
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_pe
     static_assert(NW == 4 || (NW == 1 && REL), "one-wave workgroups: relative rotator staging + discriminator epilogue only");
     constexpr int TILE_OUT = G::tile_out(NACC, NW);
     constexpr int SPAN = G::span(NACC, KS, NW);
-    static_assert(FMT == 0 || (S == 2 && ROT && !REL && EPI == 0 && NW == 4), "raw records: the plain Tuner instantiation");
+    static_assert(FMT == 0 || (S == 2 && !REL && EPI == 0 && NW == 4), "raw records: the plain Tuner / Decimator instantiations");
     // history carry (fir_history_kernel's job, saved launch): the other ping-pong buffer, raw (unrotated) samples
     if (hist_out && blockIdx.x == 0)
         for (int i = threadIdx.x; i < (M - 1) * S; i += NT) hist_out[i] = FMT ? stream_at_raw<FMT>(hist, x, n + i / S, i % S, M, n) : stream_at<S>(hist, x, n + i / S, i % S, M, n);
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_pe
 #pragma unroll
                 for (int u = 0; u < UX; u++) {
                     const int i4 = tid + u * NT;
-                    if (i4 < NF4) lds_put4<S, D>(ldsX, i4, pre[u]);
+                    if (i4 < NF4) lds_put4<S, D>(ldsX, i4, pre_of(u));
                 }
             }
         } else {

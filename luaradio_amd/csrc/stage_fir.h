@@ -220,10 +220,14 @@ struct FirStage : lrhip_stage {
             if (post_disc) return set_error("internal: discriminator epilogue without a persistent kernel variant");
             if constexpr (SS == 2 && DD == 5 && KS == 51 && NW == 4) {
                 if (raw_now) {
-                    if (!rot) return set_error("internal: raw records without the rotator instantiation");
-                    rc2 = in_fmt == RX_FMT_U8 ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 0, false, 4, RX_FMT_U8>)
-                        : in_fmt == RX_FMT_S8 ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 0, false, 4, RX_FMT_S8>)
-                                              : launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 0, false, 4, RX_FMT_S16LE>);
+                    if (rot)
+                        rc2 = in_fmt == RX_FMT_U8 ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 0, false, 4, RX_FMT_U8>)
+                            : in_fmt == RX_FMT_S8 ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 0, false, 4, RX_FMT_S8>)
+                                                  : launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 0, false, 4, RX_FMT_S16LE>);
+                    else
+                        rc2 = in_fmt == RX_FMT_U8 ? launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS, 0, false, 4, RX_FMT_U8>)
+                            : in_fmt == RX_FMT_S8 ? launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS, 0, false, 4, RX_FMT_S8>)
+                                                  : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS, 0, false, 4, RX_FMT_S16LE>);
                     if (rc2) return rc2;
                     LR_LAUNCH_CHECK();
                     return 0;
@@ -828,7 +832,7 @@ struct FirStage : lrhip_stage {
     // does this chunk reach the persistent Tuner kernel, the one with a record instantiation?  (core()'s dispatch, the D = 5 / 128-tap shape)
     bool raw_path_ok(const void *in_dev, unsigned long n_in) const
     {
-        if (!in_fmt || !rot || post_disc || pre_disc || use_fft || decfft || fft_arith || taps_complex || S != 2 || D != 5 || ksteps != 51) return false;
+        if (!in_fmt || post_disc || pre_disc || use_fft || decfft || fft_arith || taps_complex || S != 2 || D != 5 || ksteps != 51) return false;
         if (win_cplx_ok() || win_pair_ok()) return false;
         if (n_in <= index) return false;                                  // no output: nothing launches, the history kernel would read x
         return ((uintptr_t)in_dev % (in_fmt == RX_FMT_S16LE ? 4u : 2u)) == 0;

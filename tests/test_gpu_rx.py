@@ -429,8 +429,9 @@ def test_fir_fft4k_kernel_at_size_against_the_f64_oracle():
         assert float(np.max(np.abs(out - ref))) <= 1e-6 * max(1.0, float(np.max(np.abs(ref)))), o
 
 
+@pytest.mark.parametrize("rotate", [True, False])
 @pytest.mark.parametrize("fmt", ["u8", "s8", "s16le", "u16le"])
-def test_tuner_reads_raw_records_in_its_launch(fmt):
+def test_tuner_reads_raw_records_in_its_launch(fmt, rotate):
     """[IQFileSource(u8 / s8 / s16le) format stage, FrequencyTranslator, Lowpass(128), Downsampler(5)] - a fan-out branch fed from an IQ file - is ONE
     launch of the persistent Toeplitz kernel on the records, bit-equal to the same Tuner on the converted ComplexFloat32 samples (block-of-8 rotator
     staging: the stand-alone translator's phasors whatever the alignment), ragged chunks incl. one that emits nothing; another format (u16le) keeps its
@@ -444,7 +445,7 @@ def test_tuner_reads_raw_records_in_its_launch(fmt):
     fs = 1102500.0
 
     def tuner(head):
-        blocks = head + [lr.FrequencyTranslatorBlock(-350e3), lr.LowpassFilterBlock(128, 100e3), lr.DownsamplerBlock(5)]
+        blocks = head + ([lr.FrequencyTranslatorBlock(-350e3)] if rotate else []) + [lr.LowpassFilterBlock(128, 100e3), lr.DownsamplerBlock(5)]
         r, t = fs, types.ComplexFloat32
         for b in blocks[len(head):]:
             b.rate = r
