@@ -516,6 +516,31 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
     RotTab rt;
     if (ROT) rt = rot_tab(rot_step_fx);
     const int span = (int)((OW - 1) * D) + M;
+    // register prefetch (rotator form): the next tile's blocks are loaded while this tile is filtered
+    constexpr int KB = (DECIM_SPAN_MAX + 14) / 8 / 256 + 1;         // blocks of 8 samples per thread, at most
+    [[maybe_unused]] float4 raw[ROT ? KB : 1][4];
+    bool have = false;
+    auto prefetch = [&](long tt) {
+        have = false;
+        if constexpr (ROT) {
+            if (tt >= ntiles) return;
+            const long g0n = first + tt * OW * D - (M - 1);
+            const int an = (int)((rot_count0 + (uint64_t)g0n) & 7), nblkn = (span + an + 7) >> 3;
+            // blocks on 16-byte boundaries (an even absolute sample count at x[0]: every chunk the reference hands over), tile inside the chunk
+            have = g0n >= 0 && g0n + span <= n && ((g0n - an) & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && nblkn <= KB * 256;
+            if (!have) return;
+#pragma unroll
+            for (int k = 0; k < KB; k++) {
+                const int b = tid + 256 * k, w0 = 8 * b - an;
+                if (b < nblkn && w0 >= 0 && w0 + 8 <= span) {
+                    const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const cf *>(x) + g0n + w0);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) raw[k][q] = src[q];
+                }
+            }
+        }
+    };
+    prefetch(blockIdx.x);
     for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const long k0 = t * OW;                     // first output of the tile
         const long q0 = first + k0 * D;             // stream position of staged sample 0 (stream = [M-1 history | chunk])
@@ -525,6 +550,27 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
             // aligned blocks of 8 absolute samples: block b covers window positions 8b - a .. 8b - a + 7
             const int a = (int)((rot_count0 + (uint64_t)g0) & 7);
             const int nblk = (span + a + 7) >> 3;
+            // prefetched tiles: all of a thread's blocks were loaded as 16-byte words a tile ago (up to four blocks: one memory round trip per tile, hidden
+            // behind the previous tile's filter phase, instead of one per block), and are only rotated here
+            if (have) {
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    const int b = tid + 256 * k, w0 = 8 * b - a;
+                    if (b >= nblk) continue;
+                    const cf pb = phasor_poly(rot_step_fx * (rot_count0 + (uint64_t)(g0 + w0)));
+                    const bool whole = w0 >= 0 && w0 + 8 <= span;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int w = w0 + j;
+                        if (w >= 0 && w < span) {
+                            const float4 rq = raw[k][j >> 1];
+                            const cf v = whole ? ((j & 1) ? cf{rq.z, rq.w} : cf{rq.x, rq.y}) : reinterpret_cast<const cf *>(x)[g0 + w];
+                            const cf r = cmul(v, cmul(pb, rt.w[j]));
+                            *reinterpret_cast<float2 *>(ldsX + 2 * decim_phys(w)) = make_float2(r.x, r.y);
+                        }
+                    }
+                }
+            } else
             for (int b = tid; b < nblk; b += 256) {
                 const int w0 = 8 * b - a;
                 const cf pb = phasor_poly(rot_step_fx * (rot_count0 + (uint64_t)(g0 + w0)));
@@ -553,6 +599,7 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
             }
         }
         __syncthreads();
+        prefetch(t + gridDim.x);
         const long k = k0 + tid;
         if (tid < OW && k < n_out) {
             int p = tid * (int)D;
