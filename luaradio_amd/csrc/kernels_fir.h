@@ -540,7 +540,27 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
             }
         }
     };
-    prefetch(blockIdx.x);
+    // the same for the plain decimator on a ComplexFloat32 stream: lane-contiguous 16-byte words (two samples) of the next tile's window
+    constexpr int KF = (DECIM_SPAN_MAX / 2 + 1 + 255) / 256;       // 16-byte words per thread, at most
+    [[maybe_unused]] float4 rawp[(!ROT && S == 2) ? KF : 1];
+    auto prefetch_plain = [&](long tt) {
+        have = false;
+        if constexpr (!ROT && S == 2) {
+            if (tt >= ntiles) return;
+            const long g0n = first + tt * OW * D - (M - 1), gb = g0n - (g0n & 1);
+            const int nf = (span + (int)(g0n & 1) + 1) >> 1;
+            have = gb >= 0 && gb + 2L * nf <= n && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && nf <= KF * 256;
+            if (!have) return;
+            const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const cf *>(x) + gb);
+#pragma unroll
+            for (int k = 0; k < KF; k++) {
+                const int f = tid + 256 * k;
+                if (f < nf) rawp[k] = src[f];
+            }
+        }
+    };
+    if (ROT) prefetch(blockIdx.x);
+    else prefetch_plain(blockIdx.x);
     for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const long k0 = t * OW;                     // first output of the tile
         const long q0 = first + k0 * D;             // stream position of staged sample 0 (stream = [M-1 history | chunk])
@@ -585,6 +605,17 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
                     }
                 }
             }
+        } else if (S == 2 && have) {
+            const int o = (int)(g0 & 1), nf = (span + o + 1) >> 1;
+#pragma unroll
+            for (int k = 0; k < KF; k++) {
+                const int f = tid + 256 * k, w = 2 * f - o;
+                if (f < nf) {
+                    const float4 v = rawp[(!ROT && S == 2) ? k : 0];
+                    if (w >= 0) *reinterpret_cast<float2 *>(ldsX + 2 * decim_phys(w)) = make_float2(v.x, v.y);
+                    if (w + 1 < span) *reinterpret_cast<float2 *>(ldsX + 2 * decim_phys(w + 1)) = make_float2(v.z, v.w);
+                }
+            }
         } else {
             if (interior) {
                 for (int w = tid; w < span; w += 256) {
@@ -599,7 +630,8 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
             }
         }
         __syncthreads();
-        prefetch(t + gridDim.x);
+        if (ROT) prefetch(t + gridDim.x);
+        else prefetch_plain(t + gridDim.x);
         const long k = k0 + tid;
         if (tid < OW && k < n_out) {
             int p = tid * (int)D;
