@@ -444,7 +444,11 @@ struct FirStage : lrhip_stage {
                 // (run-to-run spread) for the persistent stride on 2^28 samples, same box, alternating
                 // (only when the launch is many times the resident slots: a 2^26-sample chain's 1/5-rate audio filter, 1 873 workgroups
                 // on 768 slots, keeps the persistent walk - 8 batches per workgroup would leave two thirds of the CUs idle)
-                int rounds = rounds_env >= 0 ? rounds_env : (want >= 8 * slots ? 8 : 0);
+                // Round 3, re-measured after the early first-block loads and the wave-uniform addressing (two boxes, alternating, HIP events): the persistent walk is
+                // now the faster order at every size - 2^26 samples 0.2155 against 0.2368 ms, 2^27 0.4199 / 0.4357, 2^28 0.8359 / 0.8412 and 0.8591 / 0.8646; the
+                // Float32 and complex-taps filters at 2^26 gain 9 % - a launch of 8-batch workgroups ends with a ragged last round that the one-block stride
+                // does not have.  The one-shot order stays as LRHIP_FFT_ROUNDS=8.
+                int rounds = rounds_env >= 0 ? rounds_env : 0;
                 if (want <= slots) rounds = 0;
                 unsigned grid = rounds > 0 ? (unsigned)((want + rounds - 1) / rounds) : (unsigned)(want < slots ? want : slots);
                 // tapered tail of the one-shot order (kernels_firfft.h): the last three "waves" of workgroups own rounds/2, rounds/4, rounds/8 batches
