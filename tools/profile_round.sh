@@ -44,6 +44,6 @@ python profiles/summarize_rocpd.py "$OUT/pmc_wbfm" lrhip > "$OUT/summary_pmc_wbf
 python profiles/summarize_rocpd.py "$OUT/pmc_chan" channelizer > "$OUT/summary_pmc_chan.txt" 2>&1
 # keep the kernel-trace databases (small); the counter databases are large (gpurun copies at most 64 MiB back)
 find "$OUT" -path "*pmc_*" -name "*.db" -delete
-find "$OUT" -name "*.db" -size +6M -delete
+find "$OUT" -name "*.db" -size +14M -delete
 du -sh "$OUT"
 tail -n 30 "$OUT/summary_kernel_trace.txt"
