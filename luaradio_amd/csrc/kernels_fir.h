@@ -500,25 +500,28 @@ constexpr int DECIM_SPAN_MAX = 6144;
 
 __device__ __forceinline__ int decim_phys(int p) { return p + (p >> 5); }
 
-template <int S, bool ROT, bool CT = false>      // CT: ComplexFloat32 taps (S = 2), taps_rev as {re, im} pairs
+// FMT > 0 (round 3): x holds raw IQ-file records (RX_FMT_*), converted while the tile is staged
+template <int S, bool ROT, bool CT = false, int FMT = 0>      // CT: ComplexFloat32 taps (S = 2), taps_rev as {re, im} pairs
 __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_rev,
                                                             float *__restrict__ y, int M, long n, long n_out, long first, long D, int OW, long ntiles,
                                                             uint64_t rot_step_fx, uint64_t rot_count0, float *__restrict__ hist_out)
 {
+    static_assert(FMT == 0 || (S == 2 && !CT), "raw records: (I, Q) pairs, real taps");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TS = CT ? 2 : 1;
     float *ldsT = lds;                              // M reversed taps
     float *ldsX = lds + ((TS * M + 3) & ~3);        // staged samples, S floats each, padded index
     const int tid = threadIdx.x;
     if (hist_out && blockIdx.x == 0)
-        for (int i = tid; i < (M - 1) * S; i += 256) hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
+        for (int i = tid; i < (M - 1) * S; i += 256) hist_out[i] = FMT ? stream_at_raw<FMT>(hist, x, n + i / S, i % S, M, n) : stream_at<S>(hist, x, n + i / S, i % S, M, n);
     for (int i = tid; i < TS * M; i += 256) ldsT[i] = taps_rev[i];
     RotTab rt;
     if (ROT) rt = rot_tab(rot_step_fx);
     const int span = (int)((OW - 1) * D) + M;
     // register prefetch (rotator form): the next tile's blocks are loaded while this tile is filtered
     constexpr int KB = (DECIM_SPAN_MAX + 14) / 8 / 256 + 1;         // blocks of 8 samples per thread, at most
-    [[maybe_unused]] float4 raw[ROT ? KB : 1][4];
+    [[maybe_unused]] float4 raw[(ROT && !FMT) ? KB : 1][4];
+    [[maybe_unused]] uint2 rawr[(ROT && FMT) ? KB : 1][4];       // raw records: two samples per 4- (.x) or 8-byte word
     bool have = false;
     auto prefetch = [&](long tt) {
         have = false;
@@ -527,35 +530,57 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
             const long g0n = first + tt * OW * D - (M - 1);
             const int an = (int)((rot_count0 + (uint64_t)g0n) & 7), nblkn = (span + an + 7) >> 3;
             // blocks on 16-byte boundaries (an even absolute sample count at x[0]: every chunk the reference hands over), tile inside the chunk
-            have = g0n >= 0 && g0n + span <= n && ((g0n - an) & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && nblkn <= KB * 256;
+            have = g0n >= 0 && g0n + span <= n && ((g0n - an) & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & (FMT ? 7 : 15)) == 0 && nblkn <= KB * 256;
             if (!have) return;
 #pragma unroll
             for (int k = 0; k < KB; k++) {
                 const int b = tid + 256 * k, w0 = 8 * b - an;
                 if (b < nblkn && w0 >= 0 && w0 + 8 <= span) {
-                    const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const cf *>(x) + g0n + w0);
+                    if constexpr (FMT != 0) {
+                        const uint8_t *src0 = reinterpret_cast<const uint8_t *>(x) + 2 * rx_raw_bytes<FMT>() * (g0n + w0);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) raw[k][q] = src[q];
+                        for (int q = 0; q < 4; q++) {
+                            if (FMT == RX_FMT_S16LE) rawr[k][q] = reinterpret_cast<const uint2 *>(src0)[q];
+                            else rawr[k][q].x = reinterpret_cast<const unsigned *>(src0)[q];
+                        }
+                    } else {
+                        const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const cf *>(x) + g0n + w0);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) raw[(ROT && !FMT) ? k : 0][q] = src[q];
+                    }
                 }
             }
         }
     };
     // the same for the plain decimator on a ComplexFloat32 stream: lane-contiguous 16-byte words (two samples) of the next tile's window
     constexpr int KF = (DECIM_SPAN_MAX / 2 + 1 + 255) / 256;       // 16-byte words per thread, at most
-    [[maybe_unused]] float4 rawp[(!ROT && S == 2) ? KF : 1];
+    [[maybe_unused]] float4 rawp[(!ROT && S == 2 && !FMT) ? KF : 1];
+    [[maybe_unused]] uint2 rawq[(!ROT && S == 2 && FMT) ? KF : 1];
     auto prefetch_plain = [&](long tt) {
         have = false;
         if constexpr (!ROT && S == 2) {
             if (tt >= ntiles) return;
             const long g0n = first + tt * OW * D - (M - 1), gb = g0n - (g0n & 1);
             const int nf = (span + (int)(g0n & 1) + 1) >> 1;
-            have = gb >= 0 && gb + 2L * nf <= n && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && nf <= KF * 256;
+            have = gb >= 0 && gb + 2L * nf <= n && (reinterpret_cast<uintptr_t>(x) & (FMT ? 7 : 15)) == 0 && nf <= KF * 256;
             if (!have) return;
-            const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const cf *>(x) + gb);
+            if constexpr (FMT != 0) {
+                const uint8_t *src0 = reinterpret_cast<const uint8_t *>(x) + 2 * rx_raw_bytes<FMT>() * gb;
 #pragma unroll
-            for (int k = 0; k < KF; k++) {
-                const int f = tid + 256 * k;
-                if (f < nf) rawp[k] = src[f];
+                for (int k = 0; k < KF; k++) {
+                    const int f = tid + 256 * k;
+                    if (f < nf) {
+                        if (FMT == RX_FMT_S16LE) rawq[k] = reinterpret_cast<const uint2 *>(src0)[f];
+                        else rawq[k].x = reinterpret_cast<const unsigned *>(src0)[f];
+                    }
+                }
+            } else {
+                const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const cf *>(x) + gb);
+#pragma unroll
+                for (int k = 0; k < KF; k++) {
+                    const int f = tid + 256 * k;
+                    if (f < nf) rawp[(!ROT && S == 2 && !FMT) ? k : 0] = src[f];
+                }
             }
         }
     };
@@ -583,8 +608,11 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
                     for (int j = 0; j < 8; j++) {
                         const int w = w0 + j;
                         if (w >= 0 && w < span) {
-                            const float4 rq = raw[k][j >> 1];
-                            const cf v = whole ? ((j & 1) ? cf{rq.z, rq.w} : cf{rq.x, rq.y}) : reinterpret_cast<const cf *>(x)[g0 + w];
+                            float4 rq;
+                            if constexpr (FMT != 0) rq = rx_raw_pair<FMT>(rawr[k][j >> 1]);
+                            else rq = raw[(ROT && !FMT) ? k : 0][j >> 1];
+                            const cf v = whole ? ((j & 1) ? cf{rq.z, rq.w} : cf{rq.x, rq.y})
+                                               : cf{stream_at_raw<FMT>(hist, x, q0 + w, 0, M, n), stream_at_raw<FMT>(hist, x, q0 + w, 1, M, n)};
                             const cf r = cmul(v, cmul(pb, rt.w[j]));
                             *reinterpret_cast<float2 *>(ldsX + 2 * decim_phys(w)) = make_float2(r.x, r.y);
                         }
@@ -598,8 +626,8 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
                 for (int j = 0; j < 8; j++) {
                     const int w = w0 + j;
                     if (w >= 0 && w < span) {
-                        const cf v = interior ? reinterpret_cast<const cf *>(x)[g0 + w]
-                                              : cf{stream_at<2>(hist, x, q0 + w, 0, M, n), stream_at<2>(hist, x, q0 + w, 1, M, n)};
+                        const cf v = (interior && !FMT) ? reinterpret_cast<const cf *>(x)[g0 + w]
+                                                        : cf{stream_at_raw<FMT>(hist, x, q0 + w, 0, M, n), stream_at_raw<FMT>(hist, x, q0 + w, 1, M, n)};
                         const cf r = cmul(v, cmul(pb, rt.w[j]));
                         *reinterpret_cast<float2 *>(ldsX + 2 * decim_phys(w)) = make_float2(r.x, r.y);
                     }
@@ -611,13 +639,15 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
             for (int k = 0; k < KF; k++) {
                 const int f = tid + 256 * k, w = 2 * f - o;
                 if (f < nf) {
-                    const float4 v = rawp[(!ROT && S == 2) ? k : 0];
+                    float4 v;
+                    if constexpr (FMT != 0) v = rx_raw_pair<FMT>(rawq[(!ROT && S == 2) ? k : 0]);
+                    else v = rawp[(!ROT && S == 2) ? k : 0];
                     if (w >= 0) *reinterpret_cast<float2 *>(ldsX + 2 * decim_phys(w)) = make_float2(v.x, v.y);
                     if (w + 1 < span) *reinterpret_cast<float2 *>(ldsX + 2 * decim_phys(w + 1)) = make_float2(v.z, v.w);
                 }
             }
         } else {
-            if (interior) {
+            if (interior && !FMT) {
                 for (int w = tid; w < span; w += 256) {
                     if (S == 2) *reinterpret_cast<float2 *>(ldsX + 2 * decim_phys(w)) = reinterpret_cast<const float2 *>(x)[g0 + w];
                     else ldsX[decim_phys(w)] = x[g0 + w];
@@ -625,7 +655,7 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
             } else {
                 for (int w = tid; w < span; w += 256) {
 #pragma unroll
-                    for (int c = 0; c < S; c++) ldsX[S * decim_phys(w) + c] = stream_at<S>(hist, x, q0 + w, c, M, n);
+                    for (int c = 0; c < S; c++) ldsX[S * decim_phys(w) + c] = FMT ? stream_at_raw<FMT>(hist, x, q0 + w, c, M, n) : stream_at<S>(hist, x, q0 + w, c, M, n);
                 }
             }
         }

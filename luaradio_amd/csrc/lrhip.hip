@@ -830,7 +830,8 @@ lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, u
         if (fold) { c->ops.erase(c->ops.begin() + (long)k - 1); k--; }
     }
     // ... and the same records in front of a plain fused Tuner or Decimator ([rotator +] 128-tap filter + decimation 5, no discriminator: the branch of a
-    // fan-out, TunerBlock / DecimatorBlock on its own): folded into the persistent Toeplitz kernel's staging (kernels_fir.h FMT)
+    // fan-out, TunerBlock / DecimatorBlock on its own; or the LDS-staged decimators of the AM / SSB / NBFM receivers, decimation 9 .. 50): folded into the
+    // kernel's staging (kernels_fir.h FMT)
     {
         static const bool no_tuner_fold = getenv("LRHIP_TUNER_NO_RAW_FOLD") != nullptr;      // A/B knob
         for (size_t k = 0; k + 1 < c->ops.size() && !no_tuner_fold && !(flags & LRHIP_CHAIN_NO_FUSION); k++) {
@@ -839,8 +840,8 @@ lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, u
             if (!fs || !tf || fs->pack || fs->scalars != 2 || kFormats[fs->fmt].swap) continue;
             const int fcls = kFormats[fs->fmt].cls;
             if (fcls != 0 && fcls != 1 && fcls != 3) continue;
-            if (tf->post_disc || tf->pre_disc || tf->use_fft || tf->decfft || tf->fft_arith || tf->taps_complex || tf->S != 2 || tf->D != 5 || tf->ksteps != 51 ||
-                tf->win_cplx_ok()) continue;
+            if (tf->post_disc || tf->pre_disc || tf->use_fft || tf->decfft || tf->fft_arith || tf->taps_complex || tf->S != 2 || tf->win_cplx_ok()) continue;
+            if (!((tf->D == 5 && tf->ksteps == 51) || (tf->ksteps == 0 && tf->D > 1 && tf->decim_lds_ok()))) continue;
             tf->in_fmt = fcls == 0 ? RX_FMT_U8 : fcls == 1 ? RX_FMT_S8 : RX_FMT_S16LE;
             tf->fmt_stage = fs;
             tf->in_size = fs->in_size;

@@ -504,7 +504,15 @@ struct FirStage : lrhip_stage {
             hist_in_kernel = ho != nullptr;
             return 0;
         };
-        int rc = taps_complex ? go(fir_decim_lds_kernel<2, false, true>)
+        int rc;
+        if (raw_now) {
+            if (taps_complex || S != 2) return set_error("internal: raw records reached a kernel without a record instantiation");
+            rc = rot ? (in_fmt == RX_FMT_U8 ? go(fir_decim_lds_kernel<2, true, false, RX_FMT_U8>) : in_fmt == RX_FMT_S8 ? go(fir_decim_lds_kernel<2, true, false, RX_FMT_S8>)
+                                                                                               : go(fir_decim_lds_kernel<2, true, false, RX_FMT_S16LE>))
+                     : (in_fmt == RX_FMT_U8 ? go(fir_decim_lds_kernel<2, false, false, RX_FMT_U8>) : in_fmt == RX_FMT_S8 ? go(fir_decim_lds_kernel<2, false, false, RX_FMT_S8>)
+                                                                                               : go(fir_decim_lds_kernel<2, false, false, RX_FMT_S16LE>));
+        } else
+        rc = taps_complex ? go(fir_decim_lds_kernel<2, false, true>)
                  : S == 2 ? (rot ? go(fir_decim_lds_kernel<2, true>) : go(fir_decim_lds_kernel<2, false>))
                         : (rot ? set_error("rotator fusion needs complex input") : go(fir_decim_lds_kernel<1, false>));
         if (rc) return rc;
@@ -836,8 +844,10 @@ struct FirStage : lrhip_stage {
     // does this chunk reach the persistent Tuner kernel, the one with a record instantiation?  (core()'s dispatch, the D = 5 / 128-tap shape)
     bool raw_path_ok(const void *in_dev, unsigned long n_in) const
     {
-        if (!in_fmt || post_disc || pre_disc || use_fft || decfft || fft_arith || taps_complex || S != 2 || D != 5 || ksteps != 51) return false;
-        if (win_cplx_ok() || win_pair_ok()) return false;
+        if (!in_fmt || post_disc || pre_disc || use_fft || decfft || fft_arith || taps_complex || S != 2) return false;
+        // the two kernels with record instantiations: the persistent Toeplitz kernel (128 taps, decimation 5) and the LDS-staged decimator (no Toeplitz shape)
+        if (!((D == 5 && ksteps == 51) || (ksteps == 0 && decim_lds_ok()))) return false;
+        if (win_cplx_ok() || win_pair_ok() || win_short_ok() || win_short_c_ok() || win_real_ok() || short_real_ok()) return false;
         if (n_in <= index) return false;                                  // no output: nothing launches, the history kernel would read x
         return ((uintptr_t)in_dev % (in_fmt == RX_FMT_S16LE ? 4u : 2u)) == 0;
     }

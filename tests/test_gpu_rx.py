@@ -429,11 +429,12 @@ def test_fir_fft4k_kernel_at_size_against_the_f64_oracle():
         assert float(np.max(np.abs(out - ref))) <= 1e-6 * max(1.0, float(np.max(np.abs(ref)))), o
 
 
+@pytest.mark.parametrize("decim", [5, 50, 9])
 @pytest.mark.parametrize("rotate", [True, False])
 @pytest.mark.parametrize("fmt", ["u8", "s8", "s16le", "u16le"])
-def test_tuner_reads_raw_records_in_its_launch(fmt, rotate):
-    """[IQFileSource(u8 / s8 / s16le) format stage, FrequencyTranslator, Lowpass(128), Downsampler(5)] - a fan-out branch fed from an IQ file - is ONE
-    launch of the persistent Toeplitz kernel on the records, bit-equal to the same Tuner on the converted ComplexFloat32 samples (block-of-8 rotator
+def test_tuner_reads_raw_records_in_its_launch(fmt, rotate, decim):
+    """[IQFileSource(u8 / s8 / s16le) format stage, FrequencyTranslator, Lowpass(128), Downsampler(5 / 9 / 50)] - a fan-out branch, or the tuner of the AM / SSB /
+    NBFM receivers, fed from an IQ file - is ONE launch of the persistent Toeplitz kernel (decimation 5) or the LDS-staged decimator (9, 50) on the records, bit-equal to the same Tuner on the converted ComplexFloat32 samples (block-of-8 rotator
     staging: the stand-alone translator's phasors whatever the alignment), ragged chunks incl. one that emits nothing; another format (u16le) keeps its
     conversion launch and the same bits"""
     import torch
@@ -445,7 +446,7 @@ def test_tuner_reads_raw_records_in_its_launch(fmt, rotate):
     fs = 1102500.0
 
     def tuner(head):
-        blocks = head + ([lr.FrequencyTranslatorBlock(-350e3)] if rotate else []) + [lr.LowpassFilterBlock(128, 100e3), lr.DownsamplerBlock(5)]
+        blocks = head + ([lr.FrequencyTranslatorBlock(-350e3)] if rotate else []) + [lr.LowpassFilterBlock(128, 500e3 / decim), lr.DownsamplerBlock(decim)]
         r, t = fs, types.ComplexFloat32
         for b in blocks[len(head):]:
             b.rate = r
@@ -477,5 +478,5 @@ def test_tuner_reads_raw_records_in_its_launch(fmt, rotate):
         g1.append(o1[:2 * m1].cpu().numpy().copy())
         g2.append(o2[:2 * m2].cpu().numpy().copy())
     g1, g2 = np.concatenate(g1), np.concatenate(g2)
-    assert len(g1) == 2 * ((n + 4) // 5)
+    assert len(g1) == 2 * ((n + decim - 1) // decim)
     assert np.array_equal(g1.view(np.uint32), g2.view(np.uint32))
