@@ -56,8 +56,8 @@ def main():
         ("IIR biquad cf32", blocks, ("iir_stream_kernel<2, 2, 4>",), 16, n26, 0),
         ("Decimator(5) cf32, fused", blocks, ("fir_mfma_persistent_kernel<2, 5, 2, false, 51, 0",), 9.6, n26, 102.4),
         ("Tuner(-250k, 200k, 5), fused rotator + FIR + downsampler", blocks, ("fir_mfma_persistent_kernel<2, 5, 2, true, 51, 0, false, 4, 0",), 9.6, n26, 108.4),
-        ("Tuner(-100k, 10k, 50): LDS-staged decimator with rotator (AM / SSB / NBFM receivers)", blocks, ("fir_decim_lds_kernel<2, true",), 8.16, n26, 16.2),
-        ("Decimator(25) cf32: LDS-staged decimator", blocks, ("fir_decim_lds_kernel<2, false, false",), 8.32, n26, 20.5),
+        ("Tuner(-100k, 10k, 50): LDS-staged decimator with rotator (AM / SSB / NBFM receivers)", blocks, ("fir_decim_lds_kernel<2, true, false, 0",), 8.16, n26, 16.2),
+        ("Decimator(25) cf32: LDS-staged decimator", blocks, ("fir_decim_lds_kernel<2, false, false, 0",), 8.32, n26, 20.5),
         ("Decimator / Tuner, polyphase FFT overlap-save", blocks, ("fir_decfft_kernel<5, 0>",), 9.6, n26, 62),
         ("Interpolator(5) cf32 (input samples)", blocks, ("fir_interp_kernel<5, 26>",), 48, n26, 512),
         ("RationalResampler(3, 2) cf32 (input samples)", blocks, ("fir_rational_kernel<3, 2",), 20, n26, 256),
@@ -75,6 +75,7 @@ def main():
         ("FIR 768 real taps cf32, overlap-save, one 4096-point launch (a wave per block)", blocks, ("fir_fft4kw_kernel<768",), 16, n26, 160),
         ("WBFM mono receiver from u8 IQ records, ONE launch (bench_blocks: noise input)", blocks, ("rx_fused_kernel<1>",), 2.16, n26, 167),
         ("Tuner from u8 IQ records (fan-out branch fed from a file), ONE launch", blocks, ("fir_mfma_persistent_kernel<2, 5, 2, true, 51, 0, false, 4, 1",), 3.6, n26, 108.4),
+        ("Tuner(decimation 50) from u8 IQ records, ONE launch (AM / SSB / NBFM receivers fed from a file)", blocks, ("fir_decim_lds_kernel<2, true, false, 1",), 2.16, n26, 16.2),
         ("PSD N=1024 hamming log fftshift", blocks, ("spectrum1024_kernel",), 12, n26, 58),
         ("WBFM mono receiver (bench_blocks: U(-1,1) noise input)", blocks, ("rx_fused_kernel<0>",), 8.16, n26, 167),
     ]
