@@ -24,6 +24,12 @@ __device__ __forceinline__ void nt_store(float4 *dst, float4 v)
     const nt_f32x4 w = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(w, reinterpret_cast<nt_f32x4 *>(dst));
 }
+typedef float nt_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_store(float2 *dst, float2 v)
+{
+    const nt_f32x2 w = {v.x, v.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_f32x2 *>(dst));
+}
 #endif
 
 

@@ -345,8 +345,8 @@ __device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, 
             const float b0 = acc[NOUT - 1][a][0], b1 = acc[NOUT - 1][a][1], b2 = acc[NOUT - 1][a][2], b3 = acc[NOUT - 1][a][3];
             long k = kblk + 4 * kq;
             if (out_aligned && k + 3 < n_out) {
-                *reinterpret_cast<float4 *>(y + 2 * k) = make_float4(a0, b0, a1, b1);
-                *reinterpret_cast<float4 *>(y + 2 * k + 4) = make_float4(a2, b2, a3, b3);
+                nt_store(reinterpret_cast<float4 *>(y + 2 * k), make_float4(a0, b0, a1, b1));
+                nt_store(reinterpret_cast<float4 *>(y + 2 * k + 4), make_float4(a2, b2, a3, b3));
             } else {
                 if (k < n_out) *reinterpret_cast<float2 *>(y + 2 * k) = make_float2(a0, b0);
                 if (k + 1 < n_out) *reinterpret_cast<float2 *>(y + 2 * k + 2) = make_float2(a1, b1);
@@ -356,7 +356,7 @@ __device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, 
         } else if (S == 1) {
             long k = kblk + 4 * kq;
             if (out_aligned && k + 3 < n_out) {
-                *reinterpret_cast<float4 *>(y + k) = make_float4(a0, a1, a2, a3);
+                nt_store(reinterpret_cast<float4 *>(y + k), make_float4(a0, a1, a2, a3));
             } else {
                 if (k < n_out) y[k] = a0;
                 if (k + 1 < n_out) y[k + 1] = a1;
@@ -374,7 +374,7 @@ __device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, 
             float4 o = odd ? make_float4(recv0, a2, recv1, a3) : make_float4(a0, recv0, a1, recv1);
             long k = kblk + 4 * kq + (odd ? 2 : 0);
             if (out_aligned && k + 1 < n_out) {
-                *reinterpret_cast<float4 *>(y + 2 * k) = o;
+                nt_store(reinterpret_cast<float4 *>(y + 2 * k), o);
             } else {
                 if (k < n_out) *reinterpret_cast<float2 *>(y + 2 * k) = make_float2(o.x, o.y);
                 if (k + 1 < n_out) *reinterpret_cast<float2 *>(y + 2 * k + 2) = make_float2(o.z, o.w);
@@ -416,7 +416,7 @@ __device__ __forceinline__ void disc_epilogue(float *__restrict__ y, long tile_k
         const float2 d = make_float2(discriminate(o0, p, inv_gain), discriminate(o1, o0, inv_gain));
         const long k = wave_k0 + 16 * (a * G::BPA + (col >> 1)) + 4 * kq + (odd ? 2 : 0);
         if (out_aligned && k + 1 < n_out) {
-            *reinterpret_cast<float2 *>(y + k) = d;
+            nt_store(reinterpret_cast<float2 *>(y + k), d);
         } else {
             if (k < n_out) y[k] = d.x;
             if (k + 1 < n_out) y[k + 1] = d.y;
@@ -462,7 +462,7 @@ __device__ __forceinline__ void disc_epilogue_lds(float *__restrict__ y, float *
         const float2 o0 = make_float2(u.x, u.y), o1 = make_float2(u.z, u.w), o2 = make_float2(v.x, v.y), o3 = make_float2(v.z, v.w);
         const float4 d = make_float4(discriminate(o0, p, inv_gain), discriminate(o1, o0, inv_gain), discriminate(o2, o1, inv_gain), discriminate(o3, o2, inv_gain));
         if (k + 3 < n_out && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
-            *reinterpret_cast<float4 *>(y + k) = d;
+            nt_store(reinterpret_cast<float4 *>(y + k), d);
         } else {
             y[k] = d.x;
             if (k + 1 < n_out) y[k + 1] = d.y;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
                 re = fmaf(ldsX[S * i0], h0, re);
                 if (S == 2) im = fmaf(ldsX[2 * i0 + 1], h0, im);
             }
-            if (S == 2) reinterpret_cast<float2 *>(y)[k] = make_float2(re, im);
+            if (S == 2) nt_store(reinterpret_cast<float2 *>(y) + k, make_float2(re, im));
             else y[k] = re;
         }
         __syncthreads();

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void fir_decfft_kernel(const float *__restr
                     const long k = k0 + 16 * i + u;
                     cf o = z[i];
                     if (p.rot_step_fx) o = cmul(o, cmul(base, rotT[16 * i + u]));
-                    if (k < p.n_out && (!(p.dbg & 32) || o.x == 12345.678f)) yo[k] = cf_to(o);
+                    if (k < p.n_out && (!(p.dbg & 32) || o.x == 12345.678f)) nt_store(yo + k, cf_to(o));
                 }
             } else {
 #pragma unroll

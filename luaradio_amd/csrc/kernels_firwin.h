@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void fir_win_real_kernel(const FwrParams pr
             float *yo = pr.y + c0;
             if (c0 + 16 <= n && (reinterpret_cast<uintptr_t>(pr.y) & 15) == 0) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) reinterpret_cast<float4 *>(yo)[k] = make_float4(acc[2 * k].x, acc[2 * k].y, acc[2 * k + 1].x, acc[2 * k + 1].y);
+                for (int k = 0; k < 4; k++) nt_store(reinterpret_cast<float4 *>(yo) + k, make_float4(acc[2 * k].x, acc[2 * k].y, acc[2 * k + 1].x, acc[2 * k + 1].y));
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void fir_win_real_kernel(const FwrParams pr
                     float *yo = pr.y + c0;
                     if (c0 + 16 <= n && (reinterpret_cast<uintptr_t>(pr.y) & 15) == 0) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) reinterpret_cast<float4 *>(yo)[k] = make_float4(u[4 * k], u[4 * k + 1], u[4 * k + 2], u[4 * k + 3]);
+                        for (int k = 0; k < 4; k++) nt_store(reinterpret_cast<float4 *>(yo) + k, make_float4(u[4 * k], u[4 * k + 1], u[4 * k + 2], u[4 * k + 3]));
                     } else {
 #pragma unroll
                         for (int i = 0; i < 16; i++)
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void fir_short_real_kernel(const float *__rest
         for (int i = 0; i < 4; i++) acc[i] = fmaf(w[HALO - (M - 1) + i + j], h, acc[i]);      // s[n0 + i + j], s = [history | chunk]
     }
     if (n0 + 4 <= n && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
-        *reinterpret_cast<float4 *>(y + n0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        nt_store(reinterpret_cast<float4 *>(y + n0), make_float4(acc[0], acc[1], acc[2], acc[3]));
     } else {
 #pragma unroll
         for (int i = 0; i < 4; i++)

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256, (MODE & FWC_PAIR) ? FWC_PAIR_WAVES : 2) void f
                     if (2 * m < G::TO && k < n_out) {
                         const float4 o = *reinterpret_cast<const float4 *>(ldsOut + 4 * m);
                         if (k + 1 < n_out && (reinterpret_cast<uintptr_t>(pr.y) & 15) == 0) {
-                            *reinterpret_cast<float4 *>(pr.y + 2 * k) = o;
+                            nt_store(reinterpret_cast<float4 *>(pr.y + 2 * k), o);
                         } else {
                             *reinterpret_cast<float2 *>(pr.y + 2 * k) = make_float2(o.x, o.y);
                             if (k + 1 < n_out) *reinterpret_cast<float2 *>(pr.y + 2 * k + 2) = make_float2(o.z, o.w);
