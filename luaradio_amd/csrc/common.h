@@ -24,7 +24,15 @@ __device__ __forceinline__ void nt_store(float4 *dst, float4 v)
     const nt_f32x4 w = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(w, reinterpret_cast<nt_f32x4 *>(dst));
 }
+// wave-uniform read-only tables (filter taps) through the scalar cache: a load from the constant address space at a uniform address is an
+// s_load, its result lives in SGPRs and feeds VALU instructions as a scalar operand - no LDS read, no vector register
+__device__ __forceinline__ float4 uniform_load4(const float *p)
+{
+    const nt_f32x4 v = *(const __attribute__((address_space(4))) nt_f32x4 *)p;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 typedef float nt_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ nt_f32x2 uniform_load2(const float *p) { return *(const __attribute__((address_space(4))) nt_f32x2 *)p; }
 __device__ __forceinline__ void nt_store(float2 *dst, float2 v)
 {
     const nt_f32x2 w = {v.x, v.y};

@@ -88,22 +88,45 @@ __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// Real taps are wave-uniform: read from the global table at compile-time offsets (uniform_load*, common.h) they arrive by scalar loads in SGPR
+// pairs and feed the packed FMAs as a scalar operand (SG = true) - no LDS tap reads at all.  Where the LDS pipe is the bound that is a large step
+// (RationalResampler(3, 4): 0.317 -> 0.185 ms, (2, 3): 0.26 -> 0.195, (3, 2): 0.33 -> 0.28; Interpolator(5) 0.726 -> 0.696; Hilbert(129) +1-5 %);
+// the short window kernels lose by it (16 real taps cf32: 0.172 -> 0.180 ms - a scalar load drains lgkmcnt, and with it the window reads in
+// flight, every four taps) and keep their taps in the LDS.  FW_TAPS_SGPR 0 = LDS-staged taps everywhere (A/B).
+#ifndef FW_TAPS_SGPR
+#define FW_TAPS_SGPR 1
+#endif
 // acc[i] = fma(tap, w_i, acc[i]) for the eight accumulators; the tap is the low (HI = 0) or high (HI = 1) half of t
-template <int HI>
+template <int HI, bool SG = false>
 __device__ __forceinline__ void fw_step8(cf (&a)[8], cf t, cf w0, cf w1, cf w2, cf w3, cf w4, cf w5, cf w6, cf w7)
 {
-    if constexpr (HI == 0)
-        asm("v_pk_fma_f32 %0, %8, %9, %0 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %1, %8, %10, %1 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %2, %8, %11, %2 op_sel_hi:[0,1,1]\n\t"
-            "v_pk_fma_f32 %3, %8, %12, %3 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %4, %8, %13, %4 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %5, %8, %14, %5 op_sel_hi:[0,1,1]\n\t"
-            "v_pk_fma_f32 %6, %8, %15, %6 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %7, %8, %16, %7 op_sel_hi:[0,1,1]"
-            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-            : "v"(t), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7));
-    else
-        asm("v_pk_fma_f32 %0, %8, %9, %0 op_sel:[1,0,0]\n\tv_pk_fma_f32 %1, %8, %10, %1 op_sel:[1,0,0]\n\tv_pk_fma_f32 %2, %8, %11, %2 op_sel:[1,0,0]\n\t"
-            "v_pk_fma_f32 %3, %8, %12, %3 op_sel:[1,0,0]\n\tv_pk_fma_f32 %4, %8, %13, %4 op_sel:[1,0,0]\n\tv_pk_fma_f32 %5, %8, %14, %5 op_sel:[1,0,0]\n\t"
-            "v_pk_fma_f32 %6, %8, %15, %6 op_sel:[1,0,0]\n\tv_pk_fma_f32 %7, %8, %16, %7 op_sel:[1,0,0]"
-            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-            : "v"(t), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7));
+    if constexpr (SG) {
+        if constexpr (HI == 0)
+            asm("v_pk_fma_f32 %0, %8, %9, %0 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %1, %8, %10, %1 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %2, %8, %11, %2 op_sel_hi:[0,1,1]\n\t"
+                "v_pk_fma_f32 %3, %8, %12, %3 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %4, %8, %13, %4 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %5, %8, %14, %5 op_sel_hi:[0,1,1]\n\t"
+                "v_pk_fma_f32 %6, %8, %15, %6 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %7, %8, %16, %7 op_sel_hi:[0,1,1]"
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                : "s"(t), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7));
+        else
+            asm("v_pk_fma_f32 %0, %8, %9, %0 op_sel:[1,0,0]\n\tv_pk_fma_f32 %1, %8, %10, %1 op_sel:[1,0,0]\n\tv_pk_fma_f32 %2, %8, %11, %2 op_sel:[1,0,0]\n\t"
+                "v_pk_fma_f32 %3, %8, %12, %3 op_sel:[1,0,0]\n\tv_pk_fma_f32 %4, %8, %13, %4 op_sel:[1,0,0]\n\tv_pk_fma_f32 %5, %8, %14, %5 op_sel:[1,0,0]\n\t"
+                "v_pk_fma_f32 %6, %8, %15, %6 op_sel:[1,0,0]\n\tv_pk_fma_f32 %7, %8, %16, %7 op_sel:[1,0,0]"
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                : "s"(t), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7));
+    } else {
+        if constexpr (HI == 0)
+            asm("v_pk_fma_f32 %0, %8, %9, %0 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %1, %8, %10, %1 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %2, %8, %11, %2 op_sel_hi:[0,1,1]\n\t"
+                "v_pk_fma_f32 %3, %8, %12, %3 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %4, %8, %13, %4 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %5, %8, %14, %5 op_sel_hi:[0,1,1]\n\t"
+                "v_pk_fma_f32 %6, %8, %15, %6 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %7, %8, %16, %7 op_sel_hi:[0,1,1]"
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                : "v"(t), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7));
+        else
+            asm("v_pk_fma_f32 %0, %8, %9, %0 op_sel:[1,0,0]\n\tv_pk_fma_f32 %1, %8, %10, %1 op_sel:[1,0,0]\n\tv_pk_fma_f32 %2, %8, %11, %2 op_sel:[1,0,0]\n\t"
+                "v_pk_fma_f32 %3, %8, %12, %3 op_sel:[1,0,0]\n\tv_pk_fma_f32 %4, %8, %13, %4 op_sel:[1,0,0]\n\tv_pk_fma_f32 %5, %8, %14, %5 op_sel:[1,0,0]\n\t"
+                "v_pk_fma_f32 %6, %8, %15, %6 op_sel:[1,0,0]\n\tv_pk_fma_f32 %7, %8, %16, %7 op_sel:[1,0,0]"
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                : "v"(t), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "v"(w5), "v"(w6), "v"(w7));
+    }
 }
 
 // The tap loop.  Pair i of the lane = outputs 16 L + 2i, 16 L + 2i + 1; at step j its operand starts at tile coordinate
@@ -375,7 +398,8 @@ __global__ __launch_bounds__(256, 4) void hilbert_win_kernel(const float *__rest
     const unsigned tid = threadIdx.x;
     if (hist_out && blockIdx.x == 0)
         for (int i = tid; i < M - 1; i += 256) hist_out[i] = stream_at<1>(hist, x, n + i, 0, M, n);
-    for (int i = tid; i < G::NZ; i += 256) ldsT[i] = taps_rev[2 * i + 1];
+    if (!FW_TAPS_SGPR)
+        for (int i = tid; i < G::NZ; i += 256) ldsT[i] = taps_rev[2 * i + 1];
 
     const long ntiles = (n + FWR_TILE - 1) / FWR_TILE;
     const long first_tile = (long)blockIdx.x * run;
@@ -430,14 +454,15 @@ __global__ __launch_bounds__(256, 4) void hilbert_win_kernel(const float *__rest
 #pragma unroll
             for (int i = 0; i < R; i++) acc[i] = cf{0.f, 0.f};
             static_for<R - 1 + LA>([&](auto I) { constexpr int i = decltype(I)::value; W[i % NS] = ld(i); });
-            T[0] = *reinterpret_cast<const float4 *>(ldsT);
+            if (!FW_TAPS_SGPR) T[0] = *reinterpret_cast<const float4 *>(ldsT);
             static_for<G::NZ>([&](auto K) {
                 constexpr int k = decltype(K)::value;
-                if constexpr ((k & 3) == 0 && k + 4 < G::NZ) T[((k >> 2) + 1) & 1] = *reinterpret_cast<const float4 *>(ldsT + k + 4);
+                if constexpr (!FW_TAPS_SGPR && (k & 3) == 0 && k + 4 < G::NZ) T[((k >> 2) + 1) & 1] = *reinterpret_cast<const float4 *>(ldsT + k + 4);
                 if constexpr (k + LA < G::NZ) W[(R - 1 + k + LA) % NS] = ld(R - 1 + k + LA);
                 const float4 tq = T[(k >> 2) & 1];
-                const cf tp = (k & 2) ? cf{tq.z, tq.w} : cf{tq.x, tq.y};
-                fw_step8<(k & 1)>(acc, tp, W[(0 + k) % NS], W[(1 + k) % NS], W[(2 + k) % NS], W[(3 + k) % NS], W[(4 + k) % NS], W[(5 + k) % NS],
+                // scalar form: the pair (h[2k], h[2k+1]) of the full reversed tap list, the odd one is the high half
+                const cf tp = FW_TAPS_SGPR ? uniform_load2(taps_rev + 2 * k) : (k & 2) ? cf{tq.z, tq.w} : cf{tq.x, tq.y};
+                fw_step8<FW_TAPS_SGPR ? 1 : (k & 1), FW_TAPS_SGPR>(acc, tp, W[(0 + k) % NS], W[(1 + k) % NS], W[(2 + k) % NS], W[(3 + k) % NS], W[(4 + k) % NS], W[(5 + k) % NS],
                                   W[(6 + k) % NS], W[(7 + k) % NS]);
             });
         }

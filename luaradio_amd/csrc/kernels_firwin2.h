@@ -99,19 +99,32 @@ __device__ __forceinline__ float fwc_stream_at_fixed(const FwcParams &pr, const 
     return stream_at<1>(hist, x, p, 0, M, n);
 }
 
-template <int HI>
+template <int HI, bool SG = false>
 __device__ __forceinline__ void fw_step5(cf (&a)[5], cf t, cf w0, cf w1, cf w2, cf w3, cf w4)
 {
-    if constexpr (HI == 0)
-        asm("v_pk_fma_f32 %0, %5, %6, %0 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %1, %5, %7, %1 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %2, %5, %8, %2 op_sel_hi:[0,1,1]\n\t"
-            "v_pk_fma_f32 %3, %5, %9, %3 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %4, %5, %10, %4 op_sel_hi:[0,1,1]"
-            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4])
-            : "v"(t), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4));
-    else
-        asm("v_pk_fma_f32 %0, %5, %6, %0 op_sel:[1,0,0]\n\tv_pk_fma_f32 %1, %5, %7, %1 op_sel:[1,0,0]\n\tv_pk_fma_f32 %2, %5, %8, %2 op_sel:[1,0,0]\n\t"
-            "v_pk_fma_f32 %3, %5, %9, %3 op_sel:[1,0,0]\n\tv_pk_fma_f32 %4, %5, %10, %4 op_sel:[1,0,0]"
-            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4])
-            : "v"(t), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4));
+    if constexpr (SG) {
+        if constexpr (HI == 0)
+            asm("v_pk_fma_f32 %0, %5, %6, %0 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %1, %5, %7, %1 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %2, %5, %8, %2 op_sel_hi:[0,1,1]\n\t"
+                "v_pk_fma_f32 %3, %5, %9, %3 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %4, %5, %10, %4 op_sel_hi:[0,1,1]"
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4])
+                : "s"(t), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4));
+        else
+            asm("v_pk_fma_f32 %0, %5, %6, %0 op_sel:[1,0,0]\n\tv_pk_fma_f32 %1, %5, %7, %1 op_sel:[1,0,0]\n\tv_pk_fma_f32 %2, %5, %8, %2 op_sel:[1,0,0]\n\t"
+                "v_pk_fma_f32 %3, %5, %9, %3 op_sel:[1,0,0]\n\tv_pk_fma_f32 %4, %5, %10, %4 op_sel:[1,0,0]"
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4])
+                : "s"(t), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4));
+    } else {
+        if constexpr (HI == 0)
+            asm("v_pk_fma_f32 %0, %5, %6, %0 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %1, %5, %7, %1 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %2, %5, %8, %2 op_sel_hi:[0,1,1]\n\t"
+                "v_pk_fma_f32 %3, %5, %9, %3 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %4, %5, %10, %4 op_sel_hi:[0,1,1]"
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4])
+                : "v"(t), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4));
+        else
+            asm("v_pk_fma_f32 %0, %5, %6, %0 op_sel:[1,0,0]\n\tv_pk_fma_f32 %1, %5, %7, %1 op_sel:[1,0,0]\n\tv_pk_fma_f32 %2, %5, %8, %2 op_sel:[1,0,0]\n\t"
+                "v_pk_fma_f32 %3, %5, %9, %3 op_sel:[1,0,0]\n\tv_pk_fma_f32 %4, %5, %10, %4 op_sel:[1,0,0]"
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4])
+                : "v"(t), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4));
+    }
 }
 
 // the tap loop over one staged tile: window coordinate r of the lane sits at base + 2 r floats (base = window + 2 D R L)

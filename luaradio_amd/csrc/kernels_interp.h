@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256, 3) void fir_interp_kernel(const float *__restr
             const long g = n_in - HQ + i / 2;
             hist_out[i] = g >= 0 ? x[g * 2 + i % 2] : hist[(g + HQ) * 2 + i % 2];
         }
-    for (int i = tid; i < J * G::LP; i += 256) ldsT[i] = ttab[i];
+    if (!FW_TAPS_SGPR)
+        for (int i = tid; i < J * G::LP; i += 256) ldsT[i] = ttab[i];
 
     // Persistent workgroups, register prefetch: the loads of the NEXT tile are issued before this tile's tap loop - ahead of its 51 KB of output
     // stores in the CU's memory queue - and the stores of tile t drain while tile t + 1 is filtered (one tile per workgroup measured 0.98 ms for
@@ -106,19 +107,19 @@ __global__ __launch_bounds__(256, 3) void fir_interp_kernel(const float *__restr
             auto ld = [&](int r) { return *reinterpret_cast<const cf *>(base + 2 * r); };
             static_for<R - 1 + LA>([&](auto I) { constexpr int r = decltype(I)::value; W[r % C] = ld(r); });
 #pragma unroll
-            for (int k = 0; k < G::NQ; k++) T[0][k] = *reinterpret_cast<const float4 *>(ldsT + 4 * k);
+            for (int k = 0; k < G::NQ; k++) T[0][k] = (FW_TAPS_SGPR ? uniform_load4(ttab + 4 * k) : *reinterpret_cast<const float4 *>(ldsT + 4 * k));
             static_for<J>([&](auto Sx) {
                 constexpr int s = decltype(Sx)::value, rn = R - 1 + s + LA;
                 if constexpr (s + 1 < J) {
 #pragma unroll
-                    for (int k = 0; k < G::NQ; k++) T[(s + 1) & 1][k] = *reinterpret_cast<const float4 *>(ldsT + (s + 1) * G::LP + 4 * k);
+                    for (int k = 0; k < G::NQ; k++) T[(s + 1) & 1][k] = (FW_TAPS_SGPR ? uniform_load4(ttab + (s + 1) * G::LP + 4 * k) : *reinterpret_cast<const float4 *>(ldsT + (s + 1) * G::LP + 4 * k));
                 }
                 if constexpr (rn <= R - 1 + J - 1) W[rn % C] = ld(rn);
                 static_for<L>([&](auto Px) {
                     constexpr int p = decltype(Px)::value;
                     const float4 tq = T[s & 1][p >> 2];
                     const cf tp = (p & 2) ? cf{tq.z, tq.w} : cf{tq.x, tq.y};
-                    fw_step5<(p & 1)>(acc[p], tp, W[s % C], W[(s + 1) % C], W[(s + 2) % C], W[(s + 3) % C], W[(s + 4) % C]);
+                    fw_step5<(p & 1), FW_TAPS_SGPR>(acc[p], tp, W[s % C], W[(s + 1) % C], W[(s + 2) % C], W[(s + 3) % C], W[(s + 4) % C]);
                 });
             });
         }
@@ -193,7 +194,8 @@ __global__ __launch_bounds__(256, 3) void fir_rational_kernel(const float *__res
             const long g = n_in - HQ + i / 2;
             hist_out[i] = g >= 0 ? x[g * 2 + i % 2] : hist[(g + HQ) * 2 + i % 2];
         }
-    for (int i = tid; i < J * G::LP; i += 256) ldsT[i] = ttab[i];
+    if (!FW_TAPS_SGPR)
+        for (int i = tid; i < J * G::LP; i += 256) ldsT[i] = ttab[i];
 
     // tiles are anchored at the absolute input position A0 = Q0 rounded down to a multiple of D (the up to D - 1 positions in front of the chunk
     // are history, their outputs were emitted by the previous chunk: m < m0 is skipped)
@@ -250,12 +252,12 @@ __global__ __launch_bounds__(256, 3) void fir_rational_kernel(const float *__res
             auto ld = [&](int r) { return *reinterpret_cast<const cf *>(base + 2 * (G::PADW ? r + r / R : r)); };
             static_for<R - 1 + LA>([&](auto I) { constexpr int r = decltype(I)::value; W[r % C] = ld(r); });
 #pragma unroll
-            for (int k = 0; k < G::NQ; k++) T[0][k] = *reinterpret_cast<const float4 *>(ldsT + 4 * k);
+            for (int k = 0; k < G::NQ; k++) T[0][k] = (FW_TAPS_SGPR ? uniform_load4(ttab + 4 * k) : *reinterpret_cast<const float4 *>(ldsT + 4 * k));
             static_for<J>([&](auto Sx) {
                 constexpr int s = decltype(Sx)::value, rn = R - 1 + s + LA;
                 if constexpr (s + 1 < J) {
 #pragma unroll
-                    for (int k = 0; k < G::NQ; k++) T[(s + 1) & 1][k] = *reinterpret_cast<const float4 *>(ldsT + (s + 1) * G::LP + 4 * k);
+                    for (int k = 0; k < G::NQ; k++) T[(s + 1) & 1][k] = (FW_TAPS_SGPR ? uniform_load4(ttab + (s + 1) * G::LP + 4 * k) : *reinterpret_cast<const float4 *>(ldsT + (s + 1) * G::LP + 4 * k));
                 }
                 if constexpr (rn <= R - 1 + J - 1) W[rn % C] = ld(rn);
                 static_for<OUTL>([&](auto Ax) {
