@@ -87,10 +87,12 @@ struct ResampleStage : lrhip_stage {
                 return 0;
             };
 #define LR_RAT(LL, DD, JJ, RR) gr(fir_rational_kernel<LL, DD, JJ, RR>, (size_t)FrrGeom<LL, DD, JJ, RR>::LDS_FLOATS * sizeof(float), FrrGeom<LL, DD, JJ, RR>::TQ)
-            // positions per lane (R) by measurement on MI355X, 2^26 input samples: (3,4) R = 4 / 8 / 12 -> 0.33 / 0.70 / 0.49 ms, (5,4) R = 4 / 8 -> 0.86 / 0.24,
-            // (4,5) R = 5 / 10 -> 0.80 / 0.19: the shapes are sensitive to it in a way the instruction counts do not explain (same FMAs per input)
-            int rc = (L == 3 && D == 2) ? LR_RAT(3, 2, 43, 6) : (L == 2 && D == 3) ? LR_RAT(2, 3, 64, 6) : (L == 4 && D == 3) ? LR_RAT(4, 3, 32, 6)
-                   : (L == 3 && D == 4) ? LR_RAT(3, 4, 43, 4) : (L == 5 && D == 4) ? LR_RAT(5, 4, 26, 8) : LR_RAT(4, 5, 32, 10);
+            // positions per lane (R) by measurement on MI355X, 2^26 input samples.  With the taps read from the LDS the shapes were sharply sensitive to it
+            // ((3,4) R = 4 / 8 / 12 -> 0.33 / 0.70 / 0.49 ms, (5,4) R = 4 / 8 -> 0.86 / 0.24): the LDS pipe was the bound.  With the taps in SGPRs
+            // (FW_TAPS_SGPR, kernels_firwin.h) a sweep of R = D .. 4 D moves no shape by more than 5 % ((2,3) R = 3 / 6 / 9 / 12 -> 0.242 / 0.190 / 0.180 /
+            // 0.187, (3,4) R = 4 / 8 / 12 / 16 -> 0.180 / 0.174 / 0.174 / 0.172, (3,2) 0.289-0.293 for R = 4 .. 10)
+            int rc = (L == 3 && D == 2) ? LR_RAT(3, 2, 43, 6) : (L == 2 && D == 3) ? LR_RAT(2, 3, 64, 9) : (L == 4 && D == 3) ? LR_RAT(4, 3, 32, 6)
+                   : (L == 3 && D == 4) ? LR_RAT(3, 4, 43, 8) : (L == 5 && D == 4) ? LR_RAT(5, 4, 26, 8) : LR_RAT(4, 5, 32, 10);
 #undef LR_RAT
             if (rc) return rc;
             LR_LAUNCH_CHECK();
