@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
                 } else {
 #pragma unroll
 #if LRHIP_FFT_NT >= 2
-                    for (int i = 0; i < 16; i++) v[i] = __builtin_nontemporal_load(src + 64 * i);
+                    for (int i = 0; i < 16; i++) v[i] = __builtin_nontemporal_load((srcu + 64 * i) + (unsigned)lane);
 #else
                     for (int i = 0; i < 16; i++) v[i] = (srcu + 64 * i)[(unsigned)lane];      // wave-uniform row pointer + the lane's 32-bit index
 #endif
