@@ -540,6 +540,16 @@ lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, u
     std::unique_ptr<lrhip_chain> c(new (std::nothrow) lrhip_chain());
     if (!c) { set_error("out of memory"); return nullptr; }
     c->flags = flags;
+    // Downsampler(1) is the identity (downsampler.lua:45-56 with factor 1 copies every sample; its index stays 0): it gets no launch of its own
+    // (a Tuner / Decimator built with decimation 1) - unless it is the whole chain
+    std::vector<lrhip_stage_t *> kept;
+    if (!no_fusion && nstages > 1) {
+        for (unsigned k = 0; k < nstages; k++) {
+            DownsamplerStage *d1 = dynamic_cast<DownsamplerStage *>(stages[k]);
+            if (!(d1 && d1->factor == 1)) kept.push_back(stages[k]);
+        }
+        if (!kept.empty() && kept.size() < nstages) { stages = kept.data(); nstages = (unsigned)kept.size(); }
+    }
     unsigned i = 0;
     while (i < nstages) {
         if (no_fusion) {                                    // every block runs its own kernels; edges stay on the device
@@ -655,6 +665,14 @@ lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, u
             continue;
         }
         DownsamplerStage *ds = (fusable_fir && j + 1 < nstages) ? dynamic_cast<DownsamplerStage *>(stages[j + 1]) : nullptr;
+        // a rotator in front of a filter that does NOT decimate stays a launch of its own: the rotating Toeplitz kernel at D = 1 has no register room left
+        // (112-296 bytes of scratch) and runs 2^26 samples in 0.62 ms, against 0.17 (rotator) + 0.21 (overlap-save) / 0.39 (direct form) for the pair
+        static const bool rot_fir_d1 = getenv("LRHIP_ROT_FIR_FUSE_D1") != nullptr;      // A/B knob: fuse it all the same
+        if (rot && fusable_fir && !ds && !rot_fir_d1) {
+            c->ops.push_back({stages[i], false});
+            i++;
+            continue;
+        }
         // ... [discriminator]: runs as the epilogue of the persistent kernel (ComplexFloat32 outputs never reach HBM)
         static const bool no_disc_fusion = getenv("LRHIP_NO_DISC_FUSION") != nullptr;      // A/B knob
         unsigned after = j + 1 + (ds ? 1 : 0);

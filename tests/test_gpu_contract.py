@@ -15,6 +15,7 @@ import pytest
 
 import luaradio_amd as lr
 from luaradio_amd import _lib, types
+from luaradio_amd.composites import _fft_option
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -256,3 +257,36 @@ def test_cascaded_overlap_save_filters_run_as_one_filter():
     six = lr.Chain([make(lr.FIRFilterBlock, [t, "fast"], c, FS) for t in taps + taps[:1]])
     six.process(x[:100000])
     assert six.last_launches == 2
+
+
+def test_tuner_without_decimation_is_a_rotator_and_a_filter():
+    """radio/composites/tuner.lua:32-48 with decimation 1: FrequencyTranslator -> LowpassFilter -> Downsampler(1).  The identity downsampler gets no
+    launch and the rotator is NOT folded into a filter that does not decimate (the rotating Toeplitz kernel at D = 1 is slower than the pair): two
+    launches, and with the direct form they produce the bits of the blocks run one by one."""
+    c = types.ComplexFloat32
+    n = 200003
+    x = fm_signal(n)
+    cuts = [1, 777, 65536, 100000]
+
+    def blocks(mode):
+        f = lr.LowpassFilterBlock(128, 100e3)
+        f.use_fft = _fft_option({"use_fft": mode})      # as TunerBlock.instantiate does
+        f.rate = FS
+        f.differentiate([c])
+        f.initialize()
+        return [make(lr.FrequencyTranslatorBlock, [-250e3], c, FS), f, make(lr.DownsamplerBlock, [1], c, FS)]
+
+    one_by_one = x
+    for b in blocks(False)[:2]:
+        one_by_one = b.process(one_by_one)
+    chain = lr.Chain(blocks(False))
+    got = run_chunked(chain.process, x, cuts)
+    assert chain.last_launches == 2
+    assert len(got) == n and np.array_equal(got.view(np.uint32), one_by_one.view(np.uint32))
+    fast = lr.Chain(blocks("fast"))
+    gotf = run_chunked(fast.process, x, cuts)
+    assert fast.last_launches == 2
+    assert len(gotf) == n and float(np.max(np.abs(gotf - one_by_one))) <= 2e-6
+    # a chain that is nothing but Downsampler(1) still copies
+    ident = lr.Chain([make(lr.DownsamplerBlock, [1], c, FS)])
+    assert np.array_equal(ident.process(x[:1000]), x[:1000])
