@@ -93,6 +93,9 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 // (RationalResampler(3, 4): 0.317 -> 0.185 ms, (2, 3): 0.26 -> 0.195, (3, 2): 0.33 -> 0.28; Interpolator(5) 0.726 -> 0.696; Hilbert(129) +1-5 %);
 // the short window kernels lose by it (16 real taps cf32: 0.172 -> 0.180 ms - a scalar load drains lgkmcnt, and with it the window reads in
 // flight, every four taps) and keep their taps in the LDS.  FW_TAPS_SGPR 0 = LDS-staged taps everywhere (A/B).
+#ifndef FWR_SGPR_MIN_M
+#define FWR_SGPR_MIN_M 128       /* fir_win_real_kernel: tap counts from which the taps come by scalar loads */
+#endif
 #ifndef FW_TAPS_SGPR
 #define FW_TAPS_SGPR 1
 #endif
@@ -146,14 +149,15 @@ __device__ __forceinline__ void fwr_taps(const float *ldsT, const float *baseE, 
         constexpr int q = decltype(JJ)::value + E0, par = q & 1, h = q >> 1;
         static_for<R - 1 + LA>([&](auto I) { constexpr int i = decltype(I)::value; W[par][(i + h) % NS] = ld(par, i + h); });
     });
-    T[0] = *reinterpret_cast<const float4 *>(ldsT);
+    constexpr bool SG = M >= FWR_SGPR_MIN_M;       // long tap loops: taps by scalar loads (ldsT is then the global table) - section 4.3 fact 5
+    T[0] = SG ? uniform_load4(ldsT) : *reinterpret_cast<const float4 *>(ldsT);
     static_for<M>([&](auto J) {
         constexpr int j = decltype(J)::value, q = j + E0, par = q & 1, h = q >> 1;
-        if constexpr ((j & 3) == 0 && j + 4 < M) T[((j >> 2) + 1) & 1] = *reinterpret_cast<const float4 *>(ldsT + j + 4);
+        if constexpr ((j & 3) == 0 && j + 4 < M) T[((j >> 2) + 1) & 1] = SG ? uniform_load4(ldsT + j + 4) : *reinterpret_cast<const float4 *>(ldsT + j + 4);
         if constexpr (j + 2 * LA < M) W[par][(R - 1 + h + LA) % NS] = ld(par, R - 1 + h + LA);      // needed LA same-parity steps ahead
         const float4 tq = T[(j >> 2) & 1];
         const cf tp = (j & 2) ? cf{tq.z, tq.w} : cf{tq.x, tq.y};
-        fw_step8<(j & 1)>(acc, tp, W[par][(0 + h) % NS], W[par][(1 + h) % NS], W[par][(2 + h) % NS], W[par][(3 + h) % NS], W[par][(4 + h) % NS],
+        fw_step8<(j & 1), SG>(acc, tp, W[par][(0 + h) % NS], W[par][(1 + h) % NS], W[par][(2 + h) % NS], W[par][(3 + h) % NS], W[par][(4 + h) % NS],
                           W[par][(5 + h) % NS], W[par][(6 + h) % NS], W[par][(7 + h) % NS]);
     });
 }
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void fir_win_real_kernel(const FwrParams pr
         cf acc[8];
         const bool active = !IIR || emit || wave >= 4 - pr.warm_waves;
         if (active) {
-            fwr_taps<M, G::E0>(ldsT, ldsE + 18 * tid, ldsO + 18 * tid, acc);
+            fwr_taps<M, G::E0>(M >= FWR_SGPR_MIN_M ? pr.taps_rev : ldsT, ldsE + 18 * tid, ldsO + 18 * tid, acc);
         } else {
 #pragma unroll
             for (int i = 0; i < 8; i++) acc[i] = cf{0.f, 0.f};
