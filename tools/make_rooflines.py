@@ -20,6 +20,19 @@ def parse(path):
     return rows
 
 
+def parse_pmc(path):
+    """summary_pmc_blocks.txt (tools/pmc_blocks.sh): {kernel: {"FETCH_SIZE": KB, "WRITE_SIZE": KB}} per dispatch"""
+    out = {}
+    try:
+        for line in open(path):
+            m = re.match(r"(FETCH_SIZE|WRITE_SIZE)\s+(lrhip::\S.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
+            if m:
+                out.setdefault(m.group(2), {})[m.group(1)] = float(m.group(4))
+    except OSError:
+        pass
+    return out
+
+
 def find(rows, *subs):
     hits = [(k, v) for k, v in rows.items() if all(s in k for s in subs)]
     if not hits:
@@ -32,6 +45,7 @@ def main():
     tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
     bench = parse(prof + "/summary_kernel_trace.txt")
     blocks = parse(prof + "/summary_blocks_kernel_trace.txt")
+    pmc = parse_pmc(prof + "/summary_pmc_blocks.txt")
     n28, n26, n24 = 1 << 28, 1 << 26, 1 << 24
     # (row, trace, kernel substrings, algorithmic bytes per sample, samples per launch, flops per sample or 0)
     table = [
@@ -91,6 +105,14 @@ def main():
         if flops:
             row["TFLOP/s"] = round(flops * n / (us * 1e-6) / 1e12, 2)
             row["frac_of_157.3TF"] = round(flops * n / (us * 1e-6) / FP32, 4)
+        if src is blocks and pmc:
+            # HBM traffic of the same kernel in the counter passes of the blocks table: FETCH_SIZE x 2 (gfx950 reports half of wide coalesced reads,
+            # profiles/hbm_traffic.json) + WRITE_SIZE, KB
+            hits = [c for kk, c in pmc.items() if all(t in kk for t in subs) and "FETCH_SIZE" in c and "WRITE_SIZE" in c]
+            if hits:
+                tb = (2 * hits[0]["FETCH_SIZE"] + hits[0]["WRITE_SIZE"]) * 1024
+                row["hbm_traffic_bytes"] = round(tb)
+                row["traffic_over_algorithmic"] = round(tb / alg, 3)
         rows.append(row)
     doc = {"_comment": "per-kernel rooflines of round %s: avg_us = average kernel duration over the TIMED dispatches (the last K of a kernel in its rocprofv3 kernel trace: "
                        "bench.py's 20 timed steps / bench_blocks.py's 10 repetitions; summarize_rocpd.py --last), one MI355X; frac = algorithmic bytes (SURVEY.md 8d x samples) / "
