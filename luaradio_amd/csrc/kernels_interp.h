@@ -9,8 +9,9 @@
 //
 // fir_resample_kernel computes one output per thread and reads a tap and a sample from LDS for every two FMAs (Interpolator(5): 2.2 ms
 // for 2^26 input samples, 18 % of the HBM roof).  Here a lane owns R = 5 consecutive input positions and all L phases of them: L R
-// accumulators (ComplexFloat32 in a register pair), one 8-byte window read and L broadcast taps per tap step feed L R packed FMAs
-// (fw_step5: the tap enters through op_sel, the window is a compile-time indexed register ring).  The 5 L outputs of a lane are
+// accumulators (ComplexFloat32 in a register pair), one 8-byte window read per tap step feeds L R packed FMAs whose L taps are scalar
+// operands (fw_step5<HI, SG>: an SGPR pair loaded by s_load from the tap table, the half picked by op_sel; FW_TAPS_SGPR 0 = LDS broadcasts, the
+// round-2 form; the window is a compile-time indexed register ring).  The 5 L outputs of a lane are
 // contiguous in y; they go through LDS (the window's space, reused) so that the stores are 16 bytes per lane, consecutive lanes
 // consecutive addresses.  Persistent workgroups over tiles of 1280 input positions.
 #pragma once
