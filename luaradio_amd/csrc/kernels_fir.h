@@ -504,7 +504,7 @@ __device__ __forceinline__ int decim_phys(int p) { return p + (p >> 5); }
 template <int S, bool ROT, bool CT = false, int FMT = 0>      // CT: ComplexFloat32 taps (S = 2), taps_rev as {re, im} pairs
 __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_rev,
                                                             float *__restrict__ y, int M, long n, long n_out, long first, long D, int OW, long ntiles,
-                                                            uint64_t rot_step_fx, uint64_t rot_count0, float *__restrict__ hist_out)
+                                                            uint64_t rot_step_fx, uint64_t rot_count0, float *__restrict__ hist_out, int post_op)
 {
     static_assert(FMT == 0 || (S == 2 && !CT), "raw records: (I, Q) pairs, real taps");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -701,7 +701,9 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
                 re = fmaf(ldsX[S * i0], h0, re);
                 if (S == 2) im = fmaf(ldsX[2 * i0 + 1], h0, im);
             }
-            if (S == 2) nt_store(reinterpret_cast<float2 *>(y) + k, make_float2(re, im));
+            // post_op = 1 + a complex -> real element-wise operation folded into the store (ComplexMagnitude behind the AM receiver's tuner ...): Float32 out
+            if (S == 2 && post_op) y[k] = post_op == 1 + UN_CMAG ? unary_c2r<UN_CMAG>(re, im) : post_op == 1 + UN_CPHASE ? unary_c2r<UN_CPHASE>(re, im) : post_op == 1 + UN_CREAL ? re : im;
+            else if (S == 2) nt_store(reinterpret_cast<float2 *>(y) + k, make_float2(re, im));
             else y[k] = re;
         }
         __syncthreads();

@@ -705,8 +705,18 @@ lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, u
                     fused->out_size = 4;                // ComplexFloat32 in, Float32 out
                     if (fused->reset()) { delete fused; return nullptr; }
                 }
+                // ... [complex -> real element-wise block] behind an LDS-staged decimator (decimations without a Toeplitz instantiation: the AM / SSB / NBFM
+                // receivers' Tuner(…, 50)): ComplexMagnitude / ComplexPhase / ComplexToReal / ComplexToImag run on the accumulators, one launch less and the
+                // ComplexFloat32 tuner output never reaches HBM; the same Float32 operation on the same Float32 filter outputs = the unfused bits
+                static const bool no_unary_fold = getenv("LRHIP_NO_UNARY_FOLD") != nullptr;      // A/B knob
+                UnaryStage *un = (!no_unary_fold && !with_disc && after < nstages) ? dynamic_cast<UnaryStage *>(stages[after]) : nullptr;
+                const bool with_unary = un && fused->can_post_unary() && (un->op == UN_CMAG || un->op == UN_CPHASE || un->op == UN_CREAL || un->op == UN_CIMAG);
+                if (with_unary) {
+                    fused->post_unary = 1 + un->op;
+                    fused->out_size = 4;
+                }
                 c->ops.push_back({fused, true});
-                i = j + (ds ? 2 : 1) + (with_disc ? 1 : 0);
+                i = j + (ds ? 2 : 1) + (with_disc ? 1 : 0) + (with_unary ? 1 : 0);
                 continue;
             }
         }

@@ -51,6 +51,8 @@ struct FirStage : lrhip_stage {
     bool pre_disc = false;
     // fused FrequencyDiscriminatorBlock behind the filter (chains): ComplexFloat32 in, Float32 out (persistent MFMA kernel epilogue)
     bool post_disc = false;
+    int post_unary = 0;      // 1 + UN_CMAG / UN_CPHASE / UN_CREAL / UN_CIMAG folded into the LDS-staged decimator's store (chains: tuner -> ComplexMagnitude ...), Float32 out
+    bool can_post_unary() const { return S == 2 && D > 1 && !ksteps && decim_lds_ok() && !decfft && !pre_disc && !post_disc; }
     DeviceBuf edge;
     // fix-up of the wave-first discriminator outputs (disc_epilogue): done by fir_disc_fixup_kernel, or - defer_fixup - left to the next
     // stage of the chain, a pair-mode window filter that patches the samples as it stages them (FwcParams::fix_edge): one launch less
@@ -500,7 +502,7 @@ struct FirStage : lrhip_stage {
             long slots = (long)ctx().num_cus * decim_blocks_per_cu;
             unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, (const float *)d_taps.p, y, M, n, n_out, (long)index, (long)D, OW,
-                               ntiles, rot ? rot_step : (uint64_t)0, rot ? count : (uint64_t)0, ho);
+                               ntiles, rot ? rot_step : (uint64_t)0, rot ? count : (uint64_t)0, ho, post_unary);
             hist_in_kernel = ho != nullptr;
             return 0;
         };

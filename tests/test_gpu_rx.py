@@ -480,3 +480,63 @@ def test_tuner_reads_raw_records_in_its_launch(fmt, rotate, decim):
     g1, g2 = np.concatenate(g1), np.concatenate(g2)
     assert len(g1) == 2 * ((n + decim - 1) // decim)
     assert np.array_equal(g1.view(np.uint32), g2.view(np.uint32))
+
+
+@pytest.mark.parametrize("op", ["ComplexMagnitudeBlock", "ComplexPhaseBlock", "ComplexToRealBlock", "ComplexToImagBlock"])
+@pytest.mark.parametrize("records", [False, True])
+def test_complex_to_real_block_runs_in_the_decimators_store(op, records):
+    """examples/rtlsdr_am_envelope.lua:11-14: Tuner(offset, bw, 50) -> ComplexMagnitude.  Behind an LDS-staged decimator the complex -> real element-wise block
+    (complexmagnitude.lua / complexphase.lua / complextoreal.lua / complextoimag.lua) runs on the filter's accumulators: ONE launch (also on u8 records), and the
+    bits of the same Tuner chain followed by the stand-alone block, ragged chunks incl. one that emits nothing."""
+    import torch
+    from luaradio_amd import types
+    rng = np.random.default_rng(5)
+    n = 600007
+    fs = 1102500.0
+    raw = rng.integers(0, 256, n * 2, dtype=np.uint8)
+
+    def build(head, with_op):
+        blocks = head + [lr.FrequencyTranslatorBlock(-100e3), lr.LowpassFilterBlock(128, 5e3), lr.DownsamplerBlock(50)] + ([getattr(lr, op)()] if with_op else [])
+        r, t = fs, types.ComplexFloat32
+        for b in blocks[len(head):]:
+            b.rate = r
+            b.differentiate([t])
+            b.initialize()
+            r, t = b.get_rate(), b.get_output_type()
+        return lr.Chain(blocks)
+
+    def head():
+        if not records:
+            return []
+        src = lr.IQFileSource(bytes(16), "u8", fs)
+        src.initialize()
+        return [src]
+
+    host = lr.IQFileSource(raw.tobytes(), "u8", fs)
+    host.initialize()
+    xc = host.read_all()
+    fused, tuner = build(head(), True), build([], False)
+    alone = getattr(lr, op)()
+    alone.rate = fs / 50
+    alone.differentiate([types.ComplexFloat32])
+    alone.initialize()
+    d_in = torch.from_numpy(raw.copy()).cuda() if records else torch.from_numpy(xc.view(np.float32).copy()).cuda()
+    d_x = torch.from_numpy(xc.view(np.float32).copy()).cuda()
+    isz = 2 if records else 8
+    cap = fused.max_output(n) + 64
+    o1, o2 = torch.zeros(cap, device="cuda"), torch.zeros(2 * cap, device="cuda")
+    cuts = [0, 7, 8, 100000, 100049, 400002, n]
+    g1, g2 = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        m1 = fused.process_device(d_in.data_ptr() + isz * a, b - a, o1.data_ptr(), cap)
+        if b - a > 1000:
+            assert fused.last_launches == 1
+        m2 = tuner.process_device(d_x.data_ptr() + 8 * a, b - a, o2.data_ptr(), cap)
+        assert m1 == m2
+        torch.cuda.synchronize()
+        g1.append(o1[:m1].cpu().numpy().copy())
+        g2.append(o2[:2 * m2].cpu().numpy().copy())
+    g1, g2 = np.concatenate(g1), np.concatenate(g2).view(np.complex64)
+    want = alone.process(g2)
+    assert len(g1) == len(want) == (n + 49) // 50
+    assert np.array_equal(g1.view(np.uint32), want.view(np.uint32))
