@@ -151,6 +151,21 @@ struct FirStage : lrhip_stage {
         return 0;
     }
 
+    // a stage launches several instantiations over its life (raw records / converted samples on edge chunks, the bit-exact and the window-relative
+    // rotator): each gets its own attribute call and its own occupancy figure, queried once.  Returns workgroups per CU, or -1.
+    std::vector<std::pair<const void *, int>> prepared;
+    template <typename K>
+    int prepared_blocks(K kern, size_t lds_bytes, int threads = 256)
+    {
+        const void *kp = (const void *)kern;
+        for (const auto &e : prepared)
+            if (e.first == kp) return e.second;
+        int nb = 0;
+        if (prepare_kernel(kern, lds_bytes, &nb, threads)) return -1;
+        prepared.emplace_back(kp, nb);
+        return nb;
+    }
+
     template <int SS, int DD, int NACC, int KS, int NW = 4>
     int launch_mfma_ks(const float *x, long n, float *y, long n_out)
     {
@@ -180,7 +195,7 @@ struct FirStage : lrhip_stage {
         uint64_t rs = rot ? rot_step : 0, rc = rot ? count : 0;
         if constexpr (KS > 0) {
             auto launch = [&](auto kern) -> int {
-                if (!mfma_blocks_per_cu && prepare_kernel(kern, lds_bytes, &mfma_blocks_per_cu, 64 * NW)) return -1;     // queried once per stage
+                if ((mfma_blocks_per_cu = prepared_blocks(kern, lds_bytes, 64 * NW)) < 0) return -1;     // queried once per instantiation
                 long slots = (long)ctx().num_cus * mfma_blocks_per_cu;
                 unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
                 if (post_disc && edge.reserve((size_t)ntiles * 2 * NW * sizeof(float2))) return -1;
@@ -498,7 +513,7 @@ struct FirStage : lrhip_stage {
         const float *h = (const float *)hist[cur].p + hist_pad;
         float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
         auto go = [&](auto kern) -> int {
-            if (!decim_blocks_per_cu && prepare_kernel(kern, lds_bytes, &decim_blocks_per_cu)) return -1;
+            if ((decim_blocks_per_cu = prepared_blocks(kern, lds_bytes)) < 0) return -1;
             long slots = (long)ctx().num_cus * decim_blocks_per_cu;
             unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, (const float *)d_taps.p, y, M, n, n_out, (long)index, (long)D, OW,
