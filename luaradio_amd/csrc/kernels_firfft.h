@@ -351,8 +351,16 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #pragma unroll
                 for (int i = 0; i < 16; i++)
                     if (64 * i >= V) {
-                        da[64 * i] = accumulate ? da[64 * i] + v[i].x : v[i].x;
-                        db[64 * i] = accumulate ? db[64 * i] + v[i].y : v[i].y;
+#if LRHIP_FFT_NT >= 1
+                        if (!accumulate) {
+                            __builtin_nontemporal_store(v[i].x, da + 64 * i);
+                            __builtin_nontemporal_store(v[i].y, db + 64 * i);
+                        } else
+#endif
+                        {
+                            da[64 * i] = accumulate ? da[64 * i] + v[i].x : v[i].x;
+                            db[64 * i] = accumulate ? db[64 * i] + v[i].y : v[i].y;
+                        }
                     }
             } else {
 #pragma unroll
