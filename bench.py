@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the MI355X DSP block engine.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  With N > 1 and no launcher environment
+(WORLD_SIZE / RANK unset) the script starts its own N ranks - it re-executes itself under `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1` - the way the reference forks one process per block itself (radio/core/composite.lua:568-569);
+launched by torchrun (the driver's form) it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment and checks that WORLD_SIZE == --gpus.
+A box with fewer than N devices makes it exit non-zero with a message (never a silent `"n_gpus": 1`), unless --same-device (dry runs).
 
 Workloads (BASELINE.json configs):
   fir     (default; configs[1], the configuration the metric is quoted on) 128-tap real-taps FIR
@@ -11,7 +15,7 @@ Workloads (BASELINE.json configs):
   wbfm    (configs[2]) the examples/rtlsdr_wbfm_mono.lua chain, device-resident, on 2^26 RF samples.
   fanout  (configs[3]) one IQ slab broadcast from rank 0 to all ranks over RCCL, one Tuner branch per GPU.
 
-N > 1: one process per GPU (torchrun), each rank filters its own independent stream of the same size
+N > 1: one process per GPU (self-launched or torchrun, see above), each rank filters its own independent stream of the same size
 ("scaling": "weak", no data-path collective for fir/wbfm); value = samples processed by all ranks / max time.
 
 value = MSamples/s with inputs already in HBM.  roofline.achieved = algorithmic bytes (16 B/sample, SURVEY.md
@@ -55,7 +59,44 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed FIR output")
     ap.add_argument("--headline-only", action="store_true", help="fir workload: skip the wbfm_chain / channelizer / fanout legs of the line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (seconds of CPU work)")
+    ap.add_argument("--launch-check", action="store_true", help="every rank prints {rank, local_rank, world, gpus} and exits before touching a device: "
+                                                                "the self-launch of --gpus N exercised on a box without GPUs")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 outside a launcher: become `torch.distributed.run` with N ranks of this same command line
+    (radio/core/composite.lua:568-569: the reference starts its own processes, the user never does).  Returns only if no launch is needed."""
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if launched:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+        return
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus == 1:
+        return
+    if not args.launch_check:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus and not (args.same_device and have >= 1):
+            raise SystemExit("bench.py: --gpus %d asked for, %d device(s) visible on this box - refusing to print a line for fewer GPUs than "
+                             "requested (use --same-device --dist-backend gloo for a dry run of the multi-rank plumbing on one device)" % (args.gpus, have))
+        if args.same_device and args.dist_backend == "nccl":
+            raise SystemExit("bench.py: --same-device needs --dist-backend gloo (RCCL refuses two ranks on one device)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
 
 
 def _trials(fn, samples_per_call, seconds_per_trial, ntrials=5):
@@ -487,6 +528,11 @@ def fanout_records_report(lr, L, torch, dev, x, n, fs, offset):
 
 def main():
     args = parse()
+    self_launch(args)
+    if args.launch_check:
+        print(json.dumps({"launch_check": True, "rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                          "world": int(os.environ.get("WORLD_SIZE", "1")), "gpus": args.gpus}), flush=True)
+        return
     import numpy as np
     import torch
     import luaradio_amd as lr

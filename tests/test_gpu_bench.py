@@ -41,6 +41,39 @@ def test_timeshard_workload_verifies_its_partition_seams():
     assert d["verified"] is True and d["per_rank_verified"][0]["rms_err_vs_oracle"] <= 1e-5
 
 
+def _plain(*args, expect_rc=0):
+    """`python bench.py ...` with NO launcher environment: the script has to start its own ranks (radio/core/composite.lua:568-569)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, env=env)
+    assert (r.returncode == 0) == (expect_rc == 0), (r.returncode, r.stderr[-3000:])
+    return r
+
+
+@pytest.mark.parametrize("workload", ["timeshard", "fanout"])
+def test_plain_gpus_2_starts_two_ranks_by_itself(workload):
+    """`python bench.py --gpus 2` outside torchrun: two ranks, one JSON line from rank 0 with n_gpus == 2 and one verification entry per rank.
+    Both ranks share cuda:0 over gloo here (gpurun boxes have one GPU; the RCCL twin of this test cannot exist - RCCL refuses two ranks on one
+    device - so backend "nccl" with N > 1 meets hardware first in the driver's SCALE run)."""
+    r = _plain("--gpus", "2", "--dist-backend", "gloo", "--same-device", "--workload", workload, "--steps", "2", "--warmup", "1",
+               "--log2-samples", "24" if workload == "timeshard" else "22", "--no-cpu-baseline")
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["nranks"] == 2 and d["dist_backend"] == "gloo"
+    assert len(d["per_rank_verified"]) == 2 and d["verified"] is True
+    if workload == "timeshard":
+        assert d["scaling"] == "strong" and d["per_rank_verified"][0]["partition"][1] == d["per_rank_verified"][1]["partition"][0]
+    else:
+        assert [v["branch"] for v in d["per_rank_verified"]] == [0, 1]
+
+
+def test_more_gpus_than_the_box_has_is_an_error_not_a_one_gpu_line():
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = _plain("--gpus", str(n), "--steps", "1", "--warmup", "0", expect_rc=1)
+    assert "device(s) visible" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 @pytest.mark.parametrize("branch", range(8))
 def test_configs3_branch_settings_vs_oracle(branch):
     """BASELINE.json configs[3]: Tuner(offset_b, 100e3, 5), offsets -350 kHz .. +350 kHz, on 2^22 U(-1, 1) samples against the oracle Tuner

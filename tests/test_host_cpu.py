@@ -2,6 +2,7 @@
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -217,3 +218,39 @@ def test_fir_mode_table_matches_the_lua_glue():
         assert block.fir_mode(None) == 0
     finally:
         block.TESTS_JIGS_LOADED = saved
+
+
+def _bench_plain(*args):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, env=env), env
+
+
+def test_bench_gpus_n_launches_n_ranks_by_itself():
+    """`--gpus` was parsed and dropped.  `python bench.py --gpus 2` with no launcher environment re-executes itself under
+    torch.distributed.run with two ranks (the reference forks its own processes, radio/core/composite.lua:568-569); --launch-check makes every
+    rank report and exit before it needs a device, so this runs on a box without GPUs"""
+    import json
+    r, env = _bench_plain("--gpus", "2", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = sorted((d["rank"], d["local_rank"], d["world"], d["gpus"]) for d in (json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")))
+    assert seen == [(0, 0, 2, 2), (1, 1, 2, 2)]
+    # one rank: no launcher in between
+    r, _ = _bench_plain("--gpus", "1", "--launch-check")
+    assert r.returncode == 0 and json.loads(r.stdout.strip())["world"] == 1
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    import subprocess
+    r, env = _bench_plain("--gpus", "1", "--launch-check")
+    env = dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_without_enough_devices_exits_nonzero():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("box with GPUs: covered by tests/test_gpu_bench.py")
+    r, _ = _bench_plain("--gpus", "8", "--steps", "1")
+    assert r.returncode != 0 and "8 asked for, 0 device(s) visible" in r.stderr and "n_gpus" not in r.stdout
