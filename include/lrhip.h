@@ -11,8 +11,11 @@
  *   - `lrhip_stage_execute(q, in, n, out, cap)` is one block's process(): host pointers in, host pointers
  *     out, returns the number of output samples written (>= 0) or < 0 on error.  All cross-call state
  *     (FIR history, rotator phase, downsampler index, discriminator previous sample, IIR state) lives in
- *     the stage object on the device, so arbitrary chunking gives identical sample values
- *     (the property tests/jigs.lua:213-250 pins with one-sample chunks).
+ *     the stage object on the device, so arbitrary chunking gives identical sample values for every block on
+ *     its own in direct form (the property tests/jigs.lua:213-250 pins with one-sample chunks).  Overlap-save
+ *     filters and the fused forms a DEFAULT chain takes (listed at lrhip_chain_create) agree across chunkings
+ *     to Float32 rounding (<= 1e-6 / 2e-7), not bit for bit; lrhip_chain_create_ex(.., LRHIP_CHAIN_EXACT)
+ *     restores the bits.
  *   - `lrhip_stage_destroy(q)` is bound with ffi.gc.
  *   - Sample layouts are the reference's: ComplexFloat32 = struct{float real, imag} (8 B, interleaved,
  *     radio/types/complexfloat32.lua:19-24), Float32 = struct{float value} (4 B, radio/types/float32.lua:17-21).
@@ -181,11 +184,20 @@ long lrhip_stage_execute2_device(lrhip_stage_t *q, const void *in1_dev, const vo
  * _prepare_to_run would build, radio/core/composite.lua:426): one H2D at the head, one D2H at the tail,
  * intermediate vectors never leave HBM.  The chain borrows the stages (caller keeps ownership) and fuses
  * adjacent stages where a fused kernel exists (rotator -> FIR -> downsampler, FIR -> downsampler, ... -> discriminator, the 1/5-rate
- * audio tail of the FM receivers).  A chain gives the values of its blocks run one by one - the same bits, with three stated exceptions:
- * overlap-save filters (Float32 FFT arithmetic: the blocks of a chunk fall where the chunk starts, <= 1e-6), the polyphase audio tail
- * (FIR -> single-pole IIR -> downsampler as one decimating filter, ~2e-8 RMS), and a frequency translator fused in front of a filter
- * whose output only the discriminator sees: there a tile's window is rotated relative to its first sample, which leaves the angles
- * unchanged to Float32 rounding of the filter outputs.  lrhip_chain_create_ex() below switches each of the last two off per chain. */
+ * audio tail of the FM receivers).  A chain gives the values of its blocks run one by one - the same bits, with FIVE stated exceptions
+ * (each a different rounding of the same mathematics, none above 1e-6 of the exact result):
+ *   1. overlap-save filters (Float32 FFT arithmetic: the blocks of a chunk fall where the chunk starts, <= 1e-6);
+ *   2. the polyphase audio tail (FIR -> single-pole IIR -> downsampler as one decimating filter, ~2e-8 RMS);
+ *   3. a frequency translator fused in front of a filter whose output only the discriminator sees: a tile's window is rotated relative to
+ *      its first sample, which leaves the angles unchanged to Float32 rounding of the filter outputs;
+ *   4. the FM receiver in ONE launch (kernels_rx.h; the default for the tuner + discriminator + audio-tail shape of
+ *      examples/rtlsdr_wbfm_mono.lua:12-17 whose de-emphasis pole q at the audio rate satisfies q^75 <= 2^-25): the recurrence of every
+ *      workgroup run restarts from a zero state 75 audio samples early and the runs fall with the chunk length, so the audio depends on
+ *      the chunking and on the grid to <= 2e-7 (tests/test_gpu_rx.py), and time partitions agree with the single stream to 1e-7
+ *      rather than bit for bit;
+ *   5. consecutive overlap-save filters on a ComplexFloat32 stream merged into ONE filter with the taps convolved in double (up to 1 281
+ *      taps): rounds once where the cascade rounds per stage, <= 1e-6 of the exact cascade.
+ * lrhip_chain_create_ex() below switches 2-5 off per chain (LRHIP_CHAIN_EXACT); 1 is chosen per filter (use_fft = 0: direct form). */
 lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages);
 /* The numerical contract per chain (what a LuaRadio script sets as DeviceChainBlock.exact, lua/radio/composites/devicechain.lua).
  * lrhip_chain_create(stages, n) == lrhip_chain_create_ex(stages, n, 0).  Flags:
@@ -254,6 +266,14 @@ unsigned long lrhip_chain_push_bound(const lrhip_chain_t *c, unsigned long n_in)
  * partial batch and returns its output from the same call.  0 (the default) = batches run only when full (file / benchmark sources,
  * which deliver faster than real time).  Sample values do not depend on where batches are cut. */
 int  lrhip_chain_set_latency(lrhip_chain_t *c, double max_seconds);
+/* The wall-clock side of that bound, for a source that STALLS: push() can only look at the clock when it is called, so a live graph whose
+ * upstream goes quiet would leave the partial batch unlaunched, where the reference streams every chunk through as it arrives
+ * (radio/core/block.lua:575-602).  The host waits for input at most lrhip_chain_poll_due() seconds (-1: nothing pending or no latency bound -
+ * wait forever, as PipeMux:_read_single does, radio/core/pipe.lua:495-533; 0: due now) and calls lrhip_chain_poll() when that wait timed
+ * out: a partial batch whose oldest sample has waited max_seconds is launched and its output returned from the call, finished batches are
+ * handed out either way, and with nothing due it returns 0 at once.  out_capacity >= lrhip_chain_push_bound(c, 0). */
+long lrhip_chain_poll(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
+double lrhip_chain_poll_due(const lrhip_chain_t *c);
 /* Number of kernels launched by the last chain execute (diagnostic for the fusion tests). */
 int lrhip_chain_last_launches(const lrhip_chain_t *c);
 
@@ -269,8 +289,10 @@ int lrhip_chain_last_launches(const lrhip_chain_t *c);
  *       execute(x[n0-H .. n0)) with the output discarded - so that every carried state equals the uninterrupted stream's (filter
  *       histories exactly; recurrences to Float32 underflow of their zero start).  -1 (with lrhip_strerror) when a stage of the
  *       chain has unbounded memory (AGC, frequency modulator, a recurrence that does not decay): such a chain cannot be sharded
- *       in time.  Outputs of the partition [n0, n1) are then the same VALUES as samples of the single-stream run; with partition
- *       boundaries on multiples of lrhip_chain_shard_align(c) input samples also bit for bit.
+ *       in time.  Outputs of the partition [n0, n1) are then the same VALUES as samples of the single-stream run (to the Float32
+ *       rounding stated at lrhip_chain_create: <= 1e-7 for the default single-launch receiver and overlap-save filters); with
+ *       partition boundaries on multiples of lrhip_chain_shard_align(c) input samples AND a chain built with LRHIP_CHAIN_NO_SINGLE_LAUNCH
+ *       (or LRHIP_CHAIN_EXACT) on direct-form filters also bit for bit.
  *   lrhip_chain_shard_align(c): partition boundaries on multiples of this many input samples give every scan kernel of the chain the
  *       tile grid of the uninterrupted run (1 for chains of filters / rotators / discriminators / downsamplers; 5 120 for a tuner
  *       fused with the discriminator behind it, whose tiles are rotated relative to their first sample; 128 000 for the WBFM receiver:

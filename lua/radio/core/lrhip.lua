@@ -78,6 +78,8 @@ long lrhip_chain_push(lrhip_chain_t *c, const void *in_host, unsigned long n_in,
 long lrhip_chain_flush(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
 unsigned long lrhip_chain_push_bound(const lrhip_chain_t *c, unsigned long n_in);
 int lrhip_chain_set_latency(lrhip_chain_t *c, double max_seconds);
+long lrhip_chain_poll(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
+double lrhip_chain_poll_due(const lrhip_chain_t *c);
 
 void *lrhip_malloc(unsigned long bytes);
 void lrhip_free(void *dev_ptr);

@@ -74,6 +74,8 @@ SIGNATURES = {
     "lrhip_chain_flush": (C.c_long, [_vp, _vp, _ul]),
     "lrhip_chain_push_bound": (_ul, [_vp, _ul]),
     "lrhip_chain_set_latency": (C.c_int, [_vp, C.c_double]),
+    "lrhip_chain_poll": (C.c_long, [_vp, _vp, _ul]),
+    "lrhip_chain_poll_due": (C.c_double, [_vp]),
     "lrhip_malloc": (_vp, [_ul]),
     "lrhip_free": (None, [_vp]),
     "lrhip_memcpy_h2d": (C.c_int, [_vp, _vp, _ul]),

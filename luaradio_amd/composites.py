@@ -157,6 +157,21 @@ class Chain:
         _lib.check(n, "chain:push")
         return self._ring_out[:n].copy()
 
+    def poll(self):
+        """The host's wait for input timed out (lrhip_chain_poll): a partial batch whose oldest sample has waited out the latency bound is
+        launched and returned, finished batches are handed out; empty when nothing is due."""
+        L = _lib.load()
+        need = max(1, L.lrhip_chain_push_bound(self._chain, 0))
+        if self._ring_out is None or len(self._ring_out) < need:
+            self._ring_out = np.empty(need, dtype=self.out_type.dtype)
+        n = L.lrhip_chain_poll(self._chain, self._ring_out.ctypes.data_as(C.c_void_p), len(self._ring_out))
+        _lib.check(n, "chain:poll")
+        return self._ring_out[:n].copy()
+
+    def poll_due(self):
+        """seconds the host may wait for input before calling poll() (lrhip_chain_poll_due): -1 = forever (nothing pending / no latency bound)"""
+        return float(_lib.load().lrhip_chain_poll_due(self._chain))
+
     def flush(self):
         """Launch the partly filled batch, wait, return everything still pending (EOF / cleanup)."""
         L = _lib.load()

@@ -189,6 +189,19 @@ struct CopyPool {
     std::atomic<size_t> next{0};
     std::atomic<int> generation{0}, running{0};
     bool stop = false;
+    std::mutex job;                              // one job at a time: a second host thread calling into the library meanwhile (ctypes releases the GIL;
+                                                 // two chains on two Python threads) copies on its own instead of overwriting dst / src / next
+
+    static inline void cpu_relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        __asm__ __volatile__("yield");
+#else
+        std::this_thread::yield();
+#endif
+    }
 
     void work()
     {
@@ -205,9 +218,11 @@ struct CopyPool {
         for (;;) {
             // a megabyte copies in ~25 us on four threads - less than a condition-variable wake-up: spin for a while first (chunks arrive back to
             // back while a stream runs), sleep when the stream pauses
+            // (LRHIP_COPY_SPIN iterations, default 4000 = some tens of microseconds: a LuaRadio graph is one process per block, and every one of them
+            // would otherwise keep its helper threads spinning for most of a millisecond per chunk)
             int spins = 0;
-            while (generation.load(std::memory_order_acquire) == seen && spins < 20000) {
-                __builtin_ia32_pause();
+            while (generation.load(std::memory_order_acquire) == seen && spins < spin_limit) {
+                cpu_relax();
                 spins++;
             }
             if (generation.load(std::memory_order_acquire) == seen) {
@@ -220,8 +235,10 @@ struct CopyPool {
             running.fetch_sub(1, std::memory_order_release);
         }
     }
+    int spin_limit = 4000;
     void start()
     {
+        if (const char *sp = getenv("LRHIP_COPY_SPIN")) { spin_limit = atoi(sp); if (spin_limit < 0) spin_limit = 0; }
         const char *e = getenv("LRHIP_COPY_THREADS");
         int n = e ? atoi(e) : 8;
         const unsigned hw = std::thread::hardware_concurrency();
@@ -233,6 +250,8 @@ struct CopyPool {
     }
     void copy(void *d, const void *s_, size_t n)
     {
+        std::unique_lock<std::mutex> one(job, std::try_to_lock);
+        if (!one.owns_lock()) { memcpy(d, s_, n); return; }
         dst = (char *)d; src = (const char *)s_; bytes = n;
         part = ((n / (size_t)(4 * nthreads)) + 4095) & ~(size_t)4095;      // a few parts per thread, page multiples
         if (part < 65536) part = 65536;
@@ -244,7 +263,7 @@ struct CopyPool {
         }
         cv_work.notify_all();
         work();
-        while (running.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+        while (running.load(std::memory_order_acquire) != 0) cpu_relax();
     }
 };
 inline void host_copy(void *dst, const void *src, size_t bytes)
@@ -257,6 +276,25 @@ inline void host_copy(void *dst, const void *src, size_t bytes)
     }
     if (!pool || pool->nthreads <= 1) { memcpy(dst, src, bytes); return; }
     pool->copy(dst, src, bytes);
+}
+
+// Ablation switches (LRHIP_RX_DBG, LRHIP_DECFFT_DBG, LRHIP_INTERP_DBG) remove parts of a kernel to time the rest: the results are WRONG by
+// design.  A release build ignores them (a stray environment variable must not silently corrupt audio); `make ABLATION=1` builds the
+// library that honours them, and says so on stderr the first time one is used.
+inline int ablation_bits(const char *name)
+{
+#ifdef LRHIP_ABLATION
+    const char *e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    if (v) {
+        static bool told = false;
+        if (!told) { fprintf(stderr, "liblrhip: ablation build, %s=%d - results are wrong on purpose\n", name, v); told = true; }
+    }
+    return v;
+#else
+    (void)name;
+    return 0;
+#endif
 }
 
 // Streaming kernels are launched ONE-SHOT: a workgroup per 256 work items, every thread one item (the grid-stride loops in

@@ -1110,6 +1110,34 @@ static long push_collect(lrhip_chain_t *c, char *out, unsigned long cap, bool wa
     return lrhip_chain_collect(c, out, cap);
 }
 
+// the tail of push() and all of poll(): run the partial batch if its oldest sample has waited out the latency bound (and then wait for it: a live
+// flow graph is far from the GPU's throughput, so the wait costs a launch, not the stream rate), then hand out whatever has finished, in stream order
+static long push_drain(lrhip_chain_t *c, char *dst, unsigned long out_capacity, long total)
+{
+    const int out_size = c->ops.back().stage->out_size;
+    if (c->fill && c->max_latency > 0.0 && monotonic_seconds() - c->fill_t0 >= c->max_latency) {
+        if (c->inflight == c->ring.size()) {
+            long got = push_collect(c, dst + (size_t)total * out_size, out_capacity - (unsigned long)total, true);
+            if (got < 0) return got;
+            total += got;
+        }
+        long rc = push_launch(c);
+        if (rc < 0) return rc;
+        while (c->inflight) {
+            long got = push_collect(c, dst + (size_t)total * out_size, out_capacity - (unsigned long)total, true);
+            if (got < 0) return got;
+            total += got;
+        }
+    }
+    while (c->inflight) {                                    // whatever has finished meanwhile, without waiting
+        long got = push_collect(c, dst + (size_t)total * out_size, out_capacity - (unsigned long)total, false);
+        if (got == -2) break;
+        if (got < 0) return got;
+        total += got;
+    }
+    return total;
+}
+
 unsigned long lrhip_chain_push_bound(const lrhip_chain_t *c, unsigned long n_in)
 {
     if (!c || c->ring.empty()) return 0;
@@ -1143,29 +1171,29 @@ long lrhip_chain_push(lrhip_chain_t *c, const void *in_host, unsigned long n_in,
             if (rc < 0) return rc;
         }
     }
-    // latency bound (live sources): the oldest pushed sample has waited long enough - run the partial batch now and hand its output back
-    // from this call (a live flow graph is far from the GPU's throughput, so the wait costs a launch, not the stream rate)
-    if (c->fill && c->max_latency > 0.0 && monotonic_seconds() - c->fill_t0 >= c->max_latency) {
-        if (c->inflight == c->ring.size()) {
-            long got = push_collect(c, dst + (size_t)total * out_size, out_capacity - (unsigned long)total, true);
-            if (got < 0) return got;
-            total += got;
-        }
-        long rc = push_launch(c);
-        if (rc < 0) return rc;
-        while (c->inflight) {
-            long got = push_collect(c, dst + (size_t)total * out_size, out_capacity - (unsigned long)total, true);
-            if (got < 0) return got;
-            total += got;
-        }
-    }
-    while (c->inflight) {                                    // whatever has finished meanwhile, in stream order, without waiting
-        long got = push_collect(c, dst + (size_t)total * out_size, out_capacity - (unsigned long)total, false);
-        if (got == -2) break;
-        if (got < 0) return got;
-        total += got;
-    }
-    return total;
+    return push_drain(c, dst, out_capacity, total);
+}
+
+// The wall-clock side of the latency bound.  push() can only look at the clock when it is called; a live source that STALLS (an SDR that
+// drops out, a squelched upstream block, a paused network source) would leave the partial batch on the device side of the host forever,
+// where the reference streams every chunk through as it arrives (radio/core/block.lua:575-602).  The host calls poll() whenever its wait for
+// input timed out (lua/radio/composites/devicechain.lua: DeviceChainBlock:run polls its input descriptors for lrhip_chain_poll_due()
+// seconds instead of forever): a partial batch whose oldest sample has waited max_seconds is launched and its output returned from this
+// call, like the same check at the end of push(); finished batches are handed out either way.  Nothing due: returns 0 at once.
+long lrhip_chain_poll(lrhip_chain_t *c, void *out_host, unsigned long out_capacity)
+{
+    if (!c) return set_error("null chain");
+    if (c->ring.empty()) return 0;
+    if (out_capacity < lrhip_chain_push_bound(c, 0)) return set_error("output capacity %lu < lrhip_chain_push_bound() = %lu", out_capacity, lrhip_chain_push_bound(c, 0));
+    return push_drain(c, (char *)out_host, out_capacity, 0);
+}
+
+double lrhip_chain_poll_due(const lrhip_chain_t *c)
+{
+    if (!c) { set_error("null chain"); return -1.0; }
+    if (!c->fill || !(c->max_latency > 0.0)) return -1.0;                 // nothing pending, or batches only run when full: wait for input forever
+    const double left = c->fill_t0 + c->max_latency - monotonic_seconds();
+    return left > 0.0 ? left : 0.0;
 }
 
 long lrhip_chain_flush(lrhip_chain_t *c, void *out_host, unsigned long out_capacity)

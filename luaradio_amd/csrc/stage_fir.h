@@ -456,7 +456,7 @@ struct FirStage : lrhip_stage {
                 if (!fft_blocks_per_cu && prepare_kernel(kern, lds_bytes, &fft_blocks_per_cu, 64 * FFT_WPB)) return -1;
                 long slots = (long)ctx().num_cus * fft_blocks_per_cu;
                 long want = (nffts + FFT_WPB - 1) / FFT_WPB;
-                const int rounds_env = getenv("LRHIP_FFT_ROUNDS") ? atoi(getenv("LRHIP_FFT_ROUNDS")) : -1;      // A/B knob
+                static const int rounds_env = getenv("LRHIP_FFT_ROUNDS") ? atoi(getenv("LRHIP_FFT_ROUNDS")) : -1;      // A/B knob, read once
                 // one-shot order with 8 batches per workgroup once the launch exceeds the resident slots: 316 GS/s against 263-314
                 // (run-to-run spread) for the persistent stride on 2^28 samples, same box, alternating
                 // (only when the launch is many times the resident slots: a 2^26-sample chain's 1/5-rate audio filter, 1 873 workgroups
@@ -549,13 +549,13 @@ struct FirStage : lrhip_stage {
         pr.cD = make_float2((float)std::cos(wD), (float)std::sin(wD));
         pr.inv_gain = 1.0 / disc_gain;
         pr.taps_rev = (const float *)d_taps.p; pr.taps_complex = taps_complex;
-        pr.dbg = getenv("LRHIP_DECFFT_DBG") ? atoi(getenv("LRHIP_DECFFT_DBG")) : 0;      // ablation knob (tools/ab_decfft.py)
+        pr.dbg = ablation_bits("LRHIP_DECFFT_DBG");      // ablation knob (tools/ab_decfft.py): 0 unless the library was built with -DLRHIP_ABLATION
         const float *h = (const float *)hist[cur].p + hist_pad;
         float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
         auto go = [&](auto kern) -> int {
             if (!dec_blocks_per_cu && prepare_kernel(kern, lds_bytes, &dec_blocks_per_cu)) return -1;
             const long nquads = (pr.nblocks + 3) / 4, slots = (long)ctx().num_cus * dec_blocks_per_cu;
-            const int rounds_env = getenv("LRHIP_DECFFT_ROUNDS") ? atoi(getenv("LRHIP_DECFFT_ROUNDS")) : 0;      // A/B knob
+            static const int rounds_env = getenv("LRHIP_DECFFT_ROUNDS") ? atoi(getenv("LRHIP_DECFFT_ROUNDS")) : 0;      // A/B knob, read once
             // one-shot order (common.h grid_for): workgroups of 4 waves x `rounds` consecutive quads, handed out in address order.  More
             // quads per wave amortise the table load and the first (unhidden) window request; same-box A/B at 2^26 samples:
             // rounds 1 / 2 / 4 = 0.171 / 0.167 / 0.164 ms
@@ -720,7 +720,8 @@ struct FirStage : lrhip_stage {
                 fix_src->fix_ready = false;
             }
             pr.run = (pr.ntiles + slots - 1) / slots;
-            if (getenv("LRHIP_TAIL_RUN")) pr.run = atol(getenv("LRHIP_TAIL_RUN"));      // A/B knob
+            static const long tail_run_env = getenv("LRHIP_TAIL_RUN") ? atol(getenv("LRHIP_TAIL_RUN")) : 0;      // A/B knob, read once
+            if (tail_run_env > 0) pr.run = tail_run_env;
             grid = (unsigned)((pr.ntiles + pr.run - 1) / pr.run);
         } else {
             pr.warm_waves = 4; pr.run = 1;

@@ -58,7 +58,7 @@ struct ResampleStage : lrhip_stage {
                 }
                 const long ntiles = ((long)n + tq - 1) / tq, slots = (long)ctx().num_cus * interp_blocks_per_cu;
                 hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < slots ? ntiles : slots)), dim3(256), lds_bytes, ctx().stream, h, (const float *)in_dev, (const float *)d_ttab.p,
-                                   (float *)out_dev, (long)n, HQ, c, ho, getenv("LRHIP_INTERP_DBG") ? atoi(getenv("LRHIP_INTERP_DBG")) : 0);
+                                   (float *)out_dev, (long)n, HQ, c, ho, ablation_bits("LRHIP_INTERP_DBG"));
                 return 0;
             };
 #define LR_INTERP(LL, JJ) gi(fir_interp_kernel<LL, JJ>, (size_t)FipGeom<LL, JJ>::LDS_FLOATS * sizeof(float), FipGeom<LL, JJ>::TQ)

@@ -41,9 +41,21 @@ struct RxStage : lrhip_stage {
         return lcm(lcm(A->align(), (unsigned long)A->D * B->align()), (unsigned long)RX_BATCH * RX_D);
     }
 
+    // The single launch restarts the low-rate recurrence of every workgroup run from a ZERO state RX_WARM_OUTPUTS audio samples early
+    // (kernels_rx.h: the tile in front of the run).  What is left of the true state there is q^75 of it: 1.4e-10 for the stock de-emphasis
+    // (75 us at 220.5 kHz: q = 0.739), but fuse_iir1() admits poles up to q^1280 < 1e-12 (the two-launch form warms up over up to four waves).
+    // A slower pole - the same receiver at 2.048 / 2.4 MS/s, a longer time constant - would leave a seam at every run boundary, so such chains
+    // keep the two-launch form.  Bound: half an ulp of unit-scale audio.
+    static constexpr int RX_WARM_OUTPUTS = 75;
+    static bool pole_ok(const FirStage *b)
+    {
+        const double q = std::fabs((double)b->iir_na1 + (double)b->iir_na1_lo);
+        return q < 1.0 && std::pow(q, (double)RX_WARM_OUTPUTS) <= 0x1p-25;
+    }
+
     static bool shapes_ok(const FirStage *a, const FirStage *b)
     {
-        return a && b && a->S == 2 && !a->taps_complex && a->D == 5 && a->M == RX_M && a->ksteps == RX_KS && a->rot && a->rel_rot && a->post_disc &&
+        return a && b && b->iir_fused && pole_ok(b) && a->S == 2 && !a->taps_complex && a->D == 5 && a->M == RX_M && a->ksteps == RX_KS && a->rot && a->rel_rot && a->post_disc &&
                !a->decfft && !a->fft_arith && !a->use_fft && !a->win_cplx_ok() && b->S == 1 && b->M == RX_MT && b->D == 5 && b->ksteps == RX_KST && b->d_atab.p && b->iir_fused && b->win_pair_ok();
     }
 
@@ -135,10 +147,11 @@ struct RxStage : lrhip_stage {
         pr.state_in = (const float *)B->iir_state[B->iir_cur].p; pr.state_out = (float *)B->iir_state[B->iir_cur ^ 1].p;
         // one round of workgroups: as many as fit the chip at once; a run costs one extra tile, so short chunks take fewer, longer runs
         long wgs = (long)ctx().num_cus * bpc;
-        if (getenv("LRHIP_RX_WGS_PER_CU")) wgs = (long)ctx().num_cus * atol(getenv("LRHIP_RX_WGS_PER_CU"));      // A/B knob
+        static const long env_wgs = getenv("LRHIP_RX_WGS_PER_CU") ? atol(getenv("LRHIP_RX_WGS_PER_CU")) : 0;       // A/B knob, read once
+        if (env_wgs > 0) wgs = (long)ctx().num_cus * env_wgs;
         const long most = (pr.ntiles + 7) / 8;
         if (wgs < 1 || wgs > most) wgs = most;
-        pr.dbg = getenv("LRHIP_RX_DBG") ? atoi(getenv("LRHIP_RX_DBG")) : 0;      // ablation bits (wrong results)
+        pr.dbg = ablation_bits("LRHIP_RX_DBG");      // ablation bits (WRONG results): 0 unless the library was built with -DLRHIP_ABLATION
         const unsigned grid = (unsigned)wgs;
         (void)with_kernel([&](auto kern) -> int { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, pr); return 0; });
         LR_LAUNCH_CHECK();

@@ -55,6 +55,53 @@ def test_single_launch_vs_oracle_and_two_launch_form():
     assert float(d[len(d) // 2:].max()) < 2e-7 and float(d.max()) < 2e-7
 
 
+def _oracle_receiver(fs, tau):
+    """oracle.wbfm_mono_chain with the time constant as a parameter (examples/rtlsdr_wbfm_mono.lua:12-17 with another FMDeemphasisFilter argument)"""
+    r1 = fs / 5
+    b, a = O.fm_deemphasis_taps(tau, r1)
+    return O.Chain(O.tuner(-250e3, 200e3, 5, fs, mode=O.MODE_LUA, rot_mode=O.MODE_F64).stages +
+                   [O.FMDiscriminator(1.25), O.lowpass(128, 15e3, r1, False, mode=O.MODE_LUA), O.IIR(b, a, False, O.MODE_LUA), O.Downsampler(5, False)])
+
+
+@pytest.mark.parametrize("fs,tau,single", [(1102500.0, 75e-6, True), (1102500.0, 50e-6, True), (2400000.0, 75e-6, False), (2048000.0, 75e-6, False),
+                                           (1102500.0, 750e-6, False)])
+def test_slow_deemphasis_poles_keep_the_two_launch_form(fs, tau, single):
+    """the single launch warms the low-rate recurrence of every workgroup run over 75 zero-state audio outputs, which only
+    covers poles with q^75 <= 2^-25 (stock: 75 us at 220.5 kHz, q = 0.739, q^75 = 1.4e-10).  The same receiver at 2.4 / 2.048 MS/s (q = 0.87 / 0.85)
+    or with a long time constant must NOT take it: run boundaries would carry an error of q^75 of the state, above the 1e-6 contract.  Such chains
+    run the two-launch form, whose warm-up scales with the pole, and agree with the oracle chain everywhere - also far from the stream's start."""
+    from luaradio_amd import blocks as B, composites as C
+    n = 3000000
+    rng = np.random.default_rng(21)
+    t = np.arange(n) / fs
+    m = 0.5 * np.sin(2 * np.pi * 1e3 * t) + 0.5 * np.sin(2 * np.pi * 5e3 * t)
+    x = (np.exp(1j * (2 * np.pi * 250e3 * t + 2 * np.pi * 75e3 / fs * np.cumsum(m))) + 0.01 * (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n))).astype(np.complex64)
+
+    def blocks():
+        af = B.LowpassFilterBlock(128, 15e3)
+        af.use_fft = 3
+        return [C.TunerBlock(-250e3, 200e3, 5), B.FrequencyDiscriminatorBlock(1.25), af, B.FMDeemphasisFilterBlock(tau), B.DownsamplerBlock(5)]
+
+    rx = C._receiver(blocks(), fs)
+    got = rx.process(x)
+    assert rx.chain.last_launches == (1 if single else 2)
+    two = C._receiver(blocks(), fs)
+    two._chain = lr.Chain(two._blocks, _lib.CHAIN_NO_SINGLE_LAUNCH)
+    ref = two.process(x)
+    assert len(got) == len(ref) == (n + 24) // 25
+    if single:
+        assert float(np.max(np.abs(got - ref))) < 2e-7
+    else:
+        assert np.array_equal(got, ref)                 # it IS the two-launch form
+    # against the oracle chain over the last 20 % of the stream (dozens of run boundaries in front of it)
+    lo = (n * 4 // 5) // 25 * 25
+    warm = 400000 // 25 * 25
+    want = _oracle_receiver(fs, tau).process(x[lo - warm:])[warm // 25:]
+    k = min(len(want), len(got) - lo // 25) - 8
+    err = got[lo // 25:lo // 25 + k].astype(np.float64) - want[:k]
+    assert float(np.max(np.abs(err))) < 1e-6, float(np.max(np.abs(err)))
+
+
 @pytest.mark.parametrize("cuts", [[1], [5], [24, 25, 26], [8192, 8193, 500000], [12800 * 7, 12800 * 7 + 3, 12800 * 7 + 9, 1500000],
                                   list(range(100000, 2000000, 333337)), list(range(8192, 400000, 8192))])
 def test_chunking_changes_nothing_but_float32_rounding(cuts):
