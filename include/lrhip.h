@@ -41,6 +41,10 @@ int lrhip_init(int device);
 const char *lrhip_strerror(void);
 /* Number of visible HIP devices (for the fan-out scheduler), or < 0 on error. */
 int lrhip_device_count(void);
+/* The device this process's library is bound to (what lrhip_init chose; the dst_device / src_device of lrhip_peer_copy), -1 before the
+ * first lrhip_init / stage creation.  One device per process: after a successful lrhip_init(d) a later lrhip_init(d2) with d2 >= 0 and
+ * d2 != d fails - LuaRadio runs one process per block (radio/core/composite.lua:569), so "a branch per GPU" is "a device per process". */
+int lrhip_device(void);
 /* Launch all subsequent work on an externally owned hipStream_t (NULL => the library's own non-blocking stream; HIP's explicit handles
  * hipStreamLegacy = (hipStream_t)1 and hipStreamPerThread = (hipStream_t)2 are accepted - a host that keeps its vectors on the default
  * stream passes 1).  Work already queued on the previous stream is ordered before whatever follows on the new one. */

@@ -34,10 +34,20 @@ local DeviceChainBlock = block.factory("DeviceChainBlock")
 -- call (radio/blocks/sources/iqfile.lua:52), a pipe at most 131 072 (radio/core/pipe.lua:495-533)
 DeviceChainBlock.batch_samples = 1048576
 DeviceChainBlock.ring_depth = 3
--- LIVE flow graphs: a batch is also launched once its oldest sample has waited this long (seconds, wall clock), so an RTL-SDR at
--- 1.1 MS/s sees ~22 000-sample batches every 20 ms instead of waiting a second for 2^20 samples, and an audio-rate chain does not
--- sit on minutes of samples; file and benchmark sources deliver faster than real time and still fill whole batches.  0 = off.
-DeviceChainBlock.max_latency = 0.02
+-- LIVE flow graphs (an SDR source, a network source): set max_latency (seconds, wall clock) and a batch is also launched once its
+-- oldest sample has waited that long, so an RTL-SDR at 1.1 MS/s sees ~22 000-sample batches every 20 ms instead of waiting a second
+-- for 2^20 samples, and an audio-rate chain does not sit on minutes of samples.  The bound is kept even when the source STALLS:
+-- DeviceChainBlock:run() waits for input only as long as the pending batch may still wait (lrhip_chain_poll_due) and hands the
+-- batch on when that wait times out (lrhip_chain_poll) - the reference streams every chunk through as it arrives
+-- (radio/core/block.lua:575-602).  0 (the default) = batches run only when full: file and benchmark sources deliver faster than real
+-- time, and where a batch is cut decides the Float32 rounding of overlap-save filters and of the single-launch receiver
+-- (include/lrhip.h, "chains"), so clock-cut batches would make a file's output bits differ from run to run.
+DeviceChainBlock.max_latency = 0
+-- Placement: the index of the device this chain's process binds to (lrhip.ensure wraps it over the devices of the box).  nil = the
+-- library's default device / LUARADIO_HIP_DEVICE.  collapse() numbers the chains that read ONE fanned-out output port 0, 1, 2, ...
+-- (radio/core/block.lua:119-166, radio/core/pipe.lua:617-627: one OutputPort, several readers, each reader its own process), so
+-- `source -> 8 x Tuner` runs one branch per GPU on an 8-GPU node; set it by hand on the object collapse() returns to override.
+DeviceChainBlock.device = nil
 -- the chain's numerical contract (lrhip_chain_create_ex flags): false = fused kernels with the stated roundings of
 -- include/lrhip.h (window-relative rotator staging, the polyphase audio tail, consecutive overlap-save filters merged into one
 -- filter, the single-launch FM receiver); true = lrhip.CHAIN_EXACT, what the member blocks compute one by one; or a flag number.
@@ -62,7 +72,7 @@ function DeviceChainBlock:initialize()
 end
 
 local function create_chain(self)
-    lrhip.ensure()
+    lrhip.ensure(self.device)       -- binds this process to its device BEFORE the members create their stages
     local lib = lrhip.lib
     local stages = ffi.new("lrhip_stage_t *[?]", #self.blocks)
     for i, b in ipairs(self.blocks) do
@@ -90,6 +100,72 @@ function DeviceChainBlock:process(x)
     local n = tonumber(lib.lrhip_chain_push(self.chain, x.data, x.length, self.out.data, cap))
     if n < 0 then error("lrhip_chain_push: " .. ffi.string(lib.lrhip_strerror())) end
     return self.out:resize(n)
+end
+
+-- The host's wait for input timed out (run() below): hand on what the latency bound releases.
+function DeviceChainBlock:poll()
+    local lib = lrhip.lib
+    local cap = tonumber(lib.lrhip_chain_push_bound(self.chain, 0))
+    self.out:resize(cap)
+    local n = tonumber(lib.lrhip_chain_poll(self.chain, self.out.data, cap))
+    if n < 0 then error("lrhip_chain_poll: " .. ffi.string(lib.lrhip_strerror())) end
+    return self.out:resize(n)
+end
+
+-- Block:run (radio/core/block.lua:556-608) with ONE change: in front of the blocking pipe_mux:read() the input descriptors are
+-- polled for at most lrhip_chain_poll_due() seconds, and a timeout calls poll() instead of process().  Chains without a latency
+-- bound (max_latency = 0) run the reference's loop itself.  Shared with DeviceFanoutBlock (devicefanout.lua), whose poll() launches
+-- its partial slab.
+local block_run = DeviceChainBlock.run
+local function timed_run(self, due_seconds)
+    local input_pipes, output_pipes = {}, {}
+    for i = 1, #self.inputs do input_pipes[i] = self.inputs[i].pipe end
+    for i = 1, #self.outputs do
+        output_pipes[i] = {}
+        for j = 1, #self.outputs[i].pipes do output_pipes[i][j] = self.outputs[i].pipes[j] end
+    end
+    local pipe_mux = pipe.PipeMux(input_pipes, output_pipes, self.control_socket)
+
+    local function emit(data_out)           -- block.lua:587-602: false = stop
+        if #data_out ~= #self.outputs then return false end
+        local eof, eof_pipe, shutdown = pipe_mux:write(data_out)
+        if shutdown then return false end
+        if eof then
+            io.stderr:write(string.format("[%s] Downstream block %s terminated unexpectedly.\n", self.name, eof_pipe.input.owner.name))
+            return false
+        end
+        return true
+    end
+
+    while true do
+        local timed_out = false
+        local due = due_seconds(self)
+        if due >= 0 and input_pipes[1]:_read_buffer_count() == 0 then
+            -- pollfds[0] = control socket, [1] = the input pipe (radio/core/pipe.lua:417-431)
+            local ret = ffi.C.poll(pipe_mux.input_pollfds, 2, math.ceil(due * 1000))
+            if ret < 0 then error("poll(): " .. ffi.string(ffi.C.strerror(ffi.errno()))) end
+            timed_out = (ret == 0)
+        end
+        if timed_out then
+            local tail = self:poll()
+            if tail ~= nil and tail.length > 0 and not emit({tail}) then break end
+        else
+            local data_in, eof, shutdown = pipe_mux:read()
+            if eof or shutdown then break end
+            if not emit({self:process(unpack(data_in))}) then break end
+        end
+    end
+
+    self:cleanup()
+end
+DeviceChainBlock.timed_run = timed_run
+
+function DeviceChainBlock:run()
+    if not (self.max_latency > 0) then return block_run(self) end
+    return timed_run(self, function (b)
+        if b.chain == nil then return -1 end
+        return tonumber(lrhip.lib.lrhip_chain_poll_due(b.chain))
+    end)
 end
 
 -- cleanup() runs when the input reached EOF (radio/core/block.lua:606): run the partly filled batch and hand the tail
@@ -171,6 +247,7 @@ function DeviceChainBlock.collapse(connections)
     end
 
     local result, chains = {}, {}
+    local chain_of = {}                 -- first member of a run -> its DeviceChainBlock
     for input, output in pairs(connections) do result[input] = output end
     for _, run in ipairs(runs) do
         local first, last = run[1], run[#run]
@@ -191,6 +268,23 @@ function DeviceChainBlock.collapse(connections)
         end
         first.inputs[1].pipe = {get_rate = function () return chain.inputs[1].pipe:get_rate() end}
         chains[#chains + 1] = chain
+        chain_of[first] = chain
+    end
+
+    -- placement: the chains that read ONE fanned-out output port are numbered 0, 1, 2, ... (in table order, which is as arbitrary as the
+    -- reference's own evaluation order of parallel branches: build_dependency_graph walks the same pairs(), composite.lua:386-424)
+    for output, inputs in pairs(readers) do
+        local branches = {}
+        for _, input in ipairs(inputs) do
+            local chain = chain_of[input.owner]
+            if chain then branches[#branches + 1] = chain end
+        end
+        if #branches >= 2 then
+            for k, chain in ipairs(branches) do
+                chain.device = k - 1
+                chain.fanout_port = output
+            end
+        end
     end
     return result, chains
 end

@@ -26,6 +26,7 @@ typedef struct lrhip_ipc_event lrhip_ipc_event_t;
 int lrhip_init(int device);
 const char *lrhip_strerror(void);
 int lrhip_device_count(void);
+int lrhip_device(void);
 int lrhip_set_stream(void *hip_stream);
 int lrhip_synchronize(void);
 const char *lrhip_version(void);
@@ -147,15 +148,31 @@ end
 -- The device context must be created in the block's own process: CompositeBlock calls initialize() in the
 -- parent before fork() (radio/core/composite.lua:443 vs :569), so device blocks create their stage lazily on
 -- the first process() call.  ensure() is what they call first.
-local initialized_pid = nil
-function M.ensure()
+--
+-- `device` is a PLACEMENT INDEX, not necessarily a device number: it wraps over the devices of the box
+-- (`index % lrhip_device_count()`), so a flow graph that fans out into 8 branches runs one branch per GPU on an
+-- 8-GPU node and all of them on the one GPU of a workstation, unchanged.  nil = the library's default device
+-- (or LUARADIO_HIP_DEVICE).  A process is bound to ONE device by its first ensure(); later calls with another
+-- index keep that device (top:run(false) puts every block into one process) and return it.
+local initialized_pid, initialized_device = nil, nil
+function M.ensure(device)
     local pid = ffi.C.getpid()
     if initialized_pid ~= pid then
-        if M.lib.lrhip_init(-1) ~= 0 then
+        local want = device or tonumber(os.getenv("LUARADIO_HIP_DEVICE"))
+        if want ~= nil then
+            local count = M.lib.lrhip_device_count()
+            if count < 1 then
+                error("lrhip_device_count: " .. ffi.string(M.lib.lrhip_strerror()))
+            end
+            want = want % count
+        end
+        if M.lib.lrhip_init(want or -1) ~= 0 then
             error("lrhip_init: " .. ffi.string(M.lib.lrhip_strerror()))
         end
         initialized_pid = pid
+        initialized_device = M.lib.lrhip_device()
     end
+    return initialized_device
 end
 
 ---

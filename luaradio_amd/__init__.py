@@ -17,7 +17,7 @@ from .blocks import (BandpassFilterBlock, BandstopFilterBlock, DownsamplerBlock,
                      PulseMatchedFilterBlock, ManchesterMatchedFilterBlock, AGCBlock, PowerSquelchBlock)
 from .sources import IQFileSource, RealFileSource, IQFileSink, RealFileSink  # noqa: F401
 from .meters import BenchmarkSink, RawFileSource, ZeroSource  # noqa: F401
-from . import ipc, meters, timeshard  # noqa: F401
+from . import ipc, meters, procfanout, timeshard  # noqa: F401
 from .graph import DeviceGraph  # noqa: F401
 from .composites import (Chain, CompositeBlock, DecimatorBlock, InterpolatorBlock, RationalResamplerBlock, TunerBlock, WBFMMonoDemodulator,  # noqa: F401
                          NBFMDemodulator, AMEnvelopeDemodulator, SSBDemodulator, SSBModulator, wbfm_mono_receiver, am_envelope_receiver,

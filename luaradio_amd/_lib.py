@@ -23,6 +23,7 @@ _vp, _ul, _fp = C.c_void_p, C.c_ulong, C.POINTER(C.c_float)
 SIGNATURES = {
     "lrhip_init": (C.c_int, [C.c_int]),
     "lrhip_strerror": (C.c_char_p, []),
+    "lrhip_device": (C.c_int, []),
     "lrhip_device_count": (C.c_int, []),
     "lrhip_set_stream": (C.c_int, [_vp]),
     "lrhip_synchronize": (C.c_int, []),

@@ -87,7 +87,11 @@ inline Context &ctx()
 inline int ensure_init(int device = -1)
 {
     Context &c = ctx();
-    if (c.ready && c.pid == (long)getpid()) return 0;
+    if (c.ready && c.pid == (long)getpid()) {
+        if (device >= 0 && device != c.device)
+            return set_error("this process is bound to device %d; lrhip_init(%d) refused (one device per process)", c.device, device);
+        return 0;
+    }
     if (c.ready) {
         // forked since the stream was created (CompositeBlock forks one process per block after initialize(),
         // radio/core/composite.lua:443 vs :569): the parent's stream handle means nothing here - forget it (do not destroy it:

@@ -59,6 +59,12 @@ int lrhip_init(int device)
     return ensure_init(device);
 }
 
+int lrhip_device(void)
+{
+    const Context &c = ctx();
+    return (c.ready && c.pid == (long)getpid()) ? c.device : -1;
+}
+
 int lrhip_device_count(void)
 {
     int count = 0;

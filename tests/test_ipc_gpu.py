@@ -116,3 +116,117 @@ def test_two_processes_one_device_double_buffered_slabs():
     want = O.tuner(-250e3, 100e3, 5, 1102500.0, mode=O.MODE_FMA, rot_mode=O.MODE_F64).process(np.concatenate([_slab(k) for k in range(NSLAB)]))
     assert result is not None and len(result) == len(want)
     assert float(np.max(np.abs(result - want))) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# lua/radio/composites/devicefanout.lua replayed: ONE head process and THREE branch processes, each branch bound
+# to device `b % lrhip_device_count()` as lrhip.ensure(index) does in the Lua glue.  luaradio_amd/procfanout.py is the call-for-call
+# twin of that file (same wire structs, same order of lrhip_* calls); the parent only creates the socket pairs - what
+# DeviceFanoutBlock:initialize() does before CompositeBlock forks - and collects the branch outputs.
+# ---------------------------------------------------------------------------------------------------------------------------------
+FO_N, FO_SLAB, FO_CHUNK = 200000, 1 << 15, 8192            # 200 000 samples in 8 192-sample process() vectors, slabs of 32 768: 7 slabs, the last partial
+FO_OFFSETS = [-350e3, -250e3, 150e3]
+
+
+def _fo_input():
+    rng = np.random.default_rng(77)
+    return (rng.uniform(-1, 1, FO_N) + 1j * rng.uniform(-1, 1, FO_N)).astype(np.complex64)
+
+
+def _fo_branch(index, sock, result, with_head_chain):
+    sys.path.insert(0, ROOT)
+    import luaradio_amd as lr
+    from luaradio_amd import _lib, procfanout, types
+    device = procfanout.placement(index)
+    lr.init(device)
+    assert _lib.load().lrhip_device() == device
+    if with_head_chain:
+        blk = lr.DecimatorBlock(5)                          # the head chain already translated: the branch filters and decimates
+    else:
+        blk = lr.TunerBlock(FO_OFFSETS[index], 100e3, 5)
+    blk.rate = 1102500.0
+    blk.differentiate([types.ComplexFloat32])
+    blk.initialize()
+    br = procfanout.Branch(blk, index, sock, FO_SLAB, 8)
+    outs = []
+    while True:
+        out = br.process()
+        if out is None:
+            break
+        outs.append(out)
+    br.cleanup()
+    result.send((index, device, np.concatenate(outs) if outs else np.empty(0, np.complex64)))
+    result.close()
+
+
+def _fo_head(socks, result, with_head_chain, latency):
+    sys.path.insert(0, ROOT)
+    import time
+    import luaradio_amd as lr
+    from luaradio_amd import procfanout, types
+    lr.init(procfanout.placement(0))
+    chain = None
+    if with_head_chain:
+        chain = lr.FrequencyTranslatorBlock(-250e3)
+        chain.rate = 1102500.0
+        chain.differentiate([types.ComplexFloat32])
+        chain.initialize()
+    head = procfanout.Head(chain, socks, np.complex64, np.complex64, slab_capacity=FO_SLAB, max_latency=latency)
+    x = _fo_input()
+    polled = 0
+    for a in range(0, FO_N, FO_CHUNK):
+        head.process(x[a:a + FO_CHUNK])
+        if latency and a == 5 * FO_CHUNK:
+            # the source stalls: the run loop's bounded wait times out and poll() hands the partial slab on (DeviceChainBlock.timed_run)
+            due = head.poll_due()
+            assert 0.0 <= due <= latency
+            time.sleep(due + 0.002)
+            before = head.k
+            head.poll()
+            polled += head.k - before
+    head.cleanup()
+    result.send(("head", head.k, head.peer_copies, polled))
+    result.close()
+
+
+@pytest.mark.parametrize("with_head_chain,latency", [(False, 0.0), (True, 0.0), (False, 0.02)])
+def test_one_head_three_branch_processes(with_head_chain, latency):
+    import socket
+    ctx = mp.get_context("spawn")
+    pairs = [socket.socketpair(socket.AF_UNIX, socket.SOCK_STREAM) for _ in FO_OFFSETS]
+    res_r, res_w = ctx.Pipe(duplex=False)
+    procs = [ctx.Process(target=_fo_branch, args=(b, pairs[b][1], res_w, with_head_chain)) for b in range(len(FO_OFFSETS))]
+    procs.append(ctx.Process(target=_fo_head, args=([p[0] for p in pairs], res_w, with_head_chain, latency)))
+    for p in procs:
+        p.start()
+    for a, b in pairs:
+        a.close()
+        b.close()
+    res_w.close()
+    got = {}
+    try:
+        for _ in procs:
+            assert res_r.poll(240), "a fan-out process did not report"
+            m = res_r.recv()
+            got[m[0]] = m[1:]
+    finally:
+        for p in procs:
+            p.join(60)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    import torch
+    count = torch.cuda.device_count()
+    slabs, copies, polled = got["head"]
+    assert slabs >= 7 and copies == 3 * slabs                                  # every slab went to every branch, device to device
+    assert (polled >= 1) == bool(latency)
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    x = _fo_input()
+    for b, off in enumerate(FO_OFFSETS):
+        device, y = got[b]
+        assert device == b % count                                             # branch -> GPU placement (one per GPU on an 8-GPU node)
+        if with_head_chain:
+            want = O.Chain([O.Rotator(2 * np.pi * -250e3 / 1102500.0, O.MODE_F64)] + O.decimator(5, 1102500.0, True, mode=O.MODE_FMA).stages).process(x)
+        else:
+            want = O.tuner(off, 100e3, 5, 1102500.0, mode=O.MODE_FMA, rot_mode=O.MODE_F64).process(x)
+        assert len(y) == len(want) == FO_N // 5
+        assert float(np.max(np.abs(y - want))) < 2e-6, (b, float(np.max(np.abs(y - want))))

@@ -25,7 +25,9 @@ REFERENCE_METHODS = {
     "add_type_signature", "differentiate", "get_input_type", "get_output_type", "get_rate", "initialize",   # Block
     "device_capable",                                                                                        # optional method of device variants (DelayBlock)
     "resize",                                                                                                # Vector
-    "write",                                                                                                 # Pipe
+    "write", "_read_buffer_count",                                                                           # Pipe
+    "read",                                                                                                  # PipeMux
+    "cleanup", "process", "poll",                                                                            # Block (run loop; poll = DeviceChainBlock / DeviceFanoutBlock)
     "vector",                                                                                                # data type .vector() is called with '.', listed for safety
 }
 LUA_BUILTINS = {"assert", "error", "ipairs", "pairs", "require", "tonumber", "tostring", "type", "setmetatable", "unpack", "pcall", "select", "print"}

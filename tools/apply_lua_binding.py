@@ -3,7 +3,7 @@
 
     tools/apply_lua_binding.py <luaradio-checkout> [--out DIR] [--diff]
 
-  * copies lua/radio/** (radio/core/lrhip.lua, the *_hip.lua device variants, radio/composites/devicechain.lua) into the tree;
+  * copies lua/radio/** (radio/core/lrhip.lua, the *_hip.lua device variants, radio/composites/devicechain.lua, devicefanout.lua) into the tree;
   * inserts ONE line directly above the final `return <Block>` of every block file that has a device variant:
         require('radio.core.lrhip').patch('<file>', <Block>)
     - after every top-level statement of the reference file, so that no later assignment can overwrite what the patch installs
@@ -36,6 +36,8 @@ COLLAPSE_HOOK = """
     local device_chains = {}
     if require('radio.core.lrhip').available then
         all_connections, device_chains = require('radio.composites.devicechain').collapse(all_connections)
+        -- ... and give every output port that fans out into device chains ONE upload and GPU-to-GPU copies (one branch per GPU)
+        all_connections, device_chains = require('radio.composites.devicefanout').collapse(all_connections, device_chains)
     end
 """
 INIT_HOOK = "    for _, chain in ipairs(device_chains) do chain:initialize() end\n"
