@@ -416,9 +416,54 @@ struct FirStage : lrhip_stage {
         static const int ng = getenv("LRHIP_F4K_NG") ? atoi(getenv("LRHIP_F4K_NG")) : 1;
         return ng == 2 ? launch_fft4k_ng<VV, 2>(x, n, y, n_out, &fft4k_blocks2) : launch_fft4k_ng<VV, 1>(x, n, y, n_out, &fft4k_blocks);
     }
+    // ---- partitioned overlap-save (kernels_firpols.h, round 4): 513 taps and more in one launch per 1 536 taps, ComplexFloat32 or Float32 stream
+    int pols_blocks = 0;
+    template <int SS, int PP>
+    int launch_pols_p(const float *x, long n, float *y, long n_out, int part0)
+    {
+        const size_t lds_bytes = (size_t)pols_lds_elems(PP) * sizeof(float2);
+        auto kern = fir_pols_kernel<SS, PP>;
+        if (prepared_blocks(kern, lds_bytes, 64 * POLS_WPB) < 0) return -1;
+        // a wave owns a run of consecutive blocks (its spectra delay line); runs of ~40 blocks keep the P - 1 warm-up blocks of a run under 5 %,
+        // and the number of runs is a whole number of rounds of (CUs x waves) where the launch is long enough
+        constexpr long RPW = SS == 2 ? 1 : 2;
+        const long nblocks = (n_out + POLS_HOP - 1) / POLS_HOP, per_round = (long)ctx().num_cus * POLS_WPB * RPW;
+        static const long run_env = getenv("LRHIP_POLS_RUN") ? atol(getenv("LRHIP_POLS_RUN")) : 0;      // A/B knob
+        long rounds = (nblocks + per_round * 20) / (per_round * 40);
+        if (rounds < 1) rounds = 1;
+        long run = run_env > 0 ? run_env : (nblocks + per_round * rounds - 1) / (per_round * rounds);
+        if (run < 4 * (PP - 1) + 4) run = 4 * (PP - 1) + 4;
+        const long nruns = (nblocks + run - 1) / run, nslots = (nruns + POLS_WPB * RPW - 1) / (POLS_WPB * RPW);
+        const unsigned grid = (unsigned)(nslots < ctx().num_cus ? nslots : ctx().num_cus);
+        float *ho = (M > 1 && part0 == 0) ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * POLS_WPB), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (const float2 *)d_fft_tables.p, y, M, n,
+                           n_out, nblocks, run, part0, part0 > 0 ? 1 : 0, ho);
+        if (ho) hist_in_kernel = true;
+        LR_LAUNCH_CHECK();
+        return 0;
+    }
+    template <int SS>
+    int launch_pols(const float *x, long n, float *y, long n_out)
+    {
+        const int nparts = (M + FFT_PART - 1) / FFT_PART;
+        hist_in_kernel = false;
+        for (int p0 = 0; p0 < nparts; p0 += 3) {
+            const int P = nparts - p0 < 3 ? nparts - p0 : 3;
+            const int rc = P == 3 ? launch_pols_p<SS, 3>(x, n, y, n_out, p0) : P == 2 ? launch_pols_p<SS, 2>(x, n, y, n_out, p0) : launch_pols_p<SS, 1>(x, n, y, n_out, p0);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+
     int launch_fft(const float *x, long n, float *y, long n_out)
     {
         static const bool no_4k = getenv("LRHIP_FFT_NO_4K") != nullptr;      // A/B knob: partitions of the 1024-point kernel (round 2)
+        // more than 512 taps: the partitioned form (one launch per 1 536 taps) wherever the 4096-point kernels do not apply - Float32 streams, more than
+        // 1 281 taps - instead of one accumulating pass of the 1024-point kernel per 512 taps.  LRHIP_FFT_POLS=1 / 0 forces it on (also for 513 .. 1 281
+        // taps on a ComplexFloat32 stream) / off (A/B)
+        static const int pols_knob = getenv("LRHIP_FFT_POLS") ? atoi(getenv("LRHIP_FFT_POLS")) : -1;
+        if (M > FFT_PART && !pre_disc && !post_disc && pols_knob != 0 && (pols_knob == 1 || !fft4k_V || no_4k))
+            return S == 2 ? launch_pols<2>(x, n, y, n_out) : launch_pols<1>(x, n, y, n_out);
         // one wave per 4096-point block (fir_fft4kw_kernel) once the launch has at least two rounds of four blocks per CU - measured 0-5 % (1 276 taps) and
         // 8 % (768 taps) ahead of the workgroup-per-block form on 2^26 samples; smaller launches keep the form that spreads over more CUs.
         // LRHIP_F4K_WAVE=1 / 0 forces one or the other (A/B)

@@ -134,6 +134,8 @@ def _fo_input():
 
 
 def _fo_branch(index, sock, result, with_head_chain):
+    import faulthandler
+    faulthandler.dump_traceback_later(45, exit=True)        # a stuck process says where and leaves (it must not outlive the test holding the GPU)
     sys.path.insert(0, ROOT)
     import luaradio_amd as lr
     from luaradio_amd import _lib, procfanout, types
@@ -160,6 +162,8 @@ def _fo_branch(index, sock, result, with_head_chain):
 
 
 def _fo_head(socks, result, with_head_chain, latency):
+    import faulthandler
+    faulthandler.dump_traceback_later(45, exit=True)
     sys.path.insert(0, ROOT)
     import time
     import luaradio_amd as lr
@@ -194,24 +198,29 @@ def test_one_head_three_branch_processes(with_head_chain, latency):
     import socket
     ctx = mp.get_context("spawn")
     pairs = [socket.socketpair(socket.AF_UNIX, socket.SOCK_STREAM) for _ in FO_OFFSETS]
-    res_r, res_w = ctx.Pipe(duplex=False)
-    procs = [ctx.Process(target=_fo_branch, args=(b, pairs[b][1], res_w, with_head_chain)) for b in range(len(FO_OFFSETS))]
-    procs.append(ctx.Process(target=_fo_head, args=([p[0] for p in pairs], res_w, with_head_chain, latency)))
+    # one result pipe per process (several writers on one Connection interleave their messages)
+    res = [ctx.Pipe(duplex=False) for _ in range(len(FO_OFFSETS) + 1)]
+    procs = [ctx.Process(target=_fo_branch, args=(b, pairs[b][1], res[b][1], with_head_chain)) for b in range(len(FO_OFFSETS))]
+    procs.append(ctx.Process(target=_fo_head, args=([p[0] for p in pairs], res[-1][1], with_head_chain, latency)))
     for p in procs:
         p.start()
     for a, b in pairs:
         a.close()
         b.close()
-    res_w.close()
+    for _, w in res:
+        w.close()
     got = {}
     try:
-        for _ in procs:
-            assert res_r.poll(240), "a fan-out process did not report"
-            m = res_r.recv()
+        for r, _ in res:
+            assert r.poll(60), "a fan-out process did not report (alive: %s)" % [p.is_alive() for p in procs]
+            m = r.recv()
             got[m[0]] = m[1:]
     finally:
         for p in procs:
-            p.join(60)
+            p.join(10)
+            if p.is_alive():
+                p.kill()                                     # the exact processes this test started
+                p.join(10)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     import torch
     count = torch.cuda.device_count()
