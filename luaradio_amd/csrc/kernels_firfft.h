@@ -74,7 +74,7 @@ constexpr int FFT_TABLE_ELEMS = 16 * 64 + 16 * 64 + 64;   // tw1 | Hperm | tw2, 
 // DIR = +1: forward (kernel e^{-j...}), -1: inverse.  In-place 4-point DFT, natural order out.
 // A2J: a2 carries a pending factor W_16^(4*DIR) = -j*DIR (dft16's only trivial twiddle), folded into the first butterfly.
 template <int DIR, bool A2J = false>
-__device__ __forceinline__ void radix4(cf &a0, cf &a1, cf &a2, cf &a3)
+__host__ __device__ __forceinline__ void radix4(cf &a0, cf &a1, cf &a2, cf &a3)
 {
     cf b0, b1;
     if (!A2J) { b0 = cadd(a0, a2); b1 = csub(a0, a2); }
@@ -89,7 +89,7 @@ __device__ __forceinline__ void radix4(cf &a0, cf &a1, cf &a2, cf &a3)
 
 // multiply by W_16^(DIR*p), p in {1,2,3,6,9}
 template <int DIR, int P>
-__device__ __forceinline__ cf mul_w16(cf a)
+__host__ __device__ __forceinline__ cf mul_w16(cf a)
 {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R = 0.70710678118654752f;
     constexpr float D = DIR > 0 ? -1.f : 1.f;          // sign of the imaginary part
@@ -103,7 +103,7 @@ __device__ __forceinline__ cf mul_w16(cf a)
 
 // 16-point DFT of v[0..15] (index n = 4a + b), result in natural order: v[k] = sum_n v[n] W_16^(DIR*n*k)
 template <int DIR>
-__device__ __forceinline__ void dft16(cf (&v)[16])
+__host__ __device__ __forceinline__ void dft16(cf (&v)[16])
 {
     // radix-4 over a for every b: afterwards position 4c+b holds u[b][c]
 #pragma unroll

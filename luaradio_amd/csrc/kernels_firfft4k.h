@@ -178,134 +178,9 @@ __global__ __launch_bounds__(256 * NG, NG == 2 ? 2 : 3) void fir_fft4k_kernel(co
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------------
-// The same transform with ONE WAVE per 4096-point block (second cut, round 3): a lane holds all four quarters of its 16 positions (64 points, 128
-// registers), so the radix-4 stage across the quarters is four butterflies in registers - no cross-stage buffer, no workgroup barrier at all - and the four
-// 1024-point pipelines of a block run one after the other in the same wave on its own exchange buffer.  The workgroup-per-block form above spends half of
-// its LDS instructions and all five barriers per block on the cross stages (counters: VALU 27 %, LDS 42 % busy, the rest waiting).  H does not fit the
-// registers any more (64 values per lane): it sits in LDS, [w][16 x 64], read once per block.  77 KB of LDS per workgroup of four waves = 2 per CU - but
-// the kernel needs 390 registers (256 + 134 accumulation registers; capped at 256 it spills 550-700 bytes and runs at 0.63 ms), so ONE workgroup = four
-// waves per CU is what runs: 0.44-0.46 ms for 1 276 taps on 2^26 samples against 0.46-0.475 for the workgroup-per-block form, 0.378 against 0.41 for 768 taps - a third of the
-// occupancy and still 0-8 % ahead, i.e. the barriers and cross stages are what the other form pays for.  Used for launches of at least 8 blocks per CU
-// (stage_fir.h); two workgroups per CU need the register count under 256.
-// ------------------------------------------------------------------------------------------------------------------------------------
-constexpr int F4W_LDS_TW1 = 4 * FFT_EX_ELEMS;                 // [4 per-wave exchange buffers | tw1 16x64 | tw2 64 | c 4x16 | H 4 x 1024]
-constexpr int F4W_LDS_TW2 = F4W_LDS_TW1 + 16 * 64;
-constexpr int F4W_LDS_C = F4W_LDS_TW2 + 64;
-constexpr int F4W_LDS_H = F4W_LDS_C + 64;
-constexpr int F4W_LDS_ELEMS = F4W_LDS_H + F4K_N;
-
-// one residue class: forward 1024-point pipeline, x H, inverse pipeline (fir_fft_kernel's stages on v, exchanges through the wave's own buffer)
-__device__ __forceinline__ void f4w_pipeline(cf (&v)[16], cf *ex, const cf *tw1, const cf *tw2, const cf *Hw, int lane, int sub, int k1s)
-{
-    dft16<1>(v);
-#pragma unroll
-    for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw1[k * 64 + lane]);
-    exchange(ex, v, [&](int k) { return k * FFT_E1_ROW + lane; }, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; });
-    dft16<1>(v);
-#pragma unroll
-    for (int k = 1; k < 16; k++) v[k] = cmul(v[k], tw2[k * 4 + sub]);
-    exchange(ex, v, [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; }, [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; });
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        radix4<1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-#pragma unroll
-        for (int k3 = 0; k3 < 4; k3++) v[4 * j + k3] = cmul(v[4 * j + k3], Hw[(4 * j + k3) * 64 + lane]);
-        radix4<-1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-#pragma unroll
-        for (int t2 = 1; t2 < 4; t2++) v[4 * j + t2] = cmulc(v[4 * j + t2], tw2[(4 * j + sub) * 4 + t2]);
-    }
-    exchange(ex, v, [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; }, [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; });
-    dft16<-1>(v);
-    exchange(ex, v, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; }, [&](int k) { return k * FFT_E1_ROW + lane; });
-#pragma unroll
-    for (int k = 1; k < 16; k++) v[k] = cmulc(v[k], tw1[k * 64 + lane]);
-    dft16<-1>(v);
-}
-
-template <int V>
-__global__ __launch_bounds__(256, 1) void fir_fft4kw_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float2 *__restrict__ tables,
-                                                            float *__restrict__ y, int M, long n, long n_out, long nblocks, float *__restrict__ hist_out, int xcd_map)
-{
-    static_assert(V % 64 == 0 && V >= 64 && V < F4K_N, "the overlap is a whole number of 64-sample rows");
-    constexpr int L = F4K_N - V;
-    extern __shared__ __attribute__((aligned(16))) float2 fl[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (hist_out && blockIdx.x == 0)
-        for (int i = tid; i < (M - 1) * 2; i += 256) hist_out[i] = stream_at<2>(hist, x, n + i / 2, i % 2, M, n);
-    cf *flc = reinterpret_cast<cf *>(fl);
-    cf *ex = flc + wave * FFT_EX_ELEMS;
-    const cf *tw1 = flc + F4W_LDS_TW1, *tw2 = flc + F4W_LDS_TW2, *ctab = flc + F4W_LDS_C, *Hs = flc + F4W_LDS_H;
-    for (int i = tid; i < F4K_TAB_LDS; i += 256) fl[F4W_LDS_TW1 + i] = tables[i];
-    for (int i = tid; i < F4K_N; i += 256) fl[F4W_LDS_H + i] = tables[F4K_TAB_H + i];
-    const cf *tb = reinterpret_cast<const cf *>(tables);
-    const cf b1 = tb[F4K_TAB_B + 64 + lane], b2 = tb[F4K_TAB_B + 128 + lane], b3 = tb[F4K_TAB_B + 192 + lane];      // W_4096^(lane w)
-    __syncthreads();
-    const int sub = lane & 3, k1s = lane >> 2;
-
-    // block order: a slot = four adjacent blocks (one per wave); workgroup-major (plain) or XCD-major slots
-    const long nslots = (nblocks + 3) / 4;
-    long slot0 = blockIdx.x, sstep = gridDim.x, send = nslots;
-    if (xcd_map && (gridDim.x & 7) == 0) {
-        const long per = (nslots + 7) / 8;
-        slot0 = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-        sstep = gridDim.x >> 3;
-        send = (long)((blockIdx.x & 7) + 1) * per < nslots ? (long)((blockIdx.x & 7) + 1) * per : nslots;
-    }
-    for (long slot = slot0; slot < send; slot += sstep) {
-        const long fb = slot * 4 + wave;
-        if (fb >= nblocks) continue;                         // (no workgroup barrier inside the loop: a wave may skip)
-        const long xlo = fb * L - V;
-        cf v[4][16];
-        if (xlo >= 0 && xlo + F4K_N <= n) {
-            const cf *src = reinterpret_cast<const cf *>(x) + xlo + lane;
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) v[m][i] = src[1024 * m + 64 * i];
-        } else {
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const long p = xlo + 1024 * m + 64 * i + lane + (M - 1);
-                    v[m][i] = cf{stream_at<2>(hist, x, p, 0, M, n), stream_at<2>(hist, x, p, 1, M, n)};
-                }
-        }
-        // ---- forward radix 4 over the quarters (in registers), twiddle W_4096^(n0 w) = W_4096^(lane w) W_64^(i w)
-        // (the compiler keeps the 48 twiddle products in registers across the block loop and interleaves the four pipelines - that is where the 390 registers
-        // go; laundering the lane constants and scheduling barriers between the pipelines bring the count down but not under 256 without spills, and at one
-        // wave per SIMD the interleaving is the only latency hiding there is: 0.514 ms with them, 0.443 without)
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            radix4<1>(v[0][i], v[1][i], v[2][i], v[3][i]);
-            v[1][i] = cmul(v[1][i], cmul(b1, ctab[16 + i]));
-            v[2][i] = cmul(v[2][i], cmul(b2, ctab[32 + i]));
-            v[3][i] = cmul(v[3][i], cmul(b3, ctab[48 + i]));
-        }
-        // ---- the four residue classes
-#pragma unroll
-        for (int w = 0; w < 4; w++) f4w_pipeline(v[w], ex, tw1, tw2, Hs + 1024 * w, lane, sub, k1s);
-        // ---- inverse radix 4 over the residue classes
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            v[1][i] = cmulc(v[1][i], cmul(b1, ctab[16 + i]));
-            v[2][i] = cmulc(v[2][i], cmul(b2, ctab[32 + i]));
-            v[3][i] = cmulc(v[3][i], cmul(b3, ctab[48 + i]));
-            radix4<-1>(v[0][i], v[1][i], v[2][i], v[3][i]);
-        }
-        // ---- rows at or behind the overlap are this block's outputs
-        const long ob = fb * L - V + lane;
-        cf *dst = reinterpret_cast<cf *>(y);
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int p = 1024 * m + 64 * i;
-                if (p >= V && ob + p < n_out) __builtin_nontemporal_store(v[m][i], dst + ob + p);
-            }
-    }
-}
+// (Round 3 also had a ONE-WAVE-per-block form of this decomposition, fir_fft4kw_kernel: four 1024-point pipelines one after the other in the same wave, 390
+// registers, 0-8 % ahead of the form above.  Round 4 replaced it by the 64 x 64 decomposition of kernels_firfft64.h - two in-register 64-point transforms
+// and ONE transpose per direction instead of eight exchanges per pipeline - which is what large launches now run; the workgroup-per-block form above stays
+// for launches too small to fill the chip with one workgroup per CU.)
 
 }  // namespace lrhip

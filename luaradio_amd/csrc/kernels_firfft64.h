@@ -13,29 +13,53 @@
 // LDS operations per block: 2 transposes x 4096 x (write + read) + 4096 H reads = 20 480 (the 4 x 1024 form: 36 864; the partitioned form of
 // kernels_firpols.h for the same filter: 119 KB per 512 outputs = 5 x as many bytes per output).  No workgroup barrier: a wave's DS operations execute in order.
 //
-// The transpose goes through a HALF-size buffer (32 rows x 65: 16.6 KB per wave instead of 33 KB) in two passes: all lanes write the 32 registers of one half,
-// lanes 0..31 (then 32..63) read their whole row - reads at half the lanes, the LDS pipe moves the same bytes - so that four waves + H (32 KB) + tables fit the
-// 160 KB of a CU: one 256-thread workgroup per CU, one wave per SIMD with up to 512 registers; latency is hidden by instruction-level parallelism inside the
-// wave (64 independent butterflies per stage) and by loading the next block's window while this one is transformed.
+// The transpose goes through a per-wave buffer of 64 x 65 FLOATS, the real parts first and the imaginary parts behind them through the same 16.6 KB (a wave's
+// DS operations execute in order, so the second write pass cannot overtake the first read pass): rows padded to 65 words make the row writes and the column
+// reads conflict-free with plain base + immediate addresses.  Four waves (66 KB) + H (32 KB) + the small twiddle tables = 108 KB: one 256-thread workgroup per
+// CU, one wave per SIMD with up to 512 registers.  Latency is hidden by instruction-level parallelism inside the wave (64 independent butterflies per stage).
+// Two cuts that did not survive, for the record: a half-size ComplexFloat32 buffer in two passes with the reads of a pass under `if (lane < 32)` - the
+// inactive half came back with stale registers in a few rows (register traffic to the accumulation registers inside a divergent region); and a full 64 x 64
+// ComplexFloat32 buffer with an XOR swizzle instead of padding (exactly 160 KB with H) - correct, but the swizzled addresses are 128 per-lane values that
+// lived in the accumulation registers and were fetched back 331 times per block.
 #pragma once
 #include "kernels_firfft4k.h"
 
+// WAVES per workgroup (= per CU, template parameter): 4 = one per SIMD, H whole in LDS (real or complex taps); 8 = two per SIMD - with ONE wave per SIMD every
+// scalar, LDS and memory instruction takes an issue slot the vector ALU could have used (counters: VALU 36 %, nothing else to run) - which needs 8 transpose
+// buffers + H + C in 160 KB: REAL taps only, H conjugate-symmetric, columns 0..32 stored (lane l > 32 reads conj H[63 - k1][64 - l])
+#ifndef LRHIP_F64_PREFETCH
+#define LRHIP_F64_PREFETCH 0      /* measured equal at one wave per SIMD (0.385 against 0.381 ms), impossible at two (128 more registers) */
+#endif
+#ifndef LRHIP_F64_HGROUP
+#define LRHIP_F64_HGROUP 16
+#endif
+
+#ifndef LRHIP_F64_FENCES
+#define LRHIP_F64_FENCES 0
+#endif
+#if LRHIP_F64_FENCES
+#define F64_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define F64_FENCE() ((void)0)
+#endif
+
 namespace lrhip {
 
-constexpr int F64_ROW = 65;                                   // transpose buffer row (float2 units): odd -> the 32 lanes of a row read hit 32 bank pairs
-constexpr int F64_EX = 32 * F64_ROW;                          // per wave
-// LDS map (float2 units): [4 x transpose buffer | C 16x64 = W_1024^(t c) | D 4x64 = W_4096^(t d) | H 64x64]
-constexpr int F64_LDS_C = 4 * F64_EX;
-constexpr int F64_LDS_D = F64_LDS_C + 16 * 64;
-constexpr int F64_LDS_H = F64_LDS_D + 4 * 64;
-constexpr int F64_LDS_ELEMS = F64_LDS_H + F4K_N;
-// host table (float2 units): [C 16x64 | D 4x64 | H[r][l] = H(64 k1(r) + l) / 4096, r = 16 d + c <-> k1 = d + 4 c]
+constexpr int F64_ROW = 65;                                   // transpose buffer row in FLOATS (one plane at a time): odd -> conflict-free columns
+constexpr int F64_EX = (64 * F64_ROW + 1) / 2;                // per wave, in float2 units
+// LDS map (float2 units): [4 x transpose buffer | H 64x64 | C 16x64 = W_1024^(t c)]
+constexpr int F64_HSYM_ROW = 33;                              // symmetric H storage: [k1][l = 0..32]
+__host__ __device__ constexpr int f64_lds_h(int waves) { return waves * F64_EX; }
+__host__ __device__ constexpr int f64_lds_c(int waves) { return f64_lds_h(waves) + (waves <= 4 ? F4K_N : 64 * F64_HSYM_ROW); }
+__host__ __device__ constexpr int f64_lds_elems(int waves) { return f64_lds_c(waves) + 16 * 64; }
+// host table (float2 units): [C 16x64 | D 4x64 | H[r][l] = H(64 k1(r) + l) / 4096, r = 16 d + c <-> k1 = d + 4 c | Hsym[k1][l = 0..32] = H(64 k1 + l) / 4096]
 constexpr int F64_TAB_D = 16 * 64;
 constexpr int F64_TAB_H = F64_TAB_D + 4 * 64;
-constexpr int F64_TABLE_ELEMS = F64_TAB_H + F4K_N;
+constexpr int F64_TAB_HSYM = F64_TAB_H + F4K_N;
+constexpr int F64_TABLE_ELEMS = F64_TAB_HSYM + 64 * F64_HSYM_ROW;
 
 // cos / sin of 2 pi m / 64
-__device__ constexpr float F64_COS[64] = {
+constexpr float F64_COS[64] = {
     1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f,
     7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f,
     0.0f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f,
@@ -45,13 +69,13 @@ __device__ constexpr float F64_COS[64] = {
     0.0f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f,
     7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f};
 
-template <int M> __device__ constexpr float f64_cos() { return F64_COS[M & 63]; }
-template <int M> __device__ constexpr float f64_sin() { return F64_COS[(M + 48) & 63]; }      // sin(x) = cos(x - pi/2)
+template <int M> __host__ __device__ constexpr float f64_cos() { return F64_COS[M & 63]; }
+template <int M> __host__ __device__ constexpr float f64_sin() { return F64_COS[(M + 48) & 63]; }      // sin(x) = cos(x - pi/2)
 
 // 64-point DFT in registers.  Forward (DIR = 1): input index n = 16 a + b in register 16 a + b, output X[d + 4 c] in register 16 d + c.
 // Inverse (DIR = -1): input X[d + 4 c] in register 16 d + c, output index n = 16 a + b in register 16 a + b.  No scaling.
 template <int DIR>
-__device__ __forceinline__ void dft64(cf (&v)[64])
+__host__ __device__ __forceinline__ void dft64(cf (&v)[64])
 {
     if constexpr (DIR > 0) {
 #pragma unroll
@@ -83,8 +107,8 @@ __device__ __forceinline__ void dft64(cf (&v)[64])
 // register 16 d + c of a dft64 spectrum holds index d + 4 c
 __host__ __device__ constexpr int f64_index(int r) { return (r >> 4) + 4 * (r & 15); }
 
-template <int V>
-__global__ __launch_bounds__(256, 1) void fir_fft64_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float2 *__restrict__ tables,
+template <int V, int F64_WAVES>
+__global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float2 *__restrict__ tables,
                                                            float *__restrict__ y, int M, long n, long n_out, long nblocks, float *__restrict__ hist_out, int xcd_map)
 {
     static_assert(V % 64 == 0 && V >= 64 && V < F4K_N, "the overlap is a whole number of 64-sample rows");
@@ -93,18 +117,28 @@ __global__ __launch_bounds__(256, 1) void fir_fft64_kernel(const float *__restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (hist_out && blockIdx.x == 0)
-        for (int i = tid; i < (M - 1) * 2; i += 256) hist_out[i] = stream_at<2>(hist, x, n + i / 2, i % 2, M, n);
+        for (int i = tid; i < (M - 1) * 2; i += 64 * F64_WAVES) hist_out[i] = stream_at<2>(hist, x, n + i / 2, i % 2, M, n);
     cf *flc = reinterpret_cast<cf *>(fl);
-    cf *ex = flc + wave * F64_EX;
+    float *ex = reinterpret_cast<float *>(flc + wave * F64_EX);
+    constexpr bool HSYM = F64_WAVES > 4;
+    constexpr int F64_LDS_H = f64_lds_h(F64_WAVES), F64_LDS_C = f64_lds_c(F64_WAVES);
     const cf *Ct = flc + F64_LDS_C, *Hs = flc + F64_LDS_H;
-    for (int i = tid; i < F64_TABLE_ELEMS; i += 256) fl[F64_LDS_C + i] = tables[i];
+    if (HSYM)
+        for (int i = tid; i < 64 * F64_HSYM_ROW; i += 64 * F64_WAVES) fl[F64_LDS_H + i] = tables[F64_TAB_HSYM + i];
+    else
+        for (int i = tid; i < F4K_N; i += 64 * F64_WAVES) fl[F64_LDS_H + i] = tables[F64_TAB_H + i];
+    for (int i = tid; i < 16 * 64; i += 64 * F64_WAVES) fl[F64_LDS_C + i] = tables[i];
+    // symmetric H: element index of H[k1][lane] = hs_a + k1 * hs_s, imaginary part times hs_sgn
+    const int hs_a = lane <= 32 ? lane : 63 * F64_HSYM_ROW + (64 - lane), hs_s0 = lane <= 32 ? F64_HSYM_ROW : -F64_HSYM_ROW;
+    const cf hs_sgn = cf{1.f, lane <= 32 ? 1.f : -1.f};
     __syncthreads();
-    const cf D1 = flc[F64_LDS_D + 64 + lane], D2 = flc[F64_LDS_D + 128 + lane], D3 = flc[F64_LDS_D + 192 + lane];      // W_4096^(lane d)
-    const bool lo_half = lane < 32;
+    const cf *tb = reinterpret_cast<const cf *>(tables);
+    const cf D1 = tb[F64_TAB_D + 64 + lane], D2 = tb[F64_TAB_D + 128 + lane], D3 = tb[F64_TAB_D + 192 + lane];      // W_4096^(lane d)
 
     // big twiddle W_4096^(t k2), k2 = d + 4 c in register 16 d + c: D[d][t] * C[c][t]
     auto twiddle = [&](cf (&v)[64], auto conj) {
         constexpr bool CJ = decltype(conj)::value;
+        asm volatile("" ::: "memory");                       // the table reads stay here (hoisted out of the block loop they cost 30 registers)
 #pragma unroll
         for (int c = 0; c < 16; c++) {
             const cf cc = Ct[c * 64 + lane];
@@ -118,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void fir_fft64_kernel(const float *__restri
         }
     };
 
-    const long nslots = (nblocks + 3) / 4;
+    const long nslots = (nblocks + F64_WAVES - 1) / F64_WAVES;
     long slot0 = blockIdx.x, sstep = gridDim.x, send = nslots;
     if (xcd_map && (gridDim.x & 7) == 0) {
         const long per = (nslots + 7) / 8;
@@ -126,72 +160,111 @@ __global__ __launch_bounds__(256, 1) void fir_fft64_kernel(const float *__restri
         sstep = gridDim.x >> 3;
         send = (long)((blockIdx.x & 7) + 1) * per < nslots ? (long)((blockIdx.x & 7) + 1) * per : nslots;
     }
+    // the next block's window is loaded while this block is between its two transposes (one wave per SIMD: nobody else hides the 2-3 us of a round trip to
+    // HBM, and the stores of this block hold on to its registers): 128 more registers, which is what the accumulation half of the register file is for here
+    cf pre[64];
+    bool have = false;
+    auto prefetch = [&](long nb) {
+        const long plo = nb * L - V;
+        have = LRHIP_F64_PREFETCH && nb < nblocks && plo >= 0 && plo + F4K_N <= n;
+        if (have) {
+            const cf *src = reinterpret_cast<const cf *>(x) + plo;
+#pragma unroll
+            for (int i = 0; i < 64; i++) pre[i] = (src + 64 * i)[(unsigned)lane];
+        }
+    };
     for (long slot = slot0; slot < send; slot += sstep) {
-        const long fb = slot * 4 + wave;
+        const long fb = slot * F64_WAVES + wave;
         if (fb >= nblocks) continue;                         // no workgroup barrier inside the loop: a wave may skip
         const long xlo = fb * L - V;
         cf v[64];
-        if (xlo >= 0 && xlo + F4K_N <= n) {
+        if (have) {
+#pragma unroll
+            for (int i = 0; i < 64; i++) v[i] = pre[i];
+        } else if (xlo >= 0 && xlo + F4K_N <= n) {
             const cf *src = reinterpret_cast<const cf *>(x) + xlo;
 #pragma unroll
             for (int i = 0; i < 64; i++) v[i] = (src + 64 * i)[(unsigned)lane];
         } else {
+            // edge blocks (the window reaches into the carried history or past the chunk): staged through the transpose buffer by a ROLLED loop, so that the
+            // 64 x 2 guarded loads do not compete for registers with the main path
+#pragma unroll 1
+            for (int i = 0; i < 64; i++) ex[i * 64 + lane] = stream_at<2>(hist, x, xlo + 64 * i + lane + (M - 1), 0, M, n);
 #pragma unroll
-            for (int i = 0; i < 64; i++) {
-                const long p = xlo + 64 * i + lane + (M - 1);
-                v[i] = cf{stream_at<2>(hist, x, p, 0, M, n), stream_at<2>(hist, x, p, 1, M, n)};
-            }
+            for (int i = 0; i < 64; i++) v[i].x = ex[i * 64 + lane];
+#pragma unroll 1
+            for (int i = 0; i < 64; i++) ex[i * 64 + lane] = stream_at<2>(hist, x, xlo + 64 * i + lane + (M - 1), 1, M, n);
+#pragma unroll
+            for (int i = 0; i < 64; i++) v[i].y = ex[i * 64 + lane];
         }
         // ---- forward: DFT over i, twiddle, transpose, DFT over t
+        // (F64_FENCE = scheduling fence between phases: left alone, the scheduler pulls the next phase's 64 loads up to cover their latency and the wave
+        // holds 128 + 128 values at the seams; with two waves per SIMD the other wave covers the latency and the registers are worth more)
+        F64_FENCE();
         dft64<1>(v);
         twiddle(v, std::false_type{});
+        F64_FENCE();
         cf z[64];
-        // pass A: rows k2 = 0..31 (registers with c < 8), read by lanes 0..31; pass B: rows 32..63, lanes 32..63
+        // transpose: lane t writes row k2 of register 16 d + c (k2 = d + 4 c), lane k2 reads its row (t = 0..63); real parts, then imaginary parts
 #pragma unroll
-        for (int r = 0; r < 64; r++)
-            if (f64_index(r) < 32) ex[f64_index(r) * F64_ROW + lane] = v[r];
-        if (lo_half) {
+        for (int r = 0; r < 64; r++) ex[f64_index(r) * F64_ROW + lane] = v[r].x;
 #pragma unroll
-            for (int t = 0; t < 64; t++) z[t] = ex[lane * F64_ROW + t];
-        }
+        for (int t = 0; t < 64; t++) z[t].x = ex[lane * F64_ROW + t];
+        F64_FENCE();
 #pragma unroll
-        for (int r = 0; r < 64; r++)
-            if (f64_index(r) >= 32) ex[(f64_index(r) - 32) * F64_ROW + lane] = v[r];
-        if (!lo_half) {
+        for (int r = 0; r < 64; r++) ex[f64_index(r) * F64_ROW + lane] = v[r].y;
 #pragma unroll
-            for (int t = 0; t < 64; t++) z[t] = ex[(lane - 32) * F64_ROW + t];
-        }
+        for (int t = 0; t < 64; t++) z[t].y = ex[lane * F64_ROW + t];
+        F64_FENCE();
+        prefetch((slot + sstep) * F64_WAVES + wave);                  // v is dead until the inverse transpose
         dft64<1>(z);
         // ---- x H (1 / N folded in): register r of lane l holds X[64 k1(r) + l]
+        // (scheduling fences: without them the 64 H reads are hoisted above the transform to cover their latency - 128 more live registers at the point
+        // where the wave already holds 128, and the allocator falls back to the accumulation registers and to scratch)
 #pragma unroll
-        for (int r = 0; r < 64; r++) z[r] = cmul(z[r], Hs[r * 64 + lane]);
+        for (int g = 0; g < 64; g += LRHIP_F64_HGROUP) {
+            cf h[LRHIP_F64_HGROUP];
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (HSYM) {
+                int hs_s = hs_s0;
+                asm volatile("" : "+v"(hs_s));              // opaque per group: the 64 lane-dependent addresses are recomputed (one v_mad each), not hoisted out
+                                                            // of the block loop into 64 registers the wave does not have
+#pragma unroll
+                for (int r = 0; r < LRHIP_F64_HGROUP; r++) h[r] = Hs[hs_a + f64_index(g + r) * hs_s] * hs_sgn;
+            } else {
+#pragma unroll
+                for (int r = 0; r < LRHIP_F64_HGROUP; r++) h[r] = (Hs + (g + r) * 64)[(unsigned)lane];      // row pointer + the lane's index
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < LRHIP_F64_HGROUP; r++) z[g + r] = cmul(z[g + r], h[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- inverse: IDFT over k1 -> t, transpose back, conjugate twiddle, IDFT over k2 -> i
         dft64<-1>(z);
-        if (lo_half) {
+        F64_FENCE();
 #pragma unroll
-            for (int t = 0; t < 64; t++) ex[lane * F64_ROW + t] = z[t];
-        }
+        for (int t = 0; t < 64; t++) ex[lane * F64_ROW + t] = z[t].x;
 #pragma unroll
-        for (int r = 0; r < 64; r++)
-            if (f64_index(r) < 32) v[r] = ex[f64_index(r) * F64_ROW + lane];
-        if (!lo_half) {
+        for (int r = 0; r < 64; r++) v[r].x = ex[f64_index(r) * F64_ROW + lane];
+        F64_FENCE();
 #pragma unroll
-            for (int t = 0; t < 64; t++) ex[(lane - 32) * F64_ROW + t] = z[t];
-        }
+        for (int t = 0; t < 64; t++) ex[lane * F64_ROW + t] = z[t].y;
 #pragma unroll
-        for (int r = 0; r < 64; r++)
-            if (f64_index(r) >= 32) v[r] = ex[(f64_index(r) - 32) * F64_ROW + lane];
+        for (int r = 0; r < 64; r++) v[r].y = ex[f64_index(r) * F64_ROW + lane];
+        F64_FENCE();
         twiddle(v, std::true_type{});
         dft64<-1>(v);
         // ---- rows at or behind the overlap are this block's outputs
         const long ob = fb * L - V;
         cf *dst = reinterpret_cast<cf *>(y) + ob;
+        if (ob + F4K_N <= n_out) {
 #pragma unroll
-        for (int i = 0; i < 64; i++) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int p = 64 * i;
-            if (p >= V && ob + p + lane < n_out) __builtin_nontemporal_store(v[i], (dst + p) + (unsigned)lane);
+            for (int i = V / 64; i < 64; i++) __builtin_nontemporal_store(v[i], (dst + 64 * i) + (unsigned)lane);
+        } else {
+#pragma unroll
+            for (int i = V / 64; i < 64; i++)
+                if (ob + 64 * i + lane < n_out) __builtin_nontemporal_store(v[i], (dst + 64 * i) + (unsigned)lane);
         }
     }
 }

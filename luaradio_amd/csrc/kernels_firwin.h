@@ -83,10 +83,10 @@ __device__ __forceinline__ void fwr_put4(float *ldsE, float *ldsO, int a, float4
 }
 
 template <typename F, int... Js>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Js...>) { (f(std::integral_constant<int, Js>{}), ...); }
+__host__ __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Js...>) { (f(std::integral_constant<int, Js>{}), ...); }
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): an unrolled loop whose index is a constant expression in the body
 template <int N, typename F>
-__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+__host__ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // Real taps are wave-uniform: read from the global table at compile-time offsets (uniform_load*, common.h) they arrive by scalar loads in SGPR
 // pairs and feed the packed FMAs as a scalar operand (SG = true) - no LDS tap reads at all.  Where the LDS pipe is the bound that is a large step

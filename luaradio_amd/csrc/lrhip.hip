@@ -21,6 +21,7 @@
 #include "kernels_firwin2.h"
 #include "kernels_firfft4k.h"
 #include "kernels_firpols.h"
+#include "kernels_firfft64.h"
 #include "kernels_interp.h"
 #include "kernels_rx.h"
 

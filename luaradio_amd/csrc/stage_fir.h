@@ -37,6 +37,7 @@ struct FirStage : lrhip_stage {
     bool raw_now = false;                 // set around core() while x holds raw records
     DeviceBuf d_fft_tables;
     DeviceBuf d_fft4k_tables;             // 513 .. 1281 taps on a ComplexFloat32 stream: the 4096-point kernel (kernels_firfft4k.h)
+    DeviceBuf d_fft64_tables;             // ... and its one-wave-per-block form (kernels_firfft64.h)
     int fft4k_V = 0, fft4k_blocks = 0;    // its overlap (768 / 1024 / 1280; 0 = not built)
     int fft_blocks_per_cu = 0;
     // decimating polyphase-FFT form (kernels_firdecfft.h): ComplexFloat32 stream, D >= 2, ceil(M / D) <= 32
@@ -391,22 +392,28 @@ struct FirStage : lrhip_stage {
         hist_in_kernel = true;
         return 0;
     }
-    int fft4k_blocks2 = 0, fft4kw_blocks = 0;
-    template <int VV>
-    int launch_fft4kw(const float *x, long n, float *y, long n_out)
+    int fft4k_blocks2 = 0;
+    // one WAVE per 4096-point block as 64 x 64 (kernels_firfft64.h): eight waves per CU with the conjugate-symmetric H of real taps, four with complex taps
+    template <int VV, int WAVES>
+    int launch_fft64(const float *x, long n, float *y, long n_out)
     {
         constexpr long Lf = F4K_N - VV;
-        const size_t lds_bytes = (size_t)F4W_LDS_ELEMS * sizeof(float2);
-        auto kern = fir_fft4kw_kernel<VV>;
-        if (!fft4kw_blocks && prepare_kernel(kern, lds_bytes, &fft4kw_blocks, 256)) return -1;
+        const size_t lds_bytes = (size_t)f64_lds_elems(WAVES) * sizeof(float2);
+        auto kern = fir_fft64_kernel<VV, WAVES>;
+        if (prepared_blocks(kern, lds_bytes, 64 * WAVES) < 0) return -1;
         static const int xcd_map = getenv("LRHIP_F4K_XCD_MAP") ? atoi(getenv("LRHIP_F4K_XCD_MAP")) : 1;
-        const long nblocks = (n_out + Lf - 1) / Lf, nslots = (nblocks + 3) / 4, slots = (long)ctx().num_cus * fft4kw_blocks;
-        const unsigned grid = (unsigned)(nslots < slots ? nslots : slots);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (const float2 *)d_fft4k_tables.p, y, M, n,
+        const long nblocks = (n_out + Lf - 1) / Lf, nslots = (nblocks + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)(nslots < ctx().num_cus ? nslots : ctx().num_cus);      // 108 / 158 KB of LDS: one workgroup per CU
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (const float2 *)d_fft64_tables.p, y, M, n,
                            n_out, nblocks, M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : (float *)nullptr, xcd_map);
         LR_LAUNCH_CHECK();
         hist_in_kernel = true;
         return 0;
+    }
+    template <int VV>
+    int launch_fft64_v(const float *x, long n, float *y, long n_out)
+    {
+        return taps_complex ? launch_fft64<VV, 4>(x, n, y, n_out) : launch_fft64<VV, 8>(x, n, y, n_out);
     }
     template <int VV>
     int launch_fft4k(const float *x, long n, float *y, long n_out)
@@ -464,17 +471,16 @@ struct FirStage : lrhip_stage {
         static const int pols_knob = getenv("LRHIP_FFT_POLS") ? atoi(getenv("LRHIP_FFT_POLS")) : -1;
         if (M > FFT_PART && !pre_disc && !post_disc && pols_knob != 0 && (pols_knob == 1 || !fft4k_V || no_4k))
             return S == 2 ? launch_pols<2>(x, n, y, n_out) : launch_pols<1>(x, n, y, n_out);
-        // one wave per 4096-point block (fir_fft4kw_kernel) once the launch has at least two rounds of four blocks per CU - measured 0-5 % (1 276 taps) and
-        // 8 % (768 taps) ahead of the workgroup-per-block form on 2^26 samples; smaller launches keep the form that spreads over more CUs.
-        // LRHIP_F4K_WAVE=1 / 0 forces one or the other (A/B)
+        // one wave per 4096-point block (fir_fft64_kernel, one 512- / 256-thread workgroup per CU) once the launch has at least eight blocks per CU; smaller
+        // launches keep the workgroup-per-block form, which spreads over more CUs.  LRHIP_F4K_WAVE=1 / 0 forces one or the other (A/B)
         static const int wave_knob = getenv("LRHIP_F4K_WAVE") ? atoi(getenv("LRHIP_F4K_WAVE")) : -1;
         const long nblocks4k = fft4k_V ? (n_out + (F4K_N - fft4k_V) - 1) / (F4K_N - fft4k_V) : 0;
         const bool wave4k = wave_knob >= 0 ? wave_knob != 0 : nblocks4k >= 8L * ctx().num_cus;
         if (fft4k_V && !no_4k && !pre_disc && !post_disc && wave4k) {
             switch (fft4k_V) {
-                case 768: return launch_fft4kw<768>(x, n, y, n_out);
-                case 1024: return launch_fft4kw<1024>(x, n, y, n_out);
-                default: return launch_fft4kw<1280>(x, n, y, n_out);
+                case 768: return launch_fft64_v<768>(x, n, y, n_out);
+                case 1024: return launch_fft64_v<1024>(x, n, y, n_out);
+                default: return launch_fft64_v<1280>(x, n, y, n_out);
             }
         }
         if (fft4k_V && !no_4k && !pre_disc && !post_disc) {
@@ -1178,6 +1184,26 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
                             t4[2 * o + 1] = (float)Hi[k];
                         }
             if (upload(q->d_fft4k_tables, t4.data(), t4.size() * sizeof(float))) return nullptr;
+            // tables of the 64 x 64 form: C[c][t] = W_1024^(t c) | D[d][t] = W_4096^(t d) | H[r][l] = H(64 k1(r) + l) | Hsym[k1][l <= 32] = H(64 k1 + l)
+            std::vector<float> t6((size_t)F64_TABLE_ELEMS * 2, 0.f);
+            auto put6 = [&](size_t o, double a) { t6[2 * o] = (float)std::cos(a); t6[2 * o + 1] = (float)std::sin(a); };
+            for (int c = 0; c < 16; c++)
+                for (int t = 0; t < 64; t++) put6((size_t)c * 64 + t, -PI2 * (double)((c * t) % FFTN) / FFTN);
+            for (int d = 0; d < 4; d++)
+                for (int t = 0; t < 64; t++) put6((size_t)F64_TAB_D + d * 64 + t, -PI2 * (double)(t * d) / F4K_N);
+            for (int r = 0; r < 64; r++)
+                for (int l = 0; l < 64; l++) {
+                    const int k = 64 * f64_index(r) + l;
+                    const size_t o = (size_t)F64_TAB_H + (size_t)r * 64 + l;
+                    t6[2 * o] = (float)Hr[k];
+                    t6[2 * o + 1] = (float)Hi[k];
+                    if (l <= 32) {
+                        const size_t os = (size_t)F64_TAB_HSYM + (size_t)f64_index(r) * F64_HSYM_ROW + l;
+                        t6[2 * os] = (float)Hr[k];
+                        t6[2 * os + 1] = (float)Hi[k];
+                    }
+                }
+            if (upload(q->d_fft64_tables, t6.data(), t6.size() * sizeof(float))) return nullptr;
             q->fft4k_V = (int)((ntaps - 1 + 255) / 256) * 256;
             if (q->fft4k_V < 768) q->fft4k_V = 768;
         }

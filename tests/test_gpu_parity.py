@@ -303,6 +303,36 @@ def test_partitioned_form_equals_the_4096_point_kernels_filter():
     assert G.max_abs_err(whole, O.FIR(taps, True, O.MODE_F64).process(x)) < 1e-6
 
 
+@pytest.mark.parametrize("ntaps,cplx_taps", [(600, False), (1000, False), (1276, False), (1276, True), (770, True)])
+def test_one_wave_per_4096_point_block_kernel_on_a_large_launch(ntaps, cplx_taps):
+    """513 .. 1 281 taps on a ComplexFloat32 stream, launches of at least eight 4096-point blocks per CU: fir_fft64_kernel (kernels_firfft64.h, round 4) -
+    4096 = 64 x 64 with both 64-point transforms in registers and one transpose per direction; eight waves per CU on the conjugate-symmetric H of real
+    taps, four on the full H of complex taps.  2^23 samples against the f64 oracle on slabs (first, two interior, last), then the same stream in ragged
+    chunks that straddle the small-launch kernel (workgroup per block) and this one."""
+    rng = np.random.default_rng(900 + ntaps + cplx_taps)
+    n = 1 << 23
+    x = rand_c(rng, n)
+    taps = rand_c(rng, ntaps) if cplx_taps else rand_r(rng, ntaps)
+    taps = (taps / np.sum(np.abs(taps))).astype(taps.dtype)
+    blk = make(lr.FIRFilterBlock, [taps, "fast"], x)
+    got = blk.process(x)
+    assert len(got) == n
+
+    def slab_err(y, a, b):
+        lo = max(0, a - (ntaps - 1))
+        want = O.FIR(taps, True, O.MODE_F64).process(x[lo:b])[a - lo:]
+        return G.max_abs_err(y[a:b], want)
+
+    slabs = [(0, 6000), (2816 * 700 - 100, 2816 * 700 + 6000), (n // 2 + 12345, n // 2 + 18345), (n - 6000, n)]
+    for a, b in slabs:
+        assert slab_err(got, a, b) < 1e-6, (a, b)
+    blk.reset()
+    got2 = chunked(blk, x, [1, 4097, 7000000, 7000001, 7500000])
+    for a, b in slabs:
+        assert slab_err(got2, a, b) < 1e-6, (a, b)
+    assert G.max_abs_err(got, got2) < 1e-6
+
+
 def test_fir_auto_mode_picks_the_faster_arithmetic():
     rng = np.random.default_rng(8)
     x = rand_c(rng, 30000)

@@ -254,3 +254,19 @@ def test_bench_without_enough_devices_exits_nonzero():
         pytest.skip("box with GPUs: covered by tests/test_gpu_bench.py")
     r, _ = _bench_plain("--gpus", "8", "--steps", "1")
     assert r.returncode != 0 and "8 asked for, 0 device(s) visible" in r.stderr and "n_gpus" not in r.stdout
+
+
+def test_fft_building_blocks_run_on_the_cpu(tmp_path):
+    """radix4 / dft16 / dft64 and the complex helpers of pk_math.h are __host__ __device__ (the device pass compiles the packed-f32 bodies, the host pass
+    the scalar ones), so the index algebra of the one-wave-per-block overlap-save kernel (kernels_firfft64.h: 4096 = 64 x 64, two in-register 64-point
+    transforms, one transpose, the D x C twiddle) is checked HERE, without a GPU, against double-precision DFTs: tools/host_fft_check.hip"""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "host_fft_check")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-Wno-unused-function", "-I", os.path.join(ROOT, "luaradio_amd", "csrc"),
+                        "-I", os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tools", "host_fft_check.hip")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr

@@ -41,17 +41,26 @@ static void build_tables(const std::vector<float> &taps, std::vector<float> &tab
             }
             tab[2 * ((size_t)F64_TAB_H + r * 64 + l)] = (float)(sr / F4K_N);
             tab[2 * ((size_t)F64_TAB_H + r * 64 + l) + 1] = (float)(si / F4K_N);
+            if (l <= 32) {
+                const size_t o = (size_t)F64_TAB_HSYM + (size_t)f64_index(r) * F64_HSYM_ROW + l;
+                tab[2 * o] = (float)(sr / F4K_N);
+                tab[2 * o + 1] = (float)(si / F4K_N);
+            }
         }
 }
 
+#ifndef AB_WAVES
+#define AB_WAVES 4
+#endif
+constexpr int F64_WAVES = AB_WAVES;
 template <int V>
 static void launch(const float *hist, const float *x, const float2 *tables, float *y, int M, long n, int grid, int xcd)
 {
-    const size_t lds = (size_t)F64_LDS_ELEMS * sizeof(float2);
+    const size_t lds = (size_t)f64_lds_elems(F64_WAVES) * sizeof(float2);
     static bool set = false;
-    if (!set) { CK(hipFuncSetAttribute((const void *)fir_fft64_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+    if (!set) { CK(hipFuncSetAttribute((const void *)fir_fft64_kernel<V, F64_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
     const long nblocks = (n + (F4K_N - V) - 1) / (F4K_N - V);
-    hipLaunchKernelGGL((fir_fft64_kernel<V>), dim3(grid), dim3(256), lds, 0, hist, x, tables, y, M, n, n, nblocks, (float *)nullptr, xcd);
+    hipLaunchKernelGGL((fir_fft64_kernel<V, F64_WAVES>), dim3(grid), dim3(64 * F64_WAVES), lds, 0, hist, x, tables, y, M, n, n, nblocks, (float *)nullptr, xcd);
 }
 
 int main(int argc, char **argv)
@@ -80,7 +89,7 @@ int main(int argc, char **argv)
     int dev = 0, cus = 0;
     CK(hipGetDevice(&dev));
     CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const long nblocks = (n + (F4K_N - V) - 1) / (F4K_N - V), nslots = (nblocks + 3) / 4;
+    const long nblocks = (n + (F4K_N - V) - 1) / (F4K_N - V), nslots = (nblocks + F64_WAVES - 1) / F64_WAVES;
     const int grid = (int)std::min<long>(nslots, cus);
     auto go = [&]() {
         if (V == 768) launch<768>(hist, x, tables, y, ntaps, n, grid, xcd);
@@ -108,6 +117,31 @@ int main(int argc, char **argv)
             for (int m = 0; m < ntaps; m++) acc += (double)taps[m] * sample(q - m, c);
             worst = std::max(worst, std::fabs(acc - (double)yh[(size_t)q * S + c]));
         }
+    if (getenv("AB_DEBUG")) {
+        const long Lh = F4K_N - V;
+        double wb[6] = {0, 0, 0, 0, 0, 0};
+        for (long q : pos) {
+            double acc = 0;
+            for (int m = 0; m < ntaps; m++) acc += (double)taps[m] * sample(q - m, 0);
+            const long blk = q / Lh, nb = (n + Lh - 1) / Lh;
+            const int cls = blk == 0 ? 0 : blk == 1 ? 1 : blk == nb - 1 ? 5 : blk == nb - 2 ? 4 : blk == nb - 3 ? 3 : 2;
+            wb[cls] = std::max(wb[cls], std::fabs(acc - (double)yh[(size_t)q * S]));
+        }
+        int shown = 0;
+        for (long q : pos) {
+            double acc = 0;
+            for (int m = 0; m < ntaps; m++) acc += (double)taps[m] * sample(q - m, 0);
+            const double e = std::fabs(acc - (double)yh[(size_t)q * S]);
+            if (e > 1e-6 && shown < 40) { printf("  bad q=%ld block=%ld window pos=%ld (row %ld lane %ld) err %.3g\n", q, q / Lh, q % Lh + V, (q % Lh + V) / 64, (q % Lh + V) % 64, e); shown++; }
+        }
+        printf("  max err by block: first %.3g second %.3g interior %.3g third-last %.3g second-last %.3g last %.3g\n", wb[0], wb[1], wb[2], wb[3], wb[4], wb[5]);
+        for (long q : {0L, 1L, 2L, 3000L, 3001L, 100000L, 100001L}) {
+            double acc = 0, acc1 = 0;
+            for (int m = 0; m < ntaps; m++) { acc += (double)taps[m] * sample(q - m, 0); acc1 += (double)taps[m] * sample(q - m, 1); }
+            printf("  y[%ld] = (%.6f, %.6f)   want (%.6f, %.6f)\n", q, yh[2 * q], yh[2 * q + 1], acc, acc1);
+        }
+        printf("  last error: %s\n", hipGetErrorString(hipGetLastError()));
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 5; i++) go();

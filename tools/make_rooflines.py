@@ -85,8 +85,8 @@ def main():
         ("IQ records u8 -> cf32", blocks, ("format_convert_vec_kernel<unsigned char, unsigned char",), 10, n26, 0),
         ("IQ records s16le -> cf32", blocks, ("format_convert_vec_kernel<unsigned short, short",), 12, n26, 0),
         ("IQ records f32be -> cf32", blocks, ("format_convert_vec_kernel<unsigned int, float, true",), 16, n26, 0),
-        ("FIR 1276 real taps cf32, overlap-save, one 4096-point launch (a wave per block)", blocks, ("fir_fft4kw_kernel<1280",), 16, n26, 180),
-        ("FIR 768 real taps cf32, overlap-save, one 4096-point launch (a wave per block)", blocks, ("fir_fft4kw_kernel<768",), 16, n26, 160),
+        ("FIR 1276 real taps cf32, overlap-save, one 4096-point launch (a wave per block, 64 x 64)", blocks, ("fir_fft64_kernel<1280",), 16, n26, 180),
+        ("FIR 768 real taps cf32, overlap-save, one 4096-point launch (a wave per block, 64 x 64)", blocks, ("fir_fft64_kernel<768",), 16, n26, 160),
         ("WBFM mono receiver from u8 IQ records, ONE launch (bench_blocks: noise input)", blocks, ("rx_fused_kernel<1>",), 2.16, n26, 167),
         ("Tuner from u8 IQ records (fan-out branch fed from a file), ONE launch", blocks, ("fir_mfma_persistent_kernel<2, 5, 2, true, 51, 0, false, 4, 1",), 3.6, n26, 108.4),
         ("Tuner(decimation 50) from u8 IQ records, ONE launch (AM / SSB / NBFM receivers fed from a file)", blocks, ("fir_decim_lds_kernel<2, true, false, 1",), 2.16, n26, 16.2),
