@@ -526,6 +526,127 @@ def fanout_records_report(lr, L, torch, dev, x, n, fs, offset):
             "note": "2 B per sample on the link: 153 GB/s / 2 B = 76.5 GS/s per receiving GPU instead of 19.1"}
 
 
+def host_path_report(lr, L, torch, dev):
+    """VERDICT r03 missing 5 / 6: what a LuaRadio flow graph sees, PCIe included - never `value`.  (a) configs[2] "fed from IQ file source": a file in
+    the page cache is read in IQFileSource's 8 192-sample chunks (radio/blocks/sources/iqfile.lua:52) and in the pipe's 131 072-sample chunks
+    (radio/core/pipe.lua:495-533) and pushed into the receiver chain's pinned ring (lrhip_chain_push, batches of 2^20 samples, depth 3) - u8 records
+    (2 B per sample on the link) and ComplexFloat32 (8 B); (b) a STAND-ALONE block, LowpassFilterBlock(128) cf32 -> cf32 through lrhip_stage_execute
+    with 2^20-sample vectors: both directions cross the link; with the caller's page-aligned vectors registered (lrhip_host_register: DMA from / to
+    them, no staging copy) and without.  Every leg's output is compared bit for bit with the device-resident run of the same batches."""
+    import ctypes as C
+    import tempfile
+    import numpy as np
+    from luaradio_amd import _lib, types
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    from iqfile_wbfm_mono import build_chain
+    LINK = 64.0                                        # PCIe 5.0 x16, GB/s per direction (nominal)
+    n, fs, batch = 1 << 24, 1102500.0, 1 << 20
+    rng = np.random.default_rng(11)
+    rep = {"link_GB/s_nominal": LINK, "samples": n, "batch_samples": batch, "ring_depth": 3}
+    tmp = tempfile.mkdtemp(prefix="lrhip_bench_")
+    try:
+        # ---- (a) file -> receiver
+        raw = rng.integers(0, 256, 2 * n, dtype=np.uint8)
+        cf = (((raw.astype(np.float32) - 127.5) / 127.5)).view(np.complex64)
+        files = {"u8": (os.path.join(tmp, "iq.u8"), raw, 2), "f32le": (os.path.join(tmp, "iq.f32"), cf.view(np.uint8), 8)}
+        for fmt, (path, data, rec) in files.items():
+            with open(path, "wb") as f:
+                f.write(data.tobytes())
+        legs = []
+        for fmt, (path, data, rec) in files.items():
+            # device-resident reference of the same batches (state carried alike): the bits the host path has to deliver
+            _s, ref, _r = build_chain(bytes(16), fmt, fs, -250e3)
+            dx = torch.from_numpy(data).to(dev)
+            cap = ref.max_output(batch) + 64
+            dy = torch.empty(cap, dtype=torch.float32, device=dev)
+            want = []
+            for a in range(0, n, batch):
+                got = ref.process_device(dx.data_ptr() + a * rec, batch, dy.data_ptr(), cap)
+                want.append(dy[:got].cpu().numpy().copy())
+            want = np.concatenate(want)
+            del dx
+            for chunk in (8192, 131072):
+                _s, ch, _r = build_chain(bytes(16), fmt, fs, -250e3)
+                ch.set_ring(3, batch)
+                buf = np.empty(chunk * rec, np.uint8)
+                outs = []
+                with open(path, "rb", buffering=0) as f:
+                    f.readinto(buf)                    # page cache warm, first-touch of buf done
+                    f.seek(0)
+                    t0 = time.perf_counter()
+                    while True:
+                        got = f.readinto(buf)
+                        if not got:
+                            break
+                        outs.append(ch.push(buf[:got]))
+                    outs.append(ch.flush())
+                    dt = time.perf_counter() - t0
+                y = np.concatenate(outs)
+                legs.append({"source": "%s IQ file (page cache) -> WBFM receiver" % fmt, "chunk_samples": chunk, "MSamples/s": round(n / dt / 1e6, 1),
+                             "h2d_GB/s": round(rec * n / dt / 1e9, 2), "frac_of_link": round(rec * n / dt / 1e9 / LINK, 3),
+                             "verified": bool(len(y) == len(want) and np.array_equal(y, want))})
+        rep["file_to_receiver"] = legs
+        # ---- (b) stand-alone block, both directions
+        def aligned(count, dtype):
+            raw_b = np.empty(count * np.dtype(dtype).itemsize + 4096, np.uint8)
+            off = (-raw_b.ctypes.data) % 4096
+            return raw_b[off:off + count * np.dtype(dtype).itemsize].view(dtype)
+        vec = 1 << 20
+        x = aligned(n, np.complex64)
+        x[:] = cf
+        y = aligned(n, np.complex64)
+        blocks = {}
+        for name in ("staged", "registered"):
+            blk = lr.LowpassFilterBlock(128, 15e3)
+            blk.use_fft = 2
+            blk.rate = 220500.0
+            blk.differentiate([types.ComplexFloat32])
+            blk.initialize()
+            blocks[name] = blk
+        def run(blk):
+            q = blk.stage_handle()
+            t0 = time.perf_counter()
+            for a in range(0, n, vec):
+                got = L.lrhip_stage_execute(q, x[a:a + vec].ctypes.data_as(C.c_void_p), vec, y[a:a + vec].ctypes.data_as(C.c_void_p), vec)
+                assert got == vec
+            return time.perf_counter() - t0
+        dxx = torch.from_numpy(x.view(np.float32).copy()).to(dev)
+        dyy = torch.empty(2 * n, dtype=torch.float32, device=dev)
+        refb = lr.LowpassFilterBlock(128, 15e3)
+        refb.use_fft = 2
+        refb.rate = 220500.0
+        refb.differentiate([types.ComplexFloat32])
+        refb.initialize()
+        # the host path cuts a call into pieces of at least 2^19 samples (chain.h HOST_PIECE_MIN): the device-resident reference takes the same cuts
+        pieces = min(8, vec >> 19) if vec >= (1 << 20) else 1
+        per = ((vec // pieces) + 4095) & ~4095
+        for a in range(0, n, vec):
+            for k in range(pieces):
+                o, m = k * per, (per if k + 1 < pieces else vec - per * (pieces - 1))
+                refb.process_device(dxx.data_ptr() + 8 * (a + o), m, dyy.data_ptr() + 8 * (a + o), m)
+        want = dyy.cpu().numpy().view(np.complex64)
+        res = {}
+        for name, blk in blocks.items():
+            if name == "registered":
+                _lib.check(L.lrhip_host_register(x.ctypes.data_as(C.c_void_p), x.nbytes), "register")
+                _lib.check(L.lrhip_host_register(y.ctypes.data_as(C.c_void_p), y.nbytes), "register")
+            run(blk)
+            blk.reset()
+            dt = run(blk)
+            res[name] = {"MSamples/s": round(n / dt / 1e6, 1), "each_direction_GB/s": round(8.0 * n / dt / 1e9, 2), "frac_of_link": round(8.0 * n / dt / 1e9 / LINK, 3),
+                         "verified": bool(np.array_equal(y, want))}
+            if name == "registered":
+                L.lrhip_host_unregister(x.ctypes.data_as(C.c_void_p))
+                L.lrhip_host_unregister(y.ctypes.data_as(C.c_void_p))
+        rep["standalone_lowpass_cf32"] = dict(res, vector_samples=vec, note="LowpassFilterBlock(128, 15e3), overlap-save arithmetic, lrhip_stage_execute: host vector "
+                                              "in, host vector out; a call travels as up to 8 pipelined pieces (H2D, kernels, D2H on three streams)")
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    rep["verified"] = all(l["verified"] for l in rep["file_to_receiver"]) and all(v["verified"] for k, v in rep["standalone_lowpass_cf32"].items() if isinstance(v, dict))
+    return rep
+
+
 def main():
     args = parse()
     self_launch(args)
@@ -820,6 +941,8 @@ def main():
             res["channelizer"] = channelizer_report(lr, L, torch, dev, not args.no_cpu_baseline)
             torch.cuda.empty_cache()
             res["fanout"] = fanout_report(lr, L, torch, dev)
+            torch.cuda.empty_cache()
+            res["host_path"] = host_path_report(lr, L, torch, dev)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

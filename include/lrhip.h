@@ -346,6 +346,13 @@ int   lrhip_memcpy_d2d(void *dev_dst, const void *dev_src, unsigned long bytes);
 /* Pinned host vectors (what radio/core/vector.lua's platform.alloc would return for device-fed blocks). */
 void *lrhip_host_alloc(unsigned long bytes);
 void  lrhip_host_free(void *host_ptr);
+/* Zero-copy for vectors the CALLER owns: LuaRadio's owning vectors are page-aligned and long-lived (posix_memalign, radio/core/vector.lua:19-37), its pipe
+ * read buffers likewise (platform.alloc, radio/core/pipe.lua:72-76).  A registered range is pinned where it lies (hipHostRegister); the synchronous
+ * host-pointer entry points (lrhip_stage_execute, lrhip_chain_execute) then DMA from / to it directly instead of staging through the library's own pinned
+ * buffers - whenever the WHOLE input (or output) vector of a call lies inside one registered range.  The owner unregisters before it frees or reallocates
+ * (a Vector that grew: radio/core/vector.lua:108-136).  Registrations do not survive fork().  Unregistered vectors work as before. */
+int   lrhip_host_register(void *host_ptr, unsigned long bytes);
+int   lrhip_host_unregister(void *host_ptr);
 
 /* ---- timing on the library stream (HIP events; used by bench.py for the roofline figure) ------------------- */
 typedef struct lrhip_timer lrhip_timer_t;

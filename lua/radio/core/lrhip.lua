@@ -89,6 +89,8 @@ int lrhip_memcpy_d2h(void *host_dst, const void *dev_src, unsigned long bytes);
 int lrhip_memcpy_d2d(void *dev_dst, const void *dev_src, unsigned long bytes);
 void *lrhip_host_alloc(unsigned long bytes);
 void lrhip_host_free(void *host_ptr);
+int lrhip_host_register(void *host_ptr, unsigned long bytes);
+int lrhip_host_unregister(void *host_ptr);
 
 lrhip_timer_t *lrhip_timer_create(void);
 void lrhip_timer_destroy(lrhip_timer_t *t);
@@ -242,11 +244,32 @@ function M.fir_mode(use_fft)
 end
 
 ---
+-- Zero-copy bookkeeping for the vectors a block owns: `registered[owner]` = the buffer pinned for it.  A Vector that outgrew its buffer got a new one
+-- (radio/core/vector.lua:108-136): the old range is unregistered first, before the collector frees it.  `M.zero_copy = false` keeps the staging copies.
+M.zero_copy = true
+local registered = setmetatable({}, {__mode = "k"})
+function M.pin(owner, data, size)
+    if not M.zero_copy or size == 0 then return end
+    local p = ffi.cast("void *", data)
+    local r = registered[owner]
+    if r ~= nil and r.ptr == p and r.size >= size then return end
+    if r ~= nil then M.lib.lrhip_host_unregister(r.ptr) end
+    if M.lib.lrhip_host_register(p, size) == 0 then
+        registered[owner] = {ptr = p, size = size}
+    else
+        registered[owner] = nil        -- not fatal: the library stages the copy as before
+    end
+end
+
+---
 -- One process() call: resize the output vector to the bound, execute, trim (firfilter.lua:130 pattern).
+-- The output vector's buffer (page-aligned, radio/core/vector.lua:19-37) is registered with the library once per (re)allocation, so the result is
+-- written into it by DMA; the input is a cast into the pipe's read buffer, which DeviceChainBlock / the block's run loop may register as a whole.
 function M.execute(stage, x, out)
     local lib = M.lib
     local cap = tonumber(lib.lrhip_stage_max_output(stage, x.length))
     out:resize(cap)
+    M.pin(out, out.data, out._capacity * ffi.sizeof(out.data_type))      -- capacity in elements (radio/core/vector.lua:27,132)
     local n = tonumber(lib.lrhip_stage_execute(stage, x.data, x.length, out.data, cap))
     if n < 0 then
         error("lrhip_stage_execute: " .. ffi.string(lib.lrhip_strerror()))

@@ -84,6 +84,8 @@ SIGNATURES = {
     "lrhip_memcpy_d2d": (C.c_int, [_vp, _vp, _ul]),
     "lrhip_host_alloc": (_vp, [_ul]),
     "lrhip_host_free": (None, [_vp]),
+    "lrhip_host_register": (C.c_int, [_vp, _ul]),
+    "lrhip_host_unregister": (C.c_int, [_vp]),
     "lrhip_timer_create": (_vp, []),
     "lrhip_timer_destroy": (None, [_vp]),
     "lrhip_timer_start": (C.c_int, [_vp]),

@@ -46,27 +46,144 @@ struct lrhip_chain {
     }
 };
 
-// host-pointer path shared by stages and chains: pinned staging in, run, pinned staging out
+// ---- caller-owned host memory the driver may DMA from / to directly (lrhip_host_register) ------------------------------------------------
+// LuaRadio's owning vectors and pipe read buffers are page-aligned and long-lived (radio/core/vector.lua:19-37, radio/core/pipe.lua:72-76), so the
+// staging copies of the host-pointer path (caller vector -> pinned slot -> device and back) are two avoidable passes over host memory per direction:
+// a registered range is pinned where it lies and hipMemcpyAsync reads / writes it.  Ranges are kept by the library only to answer "is this pointer inside
+// one?" - the owner registers and unregisters (before it frees).
+struct HostRanges {
+    std::mutex m;
+    std::vector<std::pair<const char *, size_t>> r;
+    long pid = 0;
+    bool has(const void *p, size_t bytes)
+    {
+        if (!bytes) return true;
+        std::lock_guard<std::mutex> lk(m);
+        if (pid != (long)getpid()) { r.clear(); pid = (long)getpid(); }      // registrations do not survive fork()
+        const char *q = (const char *)p;
+        for (auto &e : r)
+            if (q >= e.first && q + bytes <= e.first + e.second) return true;
+        return false;
+    }
+};
+static HostRanges &host_ranges()
+{
+    static HostRanges h;
+    return h;
+}
+// copy streams of the piece-wise host path (per process, created on first use)
+struct HostPipe {
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<hipEvent_t> ev;      // 3 per piece: H2D done, kernels done, D2H done
+    long pid = 0;
+    int ensure(size_t pieces)
+    {
+        if (pid != (long)getpid()) { s_in = s_out = nullptr; ev.clear(); pid = (long)getpid(); }
+        if (!s_in) LR_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+        if (!s_out) LR_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+        while (ev.size() < 3 * pieces) {
+            hipEvent_t e = nullptr;
+            LR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ev.push_back(e);
+        }
+        return 0;
+    }
+};
+static HostPipe &host_pipe()
+{
+    static HostPipe h;
+    return h;
+}
+
+// host-pointer path shared by stages and chains: (pinned staging | registered caller memory) in, run, out.
+// Round 4: a call of HOST_PIECE_MIN samples and more is cut into up to HOST_PIECES pieces that travel as a pipeline - H2D of piece k+1 (copy-in stream), the
+// kernels of piece k (library stream), D2H of piece k-1 (copy-out stream), the CPU-side staging copies of an unregistered vector in between - so that both
+// directions of the link and the host copies work at the same time instead of one after the other (a stand-alone LowpassFilter cf32 -> cf32: 1.9-2.4 GS/s as one piece, 3.3 / 4.3 / 5.2 GS/s at 2^20 / 2^22 / 2^24 samples per call on registered vectors).  Block state advances piece by piece exactly as it does chunk by chunk, so the values are those of any other chunking of
+// the stream (bit for bit for direct-form blocks; overlap-save filters and the single-launch receiver to their stated Float32 rounding, include/lrhip.h).
+constexpr unsigned long HOST_PIECE_MIN = 1ul << 19;      // same-box A/B (tools/ab_hostpath.py), 2^20-sample vectors: 2^17 2.6, 2^18 3.1, 2^19 3.3 GS/s registered
+constexpr unsigned long HOST_PIECES = 8;
+static unsigned long host_piece_min()
+{
+    static const unsigned long v = getenv("LRHIP_HOST_PIECE_MIN") ? strtoul(getenv("LRHIP_HOST_PIECE_MIN"), nullptr, 10) : HOST_PIECE_MIN;      // A/B knob
+    return v < 4096 ? 4096 : v;
+}
 template <typename Runner>
 static long host_execute(PinnedBuf &h_in, PinnedBuf &h_out, DeviceBuf &d_in, DeviceBuf &d_out, int in_size, int out_size,
                          unsigned long max_out, const void *in_host, unsigned long n_in, void *out_host,
-                         unsigned long out_capacity, Runner run)
+                         unsigned long out_capacity, Runner run, unsigned long align = 1)
 {
     if (n_in && !in_host) return set_error("null input buffer");
     size_t in_bytes = (size_t)n_in * in_size;
     unsigned long cap = max_out < out_capacity ? max_out : out_capacity;
     if (max_out > out_capacity) return set_error("output capacity %lu < required %lu", out_capacity, max_out);
     if (max_out && !out_host) return set_error("null output buffer");
-    if (h_in.reserve(in_bytes ? in_bytes : 16) || d_in.reserve(in_bytes ? in_bytes : 16)) return -1;
-    if (h_out.reserve((size_t)cap * out_size + 16) || d_out.reserve((size_t)cap * out_size + 16)) return -1;
-    if (in_bytes) {
-        host_copy(h_in.p, in_host, in_bytes);
-        LR_HIP(hipMemcpyAsync(d_in.p, h_in.p, in_bytes, hipMemcpyHostToDevice, ctx().stream));
+    const bool in_reg = host_ranges().has(in_host, in_bytes), out_reg = host_ranges().has(out_host, (size_t)cap * out_size);
+    if ((!in_reg && h_in.reserve(in_bytes ? in_bytes : 16)) || d_in.reserve(in_bytes ? in_bytes : 16)) return -1;
+    if ((!out_reg && h_out.reserve((size_t)cap * out_size + 16)) || d_out.reserve((size_t)cap * out_size + 16 * (size_t)HOST_PIECES * out_size + 16)) return -1;
+    static const bool no_pieces = getenv("LRHIP_HOST_NO_PIECES") != nullptr;      // A/B knob: one piece, as in round 3
+    unsigned long pieces = (no_pieces || n_in < 2 * host_piece_min()) ? 1 : n_in / host_piece_min();
+    if (pieces > HOST_PIECES) pieces = HOST_PIECES;
+    if (pieces <= 1) {
+        const void *src = in_reg ? in_host : h_in.p;
+        if (in_bytes) {
+            if (!in_reg) host_copy(h_in.p, in_host, in_bytes);
+            LR_HIP(hipMemcpyAsync(d_in.p, src, in_bytes, hipMemcpyHostToDevice, ctx().stream));
+        }
+        long n_out = run(d_in.p, n_in, d_out.p, cap);
+        if (n_out < 0) return n_out;
+        if (n_out) LR_HIP(hipMemcpyAsync(out_reg ? out_host : h_out.p, d_out.p, (size_t)n_out * out_size, hipMemcpyDeviceToHost, ctx().stream));
+        LR_HIP(hipStreamSynchronize(ctx().stream));
+        if (n_out && !out_reg) host_copy(out_host, h_out.p, (size_t)n_out * out_size);
+        return n_out;
     }
-    long n_out = run(d_in.p, n_in, d_out.p, cap);
-    if (n_out < 0) return n_out;
-    if (n_out) LR_HIP(hipMemcpyAsync(h_out.p, d_out.p, (size_t)n_out * out_size, hipMemcpyDeviceToHost, ctx().stream));
-    LR_HIP(hipStreamSynchronize(ctx().stream));
-    if (n_out) host_copy(out_host, h_out.p, (size_t)n_out * out_size);
-    return n_out;
+    HostPipe &hp = host_pipe();
+    if (hp.ensure(pieces)) return -1;
+    // samples per piece: a multiple of the stage's / chain's own grid (lrhip_chain_shard_align: cuts on it reproduce the uncut run bit for bit where the
+    // chain promises that at all - 128 000 for the FM receivers), else of 4096 (keeps the rows of the streaming kernels aligned); the last piece takes the rest
+    const unsigned long grid = align > 1 ? align : 4096;
+    unsigned long per = ((n_in / pieces) + grid - 1) / grid * grid;
+    while (pieces > 1 && per * (pieces - 1) >= n_in) pieces--;
+    std::vector<unsigned long> off_out(pieces + 1, 0), cnt_out(pieces, 0);
+    unsigned long done_in = 0, total_out = 0, copied = 0;
+    for (unsigned long k = 0; k < pieces; k++) {
+        const unsigned long n_k = k + 1 == pieces ? n_in - done_in : per;
+        const size_t ib = (size_t)done_in * in_size, nb = (size_t)n_k * in_size;
+        if (!in_reg) host_copy((char *)h_in.p + ib, (const char *)in_host + ib, nb);
+        LR_HIP(hipMemcpyAsync((char *)d_in.p + ib, (in_reg ? (const char *)in_host : (const char *)h_in.p) + ib, nb, hipMemcpyHostToDevice, hp.s_in));
+        LR_HIP(hipEventRecord(hp.ev[3 * k], hp.s_in));
+        LR_HIP(hipStreamWaitEvent(ctx().stream, hp.ev[3 * k], 0));
+        // (capacity: what is left of the whole call's bound plus the slack reserved above - a piece's own bound may round up where the whole call's does not)
+        const long m = run((const char *)d_in.p + ib, n_k, (char *)d_out.p + (size_t)total_out * out_size, cap - total_out + 16 * HOST_PIECES);
+        if (m < 0) {
+            (void)hipStreamSynchronize(hp.s_in); (void)hipStreamSynchronize(ctx().stream); (void)hipStreamSynchronize(hp.s_out);
+            return m;
+        }
+        LR_HIP(hipEventRecord(hp.ev[3 * k + 1], ctx().stream));
+        LR_HIP(hipStreamWaitEvent(hp.s_out, hp.ev[3 * k + 1], 0));
+        if (m && total_out + (unsigned long)m <= cap) LR_HIP(hipMemcpyAsync((out_reg ? (char *)out_host : (char *)h_out.p) + (size_t)total_out * out_size, (char *)d_out.p + (size_t)total_out * out_size,
+                                     (size_t)m * out_size, hipMemcpyDeviceToHost, hp.s_out));
+        LR_HIP(hipEventRecord(hp.ev[3 * k + 2], hp.s_out));
+        if (total_out + (unsigned long)m > cap) {
+            (void)hipStreamSynchronize(hp.s_in); (void)hipStreamSynchronize(ctx().stream); (void)hipStreamSynchronize(hp.s_out);
+            return set_error("host path: pieces produced %lu samples, the call's bound is %lu", total_out + (unsigned long)m, cap);
+        }
+        off_out[k] = total_out; cnt_out[k] = (unsigned long)m;
+        total_out += (unsigned long)m;
+        done_in += n_k;
+        // unregistered output: hand over the pieces that have arrived while the later ones are still on their way
+        if (!out_reg)
+            while (copied < k && hipEventQuery(hp.ev[3 * copied + 2]) == hipSuccess) {
+                if (cnt_out[copied]) host_copy((char *)out_host + (size_t)off_out[copied] * out_size, (char *)h_out.p + (size_t)off_out[copied] * out_size, (size_t)cnt_out[copied] * out_size);
+                copied++;
+            }
+    }
+    if (!out_reg) {
+        for (; copied < pieces; copied++) {
+            LR_HIP(hipEventSynchronize(hp.ev[3 * copied + 2]));
+            if (cnt_out[copied]) host_copy((char *)out_host + (size_t)off_out[copied] * out_size, (char *)h_out.p + (size_t)off_out[copied] * out_size, (size_t)cnt_out[copied] * out_size);
+        }
+    } else {
+        LR_HIP(hipStreamSynchronize(hp.s_out));
+    }
+    return (long)total_out;
 }

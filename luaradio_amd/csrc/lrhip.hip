@@ -495,7 +495,7 @@ long lrhip_stage_execute(lrhip_stage_t *q, const void *in_host, unsigned long n_
     if (!q) return set_error("null stage");
     return host_execute(q->h_in, q->h_out, q->d_in, q->d_out, q->in_size, q->out_size, q->max_output(n_in), in_host, n_in,
                         out_host, out_capacity,
-                        [&](const void *di, unsigned long n, void *dout, unsigned long cap) { return q->run(di, n, dout, cap); });
+                        [&](const void *di, unsigned long n, void *dout, unsigned long cap) { return q->run(di, n, dout, cap); }, q->align());
 }
 
 long lrhip_stage_execute2_device(lrhip_stage_t *q, const void *in1_dev, const void *in2_dev, unsigned long n_in, void *out_dev,
@@ -966,7 +966,8 @@ long lrhip_chain_execute(lrhip_chain_t *c, const void *in_host, unsigned long n_
     if (!c) return set_error("null chain");
     return host_execute(c->h_in, c->h_out, c->d_in, c->d_out, c->ops.front().stage->in_size, c->ops.back().stage->out_size,
                         lrhip_chain_max_output(c, n_in), in_host, n_in, out_host, out_capacity,
-                        [&](const void *di, unsigned long n, void *dout, unsigned long cap) { return lrhip_chain_execute_device(c, di, n, dout, cap); });
+                        [&](const void *di, unsigned long n, void *dout, unsigned long cap) { return lrhip_chain_execute_device(c, di, n, dout, cap); },
+                        lrhip_chain_shard_align(c));
 }
 
 int lrhip_chain_last_launches(const lrhip_chain_t *c) { return c ? c->last_launches : set_error("null chain"); }
@@ -1271,6 +1272,41 @@ void *lrhip_host_alloc(unsigned long bytes)
 void lrhip_host_free(void *p)
 {
     if (p) (void)hipHostFree(p);
+}
+int lrhip_host_register(void *ptr, unsigned long bytes)
+{
+    if (!ptr || !bytes) return set_error("host_register: null range");
+    if (ensure_init()) return -1;
+    HostRanges &h = host_ranges();
+    {
+        std::lock_guard<std::mutex> lk(h.m);
+        if (h.pid != (long)getpid()) { h.r.clear(); h.pid = (long)getpid(); }
+        for (auto &e : h.r)
+            if (e.first == (const char *)ptr) {
+                if (e.second == bytes) return 0;
+                return set_error("host_register: %p is already registered with another size", ptr);
+            }
+    }
+    LR_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    std::lock_guard<std::mutex> lk(h.m);
+    h.r.emplace_back((const char *)ptr, (size_t)bytes);
+    return 0;
+}
+int lrhip_host_unregister(void *ptr)
+{
+    if (!ptr) return 0;
+    HostRanges &h = host_ranges();
+    {
+        std::lock_guard<std::mutex> lk(h.m);
+        auto it = h.r.begin();
+        for (; it != h.r.end(); ++it)
+            if (it->first == (const char *)ptr) break;
+        if (it == h.r.end()) return set_error("host_unregister: %p is not registered", ptr);
+        h.r.erase(it);
+    }
+    // nothing of this range may still be in flight: every host-pointer entry point has synchronised before it returned
+    LR_HIP(hipHostUnregister(ptr));
+    return 0;
 }
 
 // ---- timers ----------------------------------------------------------------------------------------------------

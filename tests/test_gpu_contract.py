@@ -323,3 +323,53 @@ def test_tuner_without_decimation_is_a_rotator_and_a_filter():
     # a chain that is nothing but Downsampler(1) still copies
     ident = lr.Chain([make(lr.DownsamplerBlock, [1], c, FS)])
     assert np.array_equal(ident.process(x[:1000]), x[:1000])
+
+
+def _aligned(count, dtype):
+    raw = np.empty(count * np.dtype(dtype).itemsize + 4096, np.uint8)
+    off = (-raw.ctypes.data) % 4096
+    return raw[off:off + count * np.dtype(dtype).itemsize].view(dtype)
+
+
+def test_host_path_travels_in_pieces_and_takes_registered_vectors_without_a_copy():
+    """VERDICT r03 missing 6: radio/core/vector.lua:19-37 hands out page-aligned, long-lived buffers; lrhip_host_register pins them where they lie and the
+    synchronous host-pointer entry points DMA from / to them.  Independently, a call of 2^19 samples and more travels as up to eight pipelined pieces
+    (H2D, kernels, D2H on three streams).  Neither changes a bit of what a direct-form block computes: one big call == the same stream in small calls
+    == registered vectors, for a rate-preserving filter and for a decimating chain whose pieces end off the decimation grid."""
+    import ctypes as C
+    L = _lib.load()
+    rng = np.random.default_rng(31)
+    n = (1 << 21) + 777
+    x = _aligned(n, np.complex64)
+    x[:] = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+    taps = (rng.uniform(-1, 1, 128) / 128).astype(np.float32)
+
+    def fir():
+        return make(lr.FIRFilterBlock, [taps, False], types.ComplexFloat32, FS)
+
+    small = np.concatenate([b for blk in [fir()] for b in (blk.process(x[a:a + 100000]) for a in range(0, n, 100000))])
+    whole = fir().process(x)                                  # 8 pieces
+    assert np.array_equal(whole, small)
+    y = _aligned(n, np.complex64)
+    _lib.check(L.lrhip_host_register(x.ctypes.data_as(C.c_void_p), x.nbytes), "register")
+    _lib.check(L.lrhip_host_register(y.ctypes.data_as(C.c_void_p), y.nbytes), "register")
+    try:
+        assert L.lrhip_host_register(x.ctypes.data_as(C.c_void_p), x.nbytes) == 0           # same range again: fine
+        assert L.lrhip_host_register(x.ctypes.data_as(C.c_void_p), x.nbytes // 2) < 0       # another size: refused
+        blk = fir()
+        got = L.lrhip_stage_execute(blk.stage_handle(), x.ctypes.data_as(C.c_void_p), n, y.ctypes.data_as(C.c_void_p), n)
+        assert got == n and np.array_equal(y, small)
+        # a sub-vector of a registered range is registered; an unregistered output next to a registered input is staged
+        blk = fir()
+        part = blk.process(x[5:5 + (1 << 20)])
+        assert np.array_equal(part, fir().process(x[5:5 + (1 << 20)].copy()))
+        # decimating chain: pieces end off the decimation grid, the count and the samples are those of the small calls
+        dec = lr.Chain([make(lr.LowpassFilterBlock, [128, 0.1, 1.0], types.ComplexFloat32, FS), make(lr.DownsamplerBlock, [5], types.ComplexFloat32, FS)])
+        d_whole = dec.process(x)
+        dec2 = lr.Chain([make(lr.LowpassFilterBlock, [128, 0.1, 1.0], types.ComplexFloat32, FS), make(lr.DownsamplerBlock, [5], types.ComplexFloat32, FS)])
+        d_small = np.concatenate([dec2.process(x[a:a + 99991]) for a in range(0, n, 99991)])
+        assert len(d_whole) == len(d_small) == (n + 4) // 5 and np.array_equal(d_whole, d_small)
+    finally:
+        assert L.lrhip_host_unregister(x.ctypes.data_as(C.c_void_p)) == 0
+        assert L.lrhip_host_unregister(y.ctypes.data_as(C.c_void_p)) == 0
+    assert L.lrhip_host_unregister(x.ctypes.data_as(C.c_void_p)) < 0                        # not registered any more
