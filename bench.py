@@ -223,6 +223,25 @@ def wbfm_chain_report(lr, L, torch, dev, with_cpu):
     rep["roofline_frac"] = round(8.16 * n / ms / 1e6 / HBM_PEAK_GBS, 4)
     if with_cpu:
         rep.update(verify_wbfm_chain(torch, x, y, got_n, n, (steps - 1) * n, fs, -250e3))
+    # the same receiver on U(-1, 1) noise (one harness had timed this input 10 % slower): same clock state, same loop, both inputs in the line.
+    # profiles/r04_rx_input_dependence.txt: identical instruction and cycle counts for the two inputs - the difference was the clock ramp of the other harness
+    g2 = torch.Generator(device=dev).manual_seed(8)
+    xn = torch.rand(2 * n, dtype=torch.float32, device=dev, generator=g2) * 2 - 1
+    rxn = lr.wbfm_mono_receiver(fs, -250e3)
+    for _ in range(8):
+        rxn.process_device(xn.data_ptr(), n, y.data_ptr(), cap)
+    torch.cuda.synchronize()
+    tm = L.lrhip_timer_create()
+    L.lrhip_timer_start(tm)
+    for _ in range(steps):
+        rxn.process_device(xn.data_ptr(), n, y.data_ptr(), cap)
+    L.lrhip_timer_stop(tm)
+    torch.cuda.synchronize()
+    ms_n = L.lrhip_timer_elapsed_ms(tm) / steps
+    L.lrhip_timer_destroy(tm)
+    rep["on_uniform_noise_input"] = {"ms_per_step": round(ms_n, 4), "value": round(n / ms_n / 1e3, 1), "unit": "MSamples/s (RF samples in)",
+                                     "roofline_frac": round(8.16 * n / ms_n / 1e6 / HBM_PEAK_GBS, 4), "ratio_to_fm_signal": round(ms_n / ms, 3)}
+    del xn
     rep["from_u8_records"] = wbfm_u8_report(lr, L, torch, dev, x, n, fs, steps)
     return rep
 
