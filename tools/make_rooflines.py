@@ -42,7 +42,7 @@ def find(rows, *subs):
 
 def main():
     prof, out = sys.argv[1], sys.argv[2]
-    tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r04"
     bench = parse(prof + "/summary_kernel_trace.txt")
     blocks = parse(prof + "/summary_blocks_kernel_trace.txt")
     pmc = parse_pmc(prof + "/summary_pmc_blocks.txt")
@@ -85,14 +85,27 @@ def main():
         ("IQ records u8 -> cf32", blocks, ("format_convert_vec_kernel<unsigned char, unsigned char",), 10, n26, 0),
         ("IQ records s16le -> cf32", blocks, ("format_convert_vec_kernel<unsigned short, short",), 12, n26, 0),
         ("IQ records f32be -> cf32", blocks, ("format_convert_vec_kernel<unsigned int, float, true",), 16, n26, 0),
-        ("FIR 1276 real taps cf32, overlap-save, one 4096-point launch (a wave per block, 64 x 64)", blocks, ("fir_fft64_kernel<1280",), 16, n26, 180),
-        ("FIR 768 real taps cf32, overlap-save, one 4096-point launch (a wave per block, 64 x 64)", blocks, ("fir_fft64_kernel<768",), 16, n26, 160),
+        ("FIR 1276 real taps cf32, overlap-save, one 4096-point launch (a wave per block, 64 x 64)", blocks, ("fir_fft64_kernel<1280, 8>",), 16, n26, 180),
+        ("FIR 768 real taps cf32, overlap-save, one 4096-point launch (a wave per block, 64 x 64)", blocks, ("fir_fft64_kernel<768, 8>",), 16, n26, 160),
+        ("FIR 1276 complex taps cf32, overlap-save, 4096-point launch (a wave per block, four waves per CU, full H)", blocks, ("fir_fft64_kernel<1280, 4>",), 16, n26, 180),
+        ("FIR 1276 real taps f32, overlap-save, partitioned (kernels_firpols.h, one launch)", blocks, ("fir_pols_kernel<1, 3>",), 8, n26, 250),
+        ("FIR 4096 real taps cf32, overlap-save, partitioned: one of three launches (3 x 16 B + 2 x 8 B accumulate per sample in all)", blocks, ("fir_pols_kernel<2, 3>",), 16, n26, 250),
         ("WBFM mono receiver from u8 IQ records, ONE launch (bench_blocks: noise input)", blocks, ("rx_fused_kernel<1>",), 2.16, n26, 167),
         ("Tuner from u8 IQ records (fan-out branch fed from a file), ONE launch", blocks, ("fir_mfma_persistent_kernel<2, 5, 2, true, 51, 0, false, 4, 1",), 3.6, n26, 108.4),
         ("Tuner(decimation 50) from u8 IQ records, ONE launch (AM / SSB / NBFM receivers fed from a file)", blocks, ("fir_decim_lds_kernel<2, true, false, 1",), 2.16, n26, 16.2),
         ("PSD N=1024 hamming log fftshift", blocks, ("spectrum1024_kernel",), 12, n26, 58),
         ("WBFM mono receiver (bench_blocks: U(-1,1) noise input)", blocks, ("rx_fused_kernel<0>",), 8.16, n26, 167),
     ]
+    # un-profiled bench lines of the SAME lease (tools/profile_round.sh runs bench.py before and after the traces): what the driver's clock would have seen
+    driver = {}
+    for tagname in ("before", "after"):
+        for wl in ("fir", "wbfm"):
+            try:
+                line = [l for l in open("%s/bench_%s_%s.json" % (prof, wl, tagname)) if l.startswith("{")][0]
+                d = json.loads(line)
+                driver.setdefault(wl, {})[tagname] = {"ms_per_step": d["ms_per_step"], "launch_ms_hip_events": d["roofline"]["launch_ms_hip_events"], "frac": d["roofline"]["frac"]}
+            except (OSError, IndexError, KeyError, ValueError):
+                pass
     rows = []
     for name, src, subs, bps, n, flops in table:
         k, v = find(src, *subs)
@@ -102,6 +115,10 @@ def main():
         alg = bps * n
         row = {"row": name, "kernel": k, "samples_per_launch": n, "algorithmic_bytes_per_sample": round(bps, 4), "algorithmic_bytes_per_launch": round(alg),
                "avg_us": us, "min_us": v["min_timed_us"], "dispatches": v["calls"], "GB/s": round(alg / us / 1e3, 1), "frac_of_8TB/s": round(alg / (us * 1e-6) / HBM, 4)}
+        if src is bench and "headline" in name and "fir" in driver:
+            row["driver_like"] = driver["fir"]
+        if src is bench and "configs[2]" in name and "wbfm" in driver:
+            row["driver_like"] = driver["wbfm"]
         if flops:
             row["TFLOP/s"] = round(flops * n / (us * 1e-6) / 1e12, 2)
             row["frac_of_157.3TF"] = round(flops * n / (us * 1e-6) / FP32, 4)
@@ -118,6 +135,8 @@ def main():
                        "bench.py's 20 timed steps / bench_blocks.py's 10 repetitions; summarize_rocpd.py --last), one MI355X; frac = algorithmic bytes (SURVEY.md 8d x samples) / "
                        "avg_us / 8 TB/s.  Sources: gpurun_out/prof_%s/summary_*.txt (copied to profiles/%s_*kernel_trace.txt); the raw rocpd databases of the traces stay under "
                        "gpurun_out/prof_%s/kt*/" % (tag, tag, tag, tag),
+           "driver_like": "rows of the two bench workloads carry `driver_like`: bench.py's own line (ms_per_step = wall clock, launch_ms_hip_events, roofline.frac) run UN-profiled "
+                          "on the same lease directly before and after the traces - kernel_us (avg_us) and the driver-style step are then from one box (VERDICT r03 next 9)",
            "rows": rows}
     json.dump(doc, open(out, "w"), indent=1)
     for r in rows:

@@ -13,6 +13,9 @@ export TMPDIR=/tmp
 cd /tmp
 B="python $ROOT/bench.py --no-cpu-baseline --no-verify --headline-only"
 run() { timeout 240 rocprofv3 "$@" > /dev/null 2>&1 || echo "rocprofv3 $* failed rc=$?"; }
+# the un-profiled bench lines of THIS lease, before and after the traces (profile and driver numbers from one box)
+lines() { ( cd $ROOT && timeout 300 python bench.py --no-cpu-baseline --headline-only > "$OUT/bench_fir_$1.json" 2> /dev/null; timeout 300 python bench.py --no-cpu-baseline --workload wbfm > "$OUT/bench_wbfm_$1.json" 2> /dev/null ); }
+lines before
 # kernel traces (durations): headline FFT form, bit-exact direct form, WBFM chain, channelizer
 run --kernel-trace --stats -d "$OUT/kt/fft" -o fft -- $B --steps 20 --warmup 3
 run --kernel-trace --stats -d "$OUT/kt/direct" -o direct -- $B --steps 20 --warmup 3 --fir-mode direct
@@ -35,6 +38,7 @@ done
 run --pmc TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ -d "$OUT/pmc_fir/tcp" -o p -- $P
 # per-block table under the tracer (tools/bench_blocks.py, 2^26 samples)
 run --kernel-trace --stats -d "$OUT/kt_blocks/blocks" -o b -- python $ROOT/tools/bench_blocks.py --reps 10
+lines after
 cd "$ROOT"
 python profiles/summarize_rocpd.py "$OUT/kt" --last 20 > "$OUT/summary_kernel_trace.txt" 2>&1
 python profiles/summarize_rocpd.py "$OUT/kt_blocks" --last 10 > "$OUT/summary_blocks_kernel_trace.txt" 2>&1
