@@ -5,11 +5,12 @@
 -- same way radio/core/platform.lua:277-299 registers VOLK / liquid-dsp / FFTW3f: `platform.libs.hip` and
 -- `platform.features.hip`, with the `LUARADIO_DISABLE_HIP` escape hatch mirroring platform.lua:328-330.
 --
--- NOTE: LuaJIT is not installed in the build image, so the Lua files cannot be executed there.  They are held to the
--- C ABI and to each other by tests/test_lua_glue.py (a small Lua tokenizer: every lib.lrhip_* used is declared in the
--- cdef below with the prototype of include/lrhip.h, every method called on a block is defined by a device variant or by
--- the reference's Block class, every local function used is defined); the call sequence itself is replayed through
--- Python ctypes (luaradio_amd/_lib.py) and through tools/host_path_driver.cpp.
+-- NOTE: LuaJIT is not installed in the build image.  The Lua files are held to the C ABI and to each other by tests/test_lua_glue.py (a tokenizer
+-- model: every lib.lrhip_* used is declared in the cdef below with the prototype of include/lrhip.h, every method called on a block is defined by a
+-- device variant or by the reference's Block class, every local function used is defined, the binding survives the reference's module load order) and -
+-- since round 4 - they are EXECUTED by tests/test_lua_exec.py under a small Lua 5.1 interpreter (tests/helpers/minilua.py) with an ffi look-alike on
+-- ctypes and stand-ins for radio.core.block / pipe / platform: collapse(), the fan-out rewrite, process / cleanup / poll / run and the head / branch
+-- socket protocol run as written, against a recording fake of the library on a CPU box and against the real liblrhip.so on the GPU box.
 --
 -- @module radio.core.lrhip
 
