@@ -394,9 +394,10 @@ def make_ffi(interp, lib_proxy, sockets=None):
     def c_socketpair(domain, typ, proto, fds):
         import socket
         a, b = socket.socketpair()
-        (sockets if sockets is not None else state.setdefault("socks", [])).extend([a, b])
-        fds.lua_newindex(0, a.fileno())
-        fds.lua_newindex(1, b.fileno())
+        # raw descriptors, owned by the Lua code from here on (it closes them with ffi.C.close): a Python socket object closing the same number again
+        # later would hit whatever file got that number meanwhile
+        fds.lua_newindex(0, a.detach())
+        fds.lua_newindex(1, b.detach())
         return 0.0
 
     def c_read(fd, buf, n):
