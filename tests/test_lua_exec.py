@@ -358,7 +358,7 @@ def test_the_glue_drives_the_real_library_to_the_bits_of_the_python_chain():
     rng = np.random.default_rng(5)
     n = 300000
     x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
-    taps = lr.filter_utils.firwin_lowpass(128, 0.2).astype(np.float32)
+    taps = np.asarray(lr.filter_utils.firwin_lowpass(128, 0.2), np.float32)
     omega = -0.25
     # reference: luaradio_amd's own chain of the same three stages
     L = _lib.load()

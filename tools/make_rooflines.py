@@ -115,7 +115,7 @@ def main():
         alg = bps * n
         row = {"row": name, "kernel": k, "samples_per_launch": n, "algorithmic_bytes_per_sample": round(bps, 4), "algorithmic_bytes_per_launch": round(alg),
                "avg_us": us, "min_us": v["min_timed_us"], "dispatches": v["calls"], "GB/s": round(alg / us / 1e3, 1), "frac_of_8TB/s": round(alg / (us * 1e-6) / HBM, 4)}
-        if src is bench and "headline" in name and "fir" in driver:
+        if src is bench and "(headline" in name and "fir" in driver:
             row["driver_like"] = driver["fir"]
         if src is bench and "configs[2]" in name and "wbfm" in driver:
             row["driver_like"] = driver["wbfm"]
