@@ -48,6 +48,21 @@
 #define LRHIP_FFT_PREFETCH 0
 #endif
 
+// 1: the 15 stage-1 twiddles W_1024^(lane k1) of a lane stay in registers for the whole launch (30 registers; the kernel has 131 of the 168 that three waves
+// per SIMD allow) instead of being read from the LDS table twice per block: 30 of a block's 201 eight-byte LDS operations.  Round 4: the counters of this kernel
+// say LDS 50 % + VALU 41 % busy, the pattern of every overlap-save kernel here (section 4.7) - LDS traffic is worth removing
+#ifndef LRHIP_FFT_TW_REG
+#define LRHIP_FFT_TW_REG 1
+#endif
+
+// 2 (A/B, round 4): ALL of a lane's table values in registers - tw1 (15), tw2 forward (15), tw2 inverse (12), H (16): 116 registers, which needs two waves
+// per SIMD instead of three (256 registers each); a block then moves 128 eight-byte LDS operations (the four exchanges) instead of 201
+#if LRHIP_FFT_TW_REG == 2
+#define LRHIP_FFT_ALLREG 1
+#else
+#define LRHIP_FFT_ALLREG 0
+#endif
+
 // blocks per wave and iteration (round 3 A/B): 2 = two independent 1024-point pipelines interleaved stage by stage in one wave, each with its own
 // exchange buffer, so that the LDS exchanges and global loads of one block can overlap the butterflies of the other ("dependent phases" hypothesis); needs
 // LRHIP_FFT_WPB = 8 (one 512-thread workgroup = 8 waves per CU: 8 x 2 x 8.7 KB of exchange buffers + 17 KB of tables)
@@ -63,7 +78,7 @@ constexpr int FFT_E2_ROW = 68;
 constexpr int FFT_EX_ELEMS = LRHIP_FFT_SPLIT ? 16 * FFT_E2_ROW / 2 : 16 * FFT_E2_ROW;   // per-wave exchange buffer (float2 units)
 constexpr int FFT_WPB = LRHIP_FFT_WPB;
 constexpr int FFT_NB = LRHIP_FFT_NB;
-constexpr int FFT_WAVES_PER_SIMD = FFT_NB == 2 ? 2 : FFT_WPB == 16 ? 4 : LRHIP_FFT_SPLIT ? 4 : 3;
+constexpr int FFT_WAVES_PER_SIMD = (FFT_NB == 2 || LRHIP_FFT_ALLREG) ? 2 : FFT_WPB == 16 ? 4 : LRHIP_FFT_SPLIT ? 4 : 3;
 // LDS map (float2 units): [FFT_WPB waves x FFT_NB x FFT_EX_ELEMS | tw1 16x64 | H 16x64 | tw2 64]
 constexpr int FFT_LDS_TW1 = FFT_WPB * FFT_NB * FFT_EX_ELEMS;
 constexpr int FFT_LDS_H = FFT_LDS_TW1 + 16 * 64;
@@ -385,6 +400,25 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
     if (early) load_block(ffirst, v_first, 0);
     for (int i = tid; i < FFT_TABLE_ELEMS; i += 64 * FFT_WPB) fl[FFT_LDS_TW1 + i] = tables[i];
     __syncthreads();
+#if LRHIP_FFT_TW_REG
+    cf tw1r[16];
+#pragma unroll
+    for (int k = 1; k < 16; k++) tw1r[k] = tw1[k * 64 + lane];
+#define FFT_TW1(k) tw1r[k]
+#if LRHIP_FFT_ALLREG
+    cf tw2f[16], tw2i[16], Hr[16];
+#pragma unroll
+    for (int k = 1; k < 16; k++) tw2f[k] = tw2[k * 4 + (lane & 3)];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int t2 = 1; t2 < 4; t2++) tw2i[4 * j + t2] = tw2[(4 * j + (lane & 3)) * 4 + t2];
+#pragma unroll
+    for (int r = 0; r < 16; r++) Hr[r] = Hp[r * 64 + lane];
+#endif
+#else
+#define FFT_TW1(k) tw1[(k) * 64 + lane]
+#endif
 
     for (long fbase = ffirst; fbase * BPW < nblocks && fbase < fend; fbase += FFT_NB * fstep) {
         cf v[FFT_NB][16];
@@ -410,7 +444,7 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             if (S == 2 && b == 0) prefetch(fbase + FFT_NB * fstep);
 #endif
 #pragma unroll
-            for (int k = 1; k < 16; k++) v[b][k] = cmul(v[b][k], tw1[k * 64 + lane]);
+            for (int k = 1; k < 16; k++) v[b][k] = cmul(v[b][k], FFT_TW1(k));
         }
         // E1: write (k1, t), read (k1 = k1s, 4*t1 + t2), t2 = sub
 #pragma unroll
@@ -421,7 +455,11 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
         for (int b = 0; b < FFT_NB; b++) {
             dft16<1>(v[b]);
 #pragma unroll
+#if LRHIP_FFT_ALLREG
+            for (int k = 1; k < 16; k++) v[b][k] = cmul(v[b][k], tw2f[k]);
+#else
             for (int k = 1; k < 16; k++) v[b][k] = cmul(v[b][k], tw2[k * 4 + sub]);
+#endif
         }
         // E2: write (k1 = k1s, k2, t2 = sub), read (k1 = k1s, k2 = 4j + q, t2 = 0..3), q = sub; register 4j + t2
 #pragma unroll
@@ -435,11 +473,19 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             for (int j = 0; j < 4; j++) {
                 radix4<1>(v[b][4 * j], v[b][4 * j + 1], v[b][4 * j + 2], v[b][4 * j + 3]);
 #pragma unroll
+#if LRHIP_FFT_ALLREG
+                for (int k3 = 0; k3 < 4; k3++) v[b][4 * j + k3] = cmul(v[b][4 * j + k3], Hr[4 * j + k3]);
+#else
                 for (int k3 = 0; k3 < 4; k3++) v[b][4 * j + k3] = cmul(v[b][4 * j + k3], Hp[(4 * j + k3) * 64 + lane]);
+#endif
                 radix4<-1>(v[b][4 * j], v[b][4 * j + 1], v[b][4 * j + 2], v[b][4 * j + 3]);
                 // conj twiddle W_64^(-t2*k2), k2 = 4j + q
 #pragma unroll
+#if LRHIP_FFT_ALLREG
+                for (int t2 = 1; t2 < 4; t2++) v[b][4 * j + t2] = cmulc(v[b][4 * j + t2], tw2i[4 * j + t2]);
+#else
                 for (int t2 = 1; t2 < 4; t2++) v[b][4 * j + t2] = cmulc(v[b][4 * j + t2], tw2[(4 * j + sub) * 4 + t2]);
+#endif
             }
         }
         // E2 back: write (k1, k2 = 4j + q, t2), read (k1 = k1s, k2 = 0..15, t2 = sub)
@@ -458,13 +504,14 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) {
 #pragma unroll
-            for (int k = 1; k < 16; k++) v[b][k] = cmulc(v[b][k], tw1[k * 64 + lane]);
+            for (int k = 1; k < 16; k++) v[b][k] = cmulc(v[b][k], FFT_TW1(k));
             dft16<-1>(v[b]);
         }
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++)
             if (live[b]) store_block(fbase + b * fstep, v[b]);
     }
+#undef FFT_TW1
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -29,6 +29,11 @@
 #ifndef LRHIP_POLS_WPB
 #define LRHIP_POLS_WPB 12
 #endif
+// twiddle tables in registers instead of LDS reads per block (the kernel is LDS-bound: 55 % busy, section 4.7): 1 = tw1 (30 registers), 2 = tw1 + both tw2 sets
+// (84 registers: needs LRHIP_POLS_WPB = 8, two waves per SIMD)
+#ifndef LRHIP_POLS_TW_REG
+#define LRHIP_POLS_TW_REG 0
+#endif
 
 namespace lrhip {
 
@@ -74,6 +79,28 @@ __global__ __launch_bounds__(64 * POLS_WPB, 1) void fir_pols_kernel(const float 
     __syncthreads();
     const int sub = lane & 3, k1s = lane >> 2;
     const long delay = (long)part0 * POLS_HOP;
+#if LRHIP_POLS_TW_REG >= 1
+    cf tw1r[16];
+#pragma unroll
+    for (int q = 1; q < 16; q++) tw1r[q] = tw1[q * 64 + lane];
+#define POLS_TW1(q) tw1r[q]
+#else
+#define POLS_TW1(q) tw1[(q) * 64 + lane]
+#endif
+#if LRHIP_POLS_TW_REG >= 2
+    cf tw2f[16], tw2i[16];
+#pragma unroll
+    for (int q = 1; q < 16; q++) tw2f[q] = tw2[q * 4 + sub];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int t2 = 1; t2 < 4; t2++) tw2i[4 * j + t2] = tw2[(4 * j + sub) * 4 + t2];
+#define POLS_TW2F(q) tw2f[q]
+#define POLS_TW2I(j, t2) tw2i[4 * (j) + (t2)]
+#else
+#define POLS_TW2F(q) tw2[(q) * 4 + sub]
+#define POLS_TW2I(j, t2) tw2[(4 * (j) + sub) * 4 + (t2)]
+#endif
 
     // runs: slot s = the POLS_WPB (S = 1: 2 x POLS_WPB) adjacent runs of one workgroup pass; workgroup g walks slots g, g + gridDim.x, ...
     constexpr int RPW = S == 2 ? 1 : 2;                       // runs per wave
@@ -139,11 +166,11 @@ __global__ __launch_bounds__(64 * POLS_WPB, 1) void fir_pols_kernel(const float 
             // ---- forward 1024-point transform (kernels_firfft.h stages)
             dft16<1>(v);
 #pragma unroll
-            for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw1[q * 64 + lane]);
+            for (int q = 1; q < 16; q++) v[q] = cmul(v[q], POLS_TW1(q));
             exchange(ex, v, [&](int q) { return q * FFT_E1_ROW + lane; }, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; });
             dft16<1>(v);
 #pragma unroll
-            for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw2[q * 4 + sub]);
+            for (int q = 1; q < 16; q++) v[q] = cmul(v[q], POLS_TW2F(q));
             exchange(ex, v, [&](int q) { return k1s * FFT_E2_ROW + 17 * sub + q; }, [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; });
 #pragma unroll
             for (int j = 0; j < 4; j++) radix4<1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
@@ -174,13 +201,13 @@ __global__ __launch_bounds__(64 * POLS_WPB, 1) void fir_pols_kernel(const float 
             for (int j = 0; j < 4; j++) {
                 radix4<-1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
 #pragma unroll
-                for (int t2 = 1; t2 < 4; t2++) v[4 * j + t2] = cmulc(v[4 * j + t2], tw2[(4 * j + sub) * 4 + t2]);
+                for (int t2 = 1; t2 < 4; t2++) v[4 * j + t2] = cmulc(v[4 * j + t2], POLS_TW2I(j, t2));
             }
             exchange(ex, v, [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; }, [&](int q) { return k1s * FFT_E2_ROW + 17 * sub + q; });
             dft16<-1>(v);
             exchange(ex, v, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; }, [&](int q) { return q * FFT_E1_ROW + lane; });
 #pragma unroll
-            for (int q = 1; q < 16; q++) v[q] = cmulc(v[q], tw1[q * 64 + lane]);
+            for (int q = 1; q < 16; q++) v[q] = cmulc(v[q], POLS_TW1(q));
             dft16<-1>(v);
             // ---- rows 8..15 are the block's 512 outputs
             if (S == 2) {
