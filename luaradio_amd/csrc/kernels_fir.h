@@ -328,6 +328,53 @@ __device__ __forceinline__ void mfma_tile(const float *ldsT, int tlen, int e, co
     }
 }
 
+// The A fragments (taps) of a launch do not change from tile to tile: lane (m, kq) reads the same KS floats every time.  A persistent kernel with registers
+// to spare keeps them (round 4, the FM receiver: KS = 51 registers): the MFMA loop then makes ONE LDS read per step instead of two - the counters of that kernel
+// read LDS 55 % busy, like every kernel here whose LDS traffic turned out to matter.
+// NR <= KS: the first NR steps take their A fragment from registers, the rest from LDS as before (the register file decides NR)
+template <int S, int D, int KS, int TQS, int NR>
+__device__ __forceinline__ void mfma_load_areg(const float *ldsT, int e, float (&areg)[NR])
+{
+    using G = FirMfmaGeom<S, D>;
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 15, kq = lane >> 4;
+    const float *aptr = ldsT + kq * TQS + fir_taps_zl(D) + kq - e - col * D;
+#pragma unroll
+    for (int s = 0; s < NR; s++) areg[s] = aptr[4 * (s / G::GROUP) * G::GROUP + 4 * (s % G::GROUP)];
+}
+template <int S, int D, int NACC, int KS, int TQS, int NR>
+__device__ __forceinline__ void mfma_tile_areg(const float (&areg)[NR], const float *ldsT, int e, const float *ldsX, f32x4 (&acc)[1][NACC])
+{
+    using G = FirMfmaGeom<S, D>;
+    static_assert(NR <= KS, "register-resident steps");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int blk_in_acc = S == 2 ? (col >> 1) : col;
+    const int comp = S == 2 ? (col & 1) : 0;
+    constexpr int ACC_STRIDE = (G::ROW + G::PAD) * G::BPA;
+    const float *bptr = ldsX + (G::ROW + G::PAD) * ((wave * NACC) * G::BPA + blk_in_acc) + S * kq + comp;
+    const float *aptr = ldsT + kq * TQS + fir_taps_zl(D) + kq - e - col * D;
+#pragma unroll
+    for (int a = 0; a < NACC; a++) acc[0][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bv[2][NACC], av[2];
+    auto fetch = [&](int buf, int s) {
+        const int g = s / G::GROUP, j = s % G::GROUP;
+        const float *bp = bptr + g * (G::ROW + G::PAD);
+#pragma unroll
+        for (int a = 0; a < NACC; a++) bv[buf][a] = bp[a * ACC_STRIDE + j * 4 * S];
+        if (s >= NR) av[buf] = aptr[4 * g * G::GROUP + 4 * j];
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+        if (s + 1 < KS) fetch((s + 1) & 1, s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < NACC; a++) acc[0][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(s < NR ? areg[s < NR ? s : 0] : av[s & 1], bv[s & 1][a], acc[0][a], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // epilogue: accumulator lane (col, kq) holds rows 4*kq .. 4*kq+3 of column col
 template <int S, int D, int NACC, int NOUT>
 __device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, long n_out, int out_aligned, f32x4 (&acc)[NOUT][NACC])

@@ -30,6 +30,12 @@
 #pragma once
 #include "kernels_fir.h"
 
+// N > 0: the tuner's Toeplitz A fragments of the first N of its 51 MFMA steps stay in registers across the tiles of a launch (kernels_fir.h mfma_tile_areg):
+// one LDS read per such step instead of two.  51 would spill (123 + 51 registers against the 168 of three waves per SIMD); 0 = the round-3 loop
+#ifndef LRHIP_RX_AREG
+#define LRHIP_RX_AREG 40
+#endif
+
 namespace lrhip {
 
 struct RxParams {
@@ -156,6 +162,10 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
     // written yet (the batch in front of it, the tail of the chunk's last batch, the last window float) must be FINITE: 0 * NaN poisons a block
     for (int i = tid; i < RX_PF; i += NT) P[i] = 0.f;
     __syncthreads();
+#if LRHIP_RX_AREG
+    float areg[LRHIP_RX_AREG];                                        // the tuner's A fragments: the same floats for every tile of the launch
+    mfma_load_areg<S, D, RX_KS, RX_TQS, LRHIP_RX_AREG>(ldsT, pr.e, areg);
+#endif
 
     // ---- this workgroup's run
     // the chunk's TILES are dealt out evenly (the first ntiles mod grid workgroups take one more); a run's batches count from its own first tile,
@@ -264,7 +274,11 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
         // ---- filter: banded-Toeplitz product on the f32 matrix cores, one accumulator (128 outputs) per wave
         f32x4 acc[1][1];
         if (pr.dbg & 4) acc[0][0] = (f32x4){ldsX[tid], ldsX[tid + 256], ldsX[tid + 512], ldsX[tid + 768]};
+#if LRHIP_RX_AREG
+        else mfma_tile_areg<S, D, 1, RX_KS, RX_TQS, LRHIP_RX_AREG>(areg, ldsT, pr.e, ldsX, acc);
+#else
         else mfma_tile<S, D, 1, RX_KS, 1, RX_TQS>(ldsT, RX_TLEN, pr.e, ldsX, RX_KS, acc);
+#endif
 
         // ---- discriminator on the accumulators -> P.  After the re/im exchange a lane owns two consecutive filter outputs; the one in front of them is
         // one shuffle away - except for lane 0, whose predecessor is the previous wave's last output (through LDS, after the barrier that also

@@ -265,6 +265,7 @@ def test_elementwise_vector_kernels_equal_the_scalar_ones(n):
             _, xv = views(n * fin, off)
             ybuf = torch.zeros(n * up * fout + 16, device="cuda")
             yv = ybuf[off:off + n * up * fout]
+            torch.cuda.synchronize()       # torch filled the buffers on ITS stream; the library launches on its own
             got = blk.process_device(xv.data_ptr(), n, yv.data_ptr(), n * up)
             assert got == n * up
             # a second chunk through the same block (Delay carries state; the others must not care)
@@ -282,6 +283,7 @@ def test_elementwise_vector_kernels_equal_the_scalar_ones(n):
         bv.copy_(pool[n:2 * n])
         ybuf = torch.zeros(2 * n + 16, device="cuda")
         yv = ybuf[off:off + 2 * n]
+        torch.cuda.synchronize()
         assert _lib.check(L.lrhip_stage_execute2_device(blk.stage_handle(), av.data_ptr(), bv.data_ptr(), n, yv.data_ptr(), n), "f2c") == n
         torch.cuda.synchronize()
         outs.append(yv.cpu().numpy().copy())
@@ -301,6 +303,7 @@ def test_elementwise_vector_kernels_equal_the_scalar_ones(n):
                 rv.copy_((raw[:2 * n * nbytes] & 0x3f))
             ybuf = torch.zeros(2 * n + 16, device="cuda")
             yv = ybuf[4:4 + 2 * n]
+            torch.cuda.synchronize()       # torch filled the buffers on ITS stream; the library launches on its own
             assert _lib.check(L.lrhip_stage_execute_device(q, rv.data_ptr(), n, yv.data_ptr(), n), fmt) == n
             torch.cuda.synchronize()
             outs.append(yv.cpu().numpy().copy())
