@@ -222,8 +222,9 @@ struct CopyPool {
         for (;;) {
             // a megabyte copies in ~25 us on four threads - less than a condition-variable wake-up: spin for a while first (chunks arrive back to
             // back while a stream runs), sleep when the stream pauses
-            // (LRHIP_COPY_SPIN iterations, default 4000 = some tens of microseconds: a LuaRadio graph is one process per block, and every one of them
-            // would otherwise keep its helper threads spinning for most of a millisecond per chunk)
+            // (LRHIP_COPY_SPIN iterations, default 20000 = a few hundred microseconds; a flow graph with many device blocks per host can lower it - round 4 measured
+            // 4000 on the pipelined host path: the pieces of one call arrive further apart than that, the workers slept in between, and the staged
+            // stand-alone block fell from 2.4 to 1.0-1.7 GS/s)
             int spins = 0;
             while (generation.load(std::memory_order_acquire) == seen && spins < spin_limit) {
                 cpu_relax();
@@ -239,7 +240,7 @@ struct CopyPool {
             running.fetch_sub(1, std::memory_order_release);
         }
     }
-    int spin_limit = 4000;
+    int spin_limit = 20000;
     void start()
     {
         if (const char *sp = getenv("LRHIP_COPY_SPIN")) { spin_limit = atoi(sp); if (spin_limit < 0) spin_limit = 0; }
