@@ -342,7 +342,11 @@ __device__ __forceinline__ void mfma_load_areg(const float *ldsT, int e, float (
 #pragma unroll
     for (int s = 0; s < NR; s++) areg[s] = aptr[4 * (s / G::GROUP) * G::GROUP + 4 * (s % G::GROUP)];
 }
-template <int S, int D, int NACC, int KS, int TQS, int NR>
+// SPLIT = 2: even and odd steps accumulate in two registers sets that are added at the end.  A lone chain of v_mfma_f32_16x16x4_f32 on ONE accumulator is paced by
+// the 40-cycle dependent latency plus the cliff an LDS read between two dependent MFMAs costs (MI355X_MICROARCH.md: +43 cycles), against 32 cycles of pipe time -
+// two interleaved chains issue back to back.  The sum is no longer the single fmaf chain of the direct form: only for kernels whose contract is a tolerance
+// (the FM receiver, include/lrhip.h's rounding exceptions)
+template <int S, int D, int NACC, int KS, int TQS, int NR, int SPLIT = 1>
 __device__ __forceinline__ void mfma_tile_areg(const float (&areg)[NR], const float *ldsT, int e, const float *ldsX, f32x4 (&acc)[1][NACC])
 {
     using G = FirMfmaGeom<S, D>;
@@ -354,8 +358,9 @@ __device__ __forceinline__ void mfma_tile_areg(const float (&areg)[NR], const fl
     constexpr int ACC_STRIDE = (G::ROW + G::PAD) * G::BPA;
     const float *bptr = ldsX + (G::ROW + G::PAD) * ((wave * NACC) * G::BPA + blk_in_acc) + S * kq + comp;
     const float *aptr = ldsT + kq * TQS + fir_taps_zl(D) + kq - e - col * D;
+    f32x4 acc2[NACC];
 #pragma unroll
-    for (int a = 0; a < NACC; a++) acc[0][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < NACC; a++) acc[0][a] = acc2[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bv[2][NACC], av[2];
     auto fetch = [&](int buf, int s) {
         const int g = s / G::GROUP, j = s % G::GROUP;
@@ -370,8 +375,16 @@ __device__ __forceinline__ void mfma_tile_areg(const float (&areg)[NR], const fl
         if (s + 1 < KS) fetch((s + 1) & 1, s + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int a = 0; a < NACC; a++) acc[0][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(s < NR ? areg[s < NR ? s : 0] : av[s & 1], bv[s & 1][a], acc[0][a], 0, 0, 0);
+        for (int a = 0; a < NACC; a++) {
+            const float af = s < NR ? areg[s < NR ? s : 0] : av[s & 1];
+            if (SPLIT == 2 && (s & 1)) acc2[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bv[s & 1][a], acc2[a], 0, 0, 0);
+            else acc[0][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bv[s & 1][a], acc[0][a], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (SPLIT == 2) {
+#pragma unroll
+        for (int a = 0; a < NACC; a++) acc[0][a] += acc2[a];
     }
 }
 
@@ -954,6 +967,8 @@ __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_pe
     const int tid = threadIdx.x;
 
     for (int i = tid; i < TLEN; i += NT) ldsT[i] = taps_pad[i];
+    // (round 4, measured EQUAL and dropped: the plain decimator's A fragments in registers as in the FM receiver's tuner loop - 0.1240 against 0.1230 ms for
+    // Decimator(5) on 2^26 samples, three alternations; this kernel is not LDS-bound)
 
     auto xlo_of = [&](long t) { return first + t * (long)TILE_OUT * D - e - (M - 1); };
     auto interior = [&](long t) { long lo = xlo_of(t); return t < ntiles && lo >= 0 && lo + SPAN <= n; };

@@ -227,15 +227,26 @@ __global__ __launch_bounds__(256, 2) void fir_decfft_kernel(const float *__restr
             for (int c = 0; c < NPRE; c++) pre[c] = cf_from(src[64 * c]);
         }
     };
-    prefetch((((long)blockIdx.x * p.rounds) * 4 + wave) * 4);
+    // Which four blocks a wave takes in round r.  Adjacent (LRHIP_DECFFT_INTERLEAVE 0, rounds 1-3): blocks 4 q .. 4 q + 3 of its own quad q, one after the other -
+    // the V D = 160 samples two neighbours share are then read a whole block time apart, and with 8 waves x 10 KB per CU in flight (2.6 MB per XCD against a 4 MB L2)
+    // they came from HBM twice: FETCH_SIZE 1.13x the algorithmic bytes.  Interleaved (1): the workgroup's sixteen blocks of a round go round-robin over the waves,
+    // block 16 R + 4 bq + wave at step bq - neighbours are in flight at the same time, on the same CU (the order of the 1024-point kernel, whose overlap costs 1.03x)
+#ifndef LRHIP_DECFFT_INTERLEAVE
+#define LRHIP_DECFFT_INTERLEAVE 1
+#endif
+    auto blk = [&](int r, int bq) {
+        const long R = (long)blockIdx.x * p.rounds + r;
+        return LRHIP_DECFFT_INTERLEAVE ? R * 16 + 4 * bq + wave : (R * 4 + wave) * 4 + bq;
+    };
+    (void)nquads;
+    prefetch(blk(0, 0));
     for (int r = 0; r < p.rounds; r++) {
-        const long quad = ((long)blockIdx.x * p.rounds + r) * 4 + wave;
-        if (quad >= nquads) break;
+        if (blk(r, 0) >= p.nblocks) break;
         float T[4][8];                   // per block: partial sums over the full batches, 8 floats per lane after the row reduction
         cf left[NC][4][4];               // left-over phases: [c][block][cc] = sample mm = 16 (4 g + cc) + u of phase 4A + c
 #pragma unroll
         for (int bq = 0; bq < 4; bq++) {
-            const long b = quad * 4 + bq;
+            const long b = blk(r, bq);
             // ---- stage the block's window in natural order.  Blocks past the end of a ragged last quad compute on whatever the
             // window holds: rows never mix blocks and nothing of theirs is stored.
             if (have && !(p.dbg & 2)) {
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void fir_decfft_kernel(const float *__restr
 #pragma unroll
                     for (int cc = 0; cc < 4; cc++) left[c][bq][cc] = pre[(16 + cc + c) % NPRE];
             }
-            prefetch(bq < 3 ? b + 1 : (r + 1 < p.rounds ? (quad + 4) * 4 : p.nblocks));
+            prefetch(bq < 3 ? blk(r, bq + 1) : (r + 1 < p.rounds ? blk(r + 1, 0) : p.nblocks));
             if (A > 0 && (p.dbg & 4)) {
 #pragma unroll
                 for (int t2 = 0; t2 < 8; t2++) T[bq][t2] = cur[0][t2].x + cur[0][t2 + 8].y;
@@ -349,9 +360,9 @@ __global__ __launch_bounds__(256, 2) void fir_decfft_kernel(const float *__restr
 #pragma unroll
             for (int k = 0; k < 16; k++) z[k] = z[k] + cmul(v[k], G[k]);
         }
-        // ---- inverse: row g = block quad*4 + g; z[i] = output window position w = 16 i + u
+        // ---- inverse: row g = the wave's block bq = g of this round; z[i] = output window position w = 16 i + u
         if (!(p.dbg & 8)) df_fft_inv(ex, tw, z, g, u);
-        const long b = quad * 4 + g;
+        const long b = blk(r, g);
         const long k0 = b * DF_LO - DF_V;            // output index of window position 0
         if (b < p.nblocks) {
             if (EPI == 0) {

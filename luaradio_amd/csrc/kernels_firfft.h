@@ -546,6 +546,8 @@ __global__ __launch_bounds__(256, 3) void spectrum1024_kernel(const float *__res
     for (int i = tid; i < SPEC_TABLE_ELEMS; i += 256) fl[SPEC_LDS_TW1 + i] = tables[i];
     __syncthreads();
     const int sub = lane & 3, k1s = lane >> 2;
+    // (round 4, measured and dropped: the lane's twiddles in registers as in fir_fft_kernel - this kernel is at its 168 registers already: with both tables 0.295
+    // against 0.154 ms, with the first one alone 20 registers still spill)
 
     // rounds > 0: one-shot order - workgroup g owns the `rounds` consecutive batches of four frames from g * rounds on and the dispatcher hands workgroups out in
     // address order (what took the overlap-save filter kernel from 263-314 to 316 GS/s); 0: persistent stride

@@ -35,6 +35,11 @@
 #ifndef LRHIP_RX_AREG
 #define LRHIP_RX_AREG 40
 #endif
+// 2: the tuner's 51 MFMA steps as two interleaved chains (even / odd steps) summed at the end (mfma_tile_areg SPLIT); 1: one chain.  Measured EQUAL (0.1535 against
+// 0.1555 ms, three alternations on one box, profiles/r04_twiddle_registers_ab.txt): three waves per SIMD hide the dependent-accumulator latency already
+#ifndef LRHIP_RX_SPLITK
+#define LRHIP_RX_SPLITK 1
+#endif
 
 namespace lrhip {
 
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
         f32x4 acc[1][1];
         if (pr.dbg & 4) acc[0][0] = (f32x4){ldsX[tid], ldsX[tid + 256], ldsX[tid + 512], ldsX[tid + 768]};
 #if LRHIP_RX_AREG
-        else mfma_tile_areg<S, D, 1, RX_KS, RX_TQS, LRHIP_RX_AREG>(areg, ldsT, pr.e, ldsX, acc);
+        else mfma_tile_areg<S, D, 1, RX_KS, RX_TQS, LRHIP_RX_AREG, LRHIP_RX_SPLITK>(areg, ldsT, pr.e, ldsX, acc);
 #else
         else mfma_tile<S, D, 1, RX_KS, 1, RX_TQS>(ldsT, RX_TLEN, pr.e, ldsX, RX_KS, acc);
 #endif

@@ -17,6 +17,18 @@ struct ResampleStage : lrhip_stage {
     // (L, D) pairs with a kept-phases instantiation (fir_rational_kernel): 128 taps, ComplexFloat32, gcd(L, D) = 1
     static bool rational_supported(int L, unsigned long D) { return (L == 3 && D == 2) || (L == 2 && D == 3) || (L == 4 && D == 3) || (L == 3 && D == 4) || (L == 5 && D == 4) || (L == 4 && D == 5); }
     int interp_blocks_per_cu = 0;     // its resident workgroups per CU (occupancy query, cached)
+    // Tiles per workgroup of the register-window kernels (kernels_interp.h `rounds`): runs of consecutive tiles, workgroups handed out in address order.
+    // 0 = persistent workgroups with a grid stride and a register prefetch of the next tile (rounds 2-3; launches that do not fill the slots keep it).
+    // Measured on 2^26 input samples, same box, two alternations (profiles/r04_resampler_tile_order.txt): ONE tile per workgroup is the fastest order for
+    // every RationalResampler shape - (3,2) 0.256 against 0.281 ms persistent, (4,3) 0.224 / 0.254, (5,4) 0.207 / 0.234, (3,4) 0.156 / 0.170, (4,5) 0.169 / 0.184,
+    // (2,3) 0.166 / 0.182; runs of 2 / 3 / 4 / 16 tiles give back 2 / 4 / 6 / 12 % of it; Interpolator(5) 0.745 against 0.758.
+    // LRHIP_RESAMPLE_ROUNDS in the environment forces a run length (A/B; 0 = persistent)
+    static int resample_rounds(long ntiles, long slots)
+    {
+        static const char *e = getenv("LRHIP_RESAMPLE_ROUNDS");
+        if (e) return atoi(e) < 0 ? 0 : atoi(e);
+        return ntiles <= slots ? 0 : 1;
+    }
     static constexpr int SPAN_MAX = 6144;
     const char *kind() const override { return "resample"; }
     unsigned long max_output(unsigned long n) const override { return (n * (unsigned long)L) / D + 2; }
@@ -53,12 +65,14 @@ struct ResampleStage : lrhip_stage {
                 if (lds_bytes > 48 * 1024) LR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 if (!interp_blocks_per_cu) {
                     int nb = 0;
-                    LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds_bytes));
+                    LR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, FIP_NT, lds_bytes));
                     interp_blocks_per_cu = nb < 1 ? 1 : nb;
                 }
                 const long ntiles = ((long)n + tq - 1) / tq, slots = (long)ctx().num_cus * interp_blocks_per_cu;
-                hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < slots ? ntiles : slots)), dim3(256), lds_bytes, ctx().stream, h, (const float *)in_dev, (const float *)d_ttab.p,
-                                   (float *)out_dev, (long)n, HQ, c, ho, ablation_bits("LRHIP_INTERP_DBG"));
+                const int rounds = resample_rounds(ntiles, slots);
+                const long wgs = rounds > 0 ? (ntiles + rounds - 1) / rounds : (ntiles < slots ? ntiles : slots);
+                hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(FIP_NT), lds_bytes, ctx().stream, h, (const float *)in_dev, (const float *)d_ttab.p,
+                                   (float *)out_dev, (long)n, HQ, c, ho, ablation_bits("LRHIP_INTERP_DBG"), rounds);
                 return 0;
             };
 #define LR_INTERP(LL, JJ) gi(fir_interp_kernel<LL, JJ>, (size_t)FipGeom<LL, JJ>::LDS_FLOATS * sizeof(float), FipGeom<LL, JJ>::TQ)
@@ -82,8 +96,10 @@ struct ResampleStage : lrhip_stage {
                     rat_blocks_per_cu = nb < 1 ? 1 : nb;
                 }
                 const long ntiles = ((long)n + (long)(Q0 % D) + tq - 1) / tq, slots = (long)ctx().num_cus * rat_blocks_per_cu;
-                hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles < slots ? ntiles : slots)), dim3(256), lds_bytes, ctx().stream, h, (const float *)in_dev, (const float *)d_ttab.p,
-                                   (float *)out_dev, (long)n, n_out, m0, Q0, HQ, c, ho);
+                const int rounds = resample_rounds(ntiles, slots);
+                const long wgs = rounds > 0 ? (ntiles + rounds - 1) / rounds : (ntiles < slots ? ntiles : slots);
+                hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds_bytes, ctx().stream, h, (const float *)in_dev, (const float *)d_ttab.p,
+                                   (float *)out_dev, (long)n, n_out, m0, Q0, HQ, c, ho, rounds);
                 return 0;
             };
 #define LR_RAT(LL, DD, JJ, RR) gr(fir_rational_kernel<LL, DD, JJ, RR>, (size_t)FrrGeom<LL, DD, JJ, RR>::LDS_FLOATS * sizeof(float), FrrGeom<LL, DD, JJ, RR>::TQ)

@@ -98,6 +98,8 @@ def main():
     run("Decimator(25) cf32 (LDS-staged decimator, no rotator)", lambda: mk(lr.DecimatorBlock, [25, {"use_fft": False}], True), True, 8 + 8 / 25, 4 * 128 / 25)
     run("Decimator(5) cf32, polyphase FFT overlap-save", lambda: mk(lr.DecimatorBlock, [5, {"use_fft": "fast"}], True), True, 8 + 8 / 5, 62)
     run("Tuner(-250k,200k,5), polyphase FFT overlap-save", lambda: mk(lr.TunerBlock, [-250e3, 200e3, 5, {"use_fft": "fast"}], True), True, 8 + 8 / 5, 62)
+    # write-heavy yardstick: the zero-stuffing Upsampler moves exactly the Interpolator's bytes (8 B in, 8 L B out per input sample) with no arithmetic
+    run("Upsampler(5) cf32 (the Interpolator's traffic without arithmetic: write-heavy yardstick)", lambda: mk(lr.UpsamplerBlock, [5], True), True, 8 + 8 * 5)
     run("Interpolator(5) cf32 (polyphase, input samples)", lambda: mk(lr.InterpolatorBlock, [5], True), True, 8 + 8 * 5, 4 * 128)
     run("RationalResampler(3, 2) cf32 (polyphase, input samples)", lambda: mk(lr.RationalResamplerBlock, [3, 2], True), True, 8 + 8 * 1.5, 4 * 128 * 1.5 / 3)
     run("RationalResampler(2, 3) cf32 (polyphase, input samples)", lambda: mk(lr.RationalResamplerBlock, [2, 3], True), True, 8 + 8 * 2 / 3, 4 * 128 * (2 / 3) / 2)
