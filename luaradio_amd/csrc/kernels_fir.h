@@ -564,7 +564,7 @@ __device__ __forceinline__ int decim_phys(int p) { return p + (p >> 5); }
 template <int S, bool ROT, bool CT = false, int FMT = 0>      // CT: ComplexFloat32 taps (S = 2), taps_rev as {re, im} pairs
 __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_rev,
                                                             float *__restrict__ y, int M, long n, long n_out, long first, long D, int OW, long ntiles,
-                                                            uint64_t rot_step_fx, uint64_t rot_count0, float *__restrict__ hist_out, int post_op)
+                                                            uint64_t rot_step_fx, uint64_t rot_count0, float *__restrict__ hist_out, int post_op, int rounds)
 {
     static_assert(FMT == 0 || (S == 2 && !CT), "raw records: (I, Q) pairs, real taps");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -644,9 +644,12 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
             }
         }
     };
-    if (ROT) prefetch(blockIdx.x);
-    else prefetch_plain(blockIdx.x);
-    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // tile order: persistent grid stride (rounds == 0), or the `rounds` consecutive tiles from blockIdx.x * rounds on (workgroups in address order)
+    const long t_first = rounds > 0 ? (long)blockIdx.x * rounds : (long)blockIdx.x, t_step = rounds > 0 ? 1 : (long)gridDim.x;
+    const long t_end = rounds > 0 ? (t_first + rounds < ntiles ? t_first + rounds : ntiles) : ntiles;
+    if (ROT) prefetch(t_first);
+    else prefetch_plain(t_first);
+    for (long t = t_first; t < t_end; t += t_step) {
         const long k0 = t * OW;                     // first output of the tile
         const long q0 = first + k0 * D;             // stream position of staged sample 0 (stream = [M-1 history | chunk])
         const long g0 = q0 - (M - 1);               // the same as an index into x (negative: history)
@@ -720,8 +723,8 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
             }
         }
         __syncthreads();
-        if (ROT) prefetch(t + gridDim.x);
-        else prefetch_plain(t + gridDim.x);
+        if (ROT) prefetch(t + t_step < t_end ? t + t_step : ntiles);
+        else prefetch_plain(t + t_step < t_end ? t + t_step : ntiles);
         const long k = k0 + tid;
         if (tid < OW && k < n_out) {
             int p = tid * (int)D;
@@ -945,7 +948,7 @@ template <int S, int D, int NACC, bool ROT, int KS, int EPI = 0, bool REL = fals
 __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_persistent_kernel(
     const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_pad, float *__restrict__ y,
     int M, long n, long n_out, long first, int e, long ntiles, int out_aligned,
-    uint64_t rot_step_fx, uint64_t rot_count0, float2 *__restrict__ edge, float2 *__restrict__ prev_out, double inv_gain, float *__restrict__ hist_out)
+    uint64_t rot_step_fx, uint64_t rot_count0, float2 *__restrict__ edge, float2 *__restrict__ prev_out, double inv_gain, float *__restrict__ hist_out, int rounds)
 {
     using G = FirMfmaGeom<S, D>;
     // NW = 1: one wave per workgroup, three such workgroups per SIMD - every wave stages the window of its own 256 outputs (7 % more samples staged
@@ -1019,6 +1022,8 @@ __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_pe
     const long xt8 = (ntiles + 7) >> 3, xper = gridDim.x >> 3;
     const long xbase = (long)(blockIdx.x & 7) * xt8, xj = blockIdx.x >> 3;
     auto tile_of = [&](long k) -> long {
+        // rounds > 0 (round 4): one-shot order - workgroup b owns the `rounds` consecutive tiles from b * rounds on, workgroups handed out in address order
+        if (rounds > 0) return k < rounds ? (long)blockIdx.x * rounds + k : ntiles;
         if (!xmap) return blockIdx.x + k * (long)gridDim.x;
         const long tl = xj + k * xper;
         return tl < xt8 ? xbase + tl : ntiles;

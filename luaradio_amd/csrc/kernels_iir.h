@@ -301,6 +301,20 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
 #pragma unroll
     for (int c = 0; c < S; c++) creg[c] = (P == 1 && from_true_state) ? (ST)state_in[c] : (ST)0;
     __syncthreads();
+    // LRHIP_IIR_TPRE 1 (round 4, A/B): the scan's uniform tables (orders 1-2: 7 P^2 floats) requested HERE, ahead of the tile's loads, instead of where they are
+    // used (where each level's s_load sits directly in front of an `s_waitcnt lgkmcnt(0)`: 7 scalar-cache latencies in the dependent chain of a tile).  Measured
+    // EQUAL (0.2283 against 0.2278 ms for the 5 / 3-tap ComplexFloat32 entry, three alternations; 26 more SGPRs spill to lanes): off
+#ifndef LRHIP_IIR_TPRE
+#define LRHIP_IIR_TPRE 0
+#endif
+    constexpr bool TPRE = LRHIP_IIR_TPRE && P <= 2;
+    ST tpr[TPRE ? 7 * P * P : 1];
+    if constexpr (TPRE) {
+#pragma unroll
+        for (int i = 0; i < 7 * P * P; i++) tpr[i] = tpow[i];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const ST *tps = TPRE ? tpr : tpow;       // levels 0 .. 6 of the wave scan
 
     for (long tt = tb; tt < first_tile + run && tt * TILE < n; tt++) {
         const bool emit = tt >= first_tile;
@@ -423,11 +437,11 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
 #pragma unroll
             for (int c = 0; c < S; c++) {
                 zs[c] = (ST)st[c][0];
-                if (tid == 0) zs[c] += fma(tpow[0], creg[c], (ST)0);
+                if (tid == 0) zs[c] += fma(tps[0], creg[c], (ST)0);
 #pragma unroll
                 for (int l = 0; l < 6; l++) {
                     const ST prev = __shfl_up(zs[c], 1 << l);
-                    if (lane >= (1 << l)) zs[c] += fma(tpow[l], prev, (ST)0);
+                    if (lane >= (1 << l)) zs[c] += fma(tps[l], prev, (ST)0);
                 }
                 if (lane == 63) sst[c][wave][0] = zs[c];
             }
@@ -439,7 +453,7 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
 #pragma unroll
                 for (int w = 0; w < 4; w++) {
                     if (w == wave) Ew[c] = E;
-                    E = sst[c][w][0] + fma(tpow[6], E, (ST)0);
+                    E = sst[c][w][0] + fma(tps[6], E, (ST)0);
                 }
                 Sx[c] = zs[c] + fma(tpow[9 + lane], Ew[c], (ST)0);          // true end state of this chunk
                 const ST up = __shfl_up(Sx[c], 1);
@@ -463,7 +477,7 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
                     ST ts[P];
 #pragma unroll
                     for (int k = 0; k < P; k++) ts[k] = carry[c][k];
-                    mat_apply<P, ST>(tpow, ts, tmp);
+                    mat_apply<P, ST>(tps, ts, tmp);
 #pragma unroll
                     for (int k = 0; k < P; k++) zs[c][k] += tmp[k];
                 }
@@ -472,7 +486,7 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
                     ST prev[P];
 #pragma unroll
                     for (int k = 0; k < P; k++) prev[k] = __shfl_up(zs[c][k], 1 << l);
-                    mat_apply<P, ST>(tpow + l * P * P, prev, tmp);
+                    mat_apply<P, ST>(tps + l * P * P, prev, tmp);
                     if (lane >= (1 << l))
 #pragma unroll
                         for (int k = 0; k < P; k++) zs[c][k] += tmp[k];
@@ -495,7 +509,7 @@ __global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict
                     if (w == wave)
 #pragma unroll
                         for (int k = 0; k < P; k++) Ew[k] = E[k];
-                    mat_apply<P, ST>(tpow + 6 * P * P, E, tmp);
+                    mat_apply<P, ST>(tps + 6 * P * P, E, tmp);
 #pragma unroll
                     for (int k = 0; k < P; k++) E[k] = sst[c][w][k] + tmp[k];
                 }

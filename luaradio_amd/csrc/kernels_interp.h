@@ -30,6 +30,9 @@ namespace lrhip {
 #ifndef LRHIP_INTERP_PIN
 #define LRHIP_INTERP_PIN 1       /* pinned wait / load / multiply order of the tap loop's scalar loads (0: hipcc's own order) */
 #endif
+#ifndef LRHIP_RATIONAL_PIN
+#define LRHIP_RATIONAL_PIN 0     /* the same for fir_rational_kernel: measured EQUAL on all six shapes (its s_loads are merged four steps at a time), off */
+#endif
 #ifndef LRHIP_INTERP_WAVES
 #define LRHIP_INTERP_WAVES 3     /* waves per SIMD the register allocation aims at */
 #endif
@@ -315,11 +318,18 @@ __global__ __launch_bounds__(256, 3) void fir_rational_kernel(const float *__res
             for (int k = 0; k < G::NQ; k++) T[0][k] = (FW_TAPS_SGPR ? uniform_load4(ttab + 4 * k) : *reinterpret_cast<const float4 *>(ldsT + 4 * k));
             static_for<J>([&](auto Sx) {
                 constexpr int s = decltype(Sx)::value, rn = R - 1 + s + LA;
+                // the scalar loads' wait / load / multiply order is pinned as in fir_interp_kernel
+                if constexpr (FW_TAPS_SGPR && LRHIP_RATIONAL_PIN) {
+#pragma unroll
+                    for (int k = 0; k < G::NQ; k++) asm volatile("" ::"s"(T[s & 1][k].x), "s"(T[s & 1][k].y), "s"(T[s & 1][k].z), "s"(T[s & 1][k].w));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr (s + 1 < J) {
 #pragma unroll
                     for (int k = 0; k < G::NQ; k++) T[(s + 1) & 1][k] = (FW_TAPS_SGPR ? uniform_load4(ttab + (s + 1) * G::LP + 4 * k) : *reinterpret_cast<const float4 *>(ldsT + (s + 1) * G::LP + 4 * k));
                 }
                 if constexpr (rn <= R - 1 + J - 1) W[rn % C] = ld(rn);
+                if constexpr (FW_TAPS_SGPR && LRHIP_RATIONAL_PIN) __builtin_amdgcn_sched_barrier(0);
                 static_for<OUTL>([&](auto Ax) {
                     constexpr int a = decltype(Ax)::value, np = a * D, i = np / L, p = np % L;
                     const float4 tq = T[s & 1][p >> 2];

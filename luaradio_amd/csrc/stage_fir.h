@@ -198,11 +198,14 @@ struct FirStage : lrhip_stage {
             auto launch = [&](auto kern) -> int {
                 if ((mfma_blocks_per_cu = prepared_blocks(kern, lds_bytes, 64 * NW)) < 0) return -1;     // queried once per instantiation
                 long slots = (long)ctx().num_cus * mfma_blocks_per_cu;
-                unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+                // tile order: persistent grid stride (0), or runs of `rounds` consecutive tiles per workgroup in address order (LRHIP_FIR_ROUNDS, A/B)
+                static const int rounds_env = getenv("LRHIP_FIR_ROUNDS") ? atoi(getenv("LRHIP_FIR_ROUNDS")) : 0;
+                const int rounds = ntiles > slots && rounds_env > 0 ? rounds_env : 0;
+                unsigned grid = rounds > 0 ? (unsigned)((ntiles + rounds - 1) / rounds) : (unsigned)(ntiles < slots ? ntiles : slots);
                 if (post_disc && edge.reserve((size_t)ntiles * 2 * NW * sizeof(float2))) return -1;
                 float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, ctx().stream, h, x, atab, y, M, n, n_out, (long)index, e,
-                                   ntiles, out_aligned, rs, rc, (float2 *)edge.p, post_disc ? (float2 *)disc_prev.p + (disc_cur ^ 1) : nullptr, 1.0 / disc_gain, ho);
+                                   ntiles, out_aligned, rs, rc, (float2 *)edge.p, post_disc ? (float2 *)disc_prev.p + (disc_cur ^ 1) : nullptr, 1.0 / disc_gain, ho, rounds);
                 hist_in_kernel = ho != nullptr;
                 return 0;
             };
@@ -566,9 +569,11 @@ struct FirStage : lrhip_stage {
         auto go = [&](auto kern) -> int {
             if ((decim_blocks_per_cu = prepared_blocks(kern, lds_bytes)) < 0) return -1;
             long slots = (long)ctx().num_cus * decim_blocks_per_cu;
-            unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+            static const int rounds_env = getenv("LRHIP_DECIM_ROUNDS") ? atoi(getenv("LRHIP_DECIM_ROUNDS")) : 0;     // A/B: runs of consecutive tiles, address order
+            const int rounds = ntiles > slots && rounds_env > 0 ? rounds_env : 0;
+            unsigned grid = rounds > 0 ? (unsigned)((ntiles + rounds - 1) / rounds) : (unsigned)(ntiles < slots ? ntiles : slots);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, (const float *)d_taps.p, y, M, n, n_out, (long)index, (long)D, OW,
-                               ntiles, rot ? rot_step : (uint64_t)0, rot ? count : (uint64_t)0, ho, post_unary);
+                               ntiles, rot ? rot_step : (uint64_t)0, rot ? count : (uint64_t)0, ho, post_unary, rounds);
             hist_in_kernel = ho != nullptr;
             return 0;
         };
