@@ -73,6 +73,7 @@ def main():
         ("Tuner(-100k, 10k, 50): LDS-staged decimator with rotator (AM / SSB / NBFM receivers)", blocks, ("fir_decim_lds_kernel<2, true, false, 0",), 8.16, n26, 16.2),
         ("Decimator(25) cf32: LDS-staged decimator", blocks, ("fir_decim_lds_kernel<2, false, false, 0",), 8.32, n26, 20.5),
         ("Decimator / Tuner, polyphase FFT overlap-save", blocks, ("fir_decfft_kernel<5, 0>",), 9.6, n26, 62),
+        ("Upsampler(5) cf32: the Interpolator's bytes without arithmetic (input samples)", blocks, ("upsample_vec_kernel<HIP_vector_type<float, 2u>",), 48, n26, 0),
         ("Interpolator(5) cf32 (input samples)", blocks, ("fir_interp_kernel<5, 26>",), 48, n26, 512),
         ("RationalResampler(3, 2) cf32 (input samples)", blocks, ("fir_rational_kernel<3, 2",), 20, n26, 256),
         ("RationalResampler(2, 3) cf32", blocks, ("fir_rational_kernel<2, 3",), 8 + 16 / 3, n26, 0),
