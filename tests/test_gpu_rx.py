@@ -227,6 +227,39 @@ def test_rational_resampler_kept_phases_kernel_at_size(L, D):
     assert np.array_equal(resampler().process(x * np.float32(0.5)), (want * np.float32(0.5)).astype(np.complex64))
 
 
+@pytest.mark.parametrize("L", [5, 2, 3, 4])
+def test_interpolator_register_window_kernel_at_size(L):
+    """fir_interp_kernel on 2^21 samples in two unequal chunks: the first launch does not fill the chip (persistent workgroups, register prefetch), the
+    second does (round 4: one tile per workgroup in address order, whole tiles stored with every LDS read ahead of the first store, the chunk's ragged
+    last tile on the rolled loop) - both give the bits of the unfused device blocks MultiplyConstant -> Upsampler -> Lowpass (interpolator.lua:31-34);
+    and the same through LRHIP_RESAMPLE_ROUNDS-independent properties: linearity for a power-of-two scale"""
+    from luaradio_amd import types
+    n = (1 << 21) + 1237
+    rng = np.random.default_rng(70 + L)
+    x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+
+    def interpolator():
+        r = lr.InterpolatorBlock(L)
+        r.rate = 2.0
+        r.differentiate([types.ComplexFloat32])
+        r.initialize()
+        return r
+
+    it = interpolator()
+    cut = 700001
+    got = np.concatenate([it.process(x[:cut]), it.process(x[cut:])])
+    assert it.chain.last_launches == 1
+    want, rate = x, 2.0
+    for b in (lr.MultiplyConstantBlock(float(L)), lr.UpsamplerBlock(L), lr.LowpassFilterBlock(128, 1 / L, 1.0)):
+        b.rate = rate
+        b.differentiate([types.ComplexFloat32])
+        b.initialize()
+        want, rate = b.process(want), b.get_rate()
+    assert len(got) == len(want) == n * L
+    assert np.array_equal(got, want)
+    assert np.array_equal(interpolator().process(x * np.float32(0.5)), (want * np.float32(0.5)).astype(np.complex64))
+
+
 # ---- element-wise blocks on 16-byte accesses (round 3): the vector kernels against the one-sample kernels they replaced -----------------------------
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 1023, 1024, 1025, 300003])
 def test_elementwise_vector_kernels_equal_the_scalar_ones(n):
