@@ -557,6 +557,9 @@ __global__ __launch_bounds__(256) void fir_disc_fixup_kernel(const float2 *__res
 // thread stride of D samples off the bank period for even D.  HBM bound: S*4 B in, S*4/D B out per input sample.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int DECIM_SPAN_MAX = 6144;
+#ifndef LRHIP_DECIM_UNROLL16
+#define LRHIP_DECIM_UNROLL16 1      /* tap loop of fir_decim_lds_kernel in groups of sixteen (0: four at a time, rounds 2-3) */
+#endif
 
 __device__ __forceinline__ int decim_phys(int p) { return p + (p >> 5); }
 
@@ -739,6 +742,36 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
                     re = fmaf(xv.y, -h.y, re);
                     im = fmaf(xv.x, h.y, im);
                     im = fmaf(xv.y, h.x, im);
+                }
+            }
+            // sixteen taps at a time: all sixteen window reads and the four 16-byte tap reads are issued before the first FMA.  (Round 4: with four taps per
+            // trip the loop ran at ~90 cycles per tap - one exposed LDS round trip per group, 11.7 k cycles per tile however few samples the tile held; the
+            // fmaf chain itself is unchanged: ascending taps, one accumulator.)  Sixteen consecutive window samples cross at most one padded row of 32
+            if constexpr (LRHIP_DECIM_UNROLL16) {
+                for (; tt + 16 <= M; tt += 16) {
+                    float hh[16];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float4 h4 = *reinterpret_cast<const float4 *>(ldsT + tt + 4 * q);
+                        hh[4 * q] = h4.x; hh[4 * q + 1] = h4.y; hh[4 * q + 2] = h4.z; hh[4 * q + 3] = h4.w;
+                    }
+                    const int q0 = p + tt, ql = q0 & 31, b0 = q0 + (q0 >> 5);
+                    float xr[16], xi[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const int ix = b0 + j + ((ql + j) >> 5);
+                        if (S == 2) {
+                            const float2 v = *reinterpret_cast<const float2 *>(ldsX + 2 * ix);
+                            xr[j] = v.x; xi[j] = v.y;
+                        } else {
+                            xr[j] = ldsX[ix]; xi[j] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        re = fmaf(xr[j], hh[j], re);
+                        if (S == 2) im = fmaf(xi[j], hh[j], im);
+                    }
                 }
             }
             for (; tt + 4 <= M; tt += 4) {

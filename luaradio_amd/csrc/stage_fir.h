@@ -559,7 +559,10 @@ struct FirStage : lrhip_stage {
     int decim_blocks_per_cu = 0;
     int launch_decim_lds(const float *x, long n, float *y, long n_out)
     {
-        long ow = (DECIM_SPAN_MAX - M) / (long)D + 1;
+        // staged samples per tile: the kernel's registers allow DECIM_SPAN_MAX; LRHIP_DECIM_SPAN (A/B) asks for less = smaller tiles, more workgroups per CU
+        static const long span_env = getenv("LRHIP_DECIM_SPAN") ? atol(getenv("LRHIP_DECIM_SPAN")) : 0;
+        const long span_max = span_env >= 512 && span_env < DECIM_SPAN_MAX && span_env >= M + 64 ? span_env : DECIM_SPAN_MAX;
+        long ow = (span_max - M) / (long)D + 1;
         int OW = (int)(ow > 256 ? 256 : ow < 1 ? 1 : ow);
         long ntiles = (n_out + OW - 1) / OW;
         long span = (long)(OW - 1) * D + M;
