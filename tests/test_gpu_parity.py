@@ -616,6 +616,26 @@ def test_decimator_polyphase_fft_vs_f64_oracle(factor, ntaps):
     assert G.max_abs_err(got, whole) < 5e-7
 
 
+def test_decimator_polyphase_fft_at_the_bench_size_against_the_direct_form():
+    """2^25 samples: the launch hands every workgroup two rounds of sixteen blocks (stage_fir.h: rounds = 2 from 8 quads per resident slot on), the blocks
+    of a round go round-robin over the four waves (round 4, kernels_firdecfft.h) and the last round is ragged - sizes no oracle run reaches.  The bit-exact
+    direct-form Decimator(5) on the same device is the reference here: the two forms agree to the Float32 FFT's rounding, everywhere (a block landing on the
+    wrong wave or a dropped round is an error of order one)"""
+    rng = np.random.default_rng(77)
+    n = (1 << 25) + 1733
+    x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+    fft = make(lr.DecimatorBlock, [5, {"use_fft": "fast"}], x[:8])
+    direct = make(lr.DecimatorBlock, [5, {"use_fft": False}], x[:8])
+    a, b = fft.process(x), direct.process(x)
+    assert fft.chain.last_launches == 1 and len(a) == len(b) == (n + 4) // 5
+    assert float(np.max(np.abs(a - b))) < 3e-6
+    # and a Tuner of the same shape (rotation applied per output, table of 256 phasors per block)
+    tf = make(lr.TunerBlock, [-250e3, 200e3, 5, {"use_fft": "fast"}], x[:8], rate=1102500.0)
+    td = make(lr.TunerBlock, [-250e3, 200e3, 5, {"use_fft": False}], x[:8], rate=1102500.0)
+    a, b = tf.process(x), td.process(x)
+    assert len(a) == len(b) and float(np.max(np.abs(a - b))) < 5e-6
+
+
 def test_decimator_polyphase_fft_golden_and_one_sample_chunks():
     """the reference's decimator_spec vectors (factors 2 and 4 have a polyphase FFT instantiation) in both jig modes"""
     doc = G.load("decimator_spec")
