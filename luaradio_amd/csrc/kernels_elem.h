@@ -521,31 +521,50 @@ __global__ __launch_bounds__(256) void unary_vec_kernel(const float *__restrict_
     }
 }
 
-// UpsamplerBlock, one 16-byte store per thread (PER = samples per store: 2 ComplexFloat32 or 4 Float32): one division per thread, then the
-// position inside the zero-stuffing period is carried along.  y 16-byte aligned; `nitems` stores, thread `nitems` takes the tail.
+// UpsamplerBlock, 16-byte stores (PER = samples per store: 2 ComplexFloat32 or 4 Float32), UPS_U of them per thread, 256 stores apart (consecutive lanes,
+// consecutive 16 bytes in every instruction): ONE 64-bit division per thread, the position inside the zero-stuffing period is carried from store to store
+// and from sample to sample; all loads are issued before the first store.  (Rounds 2-3: one store and one division per thread - Upsampler(5) on 2^26
+// ComplexFloat32 samples 0.685 ms where the same bytes with no arithmetic take 0.605, tools/mb_rw15.hip.)  y 16-byte aligned; `nitems` whole stores, the
+// thread that would own store number `nitems` takes the samples behind them.
+constexpr int UPS_U = 4;
 template <typename T, int PER>
 __global__ __launch_bounds__(256) void upsample_vec_kernel(const T *__restrict__ x, float4 *__restrict__ y, unsigned long nitems, unsigned long factor, unsigned long n_out)
 {
-    const unsigned long i = (unsigned long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == nitems)                                   // the grid's spare thread: the samples behind the last whole store
-        for (unsigned long o = nitems * PER; o < n_out; o++) {
-            T v = {};
-            if (o % factor == 0) v = x[o / factor];
-            reinterpret_cast<T *>(y)[o] = v;
-        }
-    if (i >= nitems) return;
-    const unsigned long o = i * PER;
-    unsigned long q = o / factor, r = o - q * factor;
-    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned long i0 = (unsigned long)blockIdx.x * (256 * UPS_U) + threadIdx.x;
+    if (i0 > nitems) return;
+    unsigned long q = (i0 * PER) / factor, r = i0 * PER - q * factor;
+    const unsigned long dq = (256ul * PER) / factor, dr = 256ul * PER - dq * factor;      // 256 stores further on
+    float4 w[UPS_U];
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-        if (r == 0) {
-            const T v = x[q];
-            __builtin_memcpy(&w[k * (4 / PER)], &v, sizeof(T));
+    for (int j = 0; j < UPS_U; j++) {
+        const unsigned long i = i0 + 256ul * j;
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        if (i < nitems) {
+            unsigned long qq = q, rr = r;
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                if (rr == 0) {
+                    const T v = x[qq];
+                    __builtin_memcpy(&e[k * (4 / PER)], &v, sizeof(T));
+                }
+                if (++rr == factor) { rr = 0; qq++; }
+            }
         }
-        if (++r == factor) { r = 0; q++; }
+        w[j] = make_float4(e[0], e[1], e[2], e[3]);
+        q += dq; r += dr;
+        if (r >= factor) { r -= factor; q++; }
     }
-    nt_store(y + i, make_float4(w[0], w[1], w[2], w[3]));
+#pragma unroll
+    for (int j = 0; j < UPS_U; j++) {
+        const unsigned long i = i0 + 256ul * j;
+        if (i < nitems) nt_store(y + i, w[j]);
+        else if (i == nitems)                          // the samples behind the last whole store
+            for (unsigned long o = nitems * PER; o < n_out; o++) {
+                T v = {};
+                if (o % factor == 0) v = x[o / factor];
+                reinterpret_cast<T *>(y)[o] = v;
+            }
+    }
 }
 
 // FloatToComplexBlock, two samples per thread: 8-byte loads, one 16-byte store.  Pointers 8- / 16-byte aligned, `nitems` = n / 2 (+ a spare thread for an odd n).

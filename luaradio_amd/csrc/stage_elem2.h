@@ -227,9 +227,9 @@ struct UpsamplerStage : lrhip_stage {
         if (!no_vec && ((uintptr_t)out_dev % 16) == 0) {
             const unsigned long items = n_out / per;
             if (in_size == 8)
-                hipLaunchKernelGGL((upsample_vec_kernel<float2, 2>), dim3(grid_for(items + 1, 256)), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float4 *)out_dev, items, factor, n_out);
+                hipLaunchKernelGGL((upsample_vec_kernel<float2, 2>), dim3(grid_for(items + 1, 256 * UPS_U)), dim3(256), 0, ctx().stream, (const float2 *)in_dev, (float4 *)out_dev, items, factor, n_out);
             else
-                hipLaunchKernelGGL((upsample_vec_kernel<float, 4>), dim3(grid_for(items + 1, 256)), dim3(256), 0, ctx().stream, (const float *)in_dev, (float4 *)out_dev, items, factor, n_out);
+                hipLaunchKernelGGL((upsample_vec_kernel<float, 4>), dim3(grid_for(items + 1, 256 * UPS_U)), dim3(256), 0, ctx().stream, (const float *)in_dev, (float4 *)out_dev, items, factor, n_out);
             LR_LAUNCH_CHECK();
             return (long)n_out;
         }
