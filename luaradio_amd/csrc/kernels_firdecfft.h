@@ -215,7 +215,12 @@ __global__ __launch_bounds__(256, 2) void fir_decfft_kernel(const float *__restr
     auto block_xs = [&](long b) { return p.first + (long)D * (b * DF_LO - DF_V) - (D - 1); };
     // ---- register prefetch of one block: pre[c] = window[64 c + lane], coalesced
     constexpr int NL = 4 * D;                              // 8-byte loads per lane per block (256 D samples / 64 lanes)
-    constexpr int NPRE = NL <= 24 ? NL : NL / 2;           // registers spent on the prefetch; the rest of a long window loads late
+#ifndef LRHIP_DECFFT_NPRE_DIV
+#define LRHIP_DECFFT_NPRE_DIV 2      /* half of a block's loads are requested a block ahead, the rest when it is staged.  Round 4: with all 20 (D = 5) the kernel
+                                        needed 40 registers for the prefetch alone and SPILLED 13 dwords per lane at its 256-register cap: 0.1596 against 0.1456 ms
+                                        for Decimator(5) on 2^26 samples, three alternations (1: the round-3 kernel; 4: equal to 2) */
+#endif
+    constexpr int NPRE = (NL <= 24 ? NL : NL / 2) / LRHIP_DECFFT_NPRE_DIV;           // registers spent on the prefetch; the rest of a long window loads late
     cf pre[NPRE];
     bool have = false;               // pre holds the next block (interior blocks only; edge blocks are staged late, below)
     auto prefetch = [&](long b) {

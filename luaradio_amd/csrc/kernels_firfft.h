@@ -401,10 +401,16 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
     for (int i = tid; i < FFT_TABLE_ELEMS; i += 64 * FFT_WPB) fl[FFT_LDS_TW1 + i] = tables[i];
     __syncthreads();
 #if LRHIP_FFT_TW_REG
+    // (the Float32-stream instantiation sits at the 168-register cap and spills six dwords per lane with all fifteen twiddles in registers; keeping only the first
+    // 12 or 8 of them - LRHIP_FFT_TW_REG_F32, no spill - measured EQUAL, 0.1188 / 0.1188 / 0.123 ms on 2^26 samples: the spill is not in the block loop)
+#ifndef LRHIP_FFT_TW_REG_F32
+#define LRHIP_FFT_TW_REG_F32 16
+#endif
+    constexpr int TWR = S == 1 ? LRHIP_FFT_TW_REG_F32 : 16;
     cf tw1r[16];
 #pragma unroll
-    for (int k = 1; k < 16; k++) tw1r[k] = tw1[k * 64 + lane];
-#define FFT_TW1(k) tw1r[k]
+    for (int k = 1; k < TWR; k++) tw1r[k] = tw1[k * 64 + lane];
+#define FFT_TW1(k) ((k) < TWR ? tw1r[(k) < TWR ? (k) : 0] : tw1[(k) * 64 + lane])
 #if LRHIP_FFT_ALLREG
     cf tw2f[16], tw2i[16], Hr[16];
 #pragma unroll
