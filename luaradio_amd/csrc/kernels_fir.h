@@ -557,6 +557,9 @@ __global__ __launch_bounds__(256) void fir_disc_fixup_kernel(const float2 *__res
 // thread stride of D samples off the bank period for even D.  HBM bound: S*4 B in, S*4/D B out per input sample.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int DECIM_SPAN_MAX = 6144;
+#ifndef LRHIP_DECIM_EARLY_PREFETCH
+#define LRHIP_DECIM_EARLY_PREFETCH 0
+#endif
 #ifndef LRHIP_DECIM_UNROLL16
 #define LRHIP_DECIM_UNROLL16 1      /* tap loop of fir_decim_lds_kernel in groups of sixteen (0: four at a time, rounds 2-3) */
 #endif
@@ -725,9 +728,18 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
                 }
             }
         }
+        // LRHIP_DECIM_EARLY_PREFETCH 1 (round 4, A/B): the next tile's samples requested in FRONT of the barrier, as soon as this tile's are out of the registers
+        // (behind it the loads have only the tap loop to arrive in; a tile costs ~4.8 us whatever its size: time = 75 us + 430 000 us / span over
+        // LRHIP_DECIM_SPAN = 1536 .. 6144).  Measured SLOWER - Tuner(.., 50) 0.1488 against 0.1434 ms, Decimator(25) 0.124 against 0.118, three alternations: off
+        if (LRHIP_DECIM_EARLY_PREFETCH) {
+            if (ROT) prefetch(t + t_step < t_end ? t + t_step : ntiles);
+            else prefetch_plain(t + t_step < t_end ? t + t_step : ntiles);
+        }
         __syncthreads();
-        if (ROT) prefetch(t + t_step < t_end ? t + t_step : ntiles);
-        else prefetch_plain(t + t_step < t_end ? t + t_step : ntiles);
+        if (!LRHIP_DECIM_EARLY_PREFETCH) {
+            if (ROT) prefetch(t + t_step < t_end ? t + t_step : ntiles);
+            else prefetch_plain(t + t_step < t_end ? t + t_step : ntiles);
+        }
         const long k = k0 + tid;
         if (tid < OW && k < n_out) {
             int p = tid * (int)D;
