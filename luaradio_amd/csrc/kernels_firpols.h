@@ -37,13 +37,19 @@
 
 namespace lrhip {
 
-constexpr int POLS_WPB = LRHIP_POLS_WPB;
+// waves per workgroup (= per CU: one workgroup).  ComplexFloat32 streams: 12 (three per SIMD, 168 registers).  Float32 streams carry two runs per wave and
+// spilled up to 164 B per lane at that cap: 8 (two per SIMD, 220 registers, no scratch) measures 0.216 against 0.228 ms for 1 276 taps on 2^26 samples, while
+// the ComplexFloat32 kernel LOSES 10 % at 8 (1.62 against 1.47 ms for 4 096 taps) - round 4, three alternations
+#ifndef LRHIP_POLS_WPB_F32
+#define LRHIP_POLS_WPB_F32 8
+#endif
+__host__ __device__ constexpr int pols_wpb(int S) { return S == 1 ? LRHIP_POLS_WPB_F32 : LRHIP_POLS_WPB; }
 constexpr int POLS_HOP = 512;
-// LDS map (float2 units): [POLS_WPB x exchange | tw1 16x64 | tw2 64 | H P x 1024]
-constexpr int POLS_LDS_TW1 = POLS_WPB * FFT_EX_ELEMS;
-constexpr int POLS_LDS_TW2 = POLS_LDS_TW1 + 16 * 64;
-constexpr int POLS_LDS_H = POLS_LDS_TW2 + 64;
-__host__ __device__ constexpr int pols_lds_elems(int P) { return POLS_LDS_H + P * 1024; }
+// LDS map (float2 units): [WPB x exchange | tw1 16x64 | tw2 64 | H P x 1024]
+__host__ __device__ constexpr int pols_lds_tw1(int S) { return pols_wpb(S) * FFT_EX_ELEMS; }
+__host__ __device__ constexpr int pols_lds_tw2(int S) { return pols_lds_tw1(S) + 16 * 64; }
+__host__ __device__ constexpr int pols_lds_h(int S) { return pols_lds_tw2(S) + 64; }
+__host__ __device__ constexpr int pols_lds_elems(int S, int P) { return pols_lds_h(S) + P * 1024; }
 
 // a + s * h on the packed VALU: two v_pk_fma_f32
 __device__ __forceinline__ cf cmac(cf a, cf s, cf h)
@@ -57,10 +63,11 @@ __device__ __forceinline__ cf cmac(cf a, cf s, cf h)
 // part0 .. part0 + P - 1 (taps [512 part0, 512 (part0 + P)) of the Mh-tap filter) to the stream delayed by 512 part0 samples.
 // nblocks = ceil(n_out / 512); a wave owns `run` consecutive blocks (S = 1: two runs, `run` blocks apart).
 template <int S, int P>
-__global__ __launch_bounds__(64 * POLS_WPB, 1) void fir_pols_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float2 *__restrict__ tables,
+__global__ __launch_bounds__(64 * pols_wpb(S), 1) void fir_pols_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float2 *__restrict__ tables,
                                                                     float *__restrict__ y, int Mh, long n, long n_out, long nblocks, long run, int part0,
                                                                     int accumulate, float *__restrict__ hist_out)
 {
+    constexpr int POLS_WPB = pols_wpb(S), POLS_LDS_TW1 = pols_lds_tw1(S), POLS_LDS_TW2 = pols_lds_tw2(S), POLS_LDS_H = pols_lds_h(S);
     static_assert(P >= 1 && P <= 3, "the spectra delay line lives in registers");
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int tid = threadIdx.x, lane = tid & 63;

@@ -431,7 +431,8 @@ struct FirStage : lrhip_stage {
     template <int SS, int PP>
     int launch_pols_p(const float *x, long n, float *y, long n_out, int part0)
     {
-        const size_t lds_bytes = (size_t)pols_lds_elems(PP) * sizeof(float2);
+        const size_t lds_bytes = (size_t)pols_lds_elems(SS, PP) * sizeof(float2);
+        constexpr int POLS_WPB = pols_wpb(SS);
         auto kern = fir_pols_kernel<SS, PP>;
         if (prepared_blocks(kern, lds_bytes, 64 * POLS_WPB) < 0) return -1;
         // a wave owns a run of consecutive blocks (its spectra delay line); runs of ~40 blocks keep the P - 1 warm-up blocks of a run under 5 %,

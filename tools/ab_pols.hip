@@ -63,11 +63,11 @@ static void build_tables(const std::vector<float> &taps, std::vector<float> &tab
 template <int S, int P>
 static void launch(const float *hist, const float *x, const float2 *tables, float *y, int M, long n, long run, int part0, int acc, int grid)
 {
-    const size_t lds = (size_t)pols_lds_elems(P) * sizeof(float2);
+    const size_t lds = (size_t)pols_lds_elems(S, P) * sizeof(float2);
     static bool set = false;
     if (!set) { CK(hipFuncSetAttribute((const void *)fir_pols_kernel<S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
     const long nblocks = (n + POLS_HOP - 1) / POLS_HOP;
-    hipLaunchKernelGGL((fir_pols_kernel<S, P>), dim3(grid), dim3(64 * POLS_WPB), lds, 0, hist, x, tables, y, M, n, n, nblocks, run, part0, acc, (float *)nullptr);
+    hipLaunchKernelGGL((fir_pols_kernel<S, P>), dim3(grid), dim3(64 * pols_wpb(S)), lds, 0, hist, x, tables, y, M, n, n, nblocks, run, part0, acc, (float *)nullptr);
 }
 
 template <int S>
@@ -107,14 +107,14 @@ int main(int argc, char **argv)
     int dev = 0, cus = 0;
     CK(hipGetDevice(&dev));
     CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const long nblocks = (n + POLS_HOP - 1) / POLS_HOP, runs_per_round = (long)cus * POLS_WPB * (S == 2 ? 1 : 2);
+    const long nblocks = (n + POLS_HOP - 1) / POLS_HOP, runs_per_round = (long)cus * pols_wpb(S) * (S == 2 ? 1 : 2);
     if (run <= 0) {
         long k = (nblocks + runs_per_round * 40 - 1) / (runs_per_round * 40);
         if (k < 1) k = 1;
         run = (nblocks + runs_per_round * k - 1) / (runs_per_round * k);
         if (run < 4) run = 4;
     }
-    const long nruns = (nblocks + run - 1) / run, nslots = (nruns + POLS_WPB * (S == 2 ? 1 : 2) - 1) / (POLS_WPB * (S == 2 ? 1 : 2));
+    const long nruns = (nblocks + run - 1) / run, nslots = (nruns + pols_wpb(S) * (S == 2 ? 1 : 2) - 1) / (pols_wpb(S) * (S == 2 ? 1 : 2));
     const int grid = (int)std::min<long>(nslots, cus);
     auto go = [&]() { if (S == 2) filter<2>(hist, x, tables, y, ntaps, nparts, n, run, grid); else filter<1>(hist, x, tables, y, ntaps, nparts, n, run, grid); };
     go();
