@@ -346,6 +346,9 @@ __device__ __forceinline__ void mfma_load_areg(const float *ldsT, int e, float (
 // the 40-cycle dependent latency plus the cliff an LDS read between two dependent MFMAs costs (MI355X_MICROARCH.md: +43 cycles), against 32 cycles of pipe time -
 // two interleaved chains issue back to back.  The sum is no longer the single fmaf chain of the direct form: only for kernels whose contract is a tolerance
 // (the FM receiver, include/lrhip.h's rounding exceptions)
+#ifndef LRHIP_MFMA_AREG_DEPTH
+#define LRHIP_MFMA_AREG_DEPTH 1
+#endif
 template <int S, int D, int NACC, int KS, int TQS, int NR, int SPLIT = 1>
 __device__ __forceinline__ void mfma_tile_areg(const float (&areg)[NR], const float *ldsT, int e, const float *ldsX, f32x4 (&acc)[1][NACC])
 {
@@ -361,7 +364,11 @@ __device__ __forceinline__ void mfma_tile_areg(const float (&areg)[NR], const fl
     f32x4 acc2[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[0][a] = acc2[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bv[2][NACC], av[2];
+    // software pipeline: the B (and late A) fragments of step s + DEPTH are requested while step s multiplies (DEPTH + 1 register slots).  DEPTH = 1 leaves an LDS
+    // round trip between a read and the MFMA that needs it one 32-cycle step later - and 2 or 4 measure EQUAL on the receiver (0.1567 / 0.1591 / 0.1571 ms, round 4):
+    // the other two waves of the SIMD fill it
+    constexpr int DEPTH = LRHIP_MFMA_AREG_DEPTH, NB = DEPTH + 1;
+    float bv[NB][NACC], av[NB];
     auto fetch = [&](int buf, int s) {
         const int g = s / G::GROUP, j = s % G::GROUP;
         const float *bp = bptr + g * (G::ROW + G::PAD);
@@ -369,16 +376,17 @@ __device__ __forceinline__ void mfma_tile_areg(const float (&areg)[NR], const fl
         for (int a = 0; a < NACC; a++) bv[buf][a] = bp[a * ACC_STRIDE + j * 4 * S];
         if (s >= NR) av[buf] = aptr[4 * g * G::GROUP + 4 * j];
     };
-    fetch(0, 0);
+#pragma unroll
+    for (int s = 0; s < DEPTH && s < KS; s++) fetch(s % NB, s);
 #pragma unroll
     for (int s = 0; s < KS; s++) {
-        if (s + 1 < KS) fetch((s + 1) & 1, s + 1);
+        if (s + DEPTH < KS) fetch((s + DEPTH) % NB, s + DEPTH);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < NACC; a++) {
-            const float af = s < NR ? areg[s < NR ? s : 0] : av[s & 1];
-            if (SPLIT == 2 && (s & 1)) acc2[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bv[s & 1][a], acc2[a], 0, 0, 0);
-            else acc[0][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bv[s & 1][a], acc[0][a], 0, 0, 0);
+            const float af = s < NR ? areg[s < NR ? s : 0] : av[s % NB];
+            if (SPLIT == 2 && (s & 1)) acc2[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bv[s % NB][a], acc2[a], 0, 0, 0);
+            else acc[0][a] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bv[s % NB][a], acc[0][a], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
