@@ -51,6 +51,9 @@
 // 1: the 15 stage-1 twiddles W_1024^(lane k1) of a lane stay in registers for the whole launch (30 registers; the kernel has 131 of the 168 that three waves
 // per SIMD allow) instead of being read from the LDS table twice per block: 30 of a block's 201 eight-byte LDS operations.  Round 4: the counters of this kernel
 // say LDS 50 % + VALU 41 % busy, the pattern of every overlap-save kernel here (section 4.7) - LDS traffic is worth removing
+#ifndef LRHIP_FFT_STRAIGHT_STORES
+#define LRHIP_FFT_STRAIGHT_STORES 0      /* round 4 A/B, measured EQUAL with settled clocks (below): off */
+#endif
 #ifndef LRHIP_FFT_TW_REG
 #define LRHIP_FFT_TW_REG 1
 #endif
@@ -341,7 +344,14 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             const long o0 = fb * L - V;
             cf *dst = reinterpret_cast<cf *>(y) + o0 + lane;
             [[maybe_unused]] cf *dstu = reinterpret_cast<cf *>(y) + o0;
-            if (o0 + FFTN <= n_out) {
+            if (LRHIP_FFT_STRAIGHT_STORES && LRHIP_FFT_NT >= 1 && o0 + FFTN <= n_out && V == 128 && !accumulate) {
+                // the common case - 128 taps or fewer, no accumulation - as fourteen stores in a row off one base address.  (Round 4, read off the ISA: with the
+                // overlap and the accumulate flag tested per row every store sat in a basic block of its own behind two scalar branches and a recomputed
+                // 64-bit address: ~10 instructions per row, 4 of them vector.)  Behind bench.py's 250 ms clock ramp the two forms measure the same at 2^26 / 2^27 / 2^28
+                // samples (0.2056 / 0.4156 / 0.8414 against 0.2085 / 0.4062 / 0.8439 ms); the 5-7 % this form gains in a cold 20-launch loop is the clock ramp
+#pragma unroll
+                for (int i = 2; i < 16; i++) __builtin_nontemporal_store(v[i], (dstu + 64 * i) + (unsigned)lane);
+            } else if (o0 + FFTN <= n_out) {
 #pragma unroll
                 for (int i = 0; i < 16; i++)
                     if (64 * i >= V) {                                                                // wave-uniform: whole rows only
@@ -361,7 +371,14 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             }
         } else {
             const long oa = (fb * 2) * L - V, ob = oa + L;
-            if (ob + FFTN <= n_out) {
+            if (LRHIP_FFT_STRAIGHT_STORES && LRHIP_FFT_NT >= 1 && ob + FFTN <= n_out && V == 128 && !accumulate) {
+                float *da = y + oa + lane, *db = y + ob + lane;
+#pragma unroll
+                for (int i = 2; i < 16; i++) {
+                    __builtin_nontemporal_store(v[i].x, da + 64 * i);
+                    __builtin_nontemporal_store(v[i].y, db + 64 * i);
+                }
+            } else if (ob + FFTN <= n_out) {
                 float *da = y + oa + lane, *db = y + ob + lane;
 #pragma unroll
                 for (int i = 0; i < 16; i++)
