@@ -92,11 +92,22 @@ def self_launch(args):
                              "requested (use --same-device --dist-backend gloo for a dry run of the multi-rank plumbing on one device)" % (args.gpus, have))
         if args.same_device and args.dist_backend == "nccl":
             raise SystemExit("bench.py: --same-device needs --dist-backend gloo (RCCL refuses two ranks on one device)")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    import subprocess
     sys.stdout.flush()
     sys.stderr.flush()
-    os.execv(sys.executable, cmd)
+    # the launcher runs as a child (the ranks inherit stdout): a rendezvous that loses its port between _free_port() and the launcher's bind - the one
+    # failure that is nobody's fault - is retried on a fresh port instead of failing the run
+    for attempt in range(3):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(r.stderr)
+        sys.stderr.flush()
+        port_lost = any(t in r.stderr for t in ("Address already in use", "EADDRINUSE", "failed to bind", "DistNetworkError", "RendezvousConnectionError"))
+        if r.returncode == 0 or not port_lost:
+            raise SystemExit(r.returncode)
+        sys.stderr.write("bench.py: the rendezvous port was taken, launching again (attempt %d)\n" % (attempt + 2))
+    raise SystemExit(r.returncode)
 
 
 def _trials(fn, samples_per_call, seconds_per_trial, ntrials=5):
