@@ -72,7 +72,7 @@ def _free_port():
 
 
 def self_launch(args):
-    """`python bench.py --gpus N` with N > 1 outside a launcher: become `torch.distributed.run` with N ranks of this same command line
+    """`python bench.py --gpus N` with N > 1 outside a launcher: start `torch.distributed.run` with N ranks of this same command line as a child and exit with its code
     (radio/core/composite.lua:568-569: the reference starts its own processes, the user never does).  Returns only if no launch is needed."""
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if launched:
