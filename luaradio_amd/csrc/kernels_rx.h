@@ -74,16 +74,22 @@ struct RxParams {
 
 constexpr int RX_D = 5, RX_KS = 51, RX_M = 128, RX_MT = 136;
 constexpr int RX_KST = 54;                                            // audio filter: slack (0..4) + 15 x 5 + 136 <= 4 x 54
-constexpr int RX_TILE = FirMfmaGeom<2, RX_D>::tile_out(1);            // 512 tuner outputs per tile
+// LRHIP_RX_NACC 2 (round 4, VERDICT r03 next 7 - the halved skeleton): two accumulators = 256 outputs per wave, 1 024 per tile: one staging pass and one pair of
+// barriers per 1 024 outputs, 5 120 + 203 staged samples instead of 2 x (2 560 + 203); the window doubles to 43 KB, so two workgroups per CU instead of three
+#ifndef LRHIP_RX_NACC
+#define LRHIP_RX_NACC 1
+#endif
+constexpr int RX_NACC = LRHIP_RX_NACC;
+constexpr int RX_TILE = FirMfmaGeom<2, RX_D>::tile_out(RX_NACC);      // 512 (1 024) tuner outputs per tile
 #ifndef LRHIP_RX_TPB
-#define LRHIP_RX_TPB 10      /* tiles per batch: 10 = 1 024 audio outputs, an accumulator for each of the four waves, 46 KB of LDS (3 workgroups per CU); 5 = 512 audio outputs on waves 0-1, 36 KB (4 per CU) */
+#define LRHIP_RX_TPB (LRHIP_RX_NACC == 2 ? 5 : 10)      /* tiles per batch: 10 = 1 024 audio outputs, an accumulator for each of the four waves, 46 KB of LDS (3 workgroups per CU); 5 = 512 audio outputs on waves 0-1, 36 KB (4 per CU) */
 #endif
 constexpr int RX_TPB = LRHIP_RX_TPB;                                  // tiles per batch
 constexpr int RX_BATCH = RX_TILE * RX_TPB;                            // 5 120 discriminator samples
 constexpr int RX_AUDIO = RX_BATCH / 5;                                // 1 024 audio outputs per batch: one accumulator (256) per wave
 constexpr int RX_AW = RX_AUDIO / 256;                                 // waves that run the audio product
 constexpr int RX_TH = RX_MT - 1;                                      // 135 samples of tail history
-constexpr int RX_SPAN = FirMfmaGeom<2, RX_D>::span(1, RX_KS);
+constexpr int RX_SPAN = FirMfmaGeom<2, RX_D>::span(RX_NACC, RX_KS);
 constexpr int RX_TLEN = fir_taps_len(RX_D, RX_KS);
 #ifndef LRHIP_RX_TAP_COPIES
 #define LRHIP_RX_TAP_COPIES 0      /* 1: four copies of the tuner tap array, 303 floats apart (conflict-free A-fragment reads, mfma_tile TQS) - measured equal on the receiver (0.1515 against 0.1518 ms, same box): the conflicts are not on its critical path; 0: one copy */
@@ -106,11 +112,11 @@ constexpr int RX_LDS_EO = RX_LDS_XCH + 8;
 constexpr int RX_LDS_PREV = RX_LDS_EO + 16;
 constexpr int RX_LDS_FLOATS = RX_LDS_PREV + 4;
 static_assert(RX_TQS == 0 || (RX_TQS >= RX_TLEN && RX_TQS % 32 == 15), "tap copies: 16 banks apart");
-static_assert(RX_TILE == 512 && (RX_TPB == 10 || RX_TPB == 5) && RX_AUDIO == 256 * RX_AW && RX_TLEN % 4 == 0 && RX_GLEN % 4 == 0 && RX_PSPAN == RX_BATCH + RX_TH + 1, "receiver geometry");
+static_assert(RX_TILE == 512 * RX_NACC && (RX_TPB == 10 || RX_TPB == 5) && RX_AUDIO == 256 * RX_AW && RX_TLEN % 4 == 0 && RX_GLEN % 4 == 0 && RX_PSPAN == RX_BATCH + RX_TH + 1, "receiver geometry");
 static_assert(RX_XF >= RX_AUDIO, "the audio output row lives in the RF window area");
 
 #ifndef LRHIP_RX_WAVES_PER_SIMD
-#define LRHIP_RX_WAVES_PER_SIMD (LRHIP_RX_TPB == 5 ? 4 : 3)
+#define LRHIP_RX_WAVES_PER_SIMD (LRHIP_RX_NACC == 2 ? 2 : LRHIP_RX_TPB == 5 ? 4 : 3)
 #endif
 
 // discriminator sample b of the batch (-135 .. 5119: negative = the history in front of it) -> its float in the padded audio window
@@ -277,12 +283,15 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
         prefetch(t + 1 < tend ? t + 1 : tend);
 
         // ---- filter: banded-Toeplitz product on the f32 matrix cores, one accumulator (128 outputs) per wave
-        f32x4 acc[1][1];
-        if (pr.dbg & 4) acc[0][0] = (f32x4){ldsX[tid], ldsX[tid + 256], ldsX[tid + 512], ldsX[tid + 768]};
+        f32x4 acc[1][RX_NACC];
+        if (pr.dbg & 4) {
+#pragma unroll
+            for (int a = 0; a < RX_NACC; a++) acc[0][a] = (f32x4){ldsX[tid], ldsX[tid + 256], ldsX[tid + 512], ldsX[tid + 768]};
+        }
 #if LRHIP_RX_AREG
-        else mfma_tile_areg<S, D, 1, RX_KS, RX_TQS, LRHIP_RX_AREG, LRHIP_RX_SPLITK>(areg, ldsT, pr.e, ldsX, acc);
+        else mfma_tile_areg<S, D, RX_NACC, RX_KS, RX_TQS, LRHIP_RX_AREG, LRHIP_RX_SPLITK>(areg, ldsT, pr.e, ldsX, acc);
 #else
-        else mfma_tile<S, D, 1, RX_KS, 1, RX_TQS>(ldsT, RX_TLEN, pr.e, ldsX, RX_KS, acc);
+        else mfma_tile<S, D, RX_NACC, RX_KS, 1, RX_TQS>(ldsT, RX_TLEN, pr.e, ldsX, RX_KS, acc);
 #endif
 
         // ---- discriminator on the accumulators -> P.  After the re/im exchange a lane owns two consecutive filter outputs; the one in front of them is
@@ -294,33 +303,49 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
             const int col = lane & 15, kq = lane >> 4;
             const bool odd = col & 1;
             const int src = odd ? lane - 1 : kq ? lane - 15 : col ? col + 47 : 63;      // the lane that owns the output before this lane's first one
-            const float a0 = acc[0][0][0], a1 = acc[0][0][1], a2 = acc[0][0][2], a3 = acc[0][0][3];
-            const float recv0 = __shfl_xor(odd ? a0 : a2, 1);
-            const float recv1 = __shfl_xor(odd ? a1 : a3, 1);
-            const float2 o0 = odd ? make_float2(recv0, a2) : make_float2(a0, recv0);
-            const float2 o1 = odd ? make_float2(recv1, a3) : make_float2(a1, recv1);
-            float2 p = make_float2(__shfl(o1.x, src), __shfl(o1.y, src));
-            float2 *eo_t = eo + 4 * (int)(t & 1), *eo_p = eo + 4 * (int)((t & 1) ^ 1);     // last outputs of the four waves: this tile's, the previous tile's
-            if (lane == 63) eo_t[wave] = o1;
-            __syncthreads();                                          // (B) window free; the waves' last outputs are visible
-            // (+ 0: a silent stretch gives exactly +0 filter outputs, but +0 times a phasor with negative parts is -0, and the angle of a zero product
-            // is decided by the signs of the zeros - frequencydiscriminator.lua:74 via discriminate(): keep what the reference's own operands would be)
-            if (lane == 0) p = wave ? eo_t[wave - 1] : cf_to(cmulc(cf_from(eo_p[3]), tileR) + cf{0.f, 0.f});
-            float2 d = (pr.dbg & 2) ? make_float2(o0.x + p.x, o1.y) : make_float2(discriminate(o0, p, pr.inv_gain), discriminate(o1, o0, pr.inv_gain));
-            const int lk = wave * 128 + 16 * (col >> 1) + 4 * kq + (odd ? 2 : 0);          // tile-local index of o0
-            const long k = tile_k0 + lk;
-            if (t == tfirst && tid == 0) {
-                // the run's first sample: the carried output is in absolute phase (zero in front of a warm-up tile, whose first angle is never used)
-                const cf pt = phasor_poly(pr.rot_step_fx * (pr.rot_count0 + (uint64_t)xlo_of(t)));
-                d.x = discriminate(cf_to(cmul(cf_from(o0), pt) + cf{0.f, 0.f}), chunk_start ? *pr.prev_in : make_float2(0.f, 0.f), pr.inv_gain);
+            float2 o0s[RX_NACC], o1s[RX_NACC], ps[RX_NACC];
+#pragma unroll
+            for (int a = 0; a < RX_NACC; a++) {
+                const float a0 = acc[0][a][0], a1 = acc[0][a][1], a2 = acc[0][a][2], a3 = acc[0][a][3];
+                const float recv0 = __shfl_xor(odd ? a0 : a2, 1);
+                const float recv1 = __shfl_xor(odd ? a1 : a3, 1);
+                o0s[a] = odd ? make_float2(recv0, a2) : make_float2(a0, recv0);
+                o1s[a] = odd ? make_float2(recv1, a3) : make_float2(a1, recv1);
+                ps[a] = make_float2(__shfl(o1s[a].x, src), __shfl(o1s[a].y, src));
             }
-            const int b = tau * RX_TILE + lk;
-            P[rx_pos(b)] = d.x;
-            P[rx_pos(b + 1)] = d.y;
-            // the chunk's last tuner output, in absolute phase, for the next chunk
-            if (k == pr.n_out_a - 1 || k + 1 == pr.n_out_a - 1) {
-                const cf pt = phasor_poly(pr.rot_step_fx * (pr.rot_count0 + (uint64_t)xlo_of(t)));
-                *pr.prev_out = cf_to(cmul(cf_from(k == pr.n_out_a - 1 ? o0 : o1), pt) + cf{0.f, 0.f});
+            float2 *eo_t = eo + 4 * (int)(t & 1), *eo_p = eo + 4 * (int)((t & 1) ^ 1);     // last outputs of the four waves: this tile's, the previous tile's
+            if (lane == 63) eo_t[wave] = o1s[RX_NACC - 1];
+            __syncthreads();                                          // (B) window free; the waves' last outputs are visible
+#pragma unroll
+            for (int a = 0; a < RX_NACC; a++) {
+                const float2 o0 = o0s[a], o1 = o1s[a];
+                float2 p = ps[a];
+                // (+ 0: a silent stretch gives exactly +0 filter outputs, but +0 times a phasor with negative parts is -0, and the angle of a zero product
+                // is decided by the signs of the zeros - frequencydiscriminator.lua:74 via discriminate(): keep what the reference's own operands would be)
+                if (a == 0) {
+                    if (lane == 0) p = wave ? eo_t[wave - 1] : cf_to(cmulc(cf_from(eo_p[3]), tileR) + cf{0.f, 0.f});
+                } else {
+                    // the second accumulator's first output follows the first accumulator's last one: lane 63 of the same wave (ps[a] of lane 0 read lane 63 of
+                    // accumulator a; the right one is accumulator a - 1)
+                    const float2 q = make_float2(__shfl(o1s[a > 0 ? a - 1 : 0].x, 63), __shfl(o1s[a > 0 ? a - 1 : 0].y, 63));
+                    if (lane == 0) p = q;
+                }
+                float2 d = (pr.dbg & 2) ? make_float2(o0.x + p.x, o1.y) : make_float2(discriminate(o0, p, pr.inv_gain), discriminate(o1, o0, pr.inv_gain));
+                const int lk = (wave * RX_NACC + a) * 128 + 16 * (col >> 1) + 4 * kq + (odd ? 2 : 0);          // tile-local index of o0
+                const long k = tile_k0 + lk;
+                if (a == 0 && t == tfirst && tid == 0) {
+                    // the run's first sample: the carried output is in absolute phase (zero in front of a warm-up tile, whose first angle is never used)
+                    const cf pt = phasor_poly(pr.rot_step_fx * (pr.rot_count0 + (uint64_t)xlo_of(t)));
+                    d.x = discriminate(cf_to(cmul(cf_from(o0), pt) + cf{0.f, 0.f}), chunk_start ? *pr.prev_in : make_float2(0.f, 0.f), pr.inv_gain);
+                }
+                const int b = tau * RX_TILE + lk;
+                P[rx_pos(b)] = d.x;
+                P[rx_pos(b + 1)] = d.y;
+                // the chunk's last tuner output, in absolute phase, for the next chunk
+                if (k == pr.n_out_a - 1 || k + 1 == pr.n_out_a - 1) {
+                    const cf pt = phasor_poly(pr.rot_step_fx * (pr.rot_count0 + (uint64_t)xlo_of(t)));
+                    *pr.prev_out = cf_to(cmul(cf_from(k == pr.n_out_a - 1 ? o0 : o1), pt) + cf{0.f, 0.f});
+                }
             }
         }
 
