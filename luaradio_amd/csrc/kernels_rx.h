@@ -299,6 +299,42 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
         // frees the window) or, for wave 0, the previous TILE's last output, which lives in that tile's phase basis: bases of consecutive tiles
         // differ by the constant phasor R = exp(j omega TILE D), so lane 0 takes prev * conj(R).  Only a run's very first sample meets a
         // predecessor in absolute phase (the carried one) and pays for the tile's own phasor.
+#if LRHIP_RX_NACC == 1
+        // (one accumulator per wave: the round-3 epilogue, kept verbatim - the generalised form below compiles 1.6 % slower at one accumulator)
+        {
+            const int col = lane & 15, kq = lane >> 4;
+            const bool odd = col & 1;
+            const int src = odd ? lane - 1 : kq ? lane - 15 : col ? col + 47 : 63;      // the lane that owns the output before this lane's first one
+            const float a0 = acc[0][0][0], a1 = acc[0][0][1], a2 = acc[0][0][2], a3 = acc[0][0][3];
+            const float recv0 = __shfl_xor(odd ? a0 : a2, 1);
+            const float recv1 = __shfl_xor(odd ? a1 : a3, 1);
+            const float2 o0 = odd ? make_float2(recv0, a2) : make_float2(a0, recv0);
+            const float2 o1 = odd ? make_float2(recv1, a3) : make_float2(a1, recv1);
+            float2 p = make_float2(__shfl(o1.x, src), __shfl(o1.y, src));
+            float2 *eo_t = eo + 4 * (int)(t & 1), *eo_p = eo + 4 * (int)((t & 1) ^ 1);     // last outputs of the four waves: this tile's, the previous tile's
+            if (lane == 63) eo_t[wave] = o1;
+            __syncthreads();                                          // (B) window free; the waves' last outputs are visible
+            // (+ 0: a silent stretch gives exactly +0 filter outputs, but +0 times a phasor with negative parts is -0, and the angle of a zero product
+            // is decided by the signs of the zeros - frequencydiscriminator.lua:74 via discriminate(): keep what the reference's own operands would be)
+            if (lane == 0) p = wave ? eo_t[wave - 1] : cf_to(cmulc(cf_from(eo_p[3]), tileR) + cf{0.f, 0.f});
+            float2 d = (pr.dbg & 2) ? make_float2(o0.x + p.x, o1.y) : make_float2(discriminate(o0, p, pr.inv_gain), discriminate(o1, o0, pr.inv_gain));
+            const int lk = wave * 128 + 16 * (col >> 1) + 4 * kq + (odd ? 2 : 0);          // tile-local index of o0
+            const long k = tile_k0 + lk;
+            if (t == tfirst && tid == 0) {
+                // the run's first sample: the carried output is in absolute phase (zero in front of a warm-up tile, whose first angle is never used)
+                const cf pt = phasor_poly(pr.rot_step_fx * (pr.rot_count0 + (uint64_t)xlo_of(t)));
+                d.x = discriminate(cf_to(cmul(cf_from(o0), pt) + cf{0.f, 0.f}), chunk_start ? *pr.prev_in : make_float2(0.f, 0.f), pr.inv_gain);
+            }
+            const int b = tau * RX_TILE + lk;
+            P[rx_pos(b)] = d.x;
+            P[rx_pos(b + 1)] = d.y;
+            // the chunk's last tuner output, in absolute phase, for the next chunk
+            if (k == pr.n_out_a - 1 || k + 1 == pr.n_out_a - 1) {
+                const cf pt = phasor_poly(pr.rot_step_fx * (pr.rot_count0 + (uint64_t)xlo_of(t)));
+                *pr.prev_out = cf_to(cmul(cf_from(k == pr.n_out_a - 1 ? o0 : o1), pt) + cf{0.f, 0.f});
+            }
+        }
+#else
         {
             const int col = lane & 15, kq = lane >> 4;
             const bool odd = col & 1;
@@ -348,6 +384,7 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
                 }
             }
         }
+#endif
 
         const bool last_tile = t == pr.ntiles - 1;
         if (tau == RX_TPB - 1 || t == tend - 1) {
