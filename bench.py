@@ -145,7 +145,7 @@ def cpu_baseline_fir(taps, budget_s):
     x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
     y = np.empty(n, np.complex64)
     forms = {"dot_product": O.baseline_fir_dot, "overlap_save": O.baseline_fir_overlap_save}
-    per_trial = budget_s / 24.0             # 4 timed legs x 5 trials (+ probes)
+    per_trial = budget_s / 30.0             # 4 timed legs x 5 trials (+ probes) + the two half-length configs[0] legs
     out = {}
     for name, fn in forms.items():
         # pick the thread count that is actually fastest on this box (cgroup quotas make "all logical CPUs" a bad guess)
@@ -160,7 +160,10 @@ def cpu_baseline_fir(taps, budget_s):
         out[name] = {"single_core": _trials(lambda: fn(taps, x, 1, out=y), n, per_trial),
                      "all_cores": dict(_trials(lambda: fn(taps, x, cores, out=y), n, per_trial), threads=cores)}
     prod = out["overlap_save"]
-    return {"value": prod["all_cores"]["mean"], "sigma": prod["all_cores"]["sigma"], "unit": "MSamples/s", "cores": prod["all_cores"]["threads"],
+    # BASELINE.json configs[0] as the reference's benchmark runs it: LowpassFilterBlock(128, ..) over 1 Mi ComplexFloat32 samples per pass, one core
+    n0 = 1 << 20
+    configs0 = {"samples_per_pass": n0, "single_core": {name: _trials(lambda fn=fn: fn(taps, x[:n0], 1, out=y[:n0]), n0, per_trial / 2.0) for name, fn in forms.items()}}
+    return {"configs0": configs0, "slab_samples": n, "value": prod["all_cores"]["mean"], "sigma": prod["all_cores"]["sigma"], "unit": "MSamples/s", "cores": prod["all_cores"]["threads"],
             "kind": "port", "single_core_value": prod["single_core"]["mean"], "forms": out, "logical_cpus": avail,
             "sample": "oracle/lr_cpu_baseline.c on 2^22-sample slabs of the same U(-1,1) ComplexFloat32 IQ, 128 real taps; value = the reference's "
                       "production form (FFT overlap-save, firfilter.lua:320-398; self-contained Float32 Stockham FFT, not FFTW) on the fastest "
@@ -873,6 +876,35 @@ def main():
     wall = time.perf_counter() - t0
     ev_ms = L.lrhip_timer_elapsed_ms(timer)
     L.lrhip_timer_destroy(timer)
+    # spread of the GPU figure (benchmarks/luaradio_benchmark.lua:10-13, 722-738: trials, mean and deviation): five more trials of the same K steps, each
+    # between its own HIP event pair, AFTER the timed region above (which stays exactly K steps between two barriers) - and in the last of them every step
+    # between its own pair, so that a 1-2 % change from one round to the next can be told from the spread of the box
+    spread = None
+    if world == 1:
+        trial_ms = [ev_ms / args.steps]
+        for _ in range(5):
+            tt = L.lrhip_timer_create()
+            L.lrhip_timer_start(tt)
+            for _ in range(args.steps):
+                step()
+            L.lrhip_timer_stop(tt)
+            trial_ms.append(L.lrhip_timer_elapsed_ms(tt) / args.steps)
+            L.lrhip_timer_destroy(tt)
+        step_timers = [L.lrhip_timer_create() for _ in range(args.steps)]
+        for tt in step_timers:
+            L.lrhip_timer_start(tt)
+            step()
+            L.lrhip_timer_stop(tt)
+        torch.cuda.synchronize()
+        step_ms = [L.lrhip_timer_elapsed_ms(tt) for tt in step_timers]
+        for tt in step_timers:
+            L.lrhip_timer_destroy(tt)
+
+        def _stats(v):
+            m = sum(v) / len(v)
+            return {"mean": round(m, 4), "sigma": round((sum((a - m) ** 2 for a in v) / max(len(v) - 1, 1)) ** 0.5, 4), "min": round(min(v), 4), "max": round(max(v), 4), "n": len(v)}
+        spread = {"trials_of_K_steps_ms_per_step": _stats(trial_ms), "single_steps_ms": _stats(step_ms),
+                  "note": "HIP events on the launch stream; trial 1 is the timed region itself, trials 2-6 follow it; single steps: one event pair per step"}
     per_rank_wall = [wall]
     if dist is not None:
         cdev = dev if args.dist_backend == "nccl" else "cpu"
@@ -944,6 +976,11 @@ def main():
                          "fp32_tflops": round(flops / launch_s / 1e12, 2), "fp32_peak_tflops": FP32_PEAK_TFLOPS,
                          "fp32_frac": round(flops / launch_s / 1e12 / FP32_PEAK_TFLOPS, 4)},
         }
+        if spread is not None:
+            res["ms_per_step_sigma"] = spread["trials_of_K_steps_ms_per_step"]["sigma"]
+            res["ms_per_step_min"] = spread["trials_of_K_steps_ms_per_step"]["min"]
+            res["ms_per_step_max"] = spread["trials_of_K_steps_ms_per_step"]["max"]
+            res["spread"] = spread
         if args.workload == "timeshard":
             res["scaling"] = "strong"
         if rank_verified is not None:

@@ -23,7 +23,7 @@ end
 
 -- one-input process(): execute the block's stage on the chunk
 local function process(self, x)
-    return lrhip.execute(self:create_stage(), x, self.out)
+    return lrhip.execute(self:create_stage(), x, self.out, self)
 end
 
 -- a numeric or ComplexFloat32 / Float32 constant -> re, im, is_complex (addconstant.lua:33-44, multiplyconstant.lua:33-44)
@@ -124,7 +124,7 @@ end
 function M.patch_binary(Block, op)
     lrhip.device_block(Block, function (self) return lrhip.lib.lrhip_binary_create(op, is_complex(self)) end)
     local function process2(self, x, y)
-        return lrhip.execute2(self:create_stage(), x, y, self.out)
+        return lrhip.execute2(self:create_stage(), x, y, self.out, self)
     end
     Block.process = process2
     Block.process_complex = process2

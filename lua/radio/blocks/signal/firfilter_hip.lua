@@ -42,7 +42,7 @@ return function (FIRFilterBlock)
     end)
 
     local function process(self, x)
-        return lrhip.execute(self:create_stage(), x, self.out)
+        return lrhip.execute(self:create_stage(), x, self.out, self)
     end
 
     FIRFilterBlock.process_complex_input_complex_taps = process

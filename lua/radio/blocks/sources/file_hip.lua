@@ -1,0 +1,68 @@
+---
+-- Device variants of IQFileSource (radio/blocks/sources/iqfile.lua) and RealFileSource (radio/blocks/sources/realfile.lua).  Applied by ONE line
+-- directly above the final `return IQFileSource` / `return RealFileSource` of the reference files:
+--
+--     require('radio.core.lrhip').patch('iqfilesource', IQFileSource)
+--     require('radio.core.lrhip').patch('realfilesource', RealFileSource)
+--
+-- What changes: nothing for a source that feeds host blocks - instantiate(), initialize(), process() (fread of 8 192 records, byte swap, the
+-- per-sample `(value - offset) / scale` loop of iqfile.lua:82-116) and cleanup() are the reference's.  What is ADDED is what DeviceChainBlock.collapse()
+-- (radio/composites/devicechain.lua) needs to absorb the source as the HEAD of a device chain:
+--
+--   create_stage()      lrhip_format_convert_create(format, complex): the conversion of the raw records - byte swap, offset and scale of
+--                       radio/utilities/format_utils.lua:82-97 - as the chain's first stage, where it folds into the first filter's launch
+--                       (u8 / s8 / s16le records -> the receiver / tuner kernels read the records themselves);
+--   raw_record_size()   bytes per raw record (2 for 'u8' IQ, 8 for 'f32le' IQ, 4 for 'f32le' real, ...);
+--   read_raw(dst, max)  the reference's fread + EOF / repeat / ferror handling (iqfile.lua:82-96) WITHOUT the conversion loop, straight into `dst` -
+--                       which DeviceChainBlock points at the pinned input slot of the chain's ring (lrhip_chain_ring_input), so an RTL-SDR style
+--                       capture crosses the host once, as 2 bytes per complex sample, and is never touched by the interpreter.
+--
+-- The format NAME is what the library takes; the reference keeps only the table entry (iqfile.lua:48), so instantiate() is wrapped to remember it.
+
+local ffi = require('ffi')
+
+local lrhip = require('radio.core.lrhip')
+
+local M = {}
+
+local function patch_source(Source, complex_out)
+    local reference_instantiate = Source.instantiate
+
+    function Source:instantiate(file, format, rate, repeat_on_eof)
+        self.format_name = format
+        reference_instantiate(self, file, format, rate, repeat_on_eof)
+    end
+
+    lrhip.device_block(Source, function (self)
+        return lrhip.lib.lrhip_format_convert_create(self.format_name, complex_out)
+    end)
+
+    function Source:raw_record_size()
+        return ffi.sizeof((complex_out == 1) and self.format.complex_ctype or self.format.real_ctype)
+    end
+
+    -- up to `max_records` raw records into `dst`; returns the number read (0 right after a rewind, as the reference returns an empty vector from
+    -- that call, iqfile.lua:86-90), or nil at the end of the file
+    function Source:read_raw(dst, max_records)
+        local num_samples = tonumber(ffi.C.fread(dst, self:raw_record_size(), max_records, self.file))
+        if num_samples < max_records then
+            if num_samples == 0 and ffi.C.feof(self.file) ~= 0 then
+                if self.repeat_on_eof then
+                    ffi.C.rewind(self.file)
+                else
+                    return nil
+                end
+            else
+                if ffi.C.ferror(self.file) ~= 0 then
+                    error("fread(): " .. ffi.string(ffi.C.strerror(ffi.errno())))
+                end
+            end
+        end
+        return num_samples
+    end
+end
+
+function M.patch_iqfilesource(IQFileSource) patch_source(IQFileSource, 1) end
+function M.patch_realfilesource(RealFileSource) patch_source(RealFileSource, 0) end
+
+return M

@@ -43,6 +43,10 @@ DeviceChainBlock.ring_depth = 3
 -- time, and where a batch is cut decides the Float32 rounding of overlap-save filters and of the single-launch receiver
 -- (include/lrhip.h, "chains"), so clock-cut batches would make a file's output bits differ from run to run.
 DeviceChainBlock.max_latency = 0
+-- synchronous = true: no batching at all - every process() vector goes through the chain at once (lrhip_chain_execute: H2D, kernels, D2H, wait) and its
+-- output is returned from the same call, as the reference's blocks do (radio/core/block.lua:585).  The lowest latency and the fewest samples per launch;
+-- both ends are zero-copy: the vector is DMA'd from the pipe's read buffer and the result into the block's output vector (lrhip.pin_inputs, lrhip.pin).
+DeviceChainBlock.synchronous = false
 -- Placement: the index of the device this chain's process binds to (lrhip.ensure wraps it over the devices of the box).  nil = the
 -- library's default device / LUARADIO_HIP_DEVICE.  collapse() numbers the chains that read ONE fanned-out output port 0, 1, 2, ...
 -- (radio/core/block.lua:119-166, radio/core/pipe.lua:617-627: one OutputPort, several readers, each reader its own process), so
@@ -54,21 +58,42 @@ DeviceChainBlock.device = nil
 -- Set on the class before top:run(), or per chain on the object collapse() returns.
 DeviceChainBlock.exact = false
 
+-- a file source / sink with the raw-record hooks of radio/blocks/sources/file_hip.lua / radio/blocks/sinks/file_hip.lua
+local function is_raw_source(b)
+    return type(b.read_raw) == "function" and type(b.create_stage) == "function" and #b.inputs == 0 and #b.outputs == 1
+end
+local function is_raw_sink(b)
+    return type(b.write_raw) == "function" and type(b.create_stage) == "function" and #b.inputs == 1 and #b.outputs == 0
+end
+
+-- The members are device blocks in a row.  The first may be a file source (the chain then has NO input port: it reads the raw records itself, straight
+-- into the pinned input slot of its ring) and the last a file sink (NO output port: the chain's output are raw records, written by the sink's fwrite).
 function DeviceChainBlock:instantiate(blocks)
     self.blocks = assert(blocks, "Missing argument #1 (blocks)")
     local first, last = blocks[1], blocks[#blocks]
-    self:add_type_signature({block.Input("in", first:get_input_type())}, {block.Output("out", last:get_output_type())})
+    self.source = is_raw_source(first) and first or nil
+    self.sink = is_raw_sink(last) and last or nil
+    self:add_type_signature(self.source and {} or {block.Input("in", first:get_input_type())},
+                            self.sink and {} or {block.Output("out", last:get_output_type())})
 end
 
 function DeviceChainBlock:get_rate()
-    return self.blocks[#self.blocks]:get_rate()
+    local last = self.blocks[#self.blocks]
+    if self.sink then last = self.blocks[#self.blocks - 1] end
+    return last:get_rate()
 end
 
 function DeviceChainBlock:initialize()
-    -- the members' host-side initialize() (tap design etc.) has been run by their composite; device objects are created
+    -- the members' host-side initialize() (tap design, fopen() of a file source / sink) has been run by their composite; device objects are created
     -- post-fork, on the first process()
-    self.out = self:get_output_type().vector()
+    if not self.sink then self.out = self:get_output_type().vector() end
     self.chain = nil
+    self.finished = false
+    -- the descriptors the members opened stay open in this block's process (radio/core/composite.lua:594-611 closes everything that is not in
+    -- block.files or one of its pipes)
+    for _, b in ipairs(self.blocks) do
+        for file, _ in pairs(b.files or {}) do self.files[file] = true end
+    end
 end
 
 local function create_chain(self)
@@ -85,8 +110,60 @@ local function create_chain(self)
     if lib.lrhip_chain_set_ring(self.chain, self.ring_depth, self.batch_samples) ~= 0 then
         error("lrhip_chain_set_ring: " .. ffi.string(lib.lrhip_strerror()))
     end
-    if lib.lrhip_chain_set_latency(self.chain, self.max_latency) ~= 0 then
+    if lib.lrhip_chain_set_latency(self.chain, self.source and 0 or self.max_latency) ~= 0 then
         error("lrhip_chain_set_latency: " .. ffi.string(lib.lrhip_strerror()))
+    end
+    if self.sink then self.raw_size = lib.lrhip_stage_output_size(self.sink:create_stage()) end
+end
+
+-- Output of a call: `cap` samples of room, fill(ptr, cap) -> n.  Without a sink member the samples land in self.out (returned, as process() output);
+-- with one they are raw records in a pinned buffer of the library's, handed to the sink's fwrite (nothing returned: the chain has no output port).
+local function deliver(self, cap, fill, what)
+    local lib = lrhip.lib
+    if self.sink then
+        if self.raw == nil or self.raw_cap < cap then
+            if self.raw ~= nil then lib.lrhip_host_free(self.raw) end
+            self.raw = lrhip.check_object(lib.lrhip_host_alloc(math.max(cap, 1) * self.raw_size), "lrhip_host_alloc")
+            self.raw_cap = cap
+        end
+        local n = tonumber(fill(self.raw, cap))
+        if n < 0 then error(what .. ": " .. ffi.string(lib.lrhip_strerror())) end
+        self.sink:write_raw(self.raw, n)
+        return nil
+    end
+    self.out:resize(cap)
+    if self.synchronous then lrhip.pin(self.out, self.out.data, self.out._capacity * ffi.sizeof(self.out.data_type)) end
+    local n = tonumber(fill(self.out.data, cap))
+    if n < 0 then error(what .. ": " .. ffi.string(lib.lrhip_strerror())) end
+    return self.out:resize(n)
+end
+
+-- A chain headed by a file source: one call = keep the ring full, hand on the oldest finished batch.  fread() goes straight into the pinned input of the
+-- next ring slot (lrhip_chain_ring_input: no staging copy, batch_samples records per read instead of the reference's 8 192, iqfile.lua:52), submit()
+-- starts H2D -> kernels -> D2H of that slot and returns; when the ring is full (or the file has ended) the oldest batch is collected.  After the last
+-- batch process() returns nothing: block-generated EOF (radio/core/block.lua:588).
+local function process_source(self)
+    local lib = lrhip.lib
+    local chain = self.chain
+    while true do
+        local slot = nil
+        if not self.source_eof then slot = lib.lrhip_chain_ring_input(chain) end
+        if slot == nil then                          -- ring full, or the file has ended (a NULL pointer compares equal to nil)
+            if lib.lrhip_chain_in_flight(chain) == 0 then
+                self.finished = true
+                return nil, true
+            end
+            local cap = tonumber(lib.lrhip_chain_max_output(chain, self.batch_samples)) + 64
+            return deliver(self, cap, function (ptr, room) return lib.lrhip_chain_collect(chain, ptr, room) end, "lrhip_chain_collect"), false
+        end
+        local n = self.source:read_raw(slot, self.batch_samples)
+        if n == nil then
+            self.source_eof = true
+        elseif n > 0 then
+            if tonumber(lib.lrhip_chain_submit(chain, slot, n)) < 0 then
+                error("lrhip_chain_submit: " .. ffi.string(lib.lrhip_strerror()))
+            end
+        end
     end
 end
 
@@ -95,21 +172,27 @@ end
 function DeviceChainBlock:process(x)
     if self.chain == nil then create_chain(self) end
     local lib = lrhip.lib
-    local cap = tonumber(lib.lrhip_chain_push_bound(self.chain, x.length))
-    self.out:resize(cap)
-    local n = tonumber(lib.lrhip_chain_push(self.chain, x.data, x.length, self.out.data, cap))
-    if n < 0 then error("lrhip_chain_push: " .. ffi.string(lib.lrhip_strerror())) end
-    return self.out:resize(n)
+    local chain = self.chain
+    if self.source then
+        local out, eof = process_source(self)
+        if eof or self.sink then return end         -- nothing returned: end of the file, or a chain without an output port
+        return out
+    end
+    if self.synchronous then
+        lrhip.pin_inputs(self)
+        local cap = tonumber(lib.lrhip_chain_max_output(chain, x.length))
+        return deliver(self, cap, function (ptr, room) return lib.lrhip_chain_execute(chain, x.data, x.length, ptr, room) end, "lrhip_chain_execute")
+    end
+    local cap = tonumber(lib.lrhip_chain_push_bound(chain, x.length))
+    return deliver(self, cap, function (ptr, room) return lib.lrhip_chain_push(chain, x.data, x.length, ptr, room) end, "lrhip_chain_push")
 end
 
 -- The host's wait for input timed out (run() below): hand on what the latency bound releases.
 function DeviceChainBlock:poll()
     local lib = lrhip.lib
-    local cap = tonumber(lib.lrhip_chain_push_bound(self.chain, 0))
-    self.out:resize(cap)
-    local n = tonumber(lib.lrhip_chain_poll(self.chain, self.out.data, cap))
-    if n < 0 then error("lrhip_chain_poll: " .. ffi.string(lib.lrhip_strerror())) end
-    return self.out:resize(n)
+    local chain = self.chain
+    local cap = tonumber(lib.lrhip_chain_push_bound(chain, 0))
+    return deliver(self, cap, function (ptr, room) return lib.lrhip_chain_poll(chain, ptr, room) end, "lrhip_chain_poll")
 end
 
 -- Block:run (radio/core/block.lua:556-608) with ONE change: in front of the blocking pipe_mux:read() the input descriptors are
@@ -160,27 +243,72 @@ local function timed_run(self, due_seconds)
 end
 DeviceChainBlock.timed_run = timed_run
 
+-- file -> device -> file (source AND sink absorbed): a block without ports.  Block:run would wait on the control socket forever (PipeMux:_read_control,
+-- radio/core/pipe.lua:475-493), so this shape runs its own loop: process() until the file has ended, a look at the control socket in between.
+local function portless_run(self)
+    local pipe_mux = pipe.PipeMux({}, {}, self.control_socket)
+    while not self.finished do
+        self:process()
+        if self.control_socket then
+            local ret = ffi.C.poll(pipe_mux.input_pollfds, 1, 0)
+            if ret < 0 then error("poll(): " .. ffi.string(ffi.C.strerror(ffi.errno()))) end
+            if ret > 0 then break end           -- shutdown requested (pipe.lua:417-431: pollfds[0] is the control socket)
+        end
+    end
+    self:cleanup()
+end
+
 function DeviceChainBlock:run()
-    if not (self.max_latency > 0) then return block_run(self) end
+    if self.source and self.sink then return portless_run(self) end
+    if self.source or not (self.max_latency > 0) then return block_run(self) end
     return timed_run(self, function (b)
         if b.chain == nil then return -1 end
         return tonumber(lrhip.lib.lrhip_chain_poll_due(b.chain))
     end)
 end
 
+-- top:run(false) (radio/core/composite.lua:663-693) drives every block with run_once(): true = new samples, false = none, nil = EOF.
+local block_run_once = DeviceChainBlock.run_once
+function DeviceChainBlock:run_once()
+    if self.source and self.sink then
+        self:process()
+        if self.finished then return nil end
+        return true
+    end
+    return block_run_once(self)
+end
+
 -- cleanup() runs when the input reached EOF (radio/core/block.lua:606): run the partly filled batch and hand the tail
 -- to the readers of the output port, as process() output would have been (block.lua:585-593)
 function DeviceChainBlock:cleanup()
-    if self.chain == nil then return end
-    local lib = lrhip.lib
-    local cap = tonumber(lib.lrhip_chain_push_bound(self.chain, 0))
-    self.out:resize(cap)
-    local n = tonumber(lib.lrhip_chain_flush(self.chain, self.out.data, cap))
-    if n < 0 then error("lrhip_chain_flush: " .. ffi.string(lib.lrhip_strerror())) end
-    if n > 0 then
-        local tail = self.out:resize(n)
-        for _, p in ipairs(self.outputs[1].pipes) do p:write(tail) end
+    if self.chain ~= nil and not self.cleaned_up then
+        self.cleaned_up = true
+        local lib = lrhip.lib
+        local chain = self.chain
+        if self.source then
+            -- a shutdown in the middle of the file: what is in flight is still handed on
+            while lib.lrhip_chain_in_flight(chain) > 0 do
+                local cap = tonumber(lib.lrhip_chain_max_output(chain, self.batch_samples)) + 64
+                local tail = deliver(self, cap, function (ptr, room) return lib.lrhip_chain_collect(chain, ptr, room) end, "lrhip_chain_collect")
+                if tail ~= nil and tail.length > 0 then
+                    for _, p in ipairs(self.outputs[1].pipes) do p:write(tail) end
+                end
+            end
+        else
+            local cap = tonumber(lib.lrhip_chain_push_bound(chain, 0))
+            local tail = deliver(self, cap, function (ptr, room) return lib.lrhip_chain_flush(chain, ptr, room) end, "lrhip_chain_flush")
+            if tail ~= nil and tail.length > 0 then
+                for _, p in ipairs(self.outputs[1].pipes) do p:write(tail) end
+            end
+        end
+        if self.raw ~= nil then
+            lib.lrhip_host_free(self.raw)
+            self.raw = nil
+        end
     end
+    -- the absorbed file blocks are no longer in the evaluation order: their cleanup() (fclose, iqfile.lua:118-124) is this block's to call
+    if self.source then self.source:cleanup() end
+    if self.sink then self.sink:cleanup() end
 end
 
 -- Time partitions (INTEGRATION.md 3a; include/lrhip.h "time-axis sharding"): a DeviceChainBlock that starts in the middle of a recording.
@@ -199,18 +327,59 @@ function DeviceChainBlock:start_at(first_sample)
     return tonumber(seek_sample[0])
 end
 
+-- The partition helpers next to start_at(): how many input samples a partition replays in front of its first own sample (-1 with an error message for
+-- chains with unbounded memory), and the grid partition boundaries should lie on to reproduce the uninterrupted run's tiles (include/lrhip.h).
+function DeviceChainBlock:halo()
+    if self.chain == nil then create_chain(self) end
+    local h = tonumber(lrhip.lib.lrhip_chain_halo(self.chain))
+    if h < 0 then error("lrhip_chain_halo: " .. ffi.string(lrhip.lib.lrhip_strerror())) end
+    return h
+end
+
+function DeviceChainBlock:shard_align()
+    if self.chain == nil then create_chain(self) end
+    return tonumber(lrhip.lib.lrhip_chain_shard_align(self.chain))
+end
+
+-- seek(n0): forget every carried sample, the next vector is sample n0 of the stream (no replay: the caller feeds the halo itself and drops its output)
+function DeviceChainBlock:seek(n0)
+    if self.chain == nil then create_chain(self) end
+    if lrhip.lib.lrhip_chain_seek(self.chain, n0) ~= 0 then
+        error("lrhip_chain_seek: " .. ffi.string(lrhip.lib.lrhip_strerror()))
+    end
+end
+
+-- reset(): back to the initial state (a flow graph run a second time in the same process, top:run(false) twice)
+function DeviceChainBlock:reset()
+    if self.chain ~= nil and lrhip.lib.lrhip_chain_reset(self.chain) ~= 0 then
+        error("lrhip_chain_reset: " .. ffi.string(lrhip.lib.lrhip_strerror()))
+    end
+    self.finished, self.source_eof, self.cleaned_up = false, false, false
+end
+
+-- kernels launched by the last batch (diagnostic: a fused receiver is ONE launch per batch)
+function DeviceChainBlock:last_launches()
+    if self.chain == nil then return 0 end
+    return tonumber(lrhip.lib.lrhip_chain_last_launches(self.chain))
+end
+
 -- a block the library can run as a chain stage: a device variant (create_stage), one input, one output
 local function chainable(b)
     if type(b.create_stage) ~= "function" or #b.inputs ~= 1 or #b.outputs ~= 1 then return false end
     if type(b.device_capable) == "function" and not b:device_capable() then return false end      -- e.g. DelayBlock on a Bit stream
     return true
 end
+DeviceChainBlock.chainable = chainable
+DeviceChainBlock.is_raw_source = is_raw_source
+DeviceChainBlock.is_raw_sink = is_raw_sink
 
 ---
 -- Replace every maximal linear run of two or more chainable blocks in the flattened connection table
 -- {[InputPort] = OutputPort} (radio/core/composite.lua:343-384) by one DeviceChainBlock; returns the new table and the
 -- list of chain blocks created (to be initialized by the caller after the composite's own blocks).
--- A run continues from block a to block b when a's output port has exactly one reader (b) and both are chainable.
+-- A run continues from block a to block b when a's output port has exactly one reader (b) and both are chainable.  A run is extended by the file source
+-- that feeds its first block (when that block is the source's only reader) and by the file sink that reads its last block (when it is the only reader):
+-- the raw records then cross the host untouched (radio/blocks/sources/file_hip.lua, radio/blocks/sinks/file_hip.lua).
 function DeviceChainBlock.collapse(connections)
     -- readers of every output port
     local readers = {}
@@ -219,11 +388,13 @@ function DeviceChainBlock.collapse(connections)
         table.insert(readers[output], input)
     end
     local function sole_reader(b)       -- the block reading b's output port, if it is the only one
+        if #b.outputs ~= 1 then return nil end
         local r = readers[b.outputs[1]]
         if r and #r == 1 then return r[1].owner end
         return nil
     end
     local function sole_writer(b)       -- the block feeding b's input port
+        if #b.inputs ~= 1 then return nil end
         local output = connections[b.inputs[1]]
         return output and output.owner or nil
     end
@@ -242,33 +413,58 @@ function DeviceChainBlock.collapse(connections)
                 run[#run + 1] = sole_reader(run[#run])
                 seen[run[#run]] = true
             end
+            -- the file source in front, the file sink behind
+            local writer, reader = sole_writer(run[1]), sole_reader(run[#run])
+            if writer and is_raw_source(writer) and sole_reader(writer) == run[1] then
+                table.insert(run, 1, writer)
+                seen[writer] = true
+            end
+            if reader and is_raw_sink(reader) then
+                run[#run + 1] = reader
+                seen[reader] = true
+            end
             if #run >= 2 then runs[#runs + 1] = run end
+        end
+    end
+    -- file source -> file sink with nothing in between (a format conversion)
+    for input, output in pairs(connections) do
+        local b, w = input.owner, output.owner
+        if not seen[b] and not seen[w] and is_raw_sink(b) and is_raw_source(w) and sole_reader(w) == b then
+            seen[b], seen[w] = true, true
+            runs[#runs + 1] = {w, b}
         end
     end
 
     local result, chains = {}, {}
     local chain_of = {}                 -- first member of a run -> its DeviceChainBlock
+    local port_of = {}                  -- output port of a run's last member -> the chain's output port
     for input, output in pairs(connections) do result[input] = output end
     for _, run in ipairs(runs) do
         local first, last = run[1], run[#run]
         local chain = DeviceChainBlock(run)
-        chain:differentiate({first:get_input_type()})
+        chain:differentiate(chain.source and {} or {first:get_input_type()})
         -- upstream: the chain's input reads what the first member read
-        result[chain.inputs[1]] = connections[first.inputs[1]]
-        result[first.inputs[1]] = nil
-        -- downstream: every reader of the last member now reads the chain
-        for _, reader in ipairs(readers[last.outputs[1]] or {}) do
-            result[reader] = chain.outputs[1]
+        if not chain.source then
+            result[chain.inputs[1]] = connections[first.inputs[1]]
+            result[first.inputs[1]] = nil
         end
+        -- downstream: every reader of the last member now reads the chain (re-pointed below, once every chain exists: a reader may itself be the
+        -- first member of another chain, whose input entry is rewritten too)
+        if not chain.sink then port_of[last.outputs[1]] = chain.outputs[1] end
         -- interior edges leave the table (no socket, no process); the members keep rate-only pipes so that their
         -- get_rate() still walks upstream (radio/core/block.lua:383-390, radio/core/pipe.lua:36-38)
         for i = 2, #run do
             result[run[i].inputs[1]] = nil
             run[i].inputs[1].pipe = pipe.Pipe(run[i-1].outputs[1], run[i].inputs[1])
         end
-        first.inputs[1].pipe = {get_rate = function () return chain.inputs[1].pipe:get_rate() end}
+        if not chain.source then
+            first.inputs[1].pipe = {get_rate = function () return chain.inputs[1].pipe:get_rate() end}
+        end
         chains[#chains + 1] = chain
         chain_of[first] = chain
+    end
+    for input, output in pairs(result) do
+        if port_of[output] then result[input] = port_of[output] end
     end
 
     -- placement: the chains that read ONE fanned-out output port are numbered 0, 1, 2, ... (in table order, which is as arbitrary as the

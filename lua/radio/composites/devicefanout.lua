@@ -72,11 +72,15 @@ local function sock_read(fd, buf, size)
     return true
 end
 
-local function sock_write(fd, buf, size)
+-- `who`: the peer's name for the message when it has gone away (EPIPE: block processes ignore SIGPIPE, radio/core/composite.lua:577)
+local function sock_write(fd, buf, size, who)
     local p, put = ffi.cast("const char *", buf), 0
     while put < size do
         local r = tonumber(ffi.C.write(fd, p + put, size - put))
-        if r < 0 then error("write(): " .. ffi.string(ffi.C.strerror(ffi.errno()))) end
+        if r < 0 then
+            if who then error(who .. " terminated unexpectedly (write(): " .. ffi.string(ffi.C.strerror(ffi.errno())) .. ")") end
+            error("write(): " .. ffi.string(ffi.C.strerror(ffi.errno())))
+        end
         put = put + r
     end
 end
@@ -164,6 +168,17 @@ end
 
 function DeviceBranchBlock:cleanup()
     if self.sock then ffi.C.close(self.sock) end
+    if self.chain ~= nil then
+        local lib = lrhip.lib
+        check(lib.lrhip_synchronize(), "lrhip_synchronize")
+        for i = 0, 1 do
+            lib.lrhip_ipc_event_destroy(self.filled[i])
+            lib.lrhip_ipc_event_destroy(self.consumed[i])
+            lib.lrhip_free(self.slab[i])
+        end
+        lib.lrhip_free(self.d_out)
+        self.chain = nil
+    end
 end
 
 ----------------------------------------------------------------------------------------------------------------------------------
@@ -202,6 +217,17 @@ function DeviceFanoutBlock:initialize()
         branch.files[fds[1]] = true
     end
     self.chain = nil
+end
+
+-- runs in the PARENT after every block has been forked (the hook tools/apply_lua_binding.py puts next to the reference's own "close all pipe inputs and
+-- outputs in the top-level process", radio/core/composite.lua:638-642): with the parent's copies gone, a branch that dies closes the LAST descriptor of
+-- its end, the head's read() returns 0 ("terminated unexpectedly" below) and the graph tears down instead of hanging; a head that dies ends every
+-- branch's read() the same way.
+function DeviceFanoutBlock:close_parent_fds()
+    for k, fd in ipairs(self.socks or {}) do
+        ffi.C.close(fd)
+        ffi.C.close(self.branches[k].sock)
+    end
 end
 
 local function head_start(self)
@@ -279,7 +305,7 @@ local function head_launch(self)
     end
     check(lib.lrhip_ipc_event_record(self.sent[i], 1), "lrhip_ipc_event_record")
     token.k, token.n = k, m
-    for _, fd in ipairs(self.socks) do sock_write(fd, token, ffi.sizeof(token)) end
+    for b, fd in ipairs(self.socks) do sock_write(fd, token, ffi.sizeof(token), "fan-out branch " .. b) end
     self.k = k + 1
 end
 
@@ -336,6 +362,22 @@ function DeviceFanoutBlock:cleanup()
         sock_write(fd, token, ffi.sizeof(token))
         ffi.C.close(fd)
     end
+    -- the mappings of the branches' slabs and events, and this block's own
+    for _, peer in ipairs(self.peer) do
+        for i = 0, 1 do
+            lib.lrhip_ipc_event_destroy(peer.filled[i])
+            lib.lrhip_ipc_event_destroy(peer.consumed[i])
+            check(lib.lrhip_ipc_close(peer.slab[i]), "lrhip_ipc_close")
+        end
+    end
+    for i = 0, 1 do
+        lib.lrhip_ipc_event_destroy(self.ready[i])
+        lib.lrhip_ipc_event_destroy(self.sent[i])
+        lib.lrhip_free(self.my_slab[i])
+    end
+    lib.lrhip_host_free(self.staging)
+    if self.d_in ~= nil then lib.lrhip_free(self.d_in) end
+    self.started = false
 end
 
 ----------------------------------------------------------------------------------------------------------------------------------
@@ -349,7 +391,10 @@ end
 
 -- the device blocks a reader stands for: a DeviceChainBlock's members, or a single chainable block
 local function members_of(b, is_chain)
-    if is_chain[b] then return b.blocks end
+    if is_chain[b] then
+        if b.source or b.sink then return nil end       -- a chain that reads or writes a file itself has no port on that side
+        return b.blocks
+    end
     if chainable(b) then return {b} end
     return nil
 end
@@ -369,17 +414,38 @@ function M.collapse(connections, chains)
         table.insert(readers[output], input)
     end
 
+    -- An output port qualifies when it has two or more readers and ALL of them are device chains (or single device blocks) ...
+    local function all_device(output)
+        local inputs = readers[output]
+        if inputs == nil or #inputs < 2 then return false end
+        for _, input in ipairs(inputs) do
+            if members_of(input.owner, is_chain) == nil then return false end
+        end
+        return true
+    end
+    -- ... and its writer is not itself a reader of a port that is rewritten: in source -> {A -> {C, D}, B} the port of the source is rewritten (A and B
+    -- become branches), so A's own port keeps its pipes - a block plays ONE role, and C, D stay ordinary chains reading branch A's output.
+    -- Decided from the sources downwards, so a third level (C -> {E, F}) qualifies again.
+    local accepted = {}
+    local function accept(output)
+        if accepted[output] == nil then
+            accepted[output] = false                  -- (a flow graph has no cycles; this only guards the recursion)
+            if all_device(output) then
+                local writer = output.owner
+                local upstream = (#writer.inputs == 1) and connections[writer.inputs[1]] or nil
+                accepted[output] = not (upstream ~= nil and accept(upstream))
+            end
+        end
+        return accepted[output]
+    end
+
     local result, dropped, created = {}, {}, {}
     for input, output in pairs(connections) do result[input] = output end
     for output, inputs in pairs(readers) do
-        local all_device = #inputs >= 2
-        for _, input in ipairs(inputs) do
-            if members_of(input.owner, is_chain) == nil then all_device = false end
-        end
-        if all_device then
+        if accept(output) then
             local writer = output.owner
             local head
-            if is_chain[writer] then
+            if is_chain[writer] and not writer.source then
                 -- the writer is a device chain: it becomes the head chain and keeps its output on its device
                 head = DeviceFanoutBlock(writer.blocks, writer:get_input_type(), output.data_type)
                 head:differentiate({writer:get_input_type()})

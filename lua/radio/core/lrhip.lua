@@ -18,17 +18,17 @@ local ffi = require('ffi')
 
 local platform = require('radio.core.platform')
 
+-- Every entry point declared here is called by a file under lua/radio/ and executed by a test (tests/test_lua_glue.py holds the list to the header:
+-- same prototypes; NOT declared are the ones only a measurement harness or a PyTorch host needs - lrhip_set_stream, lrhip_timer_*, lrhip_ipc_event_query - and lrhip_chain_create, which is lrhip_chain_create_ex with flags 0).
 ffi.cdef[[
 typedef struct lrhip_stage lrhip_stage_t;
 typedef struct lrhip_chain lrhip_chain_t;
-typedef struct lrhip_timer lrhip_timer_t;
 typedef struct lrhip_ipc_event lrhip_ipc_event_t;
 
 int lrhip_init(int device);
 const char *lrhip_strerror(void);
 int lrhip_device_count(void);
 int lrhip_device(void);
-int lrhip_set_stream(void *hip_stream);
 int lrhip_synchronize(void);
 const char *lrhip_version(void);
 
@@ -63,7 +63,6 @@ long lrhip_stage_execute_device(lrhip_stage_t *q, const void *in_dev, unsigned l
 long lrhip_stage_execute2(lrhip_stage_t *q, const void *in1_host, const void *in2_host, unsigned long n_in, void *out_host, unsigned long out_capacity);
 long lrhip_stage_execute2_device(lrhip_stage_t *q, const void *in1_dev, const void *in2_dev, unsigned long n_in, void *out_dev, unsigned long out_capacity);
 
-lrhip_chain_t *lrhip_chain_create(lrhip_stage_t **stages, unsigned nstages);
 lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, unsigned flags);
 void lrhip_chain_destroy(lrhip_chain_t *c);
 int lrhip_chain_reset(lrhip_chain_t *c);
@@ -93,11 +92,6 @@ void lrhip_host_free(void *host_ptr);
 int lrhip_host_register(void *host_ptr, unsigned long bytes);
 int lrhip_host_unregister(void *host_ptr);
 
-lrhip_timer_t *lrhip_timer_create(void);
-void lrhip_timer_destroy(lrhip_timer_t *t);
-int lrhip_timer_start(lrhip_timer_t *t);
-int lrhip_timer_stop(lrhip_timer_t *t);
-double lrhip_timer_elapsed_ms(lrhip_timer_t *t);
 int lrhip_stage_seek(lrhip_stage_t *q, unsigned long long n0);
 int lrhip_chain_seek(lrhip_chain_t *c, unsigned long long n0);
 long lrhip_chain_halo(const lrhip_chain_t *c);
@@ -111,7 +105,6 @@ lrhip_ipc_event_t *lrhip_ipc_event_open(const void *handle);
 void lrhip_ipc_event_destroy(lrhip_ipc_event_t *e);
 int lrhip_ipc_event_record(lrhip_ipc_event_t *e, int on_copy_stream);
 int lrhip_ipc_event_wait(lrhip_ipc_event_t *e, int on_copy_stream);
-int lrhip_ipc_event_query(lrhip_ipc_event_t *e);
 int lrhip_ipc_event_synchronize(lrhip_ipc_event_t *e);
 int lrhip_peer_copy(void *dst, int dst_device, const void *src, int src_device, unsigned long bytes);
 int lrhip_copy_stream_synchronize(void);
@@ -132,6 +125,7 @@ if not os.getenv("LUARADIO_DISABLE_HIP") then
     if ok then
         M.lib = lib
         M.available = true
+        M.version = ffi.string(lib.lrhip_version())
         platform.libs.hip = lib
         platform.features.hip = true
     end
@@ -191,6 +185,19 @@ function M.device_block(Block, create)
         end
         return self.stage
     end
+    -- back to the just-created state (zero history, phase 0, index 0): a flow graph that is run a second time in the same process
+    function Block:reset_stage()
+        if self.stage ~= nil and M.lib.lrhip_stage_reset(self.stage) ~= 0 then
+            error("lrhip_stage_reset: " .. ffi.string(M.lib.lrhip_strerror()))
+        end
+    end
+    -- a stand-alone block that starts in the middle of a recording (include/lrhip.h "time-axis sharding"): forget every carried sample and set the
+    -- absolute counters (rotator phase, downsampler index) as if n0 input samples had been consumed
+    function Block:seek_stage(n0)
+        if M.lib.lrhip_stage_seek(self:create_stage(), n0) ~= 0 then
+            error("lrhip_stage_seek: " .. ffi.string(M.lib.lrhip_strerror()))
+        end
+    end
 end
 
 ---
@@ -208,10 +215,22 @@ end
 local unary_ops = {complexmagnitude = true, complexphase = true, complextoreal = true, complextoimag = true,
                    complexconjugate = true, realtocomplex = true, absolutevalue = true}
 local binary_ops = {multiply = true, multiplyconjugate = true, add = true, subtract = true, floattocomplex = true}
+local file_sources = {iqfilesource = true, realfilesource = true}
+local file_sinks = {iqfilesink = true, realfilesink = true, gnuplotspectrum = true}
 function M.patch(name, Block)
     if not M.available then return Block end
     if name == "firfilter" then
         require('radio.blocks.signal.firfilter_hip')(Block)
+        return Block
+    end
+    -- radio/blocks/sources/{iqfile,realfile}.lua, radio/blocks/sinks/{iqfile,realfile,gnuplotspectrum}.lua: two directories hold an iqfile.lua, so the
+    -- patch names carry the role (tools/apply_lua_binding.py knows which file gets which name)
+    if file_sources[name] then
+        require('radio.blocks.sources.file_hip')["patch_" .. name](Block)
+        return Block
+    end
+    if file_sinks[name] then
+        require('radio.blocks.sinks.file_hip')["patch_" .. name](Block)
         return Block
     end
     local elementwise = require('radio.blocks.signal.elementwise_hip')
@@ -225,6 +244,17 @@ function M.patch(name, Block)
         patch(Block)
     end
     return Block
+end
+
+---
+-- radio/utilities/spectrum_utils.lua returns a table of classes, not a block: the ONE line it gains, directly above its final `return {DFT = DFT, ...}`, is
+--
+--     require('radio.core.lrhip').patch_spectrum(DFT, IDFT, PSD)
+--
+-- (radio/utilities/spectrum_utils_hip.lua: initialize() / compute() of the three classes on lrhip_dft_create / lrhip_psd_create).
+function M.patch_spectrum(DFT, IDFT, PSD)
+    if not M.available then return end
+    require('radio.utilities.spectrum_utils_hip')(DFT, IDFT, PSD)
 end
 
 ---
@@ -263,11 +293,24 @@ function M.pin(owner, data, size)
 end
 
 ---
+-- The input side of zero-copy: a block's input vector is a cast into its pipe's read buffer (radio/core/vector.lua:48-65), which is page-aligned, 1 MiB
+-- and lives as long as the pipe (radio/core/pipe.lua:72-76) - registered once per process, every vector read from the pipe is DMA'd from where read(2)
+-- put it.  Blocks fed by something else than a reference Pipe (the test jig's vectors) have no such buffer and are staged as before.
+function M.pin_inputs(b)
+    if not M.zero_copy then return end
+    for _, input in ipairs(b.inputs) do
+        local p = input.pipe
+        if p ~= nil and p._rbuf ~= nil then M.pin(p, p._rbuf, p._rbuf_capacity) end
+    end
+end
+
+---
 -- One process() call: resize the output vector to the bound, execute, trim (firfilter.lua:130 pattern).
 -- The output vector's buffer (page-aligned, radio/core/vector.lua:19-37) is registered with the library once per (re)allocation, so the result is
 -- written into it by DMA; the input is a cast into the pipe's read buffer, which DeviceChainBlock / the block's run loop may register as a whole.
-function M.execute(stage, x, out)
+function M.execute(stage, x, out, owner)
     local lib = M.lib
+    if owner ~= nil then M.pin_inputs(owner) end
     local cap = tonumber(lib.lrhip_stage_max_output(stage, x.length))
     out:resize(cap)
     M.pin(out, out.data, out._capacity * ffi.sizeof(out.data_type))      -- capacity in elements (radio/core/vector.lua:27,132)
@@ -280,9 +323,11 @@ end
 
 ---
 -- Two-input variant (multiply.lua:43-57 pattern: both inputs have the same length).
-function M.execute2(stage, x, y, out)
+function M.execute2(stage, x, y, out, owner)
     local lib = M.lib
+    if owner ~= nil then M.pin_inputs(owner) end
     out:resize(x.length)
+    M.pin(out, out.data, out._capacity * ffi.sizeof(out.data_type))
     local n = tonumber(lib.lrhip_stage_execute2(stage, x.data, y.data, x.length, out.data, x.length))
     if n < 0 then
         error("lrhip_stage_execute2: " .. ffi.string(lib.lrhip_strerror()))

@@ -75,6 +75,7 @@ static HostRanges &host_ranges()
 struct HostPipe {
     hipStream_t s_in = nullptr, s_out = nullptr;
     std::vector<hipEvent_t> ev;      // 3 per piece: H2D done, kernels done, D2H done
+    std::mutex m;                    // held for the whole of a piece-wise call (host_execute)
     long pid = 0;
     int ensure(size_t pieces)
     {
@@ -123,6 +124,12 @@ static long host_execute(PinnedBuf &h_in, PinnedBuf &h_out, DeviceBuf &d_in, Dev
     static const bool no_pieces = getenv("LRHIP_HOST_NO_PIECES") != nullptr;      // A/B knob: one piece, as in round 3
     unsigned long pieces = (no_pieces || n_in < 2 * host_piece_min()) ? 1 : n_in / host_piece_min();
     if (pieces > HOST_PIECES) pieces = HOST_PIECES;
+    // ONE set of copy streams and events per process (HostPipe): a second host thread - another stage or chain; ctypes and LuaJIT release their lock around the
+    // call - must not record and wait on them while this call's pieces are in flight, or its kernels could run before their own H2D has landed.  The thread
+    // that does not get the lock takes the single-piece path, which touches only its own object's buffers and the library stream.
+    HostPipe &hp = host_pipe();
+    std::unique_lock<std::mutex> pipe_lock(hp.m, std::defer_lock);
+    if (pieces > 1 && !pipe_lock.try_lock()) pieces = 1;
     if (pieces <= 1) {
         const void *src = in_reg ? in_host : h_in.p;
         if (in_bytes) {
@@ -136,7 +143,6 @@ static long host_execute(PinnedBuf &h_in, PinnedBuf &h_out, DeviceBuf &d_in, Dev
         if (n_out && !out_reg) host_copy(out_host, h_out.p, (size_t)n_out * out_size);
         return n_out;
     }
-    HostPipe &hp = host_pipe();
     if (hp.ensure(pieces)) return -1;
     // samples per piece: a multiple of the stage's / chain's own grid (lrhip_chain_shard_align: cuts on it reproduce the uncut run bit for bit where the
     // chain promises that at all - 128 000 for the FM receivers), else of 4096 (keeps the rows of the streaming kernels aligned); the last piece takes the rest

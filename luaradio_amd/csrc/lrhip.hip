@@ -1200,7 +1200,12 @@ long lrhip_chain_poll(lrhip_chain_t *c, void *out_host, unsigned long out_capaci
 double lrhip_chain_poll_due(const lrhip_chain_t *c)
 {
     if (!c) { set_error("null chain"); return -1.0; }
-    if (!c->fill || !(c->max_latency > 0.0)) return -1.0;                 // nothing pending, or batches only run when full: wait for input forever
+    if (!(c->max_latency > 0.0)) return -1.0;                             // batches only run when full: wait for input forever
+    if (!c->fill) {
+        // nothing accumulating, but a batch launched by the last push() may still be in flight (batch == chunk, then the source stalls): its output
+        // is handed out by the next poll(), so the wait for input stays bounded by the latency bound until the ring has drained
+        return c->inflight ? c->max_latency : -1.0;
+    }
     const double left = c->fill_t0 + c->max_latency - monotonic_seconds();
     return left > 0.0 ? left : 0.0;
 }

@@ -73,9 +73,9 @@ class CData:
 
     def _wrap(self, obj, elem):
         if isinstance(obj, C.Array):
-            return CData(C.addressof(obj), obj._type_, self.owner or self, len(obj))
+            return CData(C.addressof(obj), obj._type_, (self.owner if self.owner is not None else self), len(obj))
         if isinstance(obj, C.Structure):
-            return CData(C.addressof(obj), type(obj), self.owner or self, 1, True)
+            return CData(C.addressof(obj), type(obj), (self.owner if self.owner is not None else self), 1, True)
         if isinstance(obj, bytes):
             return float(obj[0])
         return float(obj) if isinstance(obj, (int, float)) else obj
@@ -112,7 +112,7 @@ class CData:
         if op in ("+", "-") and isinstance(a, CData) and not isinstance(b, CData):
             size = C.sizeof(self.elem) if self.elem is not None else 1
             n = int(ml.tonum(b))
-            return CData(self.addr + (n if op == "+" else -n) * size, self.elem, self.owner or self, None, self.is_struct)
+            return CData(self.addr + (n if op == "+" else -n) * size, self.elem, (self.owner if self.owner is not None else self), None, self.is_struct)
         if op == "-" and isinstance(a, CData) and isinstance(b, CData):
             size = C.sizeof(self.elem) if self.elem is not None else 1
             return float((a.addr - b.addr) // size)
@@ -141,12 +141,39 @@ def parse_ctype(spec):
     return elem, stars, arr, is_struct
 
 
+class ComplexFloat32Struct(C.Structure):
+    _fields_ = [("real", C.c_float), ("imag", C.c_float)]
+
+
+class Float32Struct(C.Structure):
+    _fields_ = [("value", C.c_float)]
+
+
+class ByteStruct(C.Structure):
+    _fields_ = [("value", C.c_uint8)]
+
+
+ELEMENT_STRUCTS = {"ComplexFloat32": ComplexFloat32Struct, "Float32": Float32Struct, "Byte": ByteStruct}
+
+
+class CType:
+    """an opaque C type of the reference's tables (radio/utilities/format_utils.lua:82-97 real_ctype / complex_ctype): only its size is looked at"""
+    lua_type = "cdata"
+
+    def __init__(self, name, size):
+        self.name, self.size = name, size
+
+    def lua_tostring(self):
+        return "ctype<%s>" % self.name
+
+
 class DataType:
     """a sample type of the reference (radio.types.*): ComplexFloat32 / Float32 / Byte / Bit as far as the glue looks at them"""
     lua_type = "cdata"
 
     def __init__(self, name, dtype):
         self.name, self.dtype = name, np.dtype(dtype)
+        self.struct = ELEMENT_STRUCTS.get(name)
 
     def lua_index(self, key):
         if key == "vector":
@@ -157,6 +184,9 @@ class DataType:
 
     def lua_tostring(self):
         return self.name
+
+    def lua_eq(self, other):
+        return isinstance(other, DataType) and other.name == self.name
 
 
 class Vector:
@@ -195,7 +225,9 @@ class Vector:
 
     def lua_index(self, key):
         if key == "data":
-            return CData(self.buf.ctypes.data, None, self)
+            # a typed pointer: `x.data + n` steps whole samples, `x.data[i].value` reads one (radio/types/*.lua structs)
+            st = self.data_type.struct
+            return CData(self.buf.ctypes.data, st, self, None, st is not None)
         if key == "length":
             return float(self.length)
         if key == "size":
@@ -242,6 +274,71 @@ class FakeLib:
             return self.device
         if name == "lrhip_strerror":
             return b"fake error"
+        if name == "lrhip_version":
+            return b"fake 0.0"
+        st = self.__dict__.setdefault("stage_info", {})
+        if name in ("lrhip_format_convert_create", "lrhip_format_pack_create"):
+            fmt = args[0].decode() if isinstance(args[0], bytes) else str(args[0])
+            size = {"8": 1, "16": 2, "32": 4, "64": 8}[fmt.strip("usflbe")] * (2 if args[1] else 1)
+            self.next_handle += 0x100
+            st[self.next_handle] = {"kind": name, "in": size if "convert" in name else (8 if args[1] else 4), "out": (8 if args[1] else 4) if "convert" in name else size}
+            return self.next_handle
+        if name == "lrhip_welch_create":
+            self.next_handle += 0x100
+            st[self.next_handle] = {"kind": "welch", "n": int(args[0]), "hop": int(args[0]) - int(args[5]), "pending": 0, "frames": 0, "in": 8 if args[4] else 4, "out": 4}
+            return self.next_handle
+        if name == "lrhip_welch_read":
+            w = st[int(args[0])]
+            frames = w["frames"]
+            if args[2]:
+                w["frames"] = 0
+            return frames
+        if name == "lrhip_stage_execute" and int(args[0]) in st and st[int(args[0])]["kind"] == "welch":
+            w = st[int(args[0])]
+            total = w["pending"] + int(args[2])
+            nf = (total - w["n"]) // w["hop"] + 1 if total >= w["n"] else 0
+            w["frames"] += nf
+            w["pending"] = total - nf * w["hop"]
+            return 0
+        if name == "lrhip_chain_create_ex":
+            self.next_handle += 0x100
+            handles = list((C.c_void_p * int(args[1])).from_address(int(args[0])))
+            st[self.next_handle] = {"kind": "chain", "stages": [int(h or 0) for h in handles], "flags": int(args[2]), "queue": [], "depth": 0, "slots": []}
+            return self.next_handle
+        if name == "lrhip_chain_set_ring":
+            c = st.get(int(args[0]))
+            if c is not None:
+                c["depth"], c["chunk"] = int(args[1]), int(args[2])
+                c["slots"] = [C.create_string_buffer(int(args[2]) * 16 + 64) for _ in range(int(args[1]))]
+                c["head"] = 0
+            return 0
+        if name == "lrhip_chain_ring_input":
+            c = st[int(args[0])]
+            if len(c["queue"]) >= c["depth"]:
+                return 0
+            return C.addressof(c["slots"][c["head"] % c["depth"]])
+        if name == "lrhip_chain_submit":
+            c = st[int(args[0])]
+            c["queue"].append(int(args[2]))
+            c["head"] += 1
+            return int(args[2])
+        if name == "lrhip_chain_collect":
+            c = st[int(args[0])]
+            return c["queue"].pop(0) if c["queue"] else -2
+        if name == "lrhip_chain_in_flight":
+            return len(st[int(args[0])]["queue"])
+        if name == "lrhip_chain_last_launches":
+            return 1
+        if name == "lrhip_chain_halo":
+            return 127
+        if name == "lrhip_chain_shard_align":
+            return 1
+        if name in ("lrhip_stage_input_size", "lrhip_stage_output_size") and int(args[0]) in st and "in" in st[int(args[0])]:
+            return st[int(args[0])]["in" if name.endswith("input_size") else "out"]
+        if name in ("lrhip_stage_execute2", "lrhip_stage_execute2_device"):
+            return int(args[3])
+        if name == "lrhip_stage_execute_device":
+            return int(args[2])
         if name.endswith("_create") or name.endswith("_create_ex") or name in ("lrhip_malloc", "lrhip_host_alloc", "lrhip_ipc_open", "lrhip_ipc_event_open"):
             self.next_handle += 0x100
             if name in ("lrhip_malloc", "lrhip_host_alloc"):
@@ -349,7 +446,7 @@ def make_ffi(interp, lib_proxy, sockets=None):
     def cast(spec, value):
         elem, stars, arr, is_struct = parse_ctype(spec)
         if isinstance(value, CData):
-            return CData(value.addr, elem, value.owner or value, None, is_struct)
+            return CData(value.addr, elem, (value.owner if value.owner is not None else value), None, is_struct)
         if isinstance(value, Vector):
             return CData(value.buf.ctypes.data, elem, value)
         if isinstance(value, (int, float)):
@@ -375,11 +472,19 @@ def make_ffi(interp, lib_proxy, sockets=None):
             return float(C.sizeof(v.elem)) if v.elem is not None else 8.0
         if isinstance(v, DataType):
             return float(v.dtype.itemsize)
+        if isinstance(v, CType):
+            return float(v.size)
         if isinstance(v, str):
             elem, stars, arr, _ = parse_ctype(v)
             base = 8 if stars else C.sizeof(elem)
             return float(base * (arr if arr and arr > 0 else 1))
         raise LuaError("minilua ffi.sizeof: unsupported operand")
+
+    def istype(ct, obj):
+        return False
+
+    def fill(dst, n, c=0):
+        C.memset(dst.addr, int(ml.tonum(c or 0)), int(ml.tonum(n)))
 
     def copy(dst, src, n=None):
         if isinstance(src, str):
@@ -429,6 +534,57 @@ def make_ffi(interp, lib_proxy, sockets=None):
             return float(hook(pollfds, int(nfds), ml.tonum(timeout_ms)))
         return 0.0
 
+    # ---- stdio, as radio/blocks/sources/iqfile.lua and radio/blocks/sinks/iqfile.lua use it (FILE * = an object holding a Python file)
+    class CFile:
+        lua_type = "cdata"
+
+        def __init__(self, fh):
+            self.fh, self.eof, self.closed = fh, False, False
+
+        def lua_is_null(self):
+            return False
+
+        def lua_eq(self, other):
+            return other is self
+
+        def lua_tostring(self):
+            return "cdata<FILE *>"
+
+    def c_fopen(path, mode):
+        try:
+            return CFile(open(path, mode if "b" in mode else mode + "b"))
+        except OSError as e:
+            state["errno"] = e.errno
+            return CData(0, None)
+
+    def c_fread(buf, size, count, f):
+        size, count = int(ml.tonum(size)), int(ml.tonum(count))
+        data = f.fh.read(size * count)
+        if len(data) < size * count:
+            f.eof = True
+        whole = len(data) // size
+        C.memmove(buf.addr, data, whole * size)
+        state.setdefault("fread_sizes", []).append((size, count, whole))
+        return float(whole)
+
+    def c_fwrite(buf, size, count, f):
+        size, count = int(ml.tonum(size)), int(ml.tonum(count))
+        f.fh.write(C.string_at(buf.addr, size * count))
+        return float(count)
+
+    def c_rewind(f):
+        f.fh.seek(0)
+        f.eof = False
+
+    def c_fclose(f):
+        f.fh.close()
+        f.closed = True
+        return 0.0
+
+    for name, f in (("fopen", c_fopen), ("fread", c_fread), ("fwrite", c_fwrite), ("feof", lambda f: 1.0 if f.eof else 0.0), ("ferror", lambda f: 0.0),
+                    ("rewind", c_rewind), ("fclose", c_fclose), ("fileno", lambda f: float(f.fh.fileno()))):
+        Cns.set(name, f)
+
     for name, f in (("getpid", lambda: float(os.getpid())), ("socketpair", c_socketpair), ("read", c_read), ("write", c_write), ("close", c_close),
                     ("poll", c_poll), ("strerror", lambda e: os.strerror(int(e)).encode())):
         Cns.set(name, f)
@@ -440,7 +596,7 @@ def make_ffi(interp, lib_proxy, sockets=None):
             raise LuaError("cannot load '%s'" % name)
         return lib_proxy
 
-    for name, f in (("cdef", cdef), ("new", new), ("cast", cast), ("gc", gc), ("string", string), ("sizeof", sizeof), ("copy", copy),
+    for name, f in (("cdef", cdef), ("new", new), ("cast", cast), ("gc", gc), ("string", string), ("sizeof", sizeof), ("copy", copy), ("istype", istype), ("fill", fill),
                     ("errno", lambda: float(state["errno"])), ("load", load)):
         ffi.set(name, f)
     ffi.set("C", Cns)
@@ -466,5 +622,12 @@ def make_interpreter(real_lib=None, env_vars=None):
     for name, dt in (("ComplexFloat32", np.complex64), ("Float32", np.float32), ("Byte", np.uint8)):
         types.set(name, DataType(name, dt))
     interp.register("radio.types", types)
+    # radio/utilities/format_utils.lua:82-97 as far as the file blocks look at it: the ctypes' sizes
+    sizes = {"u8": 1, "s8": 1, "u16le": 2, "u16be": 2, "s16le": 2, "s16be": 2, "u32le": 4, "u32be": 4, "s32le": 4, "s32be": 4,
+             "f32le": 4, "f32be": 4, "f64le": 8, "f64be": 8}
+    formats = LuaTable()
+    for name, size in sizes.items():
+        formats.set(name, T(real_ctype=CType("format_%s_t" % name, size), complex_ctype=CType("iq_format_%s_t" % name, 2 * size), swap=name.endswith("be")))
+    interp.register("radio.utilities.format_utils", T(formats=formats))
     interp.globals.set("__now_us", lambda: float(time.time() * 1e6))
     return interp, proxy, ffi

@@ -29,6 +29,8 @@ REFERENCE_METHODS = {
     "read",                                                                                                  # PipeMux
     "cleanup", "process", "poll",                                                                            # Block (run loop; poll = DeviceChainBlock / DeviceFanoutBlock)
     "vector",                                                                                                # data type .vector() is called with '.', listed for safety
+    "initialize_gnuplot", "write_gnuplot",                                                                   # GnuplotSpectrumSink (radio/blocks/sinks/gnuplotspectrum.lua:73-137)
+    "run_once",                                                                                              # Block (radio/core/block.lua:493-549)
 }
 LUA_BUILTINS = {"assert", "error", "ipairs", "pairs", "require", "tonumber", "tostring", "type", "setmetatable", "unpack", "pcall", "select", "print"}
 LUA_KEYWORDS = {"and", "break", "do", "else", "elseif", "end", "false", "for", "function", "if", "in", "local", "nil", "not", "or", "repeat", "return",
@@ -136,10 +138,35 @@ def test_cdef_matches_the_header_prototype_for_prototype():
     cdef = c_prototypes(cdefs[0])
     assert len(header) > 60
     for name, proto in header.items():
+        if name in NOT_FOR_LUA:
+            assert name not in cdef, "%s is declared in the cdef again: use it from lua/radio/** and take it off NOT_FOR_LUA" % name
+            continue
         assert name in cdef, "cdef lacks %s" % name
         assert cdef[name] == proto, (name, cdef[name], proto)
     for name in cdef:
         assert name in header, "cdef declares %s, which include/lrhip.h does not" % name
+
+
+# entry points of include/lrhip.h that a LuaRadio host has no use for, each with its reason; everything else is declared in the cdef AND used (next test)
+NOT_FOR_LUA = {
+    "lrhip_set_stream": "adopts a PyTorch / HIP stream of the host program (bench.py, the torch tests); a LuaJIT host has none",
+    "lrhip_timer_create": "HIP-event timing for the measurement harness (bench.py roofline figure)",
+    "lrhip_timer_destroy": "same", "lrhip_timer_start": "same", "lrhip_timer_stop": "same", "lrhip_timer_elapsed_ms": "same",
+    "lrhip_chain_create": "lrhip_chain_create_ex(stages, n, 0) is the same call; the glue always passes the chain's flags",
+    "lrhip_ipc_event_query": "non-blocking variant of lrhip_ipc_event_synchronize; the fan-out protocol of devicefanout.lua blocks on its socket instead",
+}
+
+
+def test_every_declared_entry_point_is_called_from_the_lua_tree():
+    """"a cdef-vs-use test fails on any declared-but-unused entry point" - a third of the ABI used to be declared for Lua and
+    reachable only from Python / C"""
+    files = load()
+    cdef = c_prototypes(files[os.path.join("lua", "radio", "core", "lrhip.lua")][1][0])
+    used = set()
+    for path, (code, _) in files.items():
+        used.update(m.group(1) for m in re.finditer(r"lib\.(lrhip_\w+)", code))
+    unused = sorted(set(cdef) - used)
+    assert not unused, "declared in lua/radio/core/lrhip.lua and called by nothing under lua/: %s" % unused
 
 
 def test_every_library_call_names_a_declared_function_with_its_argument_count():

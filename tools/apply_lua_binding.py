@@ -9,7 +9,10 @@
     - after every top-level statement of the reference file, so that no later assignment can overwrite what the patch installs
     (radio/blocks/signal/firfilter.lua:400-402 / :488-490 assign process_fft_* after the dot-product ladder; block.factory(name, parent)
     copies the parent's functions when the DERIVED file loads, which is after the parent file returned - radio/core/class.lua:18-40);
-  * inserts the DeviceChainBlock.collapse() hook into CompositeBlock:_prepare_to_run (radio/core/composite.lua:426-470).
+  * does the same for the file sources / sinks and the spectrum sink (radio/blocks/sources/{iqfile,realfile}.lua, radio/blocks/sinks/{iqfile,realfile,
+    gnuplotspectrum}.lua) and puts `require('radio.core.lrhip').patch_spectrum(DFT, IDFT, PSD)` above the final return of radio/utilities/spectrum_utils.lua;
+  * inserts the collapse() hooks (devicegraph, devicechain, devicefanout) into CompositeBlock:_prepare_to_run (radio/core/composite.lua:426-470) and the
+    parent-side close of the fan-out sockets after the fork loop of CompositeBlock:start (:638-642).
 Without --out the checkout is edited in place; with --out DIR only the touched files are written below DIR (same relative paths).
 --diff prints a unified diff instead of writing anything.  tests/test_lua_glue.py runs `patched_sources()` against /root/reference
 (when it is present) and models the load order of every patched file.
@@ -30,17 +33,40 @@ BLOCK_FILES = [
     "addconstant", "multiplyconstant", "delay", "hilberttransform", "upsampler", "frequencymodulator", "agc", "powersquelch",
     "multiply", "multiplyconjugate", "add", "subtract", "floattocomplex",
 ]
+# ... and the file sources / sinks and the spectrum sink: (path below radio/blocks, patch name) - two directories hold an iqfile.lua
+IO_FILES = [
+    ("sources/iqfile", "iqfilesource"), ("sources/realfile", "realfilesource"),
+    ("sinks/iqfile", "iqfilesink"), ("sinks/realfile", "realfilesink"), ("sinks/gnuplotspectrum", "gnuplotspectrum"),
+]
+# radio/utilities/spectrum_utils.lua returns a table of classes: its line goes above that `return {DFT = DFT, ...}`
+SPECTRUM_RETURN = "return {DFT = DFT, IDFT = IDFT, PSD = PSD, fftshift = fftshift}\n"
+SPECTRUM_LINE = "require('radio.core.lrhip').patch_spectrum(DFT, IDFT, PSD)\n"
 
 COLLAPSE_HOOK = """
-    -- Collapse every maximal linear run of device blocks into one DeviceChainBlock (liblrhip.so)
+    -- Device blocks (liblrhip.so): a connected subgraph with a join becomes one DeviceGraphBlock, every maximal linear run of device blocks one
+    -- DeviceChainBlock (a file source in front and a file sink behind included) ...
     local device_chains = {}
     if require('radio.core.lrhip').available then
-        all_connections, device_chains = require('radio.composites.devicechain').collapse(all_connections)
-        -- ... and give every output port that fans out into device chains ONE upload and GPU-to-GPU copies (one branch per GPU)
-        all_connections, device_chains = require('radio.composites.devicefanout').collapse(all_connections, device_chains)
+        local graphs, chains
+        all_connections, graphs = require('radio.composites.devicegraph').collapse(all_connections)
+        all_connections, chains = require('radio.composites.devicechain').collapse(all_connections)
+        -- ... and every output port that fans out into device chains gets ONE upload and GPU-to-GPU copies (one branch per GPU)
+        all_connections, device_chains = require('radio.composites.devicefanout').collapse(all_connections, chains)
+        for _, g in ipairs(graphs) do device_chains[#device_chains + 1] = g end
     end
 """
 INIT_HOOK = "    for _, chain in ipairs(device_chains) do chain:initialize() end\n"
+# a chain that absorbed BOTH its file source and its file sink has no port left, so it is in no connection and build_dependency_graph() cannot see it
+ORDER_HOOK = """    for _, chain in ipairs(device_chains) do
+        if #chain.inputs == 0 and #chain.outputs == 0 then evaluation_order[#evaluation_order + 1] = chain end
+    end
+"""
+# CompositeBlock:start, after the fork loop, next to "Close all pipe inputs and outputs in the top-level process" (composite.lua:638-642): the parent's
+# copies of the fan-out socket pairs go too, so that a dead branch / head is seen as EOF by its peer (devicefanout.lua close_parent_fds)
+CLOSE_HOOK = """        for _, b in ipairs(evaluation_order) do
+            if b.close_parent_fds then b:close_parent_fds() end
+        end
+"""
 
 
 def patch_line(name, block_var):
@@ -64,17 +90,34 @@ def patch_block_source(name, text):
     return "".join(lines), var
 
 
+def patch_spectrum_source(text):
+    if text.count(SPECTRUM_RETURN) != 1:
+        raise ValueError("spectrum_utils.lua: final `return {DFT = ...}` not found exactly once")
+    if "radio.core.lrhip" in text:
+        raise ValueError("spectrum_utils.lua: already patched")
+    return text.replace(SPECTRUM_RETURN, SPECTRUM_LINE + "\n" + SPECTRUM_RETURN)
+
+
 def patch_composite_source(text):
-    """the two insertions into CompositeBlock:_prepare_to_run"""
+    """the four insertions into radio/core/composite.lua: collapse + initialize + evaluation order in CompositeBlock:_prepare_to_run, and the parent's
+    close of the fan-out sockets after the fork loop of CompositeBlock:start"""
     a = "    local all_connections = self:_crawl_connections()\n"
     b = "    self:_initialize()\n"
+    c = "    local evaluation_order = build_evaluation_order(build_dependency_graph(all_connections))\n"
+    d = "        -- Close all pipe inputs and outputs in the top-level process\n"
     if text.count(a) != 1:
         raise ValueError("composite.lua: `_crawl_connections()` call not found exactly once")
     head, tail = text.split(a)
     if tail.count(b) < 1:
         raise ValueError("composite.lua: `self:_initialize()` not found after the crawl")
     t0, t1 = tail.split(b, 1)
-    return head + a + COLLAPSE_HOOK + t0 + b + INIT_HOOK + t1
+    if t1.count(c) != 1:
+        raise ValueError("composite.lua: the global evaluation order is not built where expected")
+    t1a, t1b = t1.split(c)
+    if t1b.count(d) != 1:
+        raise ValueError("composite.lua: the parent's pipe close after the fork loop not found")
+    t1b0, t1b1 = t1b.split(d)
+    return head + a + COLLAPSE_HOOK + t0 + b + INIT_HOOK + t1a + c + ORDER_HOOK + t1b0 + CLOSE_HOOK + d + t1b1
 
 
 def patched_sources(checkout):
@@ -84,6 +127,13 @@ def patched_sources(checkout):
         rel = os.path.join("radio", "blocks", "signal", name + ".lua")
         old = open(os.path.join(checkout, rel)).read()
         out[rel] = (old, patch_block_source(name, old)[0])
+    for path, name in IO_FILES:
+        rel = os.path.join("radio", "blocks", path + ".lua")
+        old = open(os.path.join(checkout, rel)).read()
+        out[rel] = (old, patch_block_source(name, old)[0])
+    rel = os.path.join("radio", "utilities", "spectrum_utils.lua")
+    old = open(os.path.join(checkout, rel)).read()
+    out[rel] = (old, patch_spectrum_source(old))
     rel = os.path.join("radio", "core", "composite.lua")
     old = open(os.path.join(checkout, rel)).read()
     out[rel] = (old, patch_composite_source(old))
