@@ -620,6 +620,26 @@ def host_path_report(lr, L, torch, dev):
                 legs.append({"source": "%s IQ file (page cache) -> WBFM receiver" % fmt, "chunk_samples": chunk, "MSamples/s": round(n / dt / 1e6, 1),
                              "h2d_GB/s": round(rec * n / dt / 1e9, 2), "frac_of_link": round(rec * n / dt / 1e9 / LINK, 3),
                              "verified": bool(len(y) == len(want) and np.array_equal(y, want))})
+            # the path of an IQFileSource absorbed into the chain (lua/radio/blocks/sources/file_hip.lua submit_raw): the library reads the records itself
+            _s, ch, _r = build_chain(bytes(16), fmt, fs, -250e3)
+            ch.set_ring(3, batch)
+            outs, off = [], 0
+            with open(path, "rb", buffering=0) as f:
+                t0 = time.perf_counter()
+                while True:
+                    if ch.in_flight == 3:
+                        outs.append(ch.collect())
+                    got = ch.submit_fd(f.fileno(), off, batch)
+                    if got == 0:
+                        break
+                    off += got * rec
+                while ch.in_flight:
+                    outs.append(ch.collect())
+                dt = time.perf_counter() - t0
+            y = np.concatenate(outs)
+            legs.append({"source": "%s IQ file (page cache) -> WBFM receiver, lrhip_chain_submit_fd (the library reads the file)" % fmt, "chunk_samples": batch,
+                         "MSamples/s": round(n / dt / 1e6, 1), "h2d_GB/s": round(rec * n / dt / 1e9, 2), "frac_of_link": round(rec * n / dt / 1e9 / LINK, 3),
+                         "verified": bool(len(y) == len(want) and np.array_equal(y, want))})
         rep["file_to_receiver"] = legs
         # ---- (b) stand-alone block, both directions
         def aligned(count, dtype):
@@ -679,6 +699,34 @@ def host_path_report(lr, L, torch, dev):
                 L.lrhip_host_unregister(y.ctypes.data_as(C.c_void_p))
         rep["standalone_lowpass_cf32"] = dict(res, vector_samples=vec, note="LowpassFilterBlock(128, 15e3), overlap-save arithmetic, lrhip_stage_execute: host vector "
                                               "in, host vector out; a call travels as up to 8 pipelined pieces (H2D, kernels, D2H on three streams)")
+        # ---- (c) the same paths THROUGH C (tools/host_path_driver.cpp, built by __graft_entry__.build()): no interpreter in the loop, so the per-call cost of
+        # the library itself is visible next to the Python legs above (whose 8 192-sample figures are ~8.5 us of Python per push)
+        drv = os.path.join(ROOT, "tools", "host_path_driver")
+        if os.path.exists(drv):
+            import subprocess
+            try:
+                p = subprocess.run([drv, str(n), tmp], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+                lines = [json.loads(ln) for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+                for ln in lines:
+                    if "h2d_GB/s" in ln:
+                        ln["frac_of_link"] = round(ln["h2d_GB/s"] / LINK, 3)
+                    if "each_direction_GB/s" in ln:
+                        ln["frac_of_link"] = round(ln["each_direction_GB/s"] / LINK, 3)
+                # the legs of one input format compute the same audio (to the chain's stated chunking dependence, <= 2e-7 per sample): their checksums agree
+                agree = True
+                for fmt in ("u8", "f32le"):
+                    cs = [ln["checksum"] for ln in lines if ln.get("format") == fmt]
+                    na = {ln["audio_samples"] for ln in lines if ln.get("format") == fmt}
+                    agree = agree and len(na) == 1 and (max(cs) - min(cs)) <= 1e-3 * max(1.0, max(abs(c) for c in cs))
+                rep["through_c"] = {"legs": lines, "rc": p.returncode, "checksums_agree": bool(agree and p.returncode == 0),
+                                    "note": "tools/host_path_driver.cpp: push = read(2) + lrhip_chain_push per chunk; ring = read(2) into lrhip_chain_ring_input; "
+                                            "fd = lrhip_chain_submit_fd (the library preads on its copy threads); best of two timed passes after a warm-up pass"}
+                if p.returncode != 0:
+                    rep["through_c"]["stderr"] = p.stderr.decode(errors="replace")[-400:]
+            except Exception as e:          # noqa: BLE001 - a leg that cannot run is reported, not fatal
+                rep["through_c"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        else:
+            rep["through_c"] = {"error": "tools/host_path_driver not built (python __graft_entry__.py)"}
     finally:
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)

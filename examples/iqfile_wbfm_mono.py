@@ -40,10 +40,23 @@ def build_chain(path_or_bytes, fmt, rate, offset):
 
 
 def demodulate(src, chain, chunk_records=1 << 20):
-    """file -> pinned ring slot (readinto, no staging copy) -> device -> audio"""
+    """file -> pinned ring slot (readinto, no staging copy) -> device -> audio.  A recording on disk (a regular file) is read by the library itself
+    (Chain.submit_fd: positional reads on its copy threads); an in-memory capture goes through readinto()."""
     if getattr(chain, "_ring_chunk", 0) != chunk_records:
         chain.set_ring(3, chunk_records)       # pinned host + device slots, allocated once
     parts = []
+    if isinstance(src.file, str):
+        fd, offset = src._fh.fileno(), 0
+        while True:
+            if chain.in_flight == 3:           # ring full: take the oldest chunk out first
+                parts.append(chain.collect())
+            got = chain.submit_fd(fd, offset, chunk_records)
+            if got == 0:
+                break
+            offset += got * src.record_size
+        while chain.in_flight:
+            parts.append(chain.collect())
+        return np.concatenate(parts)
     while True:
         view = chain.ring_input()
         if view is None:                       # ring full: take the oldest chunk out first

@@ -249,6 +249,14 @@ long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_i
  * NULL when the ring is full.  A source can read()/recv() straight into it and pass the same pointer to
  * lrhip_chain_submit(), which then skips its staging copy. */
 void *lrhip_chain_ring_input(lrhip_chain_t *c);
+/* File-fed chains: what IQFileSource / RealFileSource do per chunk (radio/blocks/sources/iqfile.lua:82-96: fread of raw records) without the interpreter or a
+ * staging copy in the data path.  Reads up to max_in samples - raw records of lrhip_stage_input_size(first stage) bytes, max_in clamped to the ring's max_chunk -
+ * of the REGULAR file `fd` from byte offset `offset` (positional reads: the descriptor's own position is neither used nor moved) straight into the pinned input of
+ * the next ring slot, split over the library's copy threads (one read(2) stream gets ~10 GB/s out of the page cache, several get several times that), and submits
+ * the slot as lrhip_chain_submit() does.  Returns the number of samples read and submitted; 0 at the end of the file (nothing submitted; a trailing partial
+ * record is ignored, as fread() ignores it); < 0 on error: -3 ring full (collect first), -4 `fd` is not a regular file (pipes, sockets, devices: read() into
+ * lrhip_chain_ring_input() and call lrhip_chain_submit()). */
+long lrhip_chain_submit_fd(lrhip_chain_t *c, int fd, unsigned long long offset, unsigned long max_in);
 long lrhip_chain_collect(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
 /* Chunks submitted and not yet collected. */
 int  lrhip_chain_in_flight(const lrhip_chain_t *c);

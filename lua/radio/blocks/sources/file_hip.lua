@@ -15,7 +15,9 @@
 --   raw_record_size()   bytes per raw record (2 for 'u8' IQ, 8 for 'f32le' IQ, 4 for 'f32le' real, ...);
 --   read_raw(dst, max)  the reference's fread + EOF / repeat / ferror handling (iqfile.lua:82-96) WITHOUT the conversion loop, straight into `dst` -
 --                       which DeviceChainBlock points at the pinned input slot of the chain's ring (lrhip_chain_ring_input), so an RTL-SDR style
---                       capture crosses the host once, as 2 bytes per complex sample, and is never touched by the interpreter.
+--                       capture crosses the host once, as 2 bytes per complex sample, and is never touched by the interpreter;
+--   submit_raw(chain, max)  the same for a regular file with the read done INSIDE the library, on its copy threads (lrhip_chain_submit_fd): what
+--                       DeviceChainBlock uses first; read_raw() is the path for FIFOs and devices.
 --
 -- The format NAME is what the library takes; the reference keeps only the table entry (iqfile.lua:48), so instantiate() is wrapped to remember it.
 
@@ -59,6 +61,30 @@ local function patch_source(Source, complex_out)
             end
         end
         return num_samples
+    end
+
+    -- The same step for a REGULAR file, without fread(): the library reads the records from the page cache into the pinned input of the chain's next ring
+    -- slot itself - positional reads on its copy threads, several times what one read(2) stream delivers - and submits the slot
+    -- (lrhip_chain_submit_fd).  Returns the number of records submitted (0 right after a rewind), nil at the end of the file, false when the descriptor is
+    -- not a regular file (a FIFO, a character device: DeviceChainBlock then uses read_raw() for the rest of the run).
+    -- The FILE *'s own position is not used: the offset starts where the stream stood when the chain took over.
+    function Source:submit_raw(chain, max_records)
+        if self.raw_fd == nil then
+            self.raw_fd = ffi.C.fileno(self.file)
+            self.raw_offset = tonumber(ffi.C.lseek(self.raw_fd, 0, 1))          -- SEEK_CUR: 0 for a file opened by name, the caller's position for an fd
+            if self.raw_offset < 0 then return false end
+            self.raw_start = self.raw_offset
+        end
+        local n = tonumber(lrhip.lib.lrhip_chain_submit_fd(chain, self.raw_fd, self.raw_offset, max_records))
+        if n == -4 then return false end
+        if n < 0 then error("lrhip_chain_submit_fd: " .. ffi.string(lrhip.lib.lrhip_strerror())) end
+        if n == 0 then
+            if not self.repeat_on_eof then return nil end
+            self.raw_offset = self.raw_start
+            return 0
+        end
+        self.raw_offset = self.raw_offset + n * self:raw_record_size()
+        return n
     end
 end
 

@@ -156,14 +156,18 @@ local function process_source(self)
             local cap = tonumber(lib.lrhip_chain_max_output(chain, self.batch_samples)) + 64
             return deliver(self, cap, function (ptr, room) return lib.lrhip_chain_collect(chain, ptr, room) end, "lrhip_chain_collect"), false
         end
-        local n = self.source:read_raw(slot, self.batch_samples)
-        if n == nil then
-            self.source_eof = true
-        elseif n > 0 then
-            if tonumber(lib.lrhip_chain_submit(chain, slot, n)) < 0 then
+        local n = false
+        if self.source.submit_raw and not self.source_streamed then
+            n = self.source:submit_raw(chain, self.batch_samples)          -- regular file: read and submitted inside the library
+            if n == false then self.source_streamed = true end            -- a FIFO / device: fread() into the slot from here on
+        end
+        if n == false then
+            n = self.source:read_raw(slot, self.batch_samples)
+            if n ~= nil and n > 0 and tonumber(lib.lrhip_chain_submit(chain, slot, n)) < 0 then
                 error("lrhip_chain_submit: " .. ffi.string(lib.lrhip_strerror()))
             end
         end
+        if n == nil then self.source_eof = true end
     end
 end
 

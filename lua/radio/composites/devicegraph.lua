@@ -84,6 +84,7 @@ end
 local function start(self)
     local lib = lrhip.lib
     lrhip.ensure(self.device)
+    self.batch = self.batch_samples          -- fixed from here on: the staging buffers are sized for it
     -- readers per member (inside the subgraph)
     local readers = {}
     for _, b in ipairs(self.blocks) do
@@ -134,7 +135,7 @@ local function start(self)
     self.input = {}
     for i = 1, #self.inputs do
         local size = ffi.sizeof(self:get_input_type(i))
-        self.input[i] = {size = size, staging = lrhip.check_object(lib.lrhip_host_alloc(self.batch_samples * size), "lrhip_host_alloc"), dev = {}}
+        self.input[i] = {size = size, staging = lrhip.check_object(lib.lrhip_host_alloc(self.batch * size), "lrhip_host_alloc"), dev = {}}
     end
     self.fill = 0
     self.out_size = ffi.sizeof(self:get_output_type())
@@ -230,14 +231,14 @@ function DeviceGraphBlock:process(...)
     local n, done = vectors[1].length, 0
     local out = nil
     while done < n do
-        local take = math.min(n - done, self.batch_samples - self.fill)
+        local take = math.min(n - done, self.batch - self.fill)
         for i, x in ipairs(vectors) do
             local inp = self.input[i]
             ffi.copy(ffi.cast("char *", inp.staging) + self.fill * inp.size, ffi.cast("const char *", x.data) + done * inp.size, take * inp.size)
         end
         self.fill = self.fill + take
         done = done + take
-        if self.fill == self.batch_samples then
+        if self.fill == self.batch then
             if out ~= nil then
                 -- a second full batch inside one call (a vector longer than a batch): the first batch's output goes to the readers now
                 for _, p in ipairs(self.outputs[1].pipes) do p:write(out) end
@@ -249,14 +250,18 @@ function DeviceGraphBlock:process(...)
     return out
 end
 
+-- flush(): run what has been accumulated now (a live graph that wants its samples through; cleanup() at EOF) - returns the output vector
+function DeviceGraphBlock:flush()
+    if not self.started or self.fill == 0 then return self.out:resize(0) end
+    return run_batch(self)
+end
+
 -- EOF upstream (radio/core/block.lua:606): the partial batch, handed to the readers of the output port as process() output would have been
 function DeviceGraphBlock:cleanup()
     if not self.started then return end
-    if self.fill > 0 then
-        local tail = run_batch(self)
-        if tail.length > 0 then
-            for _, p in ipairs(self.outputs[1].pipes) do p:write(tail) end
-        end
+    local tail = self:flush()
+    if tail.length > 0 then
+        for _, p in ipairs(self.outputs[1].pipes) do p:write(tail) end
     end
     local lib = lrhip.lib
     for _, inp in ipairs(self.input) do

@@ -73,6 +73,7 @@ int lrhip_chain_last_launches(const lrhip_chain_t *c);
 int lrhip_chain_set_ring(lrhip_chain_t *c, unsigned depth, unsigned long max_chunk);
 long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_in);
 void *lrhip_chain_ring_input(lrhip_chain_t *c);
+long lrhip_chain_submit_fd(lrhip_chain_t *c, int fd, unsigned long long offset, unsigned long max_in);
 long lrhip_chain_collect(lrhip_chain_t *c, void *out_host, unsigned long out_capacity);
 int lrhip_chain_in_flight(const lrhip_chain_t *c);
 long lrhip_chain_push(lrhip_chain_t *c, const void *in_host, unsigned long n_in, void *out_host, unsigned long out_capacity);

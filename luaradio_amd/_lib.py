@@ -69,6 +69,7 @@ SIGNATURES = {
     "lrhip_chain_set_ring": (C.c_int, [_vp, C.c_uint, _ul]),
     "lrhip_chain_submit": (C.c_long, [_vp, _vp, _ul]),
     "lrhip_chain_ring_input": (_vp, [_vp]),
+    "lrhip_chain_submit_fd": (C.c_long, [_vp, C.c_int, C.c_ulonglong, _ul]),
     "lrhip_chain_collect": (C.c_long, [_vp, _vp, _ul]),
     "lrhip_chain_in_flight": (C.c_int, [_vp]),
     "lrhip_chain_push": (C.c_long, [_vp, _vp, _ul, _vp, _ul]),

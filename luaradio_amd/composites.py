@@ -116,6 +116,13 @@ class Chain:
         x, count = self._count(x)
         return _lib.check(_lib.load().lrhip_chain_submit(self._chain, x.ctypes.data_as(C.c_void_p), count), "chain:submit")
 
+    def submit_fd(self, fd, offset, max_samples=None):
+        """File-fed chain (lrhip_chain_submit_fd): up to max_samples raw records of the regular file `fd`, from byte offset `offset`, are read by the library
+        itself - positional reads on its copy threads, straight into the pinned input of the next ring slot - and the slot is submitted.  Returns the number
+        of samples submitted; 0 at the end of the file."""
+        n = _lib.load().lrhip_chain_submit_fd(self._chain, int(fd), int(offset), int(max_samples or self._ring_chunk))
+        return _lib.check(n, "chain:submit_fd")
+
     def ring_input(self):
         """numpy view (uint8 for raw-record chains, else the input dtype) of the pinned buffer the next submit() will use:
         fill it in place (file.readinto(view), socket.recv_into(view)) and submit(view[:n]) - no staging copy.  None when the

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <unistd.h>
+#include <sys/stat.h>
+#include <cerrno>
 #include <atomic>
 #include <condition_variable>
 #include <cstdarg>
@@ -58,13 +60,16 @@ inline int set_error(const char *fmt, ...)
 #define LR_HIP(call)                                                                                   \
     do {                                                                                               \
         hipError_t e__ = (call);                                                                       \
-        if (e__ != hipSuccess)                                                                         \
+        if (e__ != hipSuccess) {                                                                       \
+            (void)hipGetLastError();      /* the error is reported HERE: do not leave it for the next launch check to trip over */ \
             return lrhip::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+        }                                                                                              \
     } while (0)
 #define LR_HIP_NULL(call)                                                                              \
     do {                                                                                               \
         hipError_t e__ = (call);                                                                       \
         if (e__ != hipSuccess) {                                                                       \
+            (void)hipGetLastError();                                                                   \
             lrhip::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
             return nullptr;                                                                            \
         }                                                                                              \
@@ -93,12 +98,12 @@ inline int ensure_init(int device = -1)
         return 0;
     }
     if (c.ready) {
-        // forked since the stream was created (CompositeBlock forks one process per block after initialize(),
-        // radio/core/composite.lua:443 vs :569): the parent's stream handle means nothing here - forget it (do not destroy it:
-        // it belongs to the parent's context) and build this process's own
-        c.ready = false;
-        c.own_stream = nullptr;
-        c.stream = nullptr;
+        // forked since the device context was created.  CompositeBlock forks one process per block after initialize()
+        // (radio/core/composite.lua:443 vs :569), which is why device blocks create their objects on the first process(); a parent that DID
+        // touch the device before fork() has left this child a copy of a HIP runtime whose threads, queues and doorbells exist only in the
+        // parent - any HIP call from here may hang.  Refuse with a message instead (the block process then exits 1, composite.lua:625-629).
+        return set_error("the device was initialised in process %ld before fork(); a forked child (process %ld) cannot use it - "
+                         "create device objects after fork(): LuaRadio device blocks do so on their first process()", c.pid, (long)getpid());
     }
     int count = 0;
     LR_HIP(hipGetDeviceCount(&count));
@@ -207,13 +212,25 @@ struct CopyPool {
 #endif
     }
 
+    // a job is a memcpy, or (fd >= 0) a positional read of a regular file into dst: the page cache hands a single read(2) stream ~10 GB/s, several
+    // streams on several cores several times that
+    int fd = -1;
+    long long file_off = 0;
+    std::atomic<int> io_errno{0};
     void work()
     {
         for (;;) {
             const size_t off = next.fetch_add(part);
             if (off >= bytes) break;
             const size_t len = off + part <= bytes ? part : bytes - off;
-            memcpy(dst + off, src + off, len);
+            if (fd < 0) { memcpy(dst + off, src + off, len); continue; }
+            size_t got = 0;
+            while (got < len) {
+                const ssize_t r = pread(fd, dst + off + got, len - got, (off_t)(file_off + (long long)(off + got)));
+                if (r < 0) { if (errno == EINTR) continue; io_errno.store(errno); break; }
+                if (r == 0) { io_errno.store(EIO); break; }      // the caller sized the job from fstat(): a short file now is an error
+                got += (size_t)r;
+            }
         }
     }
     void loop()
@@ -253,11 +270,17 @@ struct CopyPool {
         for (int i = 1; i < nthreads; i++) workers.emplace_back([this] { loop(); });
         for (auto &t : workers) t.detach();        // they live as long as the process (no join at exit: the library never unloads cleanly under LuaJIT)
     }
-    void copy(void *d, const void *s_, size_t n)
+    // fd_ >= 0: read n bytes of the file from byte offset off_ into d (returns 0, or an errno)
+    int copy(void *d, const void *s_, size_t n, int fd_ = -1, long long off_ = 0)
     {
         std::unique_lock<std::mutex> one(job, std::try_to_lock);
-        if (!one.owns_lock()) { memcpy(d, s_, n); return; }
+        if (!one.owns_lock()) {
+            if (fd_ < 0) { memcpy(d, s_, n); return 0; }
+            one.lock();                                   // a file job has no lock-free fallback worth having: wait for the pool
+        }
         dst = (char *)d; src = (const char *)s_; bytes = n;
+        fd = fd_; file_off = off_;
+        io_errno.store(0);
         part = ((n / (size_t)(4 * nthreads)) + 4095) & ~(size_t)4095;      // a few parts per thread, page multiples
         if (part < 65536) part = 65536;
         next.store(0);
@@ -269,18 +292,39 @@ struct CopyPool {
         cv_work.notify_all();
         work();
         while (running.load(std::memory_order_acquire) != 0) cpu_relax();
+        fd = -1;
+        return io_errno.load();
     }
 };
-inline void host_copy(void *dst, const void *src, size_t bytes)
+inline CopyPool *copy_pool()
 {
     static CopyPool *pool = nullptr;
-    if (bytes < (512u << 10)) { memcpy(dst, src, bytes); return; }
     if (!pool || pool->pid != (long)getpid()) {
         pool = new (std::nothrow) CopyPool();      // after a fork the parent's pool object is abandoned (its threads do not exist here)
         if (pool) pool->start();
     }
+    return pool;
+}
+inline void host_copy(void *dst, const void *src, size_t bytes)
+{
+    if (bytes < (512u << 10)) { memcpy(dst, src, bytes); return; }
+    CopyPool *pool = copy_pool();
     if (!pool || pool->nthreads <= 1) { memcpy(dst, src, bytes); return; }
-    pool->copy(dst, src, bytes);
+    (void)pool->copy(dst, src, bytes);
+}
+// bytes of a regular file, from byte offset `offset`, into dst - on the copy threads when the job is large.  0, or an errno.
+inline int host_pread(void *dst, int fd, long long offset, size_t bytes)
+{
+    CopyPool *pool = bytes >= (512u << 10) ? copy_pool() : nullptr;
+    if (pool && pool->nthreads > 1) return pool->copy(dst, nullptr, bytes, fd, offset);
+    size_t got = 0;
+    while (got < bytes) {
+        const ssize_t r = pread(fd, (char *)dst + got, bytes - got, (off_t)(offset + (long long)got));
+        if (r < 0) { if (errno == EINTR) continue; return errno; }
+        if (r == 0) return EIO;
+        got += (size_t)r;
+    }
+    return 0;
 }
 
 // Ablation switches (LRHIP_RX_DBG, LRHIP_DECFFT_DBG, LRHIP_INTERP_DBG) remove parts of a kernel to time the rest: the results are WRONG by

@@ -73,11 +73,27 @@
 #define LRHIP_FFT_NB 1
 #endif
 
+// Round 5 ("one structural try on the headline"): 128 of a block's 171 LDS operations are the four register <-> LDS transposes, and the two
+// inner ones (E2 and its inverse) only move data between FOUR lanes that share k1.  1: stages 2 and 3 number their lanes (t2 or q = lane >> 4, k1 = lane & 15) -
+// the four lanes of a group then sit in the four ROWS of 16 lanes of the wave, at the same position - and E2 / its inverse become 4 x 4 register <-> row
+// transposes in the VALU (v_permlane32_swap + v_permlane16_swap: two instructions per register PAIR, no selects, no LDS): 64 swaps replace 64 ds_write_b64 +
+// 64 ds_read_b64 per block.  E1 and its inverse keep their LDS transposes with row strides re-derived for the new numbering (below).  H is host-permuted to
+// the new (register, lane) order.  fir_fft_kernel only: the partitioned kernel (kernels_firpols.h) and the 4096-point kernels keep the round-2 numbering.
+#ifndef LRHIP_FFT_E2_SWAP
+#define LRHIP_FFT_E2_SWAP 0
+#endif
+
 namespace lrhip {
 
 constexpr int FFTN = 1024;
 constexpr int FFT_E1_ROW = 68;
 constexpr int FFT_E2_ROW = 68;
+// LRHIP_FFT_E2_SWAP row strides.  E1 (forward): write element (k, lane) at k * R + lane (consecutive lanes: conflict-free for any R); read element
+// (k1s, 4 i + sub) at k1s * R + 4 i + sub - a 32-lane read group is k1s = 0..15 x sub in {0, 1} (or {2, 3}), bank pair (R k1s + sub) mod 32: R = 66 -> 2 k1s + sub,
+// all 32 distinct.  E1 inverse: WRITE element (k1s, 4 i + sub) - a 16-lane write group is k1s = 0..15 at one sub, bank pair (R k1s) mod 16: needs R odd, 65;
+// its read side (k, lane) is consecutive again.  Two strides because no single one serves both a 32-lane read group and a 16-lane write group.
+constexpr int FFT_E1F_ROW_SW = 66;
+constexpr int FFT_E1I_ROW_SW = 65;
 constexpr int FFT_EX_ELEMS = LRHIP_FFT_SPLIT ? 16 * FFT_E2_ROW / 2 : 16 * FFT_E2_ROW;   // per-wave exchange buffer (float2 units)
 constexpr int FFT_WPB = LRHIP_FFT_WPB;
 constexpr int FFT_NB = LRHIP_FFT_NB;
@@ -87,7 +103,10 @@ constexpr int FFT_LDS_TW1 = FFT_WPB * FFT_NB * FFT_EX_ELEMS;
 constexpr int FFT_LDS_H = FFT_LDS_TW1 + 16 * 64;
 constexpr int FFT_LDS_TW2 = FFT_LDS_H + 16 * 64;
 constexpr int FFT_LDS_ELEMS = FFT_LDS_TW2 + 64;
-constexpr int FFT_TABLE_ELEMS = 16 * 64 + 16 * 64 + 64;   // tw1 | Hperm | tw2, as uploaded by the host
+// tw1 | Hperm | tw2, as uploaded by the host (one set per partition); LRHIP_FFT_E2_SWAP appends H in fir_fft_kernel's (register, lane) order - the partitioned
+// kernel reads the same tables and keeps the round-2 order
+constexpr int FFT_TABLE_HSW = 16 * 64 + 16 * 64 + 64;
+constexpr int FFT_TABLE_ELEMS = 16 * 64 + 16 * 64 + 64 + (LRHIP_FFT_E2_SWAP ? 16 * 64 : 0);
 
 // DIR = +1: forward (kernel e^{-j...}), -1: inverse.  In-place 4-point DFT, natural order out.
 // A2J: a2 carries a pending factor W_16^(4*DIR) = -j*DIR (dft16's only trivial twiddle), folded into the first butterfly.
@@ -173,6 +192,31 @@ __device__ __forceinline__ void exchange(cf *ex, cf (&v)[16], WI widx, RI ridx)
 #endif
 }
 
+// 4 x 4 transpose register <-> row of 16 lanes: row b of p_s = row s of the old p_b (two swaps of 32-lane halves, two of 16-lane rows)
+__device__ __forceinline__ void fft_swap32(float &a, float &b)
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r.x);
+    b = __uint_as_float(r.y);
+}
+__device__ __forceinline__ void fft_swap16(float &a, float &b)
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r.x);
+    b = __uint_as_float(r.y);
+}
+__device__ __forceinline__ void fft_transpose_rows(cf &p0, cf &p1, cf &p2, cf &p3)
+{
+    float r0 = p0.x, r1 = p1.x, r2 = p2.x, r3 = p3.x, i0 = p0.y, i1 = p1.y, i2 = p2.y, i3 = p3.y;
+    fft_swap32(r0, r2); fft_swap32(i0, i2);
+    fft_swap32(r1, r3); fft_swap32(i1, i3);
+    fft_swap16(r0, r1); fft_swap16(i0, i1);
+    fft_swap16(r2, r3); fft_swap16(i2, i3);
+    p0 = cf{r0, i0}; p1 = cf{r1, i1}; p2 = cf{r2, i2}; p3 = cf{r3, i3};
+}
+
 // One overlap-save block per wave.  S = 2: ComplexFloat32 stream.  S = 1: Float32 stream with REAL taps, two
 // consecutive blocks packed as re/im of one complex FFT (h real => IFFT(H*(Xa + jXb)) = h*xa + j h*xb).
 // PRE = 1 (S = 1 only): fused FrequencyDiscriminatorBlock in front of the filter (frequencydiscriminator.lua:68-88): x is
@@ -225,7 +269,11 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
     // AND its stored rows start on 512-B boundaries relative to x / y (L = 897 would misalign every row)
     const int V = ((M - 1 + 63) / 64) * 64;
     const int L = FFTN - V;
+#if LRHIP_FFT_E2_SWAP
+    const int sub = lane >> 4, k1s = lane & 15;      // stages 2 and 3: sub = t2 or q = the lane's ROW of 16, k1s = k1 = its position in the row
+#else
     const int sub = lane & 3, k1s = lane >> 2;       // stages 2 and 3: sub = t2 or q, k1s = k1
+#endif
     constexpr int BPW = S == 2 ? 1 : 2;               // stream blocks per FFT
 
     // Block order.  rounds == 0: persistent, workgroup g walks batches g, g + gridDim.x, ...  rounds > 0: one-shot, workgroup g
@@ -415,7 +463,11 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
     cf v_first[16];
     const bool early = LRHIP_FFT_EARLY && FFT_NB == 1 && !LRHIP_FFT_PREFETCH && ffirst * BPW < nblocks && ffirst < fend;
     if (early) load_block(ffirst, v_first, 0);
+#if LRHIP_FFT_E2_SWAP
+    for (int i = tid; i < 16 * 64 + 16 * 64 + 64; i += 64 * FFT_WPB) fl[FFT_LDS_TW1 + i] = tables[(i >= 16 * 64 && i < 2 * 16 * 64) ? i - 16 * 64 + FFT_TABLE_HSW : i];
+#else
     for (int i = tid; i < FFT_TABLE_ELEMS; i += 64 * FFT_WPB) fl[FFT_LDS_TW1 + i] = tables[i];
+#endif
     __syncthreads();
 #if LRHIP_FFT_TW_REG
     // (the Float32-stream instantiation sits at the 168-register cap and spills six dwords per lane with all fifteen twiddles in registers; keeping only the first
@@ -472,7 +524,11 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
         // E1: write (k1, t), read (k1 = k1s, 4*t1 + t2), t2 = sub
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++)
+#if LRHIP_FFT_E2_SWAP
+            exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int k) { return k * FFT_E1F_ROW_SW + lane; }, [&](int i) { return k1s * FFT_E1F_ROW_SW + 4 * i + sub; });
+#else
             exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int k) { return k * FFT_E1_ROW + lane; }, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; });
+#endif
         // ---- forward stage 2: radix-16 over t1, twiddle W_64^(t2*k2)
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) {
@@ -487,8 +543,13 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
         // E2: write (k1 = k1s, k2, t2 = sub), read (k1 = k1s, k2 = 4j + q, t2 = 0..3), q = sub; register 4j + t2
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++)
+#if LRHIP_FFT_E2_SWAP
+#pragma unroll
+            for (int j = 0; j < 4; j++) fft_transpose_rows(v[b][4 * j], v[b][4 * j + 1], v[b][4 * j + 2], v[b][4 * j + 3]);     // row q, register 4j + t2 = old row t2, register 4j + q
+#else
             exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; },
                      [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; });       // r = 4j + t2
+#endif
         // ---- forward stage 3: radix-4 over t2 -> k3; multiply by H; inverse stage 3: radix-4 over k3 -> t2
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) {
@@ -514,15 +575,24 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
         // E2 back: write (k1, k2 = 4j + q, t2), read (k1 = k1s, k2 = 0..15, t2 = sub)
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++)
+#if LRHIP_FFT_E2_SWAP
+#pragma unroll
+            for (int j = 0; j < 4; j++) fft_transpose_rows(v[b][4 * j], v[b][4 * j + 1], v[b][4 * j + 2], v[b][4 * j + 3]);     // the transpose is its own inverse
+#else
             exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; },
                      [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; });
+#endif
         // ---- inverse stage 2: radix-16 over k2 -> t1
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) dft16<-1>(v[b]);
         // E1 back: write (k1 = k1s, 4*t1 + t2), read (k1, t = lane)
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++)
+#if LRHIP_FFT_E2_SWAP
+            exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int i) { return k1s * FFT_E1I_ROW_SW + 4 * i + sub; }, [&](int k) { return k * FFT_E1I_ROW_SW + lane; });
+#else
             exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; }, [&](int k) { return k * FFT_E1_ROW + lane; });
+#endif
         // ---- inverse stage 1: conj twiddle, radix-16 over k1 -> n1
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) {

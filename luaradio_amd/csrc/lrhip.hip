@@ -69,6 +69,7 @@ int lrhip_device(void)
 
 int lrhip_device_count(void)
 {
+    if (ctx().ready && ctx().pid != (long)getpid()) return ensure_init();      // forked after the parent initialised the device: the message, not a hang
     int count = 0;
     LR_HIP(hipGetDeviceCount(&count));
     return count;
@@ -1057,6 +1058,29 @@ long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_i
     c->head = (c->head + 1) % c->ring.size();
     c->inflight++;
     return n_out;
+}
+
+// File-fed chains (radio/blocks/sources/iqfile.lua:82-96 without the interpreter in the data path): the raw records of a regular file go from the page cache
+// straight into the pinned input of the next ring slot - positional reads split over the library's copy threads - and the slot is submitted.
+long lrhip_chain_submit_fd(lrhip_chain_t *c, int fd, unsigned long long offset, unsigned long max_in)
+{
+    if (!c) return set_error("null chain");
+    if (c->ring.empty()) return set_error("chain has no ring: call lrhip_chain_set_ring first");
+    if (c->inflight == c->ring.size()) { set_error("ring full: collect a chunk first (%u in flight)", c->inflight); return -3; }
+    if (c->fill) return set_error("chain has %lu pushed samples pending: flush before mixing submit() with push()", c->fill);
+    struct stat st;
+    if (fstat(fd, &st) != 0) return set_error("fstat(%d): %s", fd, strerror(errno));
+    if (!S_ISREG(st.st_mode)) { set_error("lrhip_chain_submit_fd: descriptor %d is not a regular file (read() into lrhip_chain_ring_input() instead)", fd); return -4; }
+    const int in_size = c->ops.front().stage->in_size;
+    unsigned long long avail = (unsigned long long)st.st_size > offset ? ((unsigned long long)st.st_size - offset) / (unsigned)in_size : 0;
+    unsigned long n = max_in < c->ring_chunk ? max_in : c->ring_chunk;
+    if (avail < n) n = (unsigned long)avail;
+    if (!n) return 0;                                        // end of the file (or less than one whole record left)
+    lrhip_chain::Slot &sl = *c->ring[c->head];
+    const int err = host_pread(sl.h_in.p, fd, (long long)offset, (size_t)n * in_size);
+    if (err) return set_error("pread(%d): %s", fd, strerror(err));
+    const long rc = lrhip_chain_submit(c, sl.h_in.p, n);
+    return rc < 0 ? rc : (long)n;
 }
 
 void *lrhip_chain_ring_input(lrhip_chain_t *c)

@@ -1147,6 +1147,13 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
                         size_t o = (size_t)16 * 64 + (size_t)(4 * j + k3) * 64 + lane;
                         tp[2 * o] = (float)Hr[k];
                         tp[2 * o + 1] = (float)Hi[k];
+#if LRHIP_FFT_E2_SWAP
+                        // fir_fft_kernel's numbering with the register <-> row transposes: q = the lane's row of 16, k1 = its position in the row
+                        const int qs = lane >> 4, k1w = lane & 15, ks = k1w + 16 * (4 * j + qs) + 256 * k3;
+                        const size_t os = (size_t)FFT_TABLE_HSW + (size_t)(4 * j + k3) * 64 + lane;
+                        tp[2 * os] = (float)Hr[ks];
+                        tp[2 * os + 1] = (float)Hi[ks];
+#endif
                     }
             for (int k2 = 0; k2 < 16; k2++)
                 for (int t2 = 0; t2 < 4; t2++) {

@@ -97,7 +97,8 @@ class CData:
 
     def lua_newindex(self, key, val):
         if isinstance(key, str):
-            setattr(self._obj(), key, int(val) if isinstance(val, float) else val)
+            field = dict((f[0], f[1]) for f in self.elem._fields_).get(key)
+            setattr(self._obj(), key, float(val) if field in (C.c_float, C.c_double) else (int(val) if isinstance(val, float) else val))
             return
         i = int(key)
         if self.elem is C.c_void_p:
@@ -317,6 +318,20 @@ class FakeLib:
             if len(c["queue"]) >= c["depth"]:
                 return 0
             return C.addressof(c["slots"][c["head"] % c["depth"]])
+        if name == "lrhip_chain_submit_fd":
+            c = st[int(args[0])]
+            if getattr(self, "fd_is_fifo", False):
+                return -4
+            if len(c["queue"]) >= c["depth"]:
+                return -3
+            rec = st[c["stages"][0]]["in"]
+            avail = max(os.fstat(int(args[1])).st_size - int(args[2]), 0) // rec
+            n = min(int(args[3]), c["chunk"], avail)
+            if n:
+                os.pread(int(args[1]), n * rec, int(args[2]))
+                c["queue"].append(n)
+                c["head"] += 1
+            return n
         if name == "lrhip_chain_submit":
             c = st[int(args[0])]
             c["queue"].append(int(args[2]))
@@ -462,7 +477,7 @@ def make_ffi(interp, lib_proxy, sockets=None):
         if isinstance(v, bytes):
             return v.decode(errors="replace")
         if isinstance(v, CData):
-            return (C.string_at(v.addr) if n is None else C.string_at(v.addr, int(n))).decode(errors="replace")
+            return C.string_at(v.addr).decode(errors="replace") if n is None else C.string_at(v.addr, int(n)).decode("latin-1")     # binary data: one character per byte
         return ml.tostr(v)
 
     def sizeof(v):
@@ -581,6 +596,7 @@ def make_ffi(interp, lib_proxy, sockets=None):
         f.closed = True
         return 0.0
 
+    Cns.set("lseek", lambda fd, off, whence: float(os.lseek(int(fd), int(ml.tonum(off)), int(ml.tonum(whence)))))
     for name, f in (("fopen", c_fopen), ("fread", c_fread), ("fwrite", c_fwrite), ("feof", lambda f: 1.0 if f.eof else 0.0), ("ferror", lambda f: 0.0),
                     ("rewind", c_rewind), ("fclose", c_fclose), ("fileno", lambda f: float(f.fh.fileno()))):
         Cns.set(name, f)

@@ -373,3 +373,54 @@ def test_host_path_travels_in_pieces_and_takes_registered_vectors_without_a_copy
         assert L.lrhip_host_unregister(x.ctypes.data_as(C.c_void_p)) == 0
         assert L.lrhip_host_unregister(y.ctypes.data_as(C.c_void_p)) == 0
     assert L.lrhip_host_unregister(x.ctypes.data_as(C.c_void_p)) < 0                        # not registered any more
+
+
+def test_poll_due_stays_bounded_while_a_launched_batch_is_in_flight():
+    """batch == chunk - push() launches the full batch, its non-waiting collect finds it unfinished, then the source stalls.  Nothing is
+    accumulating, but the batch's output still has to reach the host: poll_due() keeps the wait for input bounded until the ring has drained, and poll()
+    hands the finished batch out without another push and without EOF"""
+    x = fm_signal(50000, seed=19)
+    want = lr.Chain(receiver_blocks()).process(x)
+    chain = lr.Chain(receiver_blocks())
+    chain.set_ring(3, 50000)                                            # a batch is exactly one vector
+    chain.set_latency(0.02)
+    first = chain.push(x)                                               # launched at once; usually not finished when push() looks
+    if len(first) == 0:
+        due = chain.poll_due()
+        assert 0.0 <= due <= 0.02, due                                  # was -1 (wait for input forever): the audio sat in the ring until more input came
+        got, t0 = first, time.monotonic()
+        while len(got) == 0 and time.monotonic() - t0 < 5.0:
+            time.sleep(max(chain.poll_due(), 0.0) if chain.poll_due() >= 0 else 0.001)
+            got = chain.poll()
+    else:
+        got = first
+    assert len(got) == len(want) and float(np.max(np.abs(got - want))) < 5e-5
+    assert chain.poll_due() == -1.0                                     # drained: wait for input again
+
+
+def test_two_host_threads_on_two_objects_share_the_piece_pipeline_safely():
+    """the piece-wise host path has ONE set of copy streams and events per process.  Two host threads (ctypes releases the GIL around
+    the call) running big vectors through two different stages must not record and wait on each other's events: the thread that does not get the pipeline
+    takes the single-piece path.  Results are those of the sequential runs, bit for bit, over several rounds"""
+    import threading
+    rng = np.random.default_rng(41)
+    n = (1 << 21) + 12345
+    xs = [(rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64) for _ in range(2)]
+    taps = [(rng.uniform(-1, 1, 128) / 128).astype(np.float32) for _ in range(2)]
+    want = [make(lr.FIRFilterBlock, [taps[k], False], types.ComplexFloat32, FS).process(xs[k]) for k in range(2)]
+    for _ in range(4):
+        blks = [make(lr.FIRFilterBlock, [taps[k], False], types.ComplexFloat32, FS) for k in range(2)]
+        got = [None, None]
+        start = threading.Barrier(2)
+
+        def run(k):
+            start.wait()
+            got[k] = blks[k].process(xs[k])
+        th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(60)
+        assert all(g is not None for g in got)
+        for k in range(2):
+            assert np.array_equal(got[k], want[k]), k
