@@ -78,9 +78,12 @@
 // the four lanes of a group then sit in the four ROWS of 16 lanes of the wave, at the same position - and E2 / its inverse become 4 x 4 register <-> row
 // transposes in the VALU (v_permlane32_swap + v_permlane16_swap: two instructions per register PAIR, no selects, no LDS): 64 swaps replace 64 ds_write_b64 +
 // 64 ds_read_b64 per block.  E1 and its inverse keep their LDS transposes with row strides re-derived for the new numbering (below).  H is host-permuted to
-// the new (register, lane) order.  fir_fft_kernel only: the partitioned kernel (kernels_firpols.h) and the 4096-point kernels keep the round-2 numbering.
+// the new (register, lane) order (an extra section of the tables: FFT_TABLE_HSW).  fir_fft_kernel and the partitioned kernel (kernels_firpols.h); the 4096-point
+// kernels keep the round-2 numbering.
+// Same-box A/B, three alternations (profiles/r05_ab_e2swap.txt): 2^28 samples 0.8705 / 0.8701 / 0.8836 -> 0.8482 / 0.8453 / 0.8493 ms (-2.6 .. -3.9 %), 2^26 samples
+// 0.2581 / 0.2586 / 0.2591 -> 0.2461 / 0.2521 / 0.2473 ms (-2.5 .. -4.6 %); outputs bit-identical to the LDS form on 2^24 samples (same arithmetic, other wires).
 #ifndef LRHIP_FFT_E2_SWAP
-#define LRHIP_FFT_E2_SWAP 0
+#define LRHIP_FFT_E2_SWAP 1
 #endif
 
 namespace lrhip {

@@ -81,10 +81,18 @@ __global__ __launch_bounds__(64 * pols_wpb(S), 1) void fir_pols_kernel(const flo
         const float2 *t0 = tables + (size_t)part0 * FFT_TABLE_ELEMS;
         for (int i = tid; i < 16 * 64; i += 64 * POLS_WPB) fl[POLS_LDS_TW1 + i] = t0[i];
         for (int i = tid; i < 64; i += 64 * POLS_WPB) fl[POLS_LDS_TW2 + i] = t0[2 * 16 * 64 + i];
+#if LRHIP_FFT_E2_SWAP
+        for (int i = tid; i < P * 1024; i += 64 * POLS_WPB) fl[POLS_LDS_H + i] = tables[(size_t)(part0 + i / 1024) * FFT_TABLE_ELEMS + FFT_TABLE_HSW + (i & 1023)];
+#else
         for (int i = tid; i < P * 1024; i += 64 * POLS_WPB) fl[POLS_LDS_H + i] = tables[(size_t)(part0 + i / 1024) * FFT_TABLE_ELEMS + 16 * 64 + (i & 1023)];
+#endif
     }
     __syncthreads();
+#if LRHIP_FFT_E2_SWAP
+    const int sub = lane >> 4, k1s = lane & 15;       // kernels_firfft.h: the inner transposes as register <-> row swaps
+#else
     const int sub = lane & 3, k1s = lane >> 2;
+#endif
     const long delay = (long)part0 * POLS_HOP;
 #if LRHIP_POLS_TW_REG >= 1
     cf tw1r[16];
@@ -174,11 +182,20 @@ __global__ __launch_bounds__(64 * pols_wpb(S), 1) void fir_pols_kernel(const flo
             dft16<1>(v);
 #pragma unroll
             for (int q = 1; q < 16; q++) v[q] = cmul(v[q], POLS_TW1(q));
+#if LRHIP_FFT_E2_SWAP
+            exchange(ex, v, [&](int q) { return q * FFT_E1F_ROW_SW + lane; }, [&](int i) { return k1s * FFT_E1F_ROW_SW + 4 * i + sub; });
+#else
             exchange(ex, v, [&](int q) { return q * FFT_E1_ROW + lane; }, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; });
+#endif
             dft16<1>(v);
 #pragma unroll
             for (int q = 1; q < 16; q++) v[q] = cmul(v[q], POLS_TW2F(q));
+#if LRHIP_FFT_E2_SWAP
+#pragma unroll
+            for (int j = 0; j < 4; j++) fft_transpose_rows(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+#else
             exchange(ex, v, [&](int q) { return k1s * FFT_E2_ROW + 17 * sub + q; }, [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; });
+#endif
 #pragma unroll
             for (int j = 0; j < 4; j++) radix4<1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
             if (k < 0) {
@@ -210,9 +227,16 @@ __global__ __launch_bounds__(64 * pols_wpb(S), 1) void fir_pols_kernel(const flo
 #pragma unroll
                 for (int t2 = 1; t2 < 4; t2++) v[4 * j + t2] = cmulc(v[4 * j + t2], POLS_TW2I(j, t2));
             }
+#if LRHIP_FFT_E2_SWAP
+#pragma unroll
+            for (int j = 0; j < 4; j++) fft_transpose_rows(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+            dft16<-1>(v);
+            exchange(ex, v, [&](int i) { return k1s * FFT_E1I_ROW_SW + 4 * i + sub; }, [&](int q) { return q * FFT_E1I_ROW_SW + lane; });
+#else
             exchange(ex, v, [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; }, [&](int q) { return k1s * FFT_E2_ROW + 17 * sub + q; });
             dft16<-1>(v);
             exchange(ex, v, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; }, [&](int q) { return q * FFT_E1_ROW + lane; });
+#endif
 #pragma unroll
             for (int q = 1; q < 16; q++) v[q] = cmulc(v[q], POLS_TW1(q));
             dft16<-1>(v);

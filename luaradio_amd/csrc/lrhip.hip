@@ -705,6 +705,23 @@ lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, u
                 fused = fir_build(taps.data(), (unsigned)fir->M, fir->taps_complex, fir->S == 2, D, want_fft ? 2 : 0, want_rot, want_rot ? rot->omega : 0.0);
             if (fused && rot && !want_rot) { delete fused; fused = nullptr; }
             bool with_disc = fused && dsc_after && fused->can_post_disc();
+            // Round 5 (the receivers OFF the stock shape): the Toeplitz kernel has its discriminator epilogue at decimation 5 / 128 taps only, so
+            // an FM receiver at another input rate (Tuner /4, /8) ran its tuner, the discriminator and their fix-ups as separate launches.  The polyphase-FFT
+            // decimator has the epilogue at every decimation it supports: an AUTOMATIC filter (use_fft nil / "auto": the caller left the arithmetic to the
+            // library) that would otherwise lose the epilogue takes that form - tuner + discriminator stay one launch.  Pinned direct-form filters
+            // (use_fft = false), exact chains and unsupported decimations keep what they had.
+            static const bool no_auto_decfft = getenv("LRHIP_NO_AUTO_DECFFT") != nullptr;      // A/B knob
+            if (!no_auto_decfft && fused && dsc_after && !with_disc && !want_fft && fir->mode_req == 3 && ds && !exact_rotator && fir->S == 2 && !fir->taps_complex &&
+                FirStage::decfft_supported(D, fir->M, fir->S)) {
+                FirStage *alt = fir_build(taps.data(), (unsigned)fir->M, fir->taps_complex, true, D, 2, want_rot, want_rot ? rot->omega : 0.0);
+                if (alt && alt->decfft && alt->can_post_disc()) {
+                    delete fused;
+                    fused = alt;
+                    with_disc = true;
+                } else {
+                    delete alt;
+                }
+            }
             if (fused && !rot && !ds && !with_disc) { delete fused; fused = nullptr; }      // nothing was fused
             if (fused) {
                 if (exact_rotator) fused->rel_rot = false;     // block-of-8 staging with the stand-alone rotator's phasors: fused == unfused bit for bit

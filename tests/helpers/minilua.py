@@ -1119,6 +1119,9 @@ def install_stdlib(I):
                     ("sin", lambda x: math.sin(tonum(x))), ("cos", lambda x: math.cos(tonum(x))), ("log", lambda x: math.log(tonum(x))),
                     ("exp", lambda x: math.exp(tonum(x))), ("fmod", lambda a, b: math.fmod(tonum(a), tonum(b))), ("pow", lambda a, b: tonum(a) ** tonum(b))):
         M.set(name, f)
+    for name, f in (("tan", math.tan), ("atan", math.atan), ("asin", math.asin), ("acos", math.acos), ("log10", math.log10), ("sinh", math.sinh), ("cosh", math.cosh)):
+        M.set(name, (lambda fn: lambda x: fn(tonum(x)))(f))
+    M.set("atan2", lambda a, b: math.atan2(tonum(a), tonum(b)))
     M.set("pi", math.pi)
     M.set("huge", math.inf)
     G.set("math", M)

@@ -941,7 +941,9 @@ def test_fir_properties_at_full_tile_sizes():
     a = torch.rand(2 * n, device="cuda", generator=g) * 2 - 1
     b = torch.rand(2 * n, device="cuda", generator=g) * 2 - 1
     ya, yb, yab = (torch.empty(2 * n, device="cuda") for _ in range(3))
-    for src, dst in ((a, ya), (b, yb), (a + b, yab)):
+    ab = a + b
+    torch.cuda.synchronize()            # the library launches on its own stream: torch's kernels that produce its inputs have to be done first
+    for src, dst in ((a, ya), (b, yb), (ab, yab)):
         blk.reset()
         assert blk.process_device(src.data_ptr(), n, dst.data_ptr(), n) == n
     L.lrhip_synchronize()

@@ -44,7 +44,7 @@ static const double FS = 1102500.0;
 struct Receiver {
     std::vector<lrhip_stage_t *> st;
     lrhip_chain_t *c = nullptr;
-    Receiver(const char *format)          // IQFileSource(format) -> Tuner(-250e3, 200e3, 5) -> FrequencyDiscriminator(1.25) -> Lowpass(128, 15e3) -> FMDeemphasis(75e-6) -> Downsampler(5)
+    Receiver(const char *format, unsigned long ring_chunk = 1ul << 20)          // IQFileSource(format) -> Tuner(-250e3, 200e3, 5) -> FrequencyDiscriminator(1.25) -> Lowpass(128, 15e3) -> FMDeemphasis(75e-6) -> Downsampler(5)
     {
         std::vector<float> t1 = firwin_lowpass(128, 100e3 / (FS / 2)), t2 = firwin_lowpass(128, 15e3 / (FS / 5 / 2));
         const double tau = 75e-6, r = FS / 5, wc = 1 / tau, wca = 2 * r * std::tan(wc / (2 * r)), taua = 1 / wca;   // singlepolelowpassfilter.lua:55-67
@@ -59,7 +59,7 @@ struct Receiver {
         CHK(s = lrhip_iir_create(b, 2, a, 2, 0)); st.push_back(s);
         CHK(s = lrhip_downsampler_create(5, 4)); st.push_back(s);
         CHK(c = lrhip_chain_create(st.data(), (unsigned)st.size()));
-        CHK0(lrhip_chain_set_ring(c, 3, 1ul << 20));
+        CHK0(lrhip_chain_set_ring(c, 3, ring_chunk));
     }
     ~Receiver()
     {
@@ -98,15 +98,15 @@ int main(int argc, char **argv)
         close(fd);
     }
     for (auto &f : fmts) {
-        struct Leg { const char *mode; unsigned long chunk; } legs[] = {{"push", 8192}, {"push", 131072}, {"ring", 1ul << 20}, {"fd", 1ul << 20}};
+        struct Leg { const char *mode; unsigned long chunk; } legs[] = {{"push", 8192}, {"push", 131072}, {"ring", 1ul << 20}, {"fd", 1ul << 20}, {"fd", 1ul << 22}};
         for (auto &leg : legs) {
             double best = 0, sum = 0;
             long n_audio = 0;
             for (int pass = 0; pass < 3; pass++) {           // pass 0: warm-up (allocations, clocks, page cache); the better of the next two counts
-                Receiver rx(f.name);
+                Receiver rx(f.name, leg.chunk > (1ul << 20) ? leg.chunk : (1ul << 20));
                 int fd = open(f.path.c_str(), O_RDONLY);
                 if (fd < 0) { perror("open"); return 1; }
-                const unsigned long cap = lrhip_chain_push_bound(rx.c, 1ul << 20) + (3ul << 20);
+                const unsigned long cap = lrhip_chain_push_bound(rx.c, 1ul << 20) + (3ul << 22);
                 std::vector<float> out(cap), audio;
                 audio.reserve(total / 25 + 64);
                 std::vector<char> buf(leg.chunk * f.rec);
