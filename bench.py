@@ -103,7 +103,9 @@ def self_launch(args):
         r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
         sys.stderr.write(r.stderr)
         sys.stderr.flush()
-        port_lost = any(t in r.stderr for t in ("Address already in use", "EADDRINUSE", "failed to bind", "DistNetworkError", "RendezvousConnectionError"))
+        # only the launcher's own bind failing counts (a generic DistNetworkError of a rank that died for another reason must not re-run the
+        # bench and print a second JSON line)
+        port_lost = any(t in r.stderr for t in ("Address already in use", "EADDRINUSE", "failed to bind"))
         if r.returncode == 0 or not port_lost:
             raise SystemExit(r.returncode)
         sys.stderr.write("bench.py: the rendezvous port was taken, launching again (attempt %d)\n" % (attempt + 2))

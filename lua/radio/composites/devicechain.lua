@@ -43,6 +43,13 @@ DeviceChainBlock.ring_depth = 3
 -- time, and where a batch is cut decides the Float32 rounding of overlap-save filters and of the single-launch receiver
 -- (include/lrhip.h, "chains"), so clock-cut batches would make a file's output bits differ from run to run.
 DeviceChainBlock.max_latency = 0
+-- ... and since a script that just writes top:connect(RtlSdrSource(...), TunerBlock(...), ...) sets no knob: a chain whose stream comes from a REAL-TIME
+-- source - an SDR, a sound card, a network socket, or anything behind a ThrottleBlock - gets live_latency as its bound by default (collapse() looks upstream;
+-- the names are the reference's block names, radio/blocks/sources/*.lua).  File, signal and benchmark sources keep 0.  An explicit max_latency wins.
+DeviceChainBlock.live_latency = 0.02
+DeviceChainBlock.live_sources = {RtlSdrSource = true, AirspySource = true, AirspyHFSource = true, BladeRFSource = true, HackRFSource = true, HydraSDRSource = true,
+                                 SDRplaySource = true, SoapySDRSource = true, UHDSource = true, NetworkClientSource = true, NetworkServerSource = true,
+                                 PortAudioSource = true, PulseAudioSource = true, ThrottleBlock = true}
 -- synchronous = true: no batching at all - every process() vector goes through the chain at once (lrhip_chain_execute: H2D, kernels, D2H, wait) and its
 -- output is returned from the same call, as the reference's blocks do (radio/core/block.lua:585).  The lowest latency and the fewest samples per launch;
 -- both ends are zero-copy: the vector is DMA'd from the pipe's read buffer and the result into the block's output vector (lrhip.pin_inputs, lrhip.pin).
@@ -463,6 +470,19 @@ function DeviceChainBlock.collapse(connections)
         end
         if not chain.source then
             first.inputs[1].pipe = {get_rate = function () return chain.inputs[1].pipe:get_rate() end}
+        end
+        -- a live stream upstream (walk the first inputs up to the source): bounded latency unless the script set one
+        if not chain.source and rawget(chain, "max_latency") == nil then
+            local up, hops = connections[first.inputs[1]], 0
+            while up ~= nil and hops < 64 do
+                local b = up.owner
+                if DeviceChainBlock.live_sources[b.name] then
+                    chain.max_latency = DeviceChainBlock.live_latency
+                    break
+                end
+                up = (#b.inputs >= 1) and connections[b.inputs[1]] or nil
+                hops = hops + 1
+            end
         end
         chains[#chains + 1] = chain
         chain_of[first] = chain

@@ -186,14 +186,19 @@ end
 ----------------------------------------------------------------------------------------------------------------------------------
 local DeviceFanoutBlock = block.factory("DeviceFanoutBlock")
 
+-- blocks: the head chain's members (may be empty: upload and fan out).  When the fanned-out port belongs to a FILE SOURCE with the raw-record hooks
+-- (radio/blocks/sources/file_hip.lua) the source is absorbed as the first member: the head then has no input port at all - it reads the raw records into its
+-- pinned staging buffer itself (2 bytes per complex sample cross the host and the link for a 'u8' capture), converts them on the device and fans the
+-- ComplexFloat32 slab out: IQFileSource -> 8 x Tuner is one head and eight branches, no sample ever in the interpreter.
 function DeviceFanoutBlock:instantiate(blocks, input_type, output_type)
-    self.blocks = blocks or {}          -- the head chain's members (may be empty: upload and fan out)
+    self.blocks = blocks or {}
     self.branches = {}
     self.output_type = output_type
     self.slab_capacity = M.slab_samples
     self.max_latency = M.max_latency
     self.device = 0
-    self:add_type_signature({block.Input("in", input_type)}, {})
+    self.source = (#self.blocks > 0 and DeviceChainBlock.is_raw_source(self.blocks[1])) and self.blocks[1] or nil
+    self:add_type_signature(self.source and {} or {block.Input("in", input_type)}, {})
 end
 
 -- rate of the fanned-out port (what the branches' first members see upstream)
@@ -217,6 +222,10 @@ function DeviceFanoutBlock:initialize()
         branch.files[fds[1]] = true
     end
     self.chain = nil
+    self.finished = false
+    if self.source then
+        for file, _ in pairs(self.source.files or {}) do self.files[file] = true end
+    end
 end
 
 -- runs in the PARENT after every block has been forked (the hook tools/apply_lua_binding.py puts next to the reference's own "close all pipe inputs and
@@ -234,8 +243,9 @@ local function head_start(self)
     local lib = lrhip.lib
     self.my_device = lrhip.ensure(self.device)
     self.chain = build_chain(self)
-    local in_type, out_type = self:get_input_type(), self.output_type
-    self.in_size, self.slab_size = ffi.sizeof(in_type), ffi.sizeof(out_type)
+    local out_type = self.output_type
+    self.in_size = self.source and self.source:raw_record_size() or ffi.sizeof(self:get_input_type())
+    self.slab_size = ffi.sizeof(out_type)
     -- input samples per slab: what the head chain turns into at most slab_capacity outputs
     self.batch = self.slab_capacity
     if self.chain ~= nil then
@@ -316,6 +326,17 @@ end
 -- a sink's process() returns nothing (#data_out == #self.outputs == 0)
 function DeviceFanoutBlock:process(x)
     if not self.started then head_start(self) end
+    if self.source then
+        -- one slab per call, read by the source's own fread() straight into the pinned staging buffer
+        local n = self.source:read_raw(self.staging, self.batch)
+        if n == nil then
+            self.finished = true
+        elseif n > 0 then
+            self.fill = n
+            head_launch(self)
+        end
+        return
+    end
     local src, left = ffi.cast("const char *", x.data), x.length
     while left > 0 do
         local take = math.min(left, self.batch - self.fill)
@@ -337,6 +358,21 @@ end
 
 local block_run = DeviceFanoutBlock.run     -- Block:run, copied into the class by block.factory (radio/core/class.lua:18-40)
 function DeviceFanoutBlock:run()
+    if self.source then
+        -- no ports at all (the branches hang on their sockets): Block:run would wait on the control socket forever (PipeMux:_read_control,
+        -- radio/core/pipe.lua:475-493) - process() until the file has ended, a look at the control socket in between, as DeviceChainBlock does
+        local pipe = require('radio.core.pipe')
+        local pipe_mux = pipe.PipeMux({}, {}, self.control_socket)
+        while not self.finished do
+            self:process()
+            if self.control_socket then
+                local ret = ffi.C.poll(pipe_mux.input_pollfds, 1, 0)
+                if ret < 0 then error("poll(): " .. ffi.string(ffi.C.strerror(ffi.errno()))) end
+                if ret > 0 then break end
+            end
+        end
+        return self:cleanup()
+    end
     if not (self.max_latency > 0) then return block_run(self) end
     return DeviceChainBlock.timed_run(self, function (b)
         if not b.started or b.fill == 0 then return -1 end
@@ -378,6 +414,7 @@ function DeviceFanoutBlock:cleanup()
     lib.lrhip_host_free(self.staging)
     if self.d_in ~= nil then lib.lrhip_free(self.d_in) end
     self.started = false
+    if self.source then self.source:cleanup() end          -- fclose (iqfile.lua:118-124): the absorbed source is no longer in the evaluation order
 end
 
 ----------------------------------------------------------------------------------------------------------------------------------
@@ -445,7 +482,12 @@ function M.collapse(connections, chains)
         if accept(output) then
             local writer = output.owner
             local head
-            if is_chain[writer] and not writer.source then
+            if is_chain[writer] and writer.source then
+                -- the writer is a device chain that reads a file itself: it becomes the head chain, source included
+                head = DeviceFanoutBlock(writer.blocks, nil, output.data_type)
+                head:differentiate({})
+                dropped[writer] = true
+            elseif is_chain[writer] then
                 -- the writer is a device chain: it becomes the head chain and keeps its output on its device
                 head = DeviceFanoutBlock(writer.blocks, writer:get_input_type(), output.data_type)
                 head:differentiate({writer:get_input_type()})
@@ -453,6 +495,10 @@ function M.collapse(connections, chains)
                 result[writer.inputs[1]] = nil
                 writer.blocks[1].inputs[1].pipe = {get_rate = function () return head.inputs[1].pipe:get_rate() end}
                 dropped[writer] = true
+            elseif DeviceChainBlock.is_raw_source(writer) then
+                -- the writer is a file source: the head reads the raw records itself and converts them on its device
+                head = DeviceFanoutBlock({writer}, nil, output.data_type)
+                head:differentiate({})
             else
                 head = DeviceFanoutBlock({}, output.data_type, output.data_type)
                 head:differentiate({output.data_type})

@@ -711,7 +711,9 @@ lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, u
             // library) that would otherwise lose the epilogue takes that form - tuner + discriminator stay one launch.  Pinned direct-form filters
             // (use_fft = false), exact chains and unsupported decimations keep what they had.
             static const bool no_auto_decfft = getenv("LRHIP_NO_AUTO_DECFFT") != nullptr;      // A/B knob
-            if (!no_auto_decfft && fused && dsc_after && !with_disc && !want_fft && fir->mode_req == 3 && ds && !exact_rotator && fir->S == 2 && !fir->taps_complex &&
+            // Measured on 2^26 RF samples, one box (profiles/r05_receiver_shapes.txt): Tuner /4 0.385 -> 0.236 ms (5 -> 2 launches); Tuner /8 0.291 -> 0.367 ms, the
+            // polyphase-FFT form with eight branches is the slower tuner there - so decimation 4 only (2 is unmeasured and stays as it was).
+            if (!no_auto_decfft && fused && dsc_after && !with_disc && !want_fft && fir->mode_req == 3 && ds && D == 4 && !exact_rotator && fir->S == 2 && !fir->taps_complex &&
                 FirStage::decfft_supported(D, fir->M, fir->S)) {
                 FirStage *alt = fir_build(taps.data(), (unsigned)fir->M, fir->taps_complex, true, D, 2, want_rot, want_rot ? rot->omega : 0.0);
                 if (alt && alt->decfft && alt->can_post_disc()) {
@@ -1058,8 +1060,11 @@ long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_i
     size_t bytes = (size_t)n_in * in_size;
     // the slot was collected (ev_out waited) before it can be reused, so its buffers are free on host and device
     if (bytes) {
-        if (in_host != sl.h_in.p) host_copy(sl.h_in.p, in_host, bytes);      // lrhip_chain_ring_input(): the caller filled the slot itself
-        LR_HIP(hipMemcpyAsync(sl.d_in.p, sl.h_in.p, bytes, hipMemcpyHostToDevice, c->s_in));
+        // lrhip_chain_ring_input(): the caller filled the slot itself.  A vector inside a range registered with lrhip_host_register() is DMA'd from where it
+        // lies (a recording mmap()ed and registered once: the page cache is the staging buffer); the caller keeps it valid until the batch is collected.
+        const bool direct = in_host != sl.h_in.p && host_ranges().has(in_host, bytes);
+        if (in_host != sl.h_in.p && !direct) host_copy(sl.h_in.p, in_host, bytes);
+        LR_HIP(hipMemcpyAsync(sl.d_in.p, direct ? in_host : sl.h_in.p, bytes, hipMemcpyHostToDevice, c->s_in));
     }
     LR_HIP(hipEventRecord(sl.ev_in, c->s_in));
     LR_HIP(hipStreamWaitEvent(ctx().stream, sl.ev_in, 0));

@@ -931,3 +931,116 @@ def test_gpu_lua_channelizer_block_equals_the_python_block():
     b = I.run(src, "chan", [fvec(taps)])[0]
     got = ml.call(ml.index(b, "process"), [b, cvec(x)])[0].array()
     assert np.array_equal(got, want)
+
+
+LIVE_GRAPH = r'''
+local R = require('reference_standins')
+local block = require('radio.core.block')
+local types = require('radio.types')
+local taps, source_name, throttle = ...
+local Src = block.factory(source_name)
+function Src:instantiate() self:add_type_signature({}, {block.Output("out", types.ComplexFloat32)}) end
+function Src:get_rate() return 1102500 end
+local g = R.graph()
+local src, t, f, k = Src(), R.FrequencyTranslatorBlock(1000), R.FIRFilterBlock(taps), R.HostSink()
+src:differentiate({})
+local all = {src}
+local upstream = src
+if throttle then
+    local Thr = block.factory("ThrottleBlock")
+    function Thr:instantiate() self:add_type_signature({block.Input("in", types.ComplexFloat32)}, {block.Output("out", types.ComplexFloat32)}) end
+    upstream = Thr()
+    upstream:differentiate({types.ComplexFloat32})
+    g.connect(src, upstream)
+    all[#all + 1] = upstream
+end
+for _, b in ipairs({t, f, k}) do b:differentiate({types.ComplexFloat32}); all[#all + 1] = b end
+g.connect(upstream, t, f, k)
+local connections, device_blocks = R.prepare(g.connections, {t, f})
+return device_blocks[1]
+'''
+
+
+def test_a_chain_behind_a_real_time_source_gets_a_latency_bound_by_default():
+    """ADVICE r04 (low): with max_latency = 0 a live graph (rtlsdr_wbfm_mono at 1.1 MS/s) held its samples until a 2^20-sample batch filled - a second of
+    latency and bursty audio - unless the user knew the knob.  collapse() now looks upstream: an SDR / audio / network source or a ThrottleBlock gives the chain
+    the 20 ms bound; file and signal sources keep batches that only run when full (reproducible batch cuts)"""
+    for name, throttle, want in (("RtlSdrSource", False, 0.02), ("IQFileSource", False, 0), ("SignalSource", True, 0.02), ("NetworkClientSource", False, 0.02)):
+        I, proxy, _ = interp()
+        chain = I.run(LIVE_GRAPH, "live", [fvec(np.ones(16) / 16), name, throttle])[0]
+        assert ml.index(chain, "max_latency") == want, name
+        ml.call(ml.index(chain, "process"), [chain, cvec(np.zeros(100))])
+        assert [a[1] for n, a in proxy.fake.calls if n == "lrhip_chain_set_latency"] == [float(want)]
+
+
+FANOUT_FROM_FILE = r'''
+local R = require('reference_standins')
+local types = require('radio.types')
+local path, taps, nbranch, with_head_block = ...
+local g = R.graph()
+local src = R.IQFileSource(path, 'u8', 1102500)
+src:differentiate({})
+local all = {src}
+local upstream = src
+if with_head_block then                 -- IQFileSource -> Translator -> {branches}: the chain {source, translator} is the fanned-out port's writer
+    upstream = R.FrequencyTranslatorBlock(50e3)
+    upstream:differentiate({types.ComplexFloat32})
+    g.connect(src, upstream)
+    all[#all + 1] = upstream
+end
+for b = 1, nbranch do
+    local t, f, d, k = R.FrequencyTranslatorBlock(-100e3 * b), R.FIRFilterBlock(taps), R.DownsamplerBlock(5), R.HostSink()
+    for _, blk in ipairs({t, f, d, k}) do blk:differentiate({types.ComplexFloat32}); all[#all + 1] = blk end
+    g.connect(upstream, t, f, d, k)
+end
+require('radio.composites.devicefanout').slab_samples = 4096
+local connections, device_blocks = R.prepare(g.connections, all)
+local head, branches = nil, {}
+for _, b in ipairs(device_blocks) do
+    if b.name == "DeviceFanoutBlock" then head = b elseif b.name == "DeviceBranchBlock" then branches[b.index + 1] = b end
+end
+return connections, head, branches, #device_blocks
+'''
+
+
+@pytest.mark.parametrize("with_head_block", [False, True])
+def test_fan_out_head_reads_the_recording_itself(tmp_path, with_head_block):
+    """BASELINE configs[3] from Lua with a file source: IQFileSource('x.u8') -> 3 x Tuner.  The head absorbs the source (no input port, no data pipe anywhere in
+    front of the branches): it freads raw u8 records into its pinned staging buffer, uploads 2 bytes per sample, converts on its device (the format stage is the
+    head chain's first member) and pushes the ComplexFloat32 slab to every branch"""
+    n = 10000
+    path = tmp_path / "x.u8"
+    path.write_bytes(wbfm_u8_capture(n))
+    I, proxy, ffi = interp()
+    ffi.get("C").set("getpid", lambda: float(threading.get_ident() % 1000003))
+    conns, head, branches, ndev = I.run(FANOUT_FROM_FILE, "fanfile", [str(path), fvec(np.ones(16) / 16), 3.0, with_head_block])
+    assert ndev == 4 and len(conns.hash) == 3                          # three branch -> sink edges; nothing feeds the head through a pipe
+    assert ml.index(head, "inputs").length() == 0 and ml.index(head, "outputs").length() == 0
+    assert [ml.index(b, "name") for b in lua_list(ml.index(head, "blocks"))] == ["IQFileSource"] + (["FrequencyTranslatorBlock"] if with_head_block else [])
+    got = {}
+
+    def run_branch(k):
+        b = branches.get(k)
+        outs = []
+        while True:
+            r = ml.call(ml.index(b, "process"), [b])
+            if not r or r[0] is None:
+                break
+            outs.append(r[0].length)
+        ml.call(ml.index(b, "cleanup"), [b])
+        got[k] = outs
+    threads = [threading.Thread(target=run_branch, args=(k,), daemon=True) for k in (1, 2, 3)]
+    threads.append(threading.Thread(target=lambda: ml.call(ml.index(head, "run"), [head]), daemon=True))
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(20)
+    assert not any(t.is_alive() for t in threads)
+    assert got == {1: [4096, 4096, 1808], 2: [4096, 4096, 1808], 3: [4096, 4096, 1808]}
+    reads = ffi.get("_state")["fread_sizes"]
+    assert [r[0] for r in reads] == [2] * 4 and [r[2] for r in reads] == [4096, 4096, 1808, 0]          # raw records, a slab per fread
+    h2d = [a for nm, a in proxy.fake.calls if nm == "lrhip_memcpy_h2d"]
+    assert sorted(a[2] for a in h2d) == [1808 * 2, 4096 * 2, 4096 * 2]                                  # 2 bytes per sample cross the host
+    assert [a for nm, a in proxy.fake.calls if nm == "lrhip_format_convert_create"] == [[b"u8", 1]]
+    assert [nm for nm, _ in proxy.fake.calls].count("lrhip_peer_copy") == 9
+    assert ml.index(lua_list(ml.index(head, "blocks"))[0], "file").closed

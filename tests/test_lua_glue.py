@@ -32,7 +32,7 @@ REFERENCE_METHODS = {
     "initialize_gnuplot", "write_gnuplot",                                                                   # GnuplotSpectrumSink (radio/blocks/sinks/gnuplotspectrum.lua:73-137)
     "run_once",                                                                                              # Block (radio/core/block.lua:493-549)
 }
-LUA_BUILTINS = {"assert", "error", "ipairs", "pairs", "require", "tonumber", "tostring", "type", "setmetatable", "unpack", "pcall", "select", "print"}
+LUA_BUILTINS = {"assert", "error", "ipairs", "pairs", "require", "tonumber", "tostring", "type", "setmetatable", "unpack", "pcall", "select", "print", "rawget", "rawset"}
 LUA_KEYWORDS = {"and", "break", "do", "else", "elseif", "end", "false", "for", "function", "if", "in", "local", "nil", "not", "or", "repeat", "return",
                 "then", "true", "until", "while"}
 
