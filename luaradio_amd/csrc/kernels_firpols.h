@@ -43,13 +43,14 @@ namespace lrhip {
 #ifndef LRHIP_POLS_WPB_F32
 #define LRHIP_POLS_WPB_F32 8
 #endif
-__host__ __device__ constexpr int pols_wpb(int S) { return S == 1 ? LRHIP_POLS_WPB_F32 : LRHIP_POLS_WPB; }
+// (four partitions per launch - a delay line of three spectra, 96 registers - need the 256 registers of two waves per SIMD: 8 waves)
+__host__ __device__ constexpr int pols_wpb(int S, int P = 1) { return S == 1 ? LRHIP_POLS_WPB_F32 : P >= 4 ? 8 : LRHIP_POLS_WPB; }
 constexpr int POLS_HOP = 512;
 // LDS map (float2 units): [WPB x exchange | tw1 16x64 | tw2 64 | H P x 1024]
-__host__ __device__ constexpr int pols_lds_tw1(int S) { return pols_wpb(S) * FFT_EX_ELEMS; }
-__host__ __device__ constexpr int pols_lds_tw2(int S) { return pols_lds_tw1(S) + 16 * 64; }
-__host__ __device__ constexpr int pols_lds_h(int S) { return pols_lds_tw2(S) + 64; }
-__host__ __device__ constexpr int pols_lds_elems(int S, int P) { return pols_lds_h(S) + P * 1024; }
+__host__ __device__ constexpr int pols_lds_tw1(int S, int P = 1) { return pols_wpb(S, P) * FFT_EX_ELEMS; }
+__host__ __device__ constexpr int pols_lds_tw2(int S, int P = 1) { return pols_lds_tw1(S, P) + 16 * 64; }
+__host__ __device__ constexpr int pols_lds_h(int S, int P = 1) { return pols_lds_tw2(S, P) + 64; }
+__host__ __device__ constexpr int pols_lds_elems(int S, int P) { return pols_lds_h(S, P) + P * 1024; }
 
 // a + s * h on the packed VALU: two v_pk_fma_f32
 __device__ __forceinline__ cf cmac(cf a, cf s, cf h)
@@ -63,12 +64,12 @@ __device__ __forceinline__ cf cmac(cf a, cf s, cf h)
 // part0 .. part0 + P - 1 (taps [512 part0, 512 (part0 + P)) of the Mh-tap filter) to the stream delayed by 512 part0 samples.
 // nblocks = ceil(n_out / 512); a wave owns `run` consecutive blocks (S = 1: two runs, `run` blocks apart).
 template <int S, int P>
-__global__ __launch_bounds__(64 * pols_wpb(S), 1) void fir_pols_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float2 *__restrict__ tables,
+__global__ __launch_bounds__(64 * pols_wpb(S, P), 1) void fir_pols_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float2 *__restrict__ tables,
                                                                     float *__restrict__ y, int Mh, long n, long n_out, long nblocks, long run, int part0,
                                                                     int accumulate, float *__restrict__ hist_out)
 {
-    constexpr int POLS_WPB = pols_wpb(S), POLS_LDS_TW1 = pols_lds_tw1(S), POLS_LDS_TW2 = pols_lds_tw2(S), POLS_LDS_H = pols_lds_h(S);
-    static_assert(P >= 1 && P <= 3, "the spectra delay line lives in registers");
+    constexpr int POLS_WPB = pols_wpb(S, P), POLS_LDS_TW1 = pols_lds_tw1(S, P), POLS_LDS_TW2 = pols_lds_tw2(S, P), POLS_LDS_H = pols_lds_h(S, P);
+    static_assert(P >= 1 && P <= 4, "the spectra delay line lives in registers");
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,11 +126,11 @@ __global__ __launch_bounds__(64 * pols_wpb(S), 1) void fir_pols_kernel(const flo
         if (r0 >= nruns) continue;                            // no workgroup barrier inside the loop: a wave may skip
         const long ba = r0 * run, bend_a = ba + run < nblocks ? ba + run : nblocks;
         const long bb = ba + run, bend_b = S == 1 ? (bb + run < nblocks ? bb + run : nblocks) : 0;      // second run (S = 1), may be empty
-        cf keep[8], S1[16], S2[16];
+        cf keep[8], S1[16], S2[16], S3[16];
 #pragma unroll
         for (int i = 0; i < 8; i++) keep[i] = cf{0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 16; i++) { S1[i] = cf{0.f, 0.f}; S2[i] = cf{0.f, 0.f}; }
+        for (int i = 0; i < 16; i++) { S1[i] = cf{0.f, 0.f}; S2[i] = cf{0.f, 0.f}; S3[i] = cf{0.f, 0.f}; }
         // k = -(P-1) .. run-1: block ba + k of run A (and bb + k of run B); k < 0 = warm-up (spectrum only)
         for (long k = -(long)(P - 1); k < run; k++) {
             const long b = ba + k;
@@ -200,6 +201,10 @@ __global__ __launch_bounds__(64 * pols_wpb(S), 1) void fir_pols_kernel(const flo
             for (int j = 0; j < 4; j++) radix4<1>(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
             if (k < 0) {
                 // warm-up: the spectrum enters the delay line, nothing comes out
+                if (P >= 4) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) S3[r] = S2[r];
+                }
                 if (P >= 3) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) S2[r] = S1[r];
@@ -216,6 +221,8 @@ __global__ __launch_bounds__(64 * pols_wpb(S), 1) void fir_pols_kernel(const flo
                 cf a = cmul(v[r], Hs[r * 64 + lane]);
                 if (P >= 2) a = cmac(a, S1[r], Hs[1024 + r * 64 + lane]);
                 if (P >= 3) a = cmac(a, S2[r], Hs[2048 + r * 64 + lane]);
+                if (P >= 4) a = cmac(a, S3[r], Hs[3072 + r * 64 + lane]);
+                if (P >= 4) S3[r] = S2[r];
                 if (P >= 3) S2[r] = S1[r];
                 if (P >= 2) S1[r] = v[r];
                 v[r] = a;

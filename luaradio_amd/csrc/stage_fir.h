@@ -432,7 +432,7 @@ struct FirStage : lrhip_stage {
     int launch_pols_p(const float *x, long n, float *y, long n_out, int part0)
     {
         const size_t lds_bytes = (size_t)pols_lds_elems(SS, PP) * sizeof(float2);
-        constexpr int POLS_WPB = pols_wpb(SS);
+        constexpr int POLS_WPB = pols_wpb(SS, PP);
         auto kern = fir_pols_kernel<SS, PP>;
         if (prepared_blocks(kern, lds_bytes, 64 * POLS_WPB) < 0) return -1;
         // a wave owns a run of consecutive blocks (its spectra delay line); runs of ~40 blocks keep the P - 1 warm-up blocks of a run under 5 %,
@@ -458,9 +458,15 @@ struct FirStage : lrhip_stage {
     {
         const int nparts = (M + FFT_PART - 1) / FFT_PART;
         hist_in_kernel = false;
-        for (int p0 = 0; p0 < nparts; p0 += 3) {
-            const int P = nparts - p0 < 3 ? nparts - p0 : 3;
-            const int rc = P == 3 ? launch_pols_p<SS, 3>(x, n, y, n_out, p0) : P == 2 ? launch_pols_p<SS, 2>(x, n, y, n_out, p0) : launch_pols_p<SS, 1>(x, n, y, n_out, p0);
+        // partitions per launch: 3 (the delay line of two spectra in registers at three waves per SIMD); LRHIP_POLS_P=4 (A/B, round 5): four per launch -
+        // 4 096 taps in two launches instead of three, at the price of 32 more registers per lane
+        static const int pmax_env = getenv("LRHIP_POLS_P") ? atoi(getenv("LRHIP_POLS_P")) : 3;
+        const int PMAX = (pmax_env == 4 && SS == 2) ? 4 : 3;
+        for (int p0 = 0; p0 < nparts; p0 += PMAX) {
+            const int P = nparts - p0 < PMAX ? nparts - p0 : PMAX;
+            int rc;
+            if constexpr (SS == 2) rc = P == 4 ? launch_pols_p<SS, 4>(x, n, y, n_out, p0) : P == 3 ? launch_pols_p<SS, 3>(x, n, y, n_out, p0) : P == 2 ? launch_pols_p<SS, 2>(x, n, y, n_out, p0) : launch_pols_p<SS, 1>(x, n, y, n_out, p0);
+            else rc = P == 3 ? launch_pols_p<SS, 3>(x, n, y, n_out, p0) : P == 2 ? launch_pols_p<SS, 2>(x, n, y, n_out, p0) : launch_pols_p<SS, 1>(x, n, y, n_out, p0);
             if (rc) return rc;
         }
         return 0;

@@ -114,6 +114,7 @@ def test_iq_file_source_becomes_the_head_of_the_device_chain(tmp_path, fifo):
     assert ml.index(chain, "blocks").length() == 8 and ml.index(chain, "source") is blocks.get(1) and ml.index(chain, "sink") is None
     assert len(conns.hash) == 1                                     # chain -> sink is the only edge left: one socket, two processes
     chain.set("batch_samples", 65536.0)
+    chain.set("source_batch_bytes", 0.0)
     ml.call(ml.index(chain, "run"), [chain])
     t = proxy.trace
     # the chain's stages, in order: the format conversion first
@@ -175,6 +176,7 @@ def test_file_to_file_chain_has_no_ports_and_runs_its_own_loop(tmp_path):
     chain = devs[0]
     assert ml.index(chain, "inputs").length() == 0 and ml.index(chain, "outputs").length() == 0 and ml.index(chain, "blocks").length() == 9
     chain.set("batch_samples", 32768.0)
+    chain.set("source_batch_bytes", 0.0)
     ml.call(ml.index(chain, "run"), [chain])
     assert [a_ for n_, a_ in proxy.fake.calls if n_ == "lrhip_format_pack_create"] == [[b"f32le", 0]]
     ch = [v for v in proxy.fake.stage_info.values() if v["kind"] == "chain"][0]
@@ -671,10 +673,10 @@ def test_gpu_lua_wbfm_receiver_from_a_u8_file_gives_the_bits_of_the_python_examp
     glue against the real liblrhip.so, delivers the audio of examples/iqfile_wbfm_mono.py bit for bit (same batches of 2^20 records), in ONE launch per batch"""
     lr, L = real_lib()
     from examples.iqfile_wbfm_mono import build_chain, demodulate
-    n = 2 * (1 << 20) + 345678
+    n = 2 * (1 << 22) + 345678
     raw = wbfm_u8_capture(n)
     src, chain, rate = build_chain(raw, "u8", 1102500.0, -250e3)
-    want = demodulate(src, chain, 1 << 20)
+    want = demodulate(src, chain, 1 << 22)              # the Lua chain's default batch for a file it reads itself: 8 MiB of records (source_batch_bytes)
     path = tmp_path / "x.u8"
     path.write_bytes(raw)
     I, proxy, ffi = interp(real_lib=L)
@@ -742,6 +744,7 @@ def test_gpu_lua_file_to_file_chain_writes_the_bytes_of_the_python_blocks(tmp_pa
     c = I.run(TRANSCODE, "transcode", [str(path), str(out), fvec(taps)])[0]
     c.set("exact", True)
     c.set("batch_samples", 262144.0)
+    c.set("source_batch_bytes", 0.0)
     ml.call(ml.index(c, "run"), [c])
     got = out.read_bytes()
     assert len(got) == len(want) == 4 * ((n + 3) // 4)

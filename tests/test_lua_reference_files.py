@@ -189,6 +189,7 @@ def test_the_patched_reference_files_build_the_receiver_chain_from_a_u8_file(tmp
                     "radio/utilities/window_utils.lua", "radio/core/class.lua"):
             assert rel in loaded_real, rel
         chain.set("batch_samples", 65536.0)
+        chain.set("source_batch_bytes", 0.0)
         ml.call(ml.index(chain, "run"), [chain])
         t = proxy.trace
         i = t.index("lrhip_chain_create_ex")
