@@ -458,10 +458,12 @@ struct FirStage : lrhip_stage {
     {
         const int nparts = (M + FFT_PART - 1) / FFT_PART;
         hist_in_kernel = false;
-        // partitions per launch: 3 (the delay line of two spectra in registers at three waves per SIMD); LRHIP_POLS_P=4 (A/B, round 5): four per launch -
-        // 4 096 taps in two launches instead of three, at the price of 32 more registers per lane
-        static const int pmax_env = getenv("LRHIP_POLS_P") ? atoi(getenv("LRHIP_POLS_P")) : 3;
-        const int PMAX = (pmax_env == 4 && SS == 2) ? 4 : 3;
+        // partitions per launch: up to 3 at twelve waves per CU (a delay line of two spectra in registers, 168 registers per lane).  Round 5: a ComplexFloat32 filter of
+        // four partitions and more (1 537 taps up) takes FOUR per launch at eight waves per CU (three spectra, 256 registers): 4 096 taps in two launches instead
+        // of three - same box, three alternations (profiles/r05_ab_pols_p4.txt): 1.4846 / 1.4822 / 1.4842 -> 1.1281 / 1.1296 / 1.1158 ms on 2^26 samples.
+        // LRHIP_POLS_P=3 is the round-4 split (A/B knob).
+        static const int pmax_env = getenv("LRHIP_POLS_P") ? atoi(getenv("LRHIP_POLS_P")) : 4;
+        const int PMAX = (pmax_env == 4 && SS == 2 && nparts >= 4) ? 4 : 3;
         for (int p0 = 0; p0 < nparts; p0 += PMAX) {
             const int P = nparts - p0 < PMAX ? nparts - p0 : PMAX;
             int rc;

@@ -42,7 +42,7 @@ def find(rows, *subs):
 
 def main():
     prof, out = sys.argv[1], sys.argv[2]
-    tag = sys.argv[3] if len(sys.argv) > 3 else "r04"
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r05"
     bench = parse(prof + "/summary_kernel_trace.txt")
     blocks = parse(prof + "/summary_blocks_kernel_trace.txt")
     pmc = parse_pmc(prof + "/summary_pmc_blocks.txt")
@@ -90,7 +90,7 @@ def main():
         ("FIR 768 real taps cf32, overlap-save, one 4096-point launch (a wave per block, 64 x 64)", blocks, ("fir_fft64_kernel<768, 8>",), 16, n26, 160),
         ("FIR 1276 complex taps cf32, overlap-save, 4096-point launch (a wave per block, four waves per CU, full H)", blocks, ("fir_fft64_kernel<1280, 4>",), 16, n26, 180),
         ("FIR 1276 real taps f32, overlap-save, partitioned (kernels_firpols.h, one launch)", blocks, ("fir_pols_kernel<1, 3>",), 8, n26, 250),
-        ("FIR 4096 real taps cf32, overlap-save, partitioned: one of three launches (3 x 16 B + 2 x 8 B accumulate per sample in all)", blocks, ("fir_pols_kernel<2, 3>",), 16, n26, 250),
+        ("FIR 4096 real taps cf32, overlap-save, partitioned: one of TWO launches of four partitions each (2 x 16 B + 8 B accumulate per sample in all)", blocks, ("fir_pols_kernel<2, 4>",), 16, n26, 330),
         ("WBFM mono receiver from u8 IQ records, ONE launch (bench_blocks: noise input)", blocks, ("rx_fused_kernel<1>",), 2.16, n26, 167),
         ("Tuner from u8 IQ records (fan-out branch fed from a file), ONE launch", blocks, ("fir_mfma_persistent_kernel<2, 5, 2, true, 51, 0, false, 4, 1",), 3.6, n26, 108.4),
         ("Tuner(decimation 50) from u8 IQ records, ONE launch (AM / SSB / NBFM receivers fed from a file)", blocks, ("fir_decim_lds_kernel<2, true, false, 1",), 2.16, n26, 16.2),
