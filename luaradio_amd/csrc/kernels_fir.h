@@ -458,7 +458,8 @@ __device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, 
 // The last valid output of the chunk is published as the carried previous sample.
 template <int D, int NACC, bool REL = false>
 __device__ __forceinline__ void disc_epilogue(float *__restrict__ y, long tile_k0, long n_out, int out_aligned, f32x4 (&acc)[1][NACC],
-                                              float2 *__restrict__ edge_tile, float2 *__restrict__ prev_out, double inv_gain, cf pt = cf{1.f, 0.f})
+                                              float2 *__restrict__ edge_tile, float2 *__restrict__ prev_out, double inv_gain, cf pt = cf{1.f, 0.f},
+                                              bool stream_start = false)
 {
     using G = FirMfmaGeom<2, D>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -491,7 +492,7 @@ __device__ __forceinline__ void disc_epilogue(float *__restrict__ y, long tile_k
         }
         if (k == n_out - 1) *prev_out = leave(o0);
         if (k + 1 == n_out - 1) *prev_out = leave(o1);
-        if (a == 0 && lane == 0) edge_tile[2 * wave] = leave(o0);
+        if (a == 0 && lane == 0) edge_tile[2 * wave] = (REL && stream_start && wave == 0) ? snap_stream_first(leave(o0)) : leave(o0);
         if (a == NACC - 1 && lane == 63) edge_tile[2 * wave + 1] = leave(o1);
     }
 }
@@ -1160,7 +1161,7 @@ __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_pe
 #else
             cf pt = cf{1.f, 0.f};
             if constexpr (REL) pt = phasor_poly(rot_step_fx * (rot_count0 + (uint64_t)xlo_of(t)));
-            disc_epilogue<D, NACC, REL>(y, tile_k0, n_out, out_aligned, acc, edge + 2 * NW * t, prev_out, inv_gain, pt);
+            disc_epilogue<D, NACC, REL>(y, tile_k0, n_out, out_aligned, acc, edge + 2 * NW * t, prev_out, inv_gain, pt, REL && t == 0 && rot_count0 == 0 && first == 0);
 #endif
         }
         __syncthreads();      // everyone is done reading ldsX before it is overwritten

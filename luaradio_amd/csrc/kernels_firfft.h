@@ -91,11 +91,17 @@ namespace lrhip {
 constexpr int FFTN = 1024;
 constexpr int FFT_E1_ROW = 68;
 constexpr int FFT_E2_ROW = 68;
-// LRHIP_FFT_E2_SWAP row strides.  E1 (forward): write element (k, lane) at k * R + lane (consecutive lanes: conflict-free for any R); read element
-// (k1s, 4 i + sub) at k1s * R + 4 i + sub - a 32-lane read group is k1s = 0..15 x sub in {0, 1} (or {2, 3}), bank pair (R k1s + sub) mod 32: R = 66 -> 2 k1s + sub,
-// all 32 distinct.  E1 inverse: WRITE element (k1s, 4 i + sub) - a 16-lane write group is k1s = 0..15 at one sub, bank pair (R k1s) mod 16: needs R odd, 65;
-// its read side (k, lane) is consecutive again.  Two strides because no single one serves both a 32-lane read group and a 16-lane write group.
-constexpr int FFT_E1F_ROW_SW = 66;
+// LRHIP_FFT_E2_SWAP row stride.  hipcc pairs neighbouring accesses into ds_read2_b64 / ds_read2st64_b64 / ds_write2_b64 (the ISA of this kernel has 43 paired
+// reads, 15 paired writes and only 4 + 3 single ones), and a paired access is served in FOUR groups of 16 contiguous lanes with bank pair = (8-byte index)
+// mod 16 (MI355X_MICROARCH.md, LDS table) - reads too, not only writes.  E1 forward: write element (k, lane) at k R + lane (consecutive lanes: fine for any R);
+// read element (k1s, 4 i + sub) at k1s R + 4 i + sub - a 16-lane group is one ROW (one sub), k1s = 0..15, bank pair (R k1s) mod 16: R odd.  E1 inverse: the
+// same two patterns with read and write exchanged.  R = 65 serves all four.  (The first cut used 66 for the forward transpose - derived for single
+// ds_read_b64s, two groups of 32 lanes over 32 bank pairs - and the counters showed it: SQ_LDS_BANK_CONFLICT 4.19 M cycles per 2^26-sample launch, 12 % of
+// the LDS-active cycles, where the round-4 layout had 0; profiles/r05_streaming_rows_counters.txt.)
+#ifndef LRHIP_FFT_E1F_ROW
+#define LRHIP_FFT_E1F_ROW 65      /* A/B: 66 = the first cut */
+#endif
+constexpr int FFT_E1F_ROW_SW = LRHIP_FFT_E1F_ROW;
 constexpr int FFT_E1I_ROW_SW = 65;
 constexpr int FFT_EX_ELEMS = LRHIP_FFT_SPLIT ? 16 * FFT_E2_ROW / 2 : 16 * FFT_E2_ROW;   // per-wave exchange buffer (float2 units)
 constexpr int FFT_WPB = LRHIP_FFT_WPB;

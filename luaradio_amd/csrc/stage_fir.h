@@ -125,6 +125,8 @@ struct FirStage : lrhip_stage {
         return 1UL;
     }
 
+    // MFMA steps of the 128-tap ComplexFloat32 Toeplitz filter at decimation d (fir_mfma_ksteps(128, d, 2)): the shapes with a discriminator epilogue
+    static constexpr int disc_ksteps(int d) { return (1 + 15 * d + 128 + 3) / 4; }
     template <int SS, int DD, int NACC>
     int launch_mfma(const float *x, long n, float *y, long n_out)
     {
@@ -136,6 +138,12 @@ struct FirStage : lrhip_stage {
         }
         if constexpr (DD == 5) {
             if (ksteps == 51) return launch_mfma_ks<SS, DD, NACC, 51>(x, n, y, n_out);     // M = 128 at D = 5 (Tuner / Decimator(5))
+        }
+        // Round 5: the Tuner of an FM receiver at OTHER input rates - decimation 4, 8, 10 at 128 taps - with the discriminator epilogue (only that
+        // combination: the plain Tuner / Decimator at these decimations keep the generic kernel)
+        if constexpr (SS == 2 && (DD == 4 || DD == 8 || DD == 10)) {
+            constexpr int KSD = disc_ksteps(DD);
+            if (post_disc && rot && ksteps == KSD) return launch_mfma_ks<SS, DD, NACC, KSD>(x, n, y, n_out);
         }
         return launch_mfma_ks<SS, DD, NACC, 0>(x, n, y, n_out);
     }
@@ -210,9 +218,15 @@ struct FirStage : lrhip_stage {
                 return 0;
             };
             int rc2;
-            if constexpr (SS == 2 && (DD == 1 || DD == 5)) {
+            if constexpr (SS == 2 && (DD == 4 || DD == 8 || DD == 10)) {
+                // only the Tuner + discriminator form is instantiated at these decimations (launch_mfma)
+                if (!(post_disc && rot)) return set_error("internal: decimation %d has a persistent kernel for tuner + discriminator only", DD);
+            }
+            if constexpr (SS == 2 && (DD == 1 || DD == 5 || DD == 4 || DD == 8 || DD == 10)) {
                 if (post_disc) {
-                    if constexpr (NW == 1) rc2 = launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1, true, 1>);
+                    if constexpr (DD == 4 || DD == 8 || DD == 10)
+                        rc2 = rel_rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1, true>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1, false>);
+                    else if constexpr (NW == 1) rc2 = launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1, true, 1>);
                     else if constexpr (LRHIP_DISC_EPI_LDS) rc2 = rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS, 1>);
                     else rc2 = !rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS, 1>)
                              : rel_rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1, true>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS, 1, false>);
@@ -255,9 +269,12 @@ struct FirStage : lrhip_stage {
                 }
             }
             if (raw_now) return set_error("internal: raw records reached a kernel without a record instantiation");
-            if constexpr (SS == 2) rc2 = rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS>);
-            else rc2 = rot ? set_error("rotator fusion needs complex input") : launch(fir_mfma_persistent_kernel<1, DD, NACC, false, KS>);
-            if (rc2) return rc2;
+            if constexpr (DD == 4 || DD == 8 || DD == 10) return set_error("internal: no plain persistent kernel at decimation %d", DD);
+            else {
+                if constexpr (SS == 2) rc2 = rot ? launch(fir_mfma_persistent_kernel<2, DD, NACC, true, KS>) : launch(fir_mfma_persistent_kernel<2, DD, NACC, false, KS>);
+                else rc2 = rot ? set_error("rotator fusion needs complex input") : launch(fir_mfma_persistent_kernel<1, DD, NACC, false, KS>);
+                if (rc2) return rc2;
+            }
         } else {
             if (post_disc) return set_error("internal: discriminator epilogue without a persistent kernel variant");
             auto launch = [&](auto kern) -> int {
@@ -868,7 +885,15 @@ struct FirStage : lrhip_stage {
 
     static bool mfma_supported_decim(unsigned d) { return (d >= 1 && d <= 8) || d == 10; }
     // the discriminator epilogue exists for the persistent instantiations of the complex-stream, real-taps kernel
-    bool can_post_disc() const { return decfft || win_cplx_ok() || (S == 2 && !taps_complex && !fft_arith && !use_fft && ((D == 1 && ksteps == 36) || (D == 5 && ksteps == 51))); }
+    // (round 5: and for the Tuner - rotator fused - at decimation 4, 8, 10 with 128 taps: FM receivers at other input rates)
+    bool can_post_disc() const
+    {
+        if (decfft || win_cplx_ok()) return true;
+        if (!(S == 2 && !taps_complex && !fft_arith && !use_fft)) return false;
+        if ((D == 1 && ksteps == 36) || (D == 5 && ksteps == 51)) return true;
+        static const bool off = getenv("LRHIP_NO_DISC_EPI_OTHER_D") != nullptr;      // A/B knob: the round-4 behaviour
+        return !off && rot && (D == 4 || D == 8 || D == 10) && ksteps == disc_ksteps(D);
+    }
 
     // filter n inputs (device), emit the retained outputs; advances history / index / count
     long core(const float *x, long n, float *y, unsigned long cap)

@@ -424,3 +424,63 @@ def test_two_host_threads_on_two_objects_share_the_piece_pipeline_safely():
         assert all(g is not None for g in got)
         for k in range(2):
             assert np.array_equal(got[k], want[k]), k
+
+
+def shaped_receiver_blocks(rate, decim, audio_taps=128):
+    """the receiver of examples/rtlsdr_wbfm_mono.lua at another input rate / tuner decimation / audio tap count; every use_fft left to the library"""
+    c, f = types.ComplexFloat32, types.Float32
+    r1 = rate / decim
+    return [make(lr.FrequencyTranslatorBlock, [-250e3], c, rate), make(lr.LowpassFilterBlock, [128, 100e3], c, rate),
+            make(lr.DownsamplerBlock, [decim], c, rate), make(lr.FrequencyDiscriminatorBlock, [1.25], c, r1),
+            make(lr.LowpassFilterBlock, [audio_taps, 15e3], f, r1), make(lr.FMDeemphasisFilterBlock, [75e-6], f, r1),
+            make(lr.DownsamplerBlock, [5], f, r1)]
+
+
+def shaped_fm_signal(rate, n, seed=3):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / rate
+    m = 0.5 * np.sin(2 * np.pi * 1e3 * t) + 0.5 * np.sin(2 * np.pi * 5e3 * t)
+    ph = 2 * np.pi * 250e3 * t + 2 * np.pi * 75e3 / rate * np.cumsum(m)
+    return (np.exp(1j * ph) + 0.01 * (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n))).astype(np.complex64)
+
+
+@pytest.mark.parametrize("decim,audio_taps,max_launches", [(4, 128, 3), (8, 128, 3), (10, 128, 3), (5, 96, 4), (10, 160, 5)])
+def test_fm_receivers_off_the_stock_shape(decim, audio_taps, max_launches):
+    """the receiver at other tuner decimations (input rates 0.882 / 1.764 / 2.205 MS/s) and audio tap counts.  Round 5 gives the Toeplitz tuner
+    its discriminator epilogue at decimation 4, 8 and 10 too (tuner + discriminator = one launch instead of four).  Parity as for the stock shape: RMS <= 1e-5
+    against the oracle's chain (measured ~2e-8), for one chunk and for ragged chunks; the exact chain gives the bits of the blocks run one by one; and a
+    recording that starts ON the real axis - where the first angle is decided by the signs of zeros - gets the reference's first sample"""
+    rate = 220500.0 * decim
+    n = 300000
+    x = shaped_fm_signal(rate, n)
+    bb, aa = O.fm_deemphasis_taps(75e-6, rate / decim)
+    ora = O.Chain(O.tuner(-250e3, 200e3, decim, rate, mode=O.MODE_LUA, rot_mode=O.MODE_F64).stages +
+                  [O.FMDiscriminator(1.25), O.lowpass(audio_taps, 15e3, rate / decim, False, mode=O.MODE_LUA), O.IIR(bb, aa, False, O.MODE_LUA), O.Downsampler(5, False)])
+    want = ora.process(x)
+    chain = lr.Chain(shaped_receiver_blocks(rate, decim, audio_taps))
+    got = chain.process(x)
+    assert chain.last_launches <= max_launches, chain.last_launches
+    assert len(got) == len(want)
+    assert float(np.sqrt(np.mean((got.astype(np.float64) - want) ** 2))) <= 1e-5
+    assert float(np.max(np.abs(got.astype(np.float64) - want))) < 1e-5
+    ragged = lr.Chain(shaped_receiver_blocks(rate, decim, audio_taps))
+    got_r = run_chunked(ragged.process, x, [1, 7, 8192, 8193, 100000, 100001, 222222])
+    assert len(got_r) == len(want) and float(np.max(np.abs(got_r.astype(np.float64) - want))) < 1e-5
+    # the exact chain: what the blocks compute one by one, bit for bit, on the same chunks
+    cuts = [8192, 100001]
+    blocks = shaped_receiver_blocks(rate, decim, audio_taps)
+
+    def one_by_one(v):
+        for b in blocks:
+            v = b.process(v)
+        return v
+    exact = lr.Chain(shaped_receiver_blocks(rate, decim, audio_taps), exact=True)
+    assert np.array_equal(run_chunked(exact.process, x, cuts), run_chunked(one_by_one, x, cuts))
+    # tuner + discriminator alone on a clean carrier that starts at phase 0: sample 0 is arg(y[0] conj(0)) - zeros whose signs the reference's arithmetic
+    # decides (0 here for every decimation, also where the filter's first tap is negative)
+    t = np.arange(4096) / rate
+    clean = np.exp(1j * 2 * np.pi * 250e3 * t).astype(np.complex64)
+    td = lr.Chain(shaped_receiver_blocks(rate, decim, audio_taps)[:4])
+    ang = td.process(clean)
+    want_ang = O.Chain(O.tuner(-250e3, 200e3, decim, rate, mode=O.MODE_LUA, rot_mode=O.MODE_F64).stages + [O.FMDiscriminator(1.25)]).process(clean)
+    assert abs(float(ang[0]) - float(want_ang[0])) < 1e-6 and float(np.max(np.abs(ang - want_ang))) < 2e-6

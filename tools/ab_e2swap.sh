@@ -4,7 +4,7 @@
 ROOT=$(pwd)
 for lg in ${@:-28 26}; do
   for rnd in 1 2 3; do
-    for v in base e2swap; do
+    for v in base ${AB_VARIANT:-e2swap}; do
       lib=$ROOT/luaradio_amd/ab/liblrhip_$v.so; [ $v = base ] && lib=$ROOT/luaradio_amd/liblrhip.so
       LRHIP_LIB_PATH=$lib python tools/ab_knobs.py LRHIP_DUMMY $v --log2-samples $lg --reps 20 2>/dev/null | grep "round 1" | sed "s/^/2^$lg alt $rnd /"
     done
