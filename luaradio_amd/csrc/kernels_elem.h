@@ -171,18 +171,6 @@ __device__ __forceinline__ float discriminate(float2 a, float2 b, double inv_gai
     return fast_atan2f(ti, tr) * (float)inv_gain;
 }
 
-// The STREAM's first filter output meets the zero initial state: o[0] conj(0) is a zero product, and the reference's angle is then decided by the signs of
-// those zeros (discriminate()).  Under the window-relative rotator staging o[0] is the exact filter output times two phasors that multiply to one - a component
-// that is exactly zero in the unrotated arithmetic (a recording that starts on the real axis) comes back as rounding noise of either sign and would flip the
-// angle between 0 and pi.  A component below 2^-20 of the other one stands for that zero.  (Only this one sample of a stream: every later previous sample is
-// non-zero, or the product is zero in both arithmetics.)
-__device__ __forceinline__ float2 snap_stream_first(float2 o)
-{
-    if (fabsf(o.y) < 0x1p-20f * fabsf(o.x)) o.y = 0.f;
-    else if (fabsf(o.x) < 0x1p-20f * fabsf(o.y)) o.x = 0.f;
-    return o;
-}
-
 __global__ __launch_bounds__(256) void fmdiscrim_kernel(const float2 *__restrict__ x, float *__restrict__ y,
                                                         unsigned long n, double inv_gain,
                                                         const float2 *__restrict__ prev_in, float2 *__restrict__ prev_out)

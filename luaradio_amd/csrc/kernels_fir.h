@@ -459,7 +459,7 @@ __device__ __forceinline__ void store_tile(float *__restrict__ y, long tile_k0, 
 template <int D, int NACC, bool REL = false>
 __device__ __forceinline__ void disc_epilogue(float *__restrict__ y, long tile_k0, long n_out, int out_aligned, f32x4 (&acc)[1][NACC],
                                               float2 *__restrict__ edge_tile, float2 *__restrict__ prev_out, double inv_gain, cf pt = cf{1.f, 0.f},
-                                              bool stream_start = false)
+                                              bool stream_start = false, float2 o_first = make_float2(0.f, 0.f))
 {
     using G = FirMfmaGeom<2, D>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -492,7 +492,11 @@ __device__ __forceinline__ void disc_epilogue(float *__restrict__ y, long tile_k
         }
         if (k == n_out - 1) *prev_out = leave(o0);
         if (k + 1 == n_out - 1) *prev_out = leave(o1);
-        if (a == 0 && lane == 0) edge_tile[2 * wave] = (REL && stream_start && wave == 0) ? snap_stream_first(leave(o0)) : leave(o0);
+        // (stream_start: the stream's first output meets the zero initial state - o[0] conj(0) is a zero product and the reference's angle is then decided by
+        // the SIGNS of those zeros (discriminate()).  Under the window-relative staging o[0] is the exact output times two phasors that multiply to one: a
+        // component that is zero or tiny in the unrotated arithmetic comes back as rounding noise of either sign.  That ONE record takes its direct-form
+        // value, computed by the caller: h[0] x[0].)
+        if (a == 0 && lane == 0) edge_tile[2 * wave] = (REL && stream_start && wave == 0) ? o_first : leave(o0);
         if (a == NACC - 1 && lane == 63) edge_tile[2 * wave + 1] = leave(o1);
     }
 }
@@ -1161,7 +1165,17 @@ __global__ __launch_bounds__(64 * NW, LRHIP_FIR_WAVES_PER_SIMD) void fir_mfma_pe
 #else
             cf pt = cf{1.f, 0.f};
             if constexpr (REL) pt = phasor_poly(rot_step_fx * (rot_count0 + (uint64_t)xlo_of(t)));
-            disc_epilogue<D, NACC, REL>(y, tile_k0, n_out, out_aligned, acc, edge + 2 * NW * t, prev_out, inv_gain, pt, REL && t == 0 && rot_count0 == 0 && first == 0);
+            // the stream's first output in direct form (history is zero there: one product per component, the fmaf chain's value)
+            const bool stream_start = REL && t == 0 && rot_count0 == 0 && first == 0 && n > 0;
+            float2 o_first = make_float2(0.f, 0.f);
+            if constexpr (REL) {
+                if (stream_start) {
+                    const float h0 = ldsT[fir_taps_zl(D) + M - 1];
+                    const float2 x0 = rotate_sample(*reinterpret_cast<const float2 *>(x), rot_step_fx, (uint64_t)0);
+                    o_first = make_float2(fmaf(h0, x0.x, 0.f), fmaf(h0, x0.y, 0.f));
+                }
+            }
+            disc_epilogue<D, NACC, REL>(y, tile_k0, n_out, out_aligned, acc, edge + 2 * NW * t, prev_out, inv_gain, pt, stream_start, o_first);
 #endif
         }
         __syncthreads();      // everyone is done reading ldsX before it is overwritten
