@@ -579,6 +579,18 @@ constexpr int DECIM_SPAN_MAX = 6144;
 
 __device__ __forceinline__ int decim_phys(int p) { return p + (p >> 5); }
 
+// tools/ab_decim.hip builds this header with -DLRHIP_DECIM_TRACE: lane 0 of every wave of the first workgroups stamps the phases of its first tiles
+#ifdef LRHIP_DECIM_TRACE
+__device__ unsigned long long *lrhip_decim_trace;       // [block][wave][tile][8]
+#define DECIM_STAMP(i)                                                                                                                              \
+    do {                                                                                                                                            \
+        if (lrhip_decim_trace && blockIdx.x < 8 && trace_tile < 32 && (threadIdx.x & 63) == 0)                                                      \
+            lrhip_decim_trace[(((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + trace_tile) * 8 + (i)] = clock64();                               \
+    } while (0)
+#else
+#define DECIM_STAMP(i) do { } while (0)
+#endif
+
 // FMT > 0 (round 3): x holds raw IQ-file records (RX_FMT_*), converted while the tile is staged
 template <int S, bool ROT, bool CT = false, int FMT = 0>      // CT: ComplexFloat32 taps (S = 2), taps_rev as {re, im} pairs
 __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_rev,
@@ -668,7 +680,9 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
     const long t_end = rounds > 0 ? (t_first + rounds < ntiles ? t_first + rounds : ntiles) : ntiles;
     if (ROT) prefetch(t_first);
     else prefetch_plain(t_first);
+    [[maybe_unused]] int trace_tile = 0;
     for (long t = t_first; t < t_end; t += t_step) {
+        DECIM_STAMP(0);
         const long k0 = t * OW;                     // first output of the tile
         const long q0 = first + k0 * D;             // stream position of staged sample 0 (stream = [M-1 history | chunk])
         const long g0 = q0 - (M - 1);               // the same as an index into x (negative: history)
@@ -748,11 +762,14 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
             if (ROT) prefetch(t + t_step < t_end ? t + t_step : ntiles);
             else prefetch_plain(t + t_step < t_end ? t + t_step : ntiles);
         }
+        DECIM_STAMP(1);
         __syncthreads();
+        DECIM_STAMP(2);
         if (!LRHIP_DECIM_EARLY_PREFETCH) {
             if (ROT) prefetch(t + t_step < t_end ? t + t_step : ntiles);
             else prefetch_plain(t + t_step < t_end ? t + t_step : ntiles);
         }
+        DECIM_STAMP(3);
         const long k = k0 + tid;
         if (tid < OW && k < n_out) {
             int p = tid * (int)D;
@@ -827,7 +844,12 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
             else if (S == 2) nt_store(reinterpret_cast<float2 *>(y) + k, make_float2(re, im));
             else y[k] = re;
         }
+        DECIM_STAMP(4);
         __syncthreads();
+        DECIM_STAMP(5);
+#ifdef LRHIP_DECIM_TRACE
+        trace_tile++;
+#endif
     }
 }
 

@@ -14,6 +14,7 @@
 #include "kernels_fir.h"
 #include "kernels_firfft.h"
 #include "kernels_firdecfft.h"
+#include "kernels_firdecim.h"
 #include "kernels_channelizer.h"
 #include "kernels_iir.h"
 #include "kernels_agc.h"

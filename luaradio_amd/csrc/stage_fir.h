@@ -583,16 +583,25 @@ struct FirStage : lrhip_stage {
     // decimations without a Toeplitz instantiation (and taps too long for its LDS table): LDS-staged one-output-per-thread kernel
     bool decim_lds_ok() const { return !fft_arith && !use_fft && M + 255 <= DECIM_SPAN_MAX && !(taps_complex && rot); }
     int decim_blocks_per_cu = 0;
+    // round 5: the second form (kernels_firdecim.h) for a ComplexFloat32 stream, real taps and a decimation that is no multiple of four; LRHIP_DECIM_V1=1 keeps the first
+    bool decim_lds2_ok() const
+    {
+        static const bool v1_env = getenv("LRHIP_DECIM_V1") != nullptr;
+        return !v1_env && S == 2 && !taps_complex && D >= 2 && (D & 3) != 0 && M + 255 <= DECIM2_SPAN_MAX;
+    }
     int launch_decim_lds(const float *x, long n, float *y, long n_out)
     {
+        const bool v2 = decim_lds2_ok();
         // staged samples per tile: the kernel's registers allow DECIM_SPAN_MAX; LRHIP_DECIM_SPAN (A/B) asks for less = smaller tiles, more workgroups per CU
         static const long span_env = getenv("LRHIP_DECIM_SPAN") ? atol(getenv("LRHIP_DECIM_SPAN")) : 0;
-        const long span_max = span_env >= 512 && span_env < DECIM_SPAN_MAX && span_env >= M + 64 ? span_env : DECIM_SPAN_MAX;
+        const long span_cap = v2 ? DECIM2_SPAN_MAX : DECIM_SPAN_MAX;
+        const long span_max = span_env >= 512 && span_env < span_cap && span_env >= M + 64 ? span_env : span_cap;
         long ow = (span_max - M) / (long)D + 1;
         int OW = (int)(ow > 256 ? 256 : ow < 1 ? 1 : ow);
         long ntiles = (n_out + OW - 1) / OW;
         long span = (long)(OW - 1) * D + M;
-        size_t lds_bytes = ((size_t)(((taps_complex ? 2 : 1) * M + 3) & ~3) + (size_t)S * (span + (span >> 5) + 2)) * sizeof(float);
+        size_t lds_bytes = v2 ? ((size_t)((M + 3) & ~3) + (size_t)2 * (span + DECIM2_PAD_SLOTS)) * sizeof(float)
+                              : ((size_t)(((taps_complex ? 2 : 1) * M + 3) & ~3) + (size_t)S * (span + (span >> 5) + 2)) * sizeof(float);
         const float *h = (const float *)hist[cur].p + hist_pad;
         float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
         auto go = [&](auto kern) -> int {
@@ -607,7 +616,16 @@ struct FirStage : lrhip_stage {
             return 0;
         };
         int rc;
-        if (raw_now) {
+        if (v2) {
+            {
+                if (raw_now)
+                    rc = rot ? (in_fmt == RX_FMT_U8 ? go(fir_decim_lds2_kernel<true, RX_FMT_U8>) : in_fmt == RX_FMT_S8 ? go(fir_decim_lds2_kernel<true, RX_FMT_S8>)
+                                                                                                  : go(fir_decim_lds2_kernel<true, RX_FMT_S16LE>))
+                             : (in_fmt == RX_FMT_U8 ? go(fir_decim_lds2_kernel<false, RX_FMT_U8>) : in_fmt == RX_FMT_S8 ? go(fir_decim_lds2_kernel<false, RX_FMT_S8>)
+                                                                                                   : go(fir_decim_lds2_kernel<false, RX_FMT_S16LE>));
+                else rc = rot ? go(fir_decim_lds2_kernel<true>) : go(fir_decim_lds2_kernel<false>);
+            }
+        } else if (raw_now) {
             if (taps_complex || S != 2) return set_error("internal: raw records reached a kernel without a record instantiation");
             rc = rot ? (in_fmt == RX_FMT_U8 ? go(fir_decim_lds_kernel<2, true, false, RX_FMT_U8>) : in_fmt == RX_FMT_S8 ? go(fir_decim_lds_kernel<2, true, false, RX_FMT_S8>)
                                                                                                : go(fir_decim_lds_kernel<2, true, false, RX_FMT_S16LE>))
