@@ -139,6 +139,18 @@ __device__ __forceinline__ cf rx_stream_at(const float *__restrict__ hist, const
     return rx_raw_sample<FMT>(b[0], b[1]);
 }
 
+// -DLRHIP_RX_TRACE (a variant library, tools/rx_trace.sh): lane 0 of every wave of the first workgroups stamps the phases of its first tiles with clock64()
+#ifdef LRHIP_RX_TRACE
+__device__ unsigned long long *lrhip_rx_trace;          // [block 8][wave 4][tile 64][8]
+#define RX_STAMP(i)                                                                                                                                 \
+    do {                                                                                                                                            \
+        if (lrhip_rx_trace && blockIdx.x < 8 && trace_tile < 64 && (threadIdx.x & 63) == 0)                                                         \
+            lrhip_rx_trace[(((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + trace_tile) * 8 + (i)] = clock64();                                  \
+    } while (0)
+#else
+#define RX_STAMP(i) do { } while (0)
+#endif
+
 template <int FMT>
 __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(const RxParams pr)
 {
@@ -239,7 +251,9 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
     };
     prefetch(t);
 
+    [[maybe_unused]] int trace_tile = 0;
     for (; t < tend; t++) {
+        RX_STAMP(0);
         const bool warm = t < t0;
         const int tau = warm ? RX_TPB - 1 : (int)((t - t0) % RX_TPB);  // place of the tile in its batch (the warm-up tile: the last of the batch in front)
         const long bidx = warm ? 0 : (t - t0) / RX_TPB;               // batch of the run
@@ -279,8 +293,11 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
         } else {
             stage_edge<S, D, true, true, NT>(ldsX, hist, x, pr.first_a + tile_k0 * D - pr.e, RX_SPAN, M, n, pr.rot_step_fx, pr.rot_count0);
         }
+        RX_STAMP(1);
         __syncthreads();                                              // (A) window staged; the previous tile's patches and history copy are visible
+        RX_STAMP(2);
         prefetch(t + 1 < tend ? t + 1 : tend);
+        RX_STAMP(3);
 
         // ---- filter: banded-Toeplitz product on the f32 matrix cores, one accumulator (128 outputs) per wave
         f32x4 acc[1][RX_NACC];
@@ -299,6 +316,7 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
         // frees the window) or, for wave 0, the previous TILE's last output, which lives in that tile's phase basis: bases of consecutive tiles
         // differ by the constant phasor R = exp(j omega TILE D), so lane 0 takes prev * conj(R).  Only a run's very first sample meets a
         // predecessor in absolute phase (the carried one) and pays for the tile's own phasor.
+        RX_STAMP(4);
 #if LRHIP_RX_NACC == 1
         // (one accumulator per wave: the round-3 epilogue, kept verbatim - the generalised form below compiles 1.6 % slower at one accumulator)
         {
@@ -313,7 +331,9 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
             float2 p = make_float2(__shfl(o1.x, src), __shfl(o1.y, src));
             float2 *eo_t = eo + 4 * (int)(t & 1), *eo_p = eo + 4 * (int)((t & 1) ^ 1);     // last outputs of the four waves: this tile's, the previous tile's
             if (lane == 63) eo_t[wave] = o1;
+            RX_STAMP(5);
             __syncthreads();                                          // (B) window free; the waves' last outputs are visible
+            RX_STAMP(6);
             // (+ 0: a silent stretch gives exactly +0 filter outputs, but +0 times a phasor with negative parts is -0, and the angle of a zero product
             // is decided by the signs of the zeros - frequencydiscriminator.lua:74 via discriminate(): keep what the reference's own operands would be)
             if (lane == 0) p = wave ? eo_t[wave - 1] : cf_to(cmulc(cf_from(eo_p[3]), tileR) + cf{0.f, 0.f});
@@ -386,6 +406,10 @@ __global__ __launch_bounds__(256, LRHIP_RX_WAVES_PER_SIMD) void rx_fused_kernel(
         }
 #endif
 
+        RX_STAMP(7);
+#ifdef LRHIP_RX_TRACE
+        trace_tile++;
+#endif
         const bool last_tile = t == pr.ntiles - 1;
         if (tau == RX_TPB - 1 || t == tend - 1) {
             __syncthreads();                                          // (P) the batch's angles are all in P

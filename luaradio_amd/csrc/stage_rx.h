@@ -153,8 +153,45 @@ struct RxStage : lrhip_stage {
         if (wgs < 1 || wgs > most) wgs = most;
         pr.dbg = ablation_bits("LRHIP_RX_DBG");      // ablation bits (WRONG results): 0 unless the library was built with -DLRHIP_ABLATION
         const unsigned grid = (unsigned)wgs;
+#ifdef LRHIP_RX_TRACE
+        static unsigned long long *trace = nullptr;
+        static long trace_launches = 0;
+        const size_t trace_n = (size_t)8 * 4 * 64 * 8;
+        if (!trace) {
+            LR_HIP(hipMalloc(&trace, trace_n * 8));
+            LR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(lrhip_rx_trace), &trace, sizeof(trace)));
+        }
+        if (++trace_launches == 12) LR_HIP(hipMemsetAsync(trace, 0, trace_n * 8, ctx().stream));
+#endif
         (void)with_kernel([&](auto kern) -> int { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, pr); return 0; });
         LR_LAUNCH_CHECK();
+#ifdef LRHIP_RX_TRACE
+        if (trace_launches == 12) {
+            // stamps: 0 loop top, 1 staged, 2 behind barrier A, 3 prefetch issued, 4 matrix product done, 5 exchange done, 6 behind barrier B, 7 angles in P; the
+            // time from 7 to the next tile's 0 is the audio tail (every RX_TPB-th tile)
+            LR_HIP(hipStreamSynchronize(ctx().stream));
+            std::vector<unsigned long long> tr(trace_n);
+            LR_HIP(hipMemcpy(tr.data(), trace, trace_n * 8, hipMemcpyDeviceToHost));
+            static const char *names[8] = {"stage", "barrierA", "prefetch", "mfma", "exchange", "barrierB", "disc", "tail"};
+            for (int w = 0; w < 4; w++) {
+                double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tile = 0;
+                int cnt = 0;
+                for (int b = 0; b < 8; b++)
+                    for (int t = 2; t < 62; t++) {
+                        const unsigned long long *s = &tr[(((size_t)b * 4 + w) * 64 + t) * 8], *nx = s + 8;
+                        if (!s[0] || !s[7] || !nx[0]) continue;
+                        for (int i = 0; i < 7; i++) sum[i] += (double)(s[i + 1] - s[i]);
+                        sum[7] += (double)(nx[0] - s[7]);
+                        tile += (double)(nx[0] - s[0]);
+                        cnt++;
+                    }
+                if (!cnt) continue;
+                fprintf(stderr, "rx trace wave %d (%d tiles):", w, cnt);
+                for (int i = 0; i < 8; i++) fprintf(stderr, "  %s %.0f", names[i], sum[i] / cnt);
+                fprintf(stderr, "  | tile %.0f clocks\n", tile / cnt);
+            }
+        }
+#endif
         // what FirStage::core() does for each of the two stages
         A->hist_in_kernel = true; A->fix_ready = false;
         A->cur ^= 1; A->disc_cur ^= 1;

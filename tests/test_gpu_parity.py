@@ -841,6 +841,36 @@ def test_randomized_chunkings_fused_chains_equal_unfused_blocks(seed):
             assert np.array_equal(got, want), name
 
 
+@pytest.mark.parametrize("decim,ntaps", [(50, 128), (25, 128), (18, 64), (75, 200), (50, 16), (6, 77), (9, 33)])
+@pytest.mark.parametrize("rotate", [True, False])
+def test_lds_staged_decimator_second_form_many_tiles(decim, ntaps, rotate):
+    """kernels_firdecim.h (ComplexFloat32 stream, real taps, decimation not a multiple of four): hundreds of tiles per workgroup slot, the cuts at odd and
+    even absolute offsets (whole-block staging on the aligned ones, the per-sample path on the others and on the tiles that touch the carried history), tiles
+    of <= 128 outputs spread over the four waves - with the rotator their taps split over the two half-waves, so the Tuner is compared with the oracle to
+    Float32 rounding and, bit for bit, with itself under another chunking; without it the result is the direct form's fmaf chain exactly."""
+    rng = np.random.default_rng(7 * decim + ntaps + rotate)
+    rate = 1102500.0
+    n = 1_500_001
+    x = rand_c(rng, n)
+    bw = rate / decim * 0.8
+
+    def blk():
+        if rotate:
+            return make(lr.TunerBlock, [-100e3, bw, decim, {"num_taps": ntaps}], x, rate=rate)
+        return make(lr.DecimatorBlock, [decim, {"num_taps": ntaps}], x, rate=rate)
+
+    whole = blk().process(x)
+    got = chunked(blk(), x, [1, 2, 7, 400001, 400004, 400005, 1200005, 1200006])
+    assert len(got) == len(whole) == (n + decim - 1) // decim
+    assert np.array_equal(got, whole)
+    if rotate:
+        want = O.tuner(-100e3, bw, decim, rate, num_taps=ntaps, mode=O.MODE_FMA, rot_mode=O.MODE_F64).process(x)
+        assert G.max_abs_err(got, want) < 2e-6
+    else:
+        want = O.decimator(decim, rate, True, num_taps=ntaps, mode=O.MODE_FMA).process(x)
+        assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("decim", [1, 5])
 def test_rotator_fir_fusion_odd_sample_offsets(decim):
     """the fused rotator stages aligned blocks of 8 samples; after an odd number of consumed samples the blocks no longer line

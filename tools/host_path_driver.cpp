@@ -5,7 +5,7 @@
 //     push      read(2) of 8 192 / 131 072 records into a user buffer + lrhip_chain_push per read     (a DeviceChainBlock fed by a pipe: pipe.lua:495-533)
 //     ring      read(2) of 2^20 records straight into lrhip_chain_ring_input + lrhip_chain_submit      (IQFileSource absorbed, FIFO / device path)
 //     fd        lrhip_chain_submit_fd: the library preads the records itself on its copy threads       (IQFileSource absorbed, regular file)
-//   stand-alone LowpassFilterBlock(128) ComplexFloat32 -> ComplexFloat32, 2^20-sample vectors, lrhip_stage_execute: staged and with registered vectors.
+//   stand-alone LowpassFilterBlock(128) ComplexFloat32 -> ComplexFloat32, 2^20-sample vectors, lrhip_stage_execute: staged and with registered vectors; 2^22-sample vectors registered.
 //
 // One JSON object per line on stdout; bench.py folds them into its host_path leg.  Every leg's output is checksummed (sum of the output samples in double) and
 // the legs of one input format must agree with each other to the chain's stated rounding - bench.py checks that; bit-level verification of the same paths is
@@ -181,14 +181,15 @@ int main(int argc, char **argv)
     }
     // stand-alone block, both directions over the link
     {
-        const unsigned long vec = 1ul << 20;
         std::vector<float> taps = firwin_lowpass(128, 15e3 / (220500.0 / 2));
         float *x = nullptr, *y = nullptr;
         if (posix_memalign((void **)&x, 4096, total * 8) || posix_memalign((void **)&y, 4096, total * 8)) return 1;
         memcpy(x, cf.data(), total * 8);
         memset(y, 0, total * 8);
-        for (int registered = 0; registered < 2; registered++) {
-            if (registered) { CHK0(lrhip_host_register(x, total * 8)); CHK0(lrhip_host_register(y, total * 8)); }
+        for (int leg = 0; leg < 3; leg++) {                    // 2^20-sample vectors staged / registered, 2^22-sample vectors registered
+            const int registered = leg > 0;
+            const unsigned long vec = leg == 2 && total >= (1ul << 22) ? (1ul << 22) : (1ul << 20);
+            if (leg == 1) { CHK0(lrhip_host_register(x, total * 8)); CHK0(lrhip_host_register(y, total * 8)); }
             double best = 0;
             for (int pass = 0; pass < 3; pass++) {
                 lrhip_stage_t *q;
@@ -203,7 +204,7 @@ int main(int argc, char **argv)
             printf("{\"leg\": \"standalone_lowpass_cf32\", \"mode\": \"%s\", \"vector_samples\": %lu, \"MSamples/s\": %.1f, \"each_direction_GB/s\": %.2f, \"checksum\": %.9g}\n",
                    registered ? "registered" : "staged", vec, best / 1e6, 8.0 * best / 1e9, checksum(y, (long)(2 * total)));
             fflush(stdout);
-            if (registered) { lrhip_host_unregister(x); lrhip_host_unregister(y); }
+            if (leg == 2) { lrhip_host_unregister(x); lrhip_host_unregister(y); }
         }
         free(x); free(y);
     }
