@@ -32,6 +32,18 @@ constexpr int DECIM2_PAD_SLOTS = 16;
 #define LRHIP_DECIM2_SPLIT 1      /* rotator form, tiles of <= 128 outputs: 1 - the upper half-wave takes the second half of the taps; 0 - it idles as in the plain form */
 #endif                          // slots in front of / behind the window that the whole-block staging may write
 
+// Decimations that are a multiple of four: a thread stride of D samples would put 4 .. 32 lanes of a half-wave on one bank pair, so the window is dealt out
+// over E = 4 / 8 / 16 phase arrays (sample p -> array p mod E, index p / E).  D is a multiple of E: a thread's tap r lies in array (a + r) mod E for EVERY
+// lane, at index oi D / E + (a + r) / E - a lane stride of D / E samples, odd for D = E x odd (TunerBlock(.., 80) of rtlsdr_pocsag.lua / rtlsdr_ax25.lua: 5).
+// The array stride is 16 / E mod 16 so that the staging writes of sixteen consecutive lanes (which walk through the arrays) fall on sixteen bank pairs.
+__host__ __device__ __forceinline__ int decim2_esh(long D) { return (D & 3) ? 0 : (D & 7) ? 2 : (D & 15) ? 3 : 4; }
+__host__ __device__ __forceinline__ int decim2_arr(int span, int esh) { return ((((span + DECIM2_PAD_SLOTS) >> esh) + 1 + 15) & ~15) + (16 >> esh); }
+__host__ __device__ __forceinline__ int decim2_slots(int span, long D)
+{
+    const int esh = decim2_esh(D);
+    return esh ? (decim2_arr(span, esh) << esh) : span + DECIM2_PAD_SLOTS;
+}
+
 // acc += x * h for a (re, im) pair and ONE real tap: HI = 0 takes the tap from the low half of `hp`, 1 from the high half (the taps arrive as float4 = two
 // pairs, no register moves).  The two lanes of v_pk_fma_f32 are IEEE fma: the bits of fmaf(x.x, h, acc.x), fmaf(x.y, h, acc.y).
 template <int HI>
@@ -53,7 +65,8 @@ __device__ __forceinline__ float quad_bcast(float v, int j)       // j: a consta
     }
 }
 
-template <bool ROT, int FMT = 0>
+// PH: the phase-array layout (decimations that are a multiple of four); without it `esh` is the constant 0 and none of its code exists
+template <bool ROT, int FMT = 0, bool PH = false>
 __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_rev,
                                                              float *__restrict__ y, int M, long n, long n_out, long first, long D, int OW, long ntiles,
                                                              uint64_t rot_step_fx, uint64_t rot_count0, float *__restrict__ hist_out, int post_op, int rounds)
@@ -66,6 +79,8 @@ __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__r
         for (int i = tid; i < (M - 1) * 2; i += 256) hist_out[i] = stream_at_raw<FMT>(hist, x, n + i / 2, i % 2, M, n);
     for (int i = tid; i < M; i += 256) ldsT[i] = taps_rev[i];
     const int span = (int)((OW - 1) * D) + M;
+    const int esh = PH ? decim2_esh(D) : 0, emask = (1 << esh) - 1, arr = PH ? decim2_arr(span, esh) : 0;
+    auto slot_of = [&](int p) { return esh ? (p & emask) * arr + (p >> esh) : p; };
     // Rotator form: a thread takes the 16-byte words tid + 256 k of the window (lane-contiguous loads and LDS writes): always pair q = tid & 3 of an aligned
     // block of eight - it needs W[2q], W[2q + 1] only - and block (tid >> 2) + 64 k.  The block phasors P() are the expensive part (one polynomial each);
     // the four lanes of a quad share a block, so lane i of the quad evaluates the polynomials of the loads k = i, i + 4, i + 8 and the others fetch them with
@@ -134,6 +149,14 @@ __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__r
     const int t_lo = part ? (Mh < M ? Mh : M) : 0, t_hi = part ? (split ? M : 0) : (Mh < M ? Mh : M);
     const long t_first = rounds > 0 ? (long)blockIdx.x * rounds : (long)blockIdx.x, t_step = rounds > 0 ? 1 : (long)gridDim.x;
     const long t_end = rounds > 0 ? (t_first + rounds < ntiles ? t_first + rounds : ntiles) : ntiles;
+    // phase arrays: E | D, so the window's alignment modulo E is the launch's (tiles start OW D samples apart)
+    [[maybe_unused]] int eoff[PH ? 16 : 1];
+    if constexpr (PH) {
+        const long g00 = first - (M - 1);
+        const int a_lo = (ROT ? (int)((rot_count0 + (uint64_t)g00) & 7) : (int)(g00 & 1)) & emask;
+#pragma unroll
+        for (int j = 0; j < 16; j++) eoff[j] = ((a_lo + j) & emask) * arr + ((a_lo + j) >> esh);
+    }
     prefetch(t_first);
     [[maybe_unused]] int trace_tile = 0;
     for (long t = t_first; t < t_end; t += t_step) {
@@ -149,27 +172,64 @@ __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__r
 #pragma unroll
                 for (int kk = 0; kk < KF / 4; kk++)
                     pm[kk] = phasor_poly(rot_step_fx * (rot_count0 + (uint64_t)(g0 - a + 8L * ((tid >> 2) + 64 * (4 * kk + (tid & 3))))));
-#pragma unroll
-                for (int k = 0; k < KF; k++) {
-                    const int f = tid + 256 * k;
+                // (the layout test outside the unrolled loop: a branch per load would cost the loop its staggered s_waitcnt vmcnt(11 - k))
+                auto rotated = [&](int k, cf &r0, cf &r1) {
                     cf pb;
                     pb.x = quad_bcast(pm[k >> 2].x, k);
                     pb.y = quad_bcast(pm[k >> 2].y, k);
                     float4 rq;
                     if constexpr (FMT != 0) rq = rx_raw_pair<FMT>(rawr[k]);
                     else rq = raw[(ROT && !FMT) ? k : 0];
-                    const cf r0 = cmul(cf{rq.x, rq.y}, cmul(pb, wq0)), r1 = cmul(cf{rq.z, rq.w}, cmul(pb, wq1));
-                    if (f < nf) reinterpret_cast<float4 *>(ldsX)[f] = make_float4(r0.x, r0.y, r1.x, r1.y);
+                    r0 = cmul(cf{rq.x, rq.y}, cmul(pb, wq0));
+                    r1 = cmul(cf{rq.z, rq.w}, cmul(pb, wq1));
+                };
+                if (!PH || esh == 0) {
+#pragma unroll
+                    for (int k = 0; k < KF; k++) {
+                        const int f = tid + 256 * k;
+                        cf r0, r1;
+                        rotated(k, r0, r1);
+                        if (f < nf) reinterpret_cast<float4 *>(ldsX)[f] = make_float4(r0.x, r0.y, r1.x, r1.y);
+                    }
+                } else {
+                    // sample 2 tid + 512 k: array (2 tid) mod E - the thread's own, for every k - at index (2 tid) / E + 512 k / E; the odd sample one array on
+                    cf *dst = reinterpret_cast<cf *>(ldsX) + slot_of(2 * tid);
+                    const int kstep = 512 >> esh;
+#pragma unroll
+                    for (int k = 0; k < KF; k++) {
+                        const int f = tid + 256 * k;
+                        cf r0, r1;
+                        rotated(k, r0, r1);
+                        if (f < nf) {
+                            dst[k * kstep] = r0;
+                            dst[k * kstep + arr] = r1;
+                        }
+                    }
                 }
             } else {
                 const int nf = (span + a + 1) >> 1;
+                if (!PH || esh == 0) {
 #pragma unroll
-                for (int k = 0; k < KF; k++) {
-                    const int f = min(tid + 256 * k, nf - 1);
-                    float4 v;
-                    if constexpr (FMT != 0) v = rx_raw_pair<FMT>(rawq[k]);
-                    else v = rawp[(!ROT && !FMT) ? k : 0];
-                    reinterpret_cast<float4 *>(ldsX)[f] = v;
+                    for (int k = 0; k < KF; k++) {
+                        const int f = min(tid + 256 * k, nf - 1);
+                        float4 v;
+                        if constexpr (FMT != 0) v = rx_raw_pair<FMT>(rawq[k]);
+                        else v = rawp[(!ROT && !FMT) ? k : 0];
+                        reinterpret_cast<float4 *>(ldsX)[f] = v;
+                    }
+                } else {
+                    cf *dst = reinterpret_cast<cf *>(ldsX) + slot_of(2 * tid);
+                    const int kstep = 512 >> esh;
+#pragma unroll
+                    for (int k = 0; k < KF; k++) {
+                        float4 v;
+                        if constexpr (FMT != 0) v = rx_raw_pair<FMT>(rawq[k]);
+                        else v = rawp[(!ROT && !FMT) ? k : 0];
+                        if (tid + 256 * k < nf) {
+                            dst[k * kstep] = cf{v.x, v.y};
+                            dst[k * kstep + arr] = cf{v.z, v.w};
+                        }
+                    }
                 }
             }
         } else {
@@ -177,7 +237,7 @@ __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__r
             for (int w = tid; w < span; w += 256) {
                 float2 v = make_float2(stream_at_raw<FMT>(hist, x, q0 + w, 0, M, n), stream_at_raw<FMT>(hist, x, q0 + w, 1, M, n));
                 if constexpr (ROT) v = rotate_sample(v, rot_step_fx, rot_count0 + (uint64_t)(g0 + w));
-                *reinterpret_cast<float2 *>(ldsX + 2 * (w + a)) = v;
+                *reinterpret_cast<float2 *>(ldsX + 2 * slot_of(w + a)) = v;
             }
         }
         DECIM_STAMP(1);
@@ -188,7 +248,7 @@ __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__r
         const long k = k0 + oi;
         const bool active = oi < OW && k < n_out && t_lo < t_hi;
         cf acc = cf{0.f, 0.f};
-        if (active) {
+        if (active && (!PH || esh == 0)) {
             const cf *xs = reinterpret_cast<const cf *>(ldsX) + oi * (int)D + a;
             int tt = t_lo;
             for (; tt + 16 <= t_hi; tt += 16) {
@@ -210,6 +270,33 @@ __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__r
             for (; tt < t_hi; tt++) {
                 const float h0 = ldsT[tt];
                 acc = __builtin_elementwise_fma(xs[tt], cf{h0, h0}, acc);
+            }
+        } else if (active) {
+            // phase arrays: the same chain; tap r of every lane lies in array (a + r) mod E at the lane's base + (a + r) / E.  With r = tt + j, tt a multiple
+            // of 16 and E | 16: array (a_lo + j) mod E, index (a_lo + j) / E + a / E + tt / E - the sixteen offsets eoff[j] are the same for every tile of the launch
+            const cf *xl = reinterpret_cast<const cf *>(ldsX) + oi * (int)(D >> esh) + (a >> esh);
+            int tt = t_lo;
+            for (; tt + 16 <= t_hi; tt += 16) {
+                cf hp[8], xv[16];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float4 h4 = *reinterpret_cast<const float4 *>(ldsT + tt + 4 * q);
+                    hp[2 * q] = cf{h4.x, h4.y};
+                    hp[2 * q + 1] = cf{h4.z, h4.w};
+                }
+                const cf *xg = xl + (tt >> esh);
+#pragma unroll
+                for (int j = 0; j < 16; j++) xv[j] = xg[eoff[PH ? j : 0]];
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) {
+                    pk_fma_tap<0>(acc, xv[j], hp[j >> 1]);
+                    pk_fma_tap<1>(acc, xv[j + 1], hp[j >> 1]);
+                }
+            }
+            for (; tt < t_hi; tt++) {
+                const float h0 = ldsT[tt];
+                const int al = (a & emask) + tt;
+                acc = __builtin_elementwise_fma(xl[(al & emask) * arr + (al >> esh)], cf{h0, h0}, acc);
             }
         }
         if (split) {

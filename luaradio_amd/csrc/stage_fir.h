@@ -583,11 +583,11 @@ struct FirStage : lrhip_stage {
     // decimations without a Toeplitz instantiation (and taps too long for its LDS table): LDS-staged one-output-per-thread kernel
     bool decim_lds_ok() const { return !fft_arith && !use_fft && M + 255 <= DECIM_SPAN_MAX && !(taps_complex && rot); }
     int decim_blocks_per_cu = 0;
-    // round 5: the second form (kernels_firdecim.h) for a ComplexFloat32 stream, real taps and a decimation that is no multiple of four; LRHIP_DECIM_V1=1 keeps the first
+    // round 5: the second form (kernels_firdecim.h) for a ComplexFloat32 stream and real taps; LRHIP_DECIM_V1=1 keeps the first
     bool decim_lds2_ok() const
     {
         static const bool v1_env = getenv("LRHIP_DECIM_V1") != nullptr;
-        return !v1_env && S == 2 && !taps_complex && D >= 2 && (D & 3) != 0 && M + 255 <= DECIM2_SPAN_MAX;
+        return !v1_env && S == 2 && !taps_complex && D >= 2 && M + 255 <= DECIM2_SPAN_MAX;
     }
     int launch_decim_lds(const float *x, long n, float *y, long n_out)
     {
@@ -600,7 +600,7 @@ struct FirStage : lrhip_stage {
         int OW = (int)(ow > 256 ? 256 : ow < 1 ? 1 : ow);
         long ntiles = (n_out + OW - 1) / OW;
         long span = (long)(OW - 1) * D + M;
-        size_t lds_bytes = v2 ? ((size_t)((M + 3) & ~3) + (size_t)2 * (span + DECIM2_PAD_SLOTS)) * sizeof(float)
+        size_t lds_bytes = v2 ? ((size_t)((M + 3) & ~3) + (size_t)2 * decim2_slots((int)span, (long)D)) * sizeof(float)
                               : ((size_t)(((taps_complex ? 2 : 1) * M + 3) & ~3) + (size_t)S * (span + (span >> 5) + 2)) * sizeof(float);
         const float *h = (const float *)hist[cur].p + hist_pad;
         float *ho = M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
@@ -617,14 +617,16 @@ struct FirStage : lrhip_stage {
         };
         int rc;
         if (v2) {
-            {
+            auto pick = [&](auto ph) -> int {
+                constexpr bool PH = decltype(ph)::value;
                 if (raw_now)
-                    rc = rot ? (in_fmt == RX_FMT_U8 ? go(fir_decim_lds2_kernel<true, RX_FMT_U8>) : in_fmt == RX_FMT_S8 ? go(fir_decim_lds2_kernel<true, RX_FMT_S8>)
-                                                                                                  : go(fir_decim_lds2_kernel<true, RX_FMT_S16LE>))
-                             : (in_fmt == RX_FMT_U8 ? go(fir_decim_lds2_kernel<false, RX_FMT_U8>) : in_fmt == RX_FMT_S8 ? go(fir_decim_lds2_kernel<false, RX_FMT_S8>)
-                                                                                                   : go(fir_decim_lds2_kernel<false, RX_FMT_S16LE>));
-                else rc = rot ? go(fir_decim_lds2_kernel<true>) : go(fir_decim_lds2_kernel<false>);
-            }
+                    return rot ? (in_fmt == RX_FMT_U8 ? go(fir_decim_lds2_kernel<true, RX_FMT_U8, PH>) : in_fmt == RX_FMT_S8 ? go(fir_decim_lds2_kernel<true, RX_FMT_S8, PH>)
+                                                                                                        : go(fir_decim_lds2_kernel<true, RX_FMT_S16LE, PH>))
+                               : (in_fmt == RX_FMT_U8 ? go(fir_decim_lds2_kernel<false, RX_FMT_U8, PH>) : in_fmt == RX_FMT_S8 ? go(fir_decim_lds2_kernel<false, RX_FMT_S8, PH>)
+                                                                                                         : go(fir_decim_lds2_kernel<false, RX_FMT_S16LE, PH>));
+                return rot ? go(fir_decim_lds2_kernel<true, RX_FMT_CF32, PH>) : go(fir_decim_lds2_kernel<false, RX_FMT_CF32, PH>);
+            };
+            rc = decim2_esh((long)D) ? pick(std::true_type{}) : pick(std::false_type{});
         } else if (raw_now) {
             if (taps_complex || S != 2) return set_error("internal: raw records reached a kernel without a record instantiation");
             rc = rot ? (in_fmt == RX_FMT_U8 ? go(fir_decim_lds_kernel<2, true, false, RX_FMT_U8>) : in_fmt == RX_FMT_S8 ? go(fir_decim_lds_kernel<2, true, false, RX_FMT_S8>)

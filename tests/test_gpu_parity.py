@@ -841,10 +841,11 @@ def test_randomized_chunkings_fused_chains_equal_unfused_blocks(seed):
             assert np.array_equal(got, want), name
 
 
-@pytest.mark.parametrize("decim,ntaps", [(50, 128), (25, 128), (18, 64), (75, 200), (50, 16), (6, 77), (9, 33)])
+@pytest.mark.parametrize("decim,ntaps", [(50, 128), (25, 128), (18, 64), (75, 200), (50, 16), (6, 77), (9, 33), (80, 128), (20, 96), (12, 40), (32, 128), (100, 130)])
 @pytest.mark.parametrize("rotate", [True, False])
 def test_lds_staged_decimator_second_form_many_tiles(decim, ntaps, rotate):
-    """kernels_firdecim.h (ComplexFloat32 stream, real taps, decimation not a multiple of four): hundreds of tiles per workgroup slot, the cuts at odd and
+    """kernels_firdecim.h (ComplexFloat32 stream, real taps; decimations that are a multiple of four - TunerBlock(.., 80) of rtlsdr_pocsag.lua / rtlsdr_ax25.lua -
+    through its phase-array layout): hundreds of tiles per workgroup slot, the cuts at odd and
     even absolute offsets (whole-block staging on the aligned ones, the per-sample path on the others and on the tiles that touch the carried history), tiles
     of <= 128 outputs spread over the four waves - with the rotator their taps split over the two half-waves, so the Tuner is compared with the oracle to
     Float32 rounding and, bit for bit, with itself under another chunking; without it the result is the direct form's fmaf chain exactly."""

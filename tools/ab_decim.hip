@@ -18,9 +18,18 @@ using namespace lrhip;
 
 #ifdef AB_V2
 #include "kernels_firdecim.h"
+#ifdef AB_PH
+#define AB_KERNEL_ROT fir_decim_lds2_kernel<true, 0, true>
+#define AB_KERNEL_PLAIN fir_decim_lds2_kernel<false, 0, true>
+#else
 #define AB_KERNEL_ROT fir_decim_lds2_kernel<true>
 #define AB_KERNEL_PLAIN fir_decim_lds2_kernel<false>
+#endif
+#ifdef AB_PH
+#define AB_LDS_BYTES(M, span) (((size_t)(((M) + 3) & ~3) + (size_t)2 * decim2_slots((int)(span), (long)D)) * sizeof(float))
+#else
 #define AB_LDS_BYTES(M, span) (((size_t)(((M) + 3) & ~3) + (size_t)2 * ((span) + DECIM2_PAD_SLOTS)) * sizeof(float))
+#endif
 #define AB_SPAN_MAX DECIM2_SPAN_MAX
 #else
 #define AB_SPAN_MAX DECIM_SPAN_MAX

@@ -95,6 +95,7 @@ def main():
     run("Decimator(5) cf32 (fused FIR+downsample)", lambda: mk(lr.DecimatorBlock, [5, {"use_fft": False}], True), True, 8 + 8 / 5, 4 * 128 / 5)
     run("Tuner(-250k,200k,5) (fused rot+FIR+downsample)", lambda: mk(lr.TunerBlock, [-250e3, 200e3, 5, {"use_fft": False}], True), True, 8 + 8 / 5, 4 * 128 / 5 + 6)
     run("Tuner(-100k,10k,50) (the AM / SSB / NBFM receivers' tuner: LDS-staged decimator)", lambda: mk(lr.TunerBlock, [-100e3, 10e3, 50, {"use_fft": False}], True), True, 8 + 8 / 50, 4 * 128 / 50 + 6)
+    run("Tuner(-100k,12k,80) (rtlsdr_pocsag.lua / rtlsdr_ax25.lua: LDS-staged decimator, phase-array layout)", lambda: mk(lr.TunerBlock, [-100e3, 12e3, 80, {"use_fft": False}], True), True, 8 + 8 / 80, 4 * 128 / 80 + 6)
     run("Decimator(25) cf32 (LDS-staged decimator, no rotator)", lambda: mk(lr.DecimatorBlock, [25, {"use_fft": False}], True), True, 8 + 8 / 25, 4 * 128 / 25)
     run("Decimator(5) cf32, polyphase FFT overlap-save", lambda: mk(lr.DecimatorBlock, [5, {"use_fft": "fast"}], True), True, 8 + 8 / 5, 62)
     run("Tuner(-250k,200k,5), polyphase FFT overlap-save", lambda: mk(lr.TunerBlock, [-250e3, 200e3, 5, {"use_fft": "fast"}], True), True, 8 + 8 / 5, 62)

@@ -70,8 +70,9 @@ def main():
         ("IIR biquad cf32", blocks, ("iir_stream_kernel<2, 2, 4>",), 16, n26, 0),
         ("Decimator(5) cf32, fused", blocks, ("fir_mfma_persistent_kernel<2, 5, 2, false, 51, 0",), 9.6, n26, 102.4),
         ("Tuner(-250k, 200k, 5), fused rotator + FIR + downsampler", blocks, ("fir_mfma_persistent_kernel<2, 5, 2, true, 51, 0, false, 4, 0",), 9.6, n26, 108.4),
-        ("Tuner(-100k, 10k, 50): LDS-staged decimator with rotator (AM / SSB / NBFM receivers)", blocks, ("fir_decim_lds_kernel<2, true, false, 0",), 8.16, n26, 16.2),
-        ("Decimator(25) cf32: LDS-staged decimator", blocks, ("fir_decim_lds_kernel<2, false, false, 0",), 8.32, n26, 20.5),
+        ("Tuner(-100k, 10k, 50): LDS-staged decimator with rotator (AM / SSB / NBFM receivers)", blocks, ("fir_decim_lds2_kernel<true, 0, false>",), 8.16, n26, 16.2),
+        ("Tuner(-100k, 12k, 80): the same with the phase-array layout (rtlsdr_pocsag.lua / rtlsdr_ax25.lua)", blocks, ("fir_decim_lds2_kernel<true, 0, true>",), 8.1, n26, 12.4),
+        ("Decimator(25) cf32: LDS-staged decimator", blocks, ("fir_decim_lds2_kernel<false, 0, false>",), 8.32, n26, 20.5),
         ("Decimator / Tuner, polyphase FFT overlap-save", blocks, ("fir_decfft_kernel<5, 0>",), 9.6, n26, 62),
         ("Upsampler(5) cf32: the Interpolator's bytes without arithmetic (input samples)", blocks, ("upsample_vec_kernel<HIP_vector_type<float, 2u>",), 48, n26, 0),
         ("Interpolator(5) cf32 (input samples)", blocks, ("fir_interp_kernel<5, 26>",), 48, n26, 512),
@@ -93,7 +94,7 @@ def main():
         ("FIR 4096 real taps cf32, overlap-save, partitioned: one of TWO launches of four partitions each (2 x 16 B + 8 B accumulate per sample in all)", blocks, ("fir_pols_kernel<2, 4>",), 16, n26, 330),
         ("WBFM mono receiver from u8 IQ records, ONE launch (bench_blocks: noise input)", blocks, ("rx_fused_kernel<1>",), 2.16, n26, 167),
         ("Tuner from u8 IQ records (fan-out branch fed from a file), ONE launch", blocks, ("fir_mfma_persistent_kernel<2, 5, 2, true, 51, 0, false, 4, 1",), 3.6, n26, 108.4),
-        ("Tuner(decimation 50) from u8 IQ records, ONE launch (AM / SSB / NBFM receivers fed from a file)", blocks, ("fir_decim_lds_kernel<2, true, false, 1",), 2.16, n26, 16.2),
+        ("Tuner(decimation 50) from u8 IQ records, ONE launch (AM / SSB / NBFM receivers fed from a file)", blocks, ("fir_decim_lds2_kernel<true, 1, false>",), 2.16, n26, 16.2),
         ("PSD N=1024 hamming log fftshift", blocks, ("spectrum1024_kernel",), 12, n26, 58),
         ("WBFM mono receiver (bench_blocks: U(-1,1) noise input)", blocks, ("rx_fused_kernel<0>",), 8.16, n26, 167),
     ]
