@@ -254,6 +254,18 @@ __global__ __launch_bounds__(256) void fir_fft_pre_history_kernel(const float *_
     if (i == 0 && n > 0) *prev_out = reinterpret_cast<const float2 *>(x)[n - 1];
 }
 
+// -DLRHIP_FFT_TRACE (a variant library, tools/fft_trace.sh): lane 0 of the waves of the first workgroups stamps the phases of its first blocks with clock64()
+#ifdef LRHIP_FFT_TRACE
+__device__ unsigned long long *lrhip_fft_trace;         // [block 8][wave FFT_WPB][iteration 32][12]
+#define FFT_STAMP(i)                                                                                                                                \
+    do {                                                                                                                                            \
+        if (lrhip_fft_trace && blockIdx.x < 8 && trace_it < 32 && (threadIdx.x & 63) == 0)                                                          \
+            lrhip_fft_trace[(((size_t)blockIdx.x * FFT_WPB + (threadIdx.x >> 6)) * 32 + trace_it) * 12 + (i)] = clock64();                            \
+    } while (0)
+#else
+#define FFT_STAMP(i) do { } while (0)
+#endif
+
 template <int S, int PRE>
 __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kernel(const float *__restrict__ hist, const float *__restrict__ x,
                                                           const float2 *__restrict__ tables, float *__restrict__ y,
@@ -504,7 +516,9 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #define FFT_TW1(k) tw1[(k) * 64 + lane]
 #endif
 
+    [[maybe_unused]] int trace_it = 0;
     for (long fbase = ffirst; fbase * BPW < nblocks && fbase < fend; fbase += FFT_NB * fstep) {
+        FFT_STAMP(0);
         cf v[FFT_NB][16];
         bool live[FFT_NB];
 #pragma unroll
@@ -520,6 +534,7 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
                 for (int i = 0; i < 16; i++) v[b][i] = cf{0.f, 0.f};
             }
         }
+        FFT_STAMP(1);
         // ---- forward stage 1: radix-16 over n1, twiddle W_1024^(t*k1)
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) {
@@ -530,6 +545,7 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #pragma unroll
             for (int k = 1; k < 16; k++) v[b][k] = cmul(v[b][k], FFT_TW1(k));
         }
+        FFT_STAMP(2);
         // E1: write (k1, t), read (k1 = k1s, 4*t1 + t2), t2 = sub
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++)
@@ -538,6 +554,7 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #else
             exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int k) { return k * FFT_E1_ROW + lane; }, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; });
 #endif
+        FFT_STAMP(3);
         // ---- forward stage 2: radix-16 over t1, twiddle W_64^(t2*k2)
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) {
@@ -559,6 +576,7 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; },
                      [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; });       // r = 4j + t2
 #endif
+        FFT_STAMP(4);
         // ---- forward stage 3: radix-4 over t2 -> k3; multiply by H; inverse stage 3: radix-4 over k3 -> t2
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) {
@@ -591,9 +609,11 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; },
                      [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; });
 #endif
+        FFT_STAMP(5);
         // ---- inverse stage 2: radix-16 over k2 -> t1
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) dft16<-1>(v[b]);
+        FFT_STAMP(6);
         // E1 back: write (k1 = k1s, 4*t1 + t2), read (k1, t = lane)
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++)
@@ -602,6 +622,7 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #else
             exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; }, [&](int k) { return k * FFT_E1_ROW + lane; });
 #endif
+        FFT_STAMP(7);
         // ---- inverse stage 1: conj twiddle, radix-16 over k1 -> n1
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) {
@@ -609,9 +630,14 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             for (int k = 1; k < 16; k++) v[b][k] = cmulc(v[b][k], FFT_TW1(k));
             dft16<-1>(v[b]);
         }
+        FFT_STAMP(8);
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++)
             if (live[b]) store_block(fbase + b * fstep, v[b]);
+        FFT_STAMP(9);
+#ifdef LRHIP_FFT_TRACE
+        trace_it++;
+#endif
     }
 #undef FFT_TW1
 }

@@ -568,8 +568,43 @@ struct FirStage : lrhip_stage {
                 }
                 const float2 *dp = pre_disc ? (const float2 *)disc_prev.p + disc_cur : nullptr;
                 float *ho = (!pre_disc && M > 1 && part == 0) ? (float *)hist[cur ^ 1].p + hist_pad : nullptr;
+#ifdef LRHIP_FFT_TRACE
+                static unsigned long long *trace = nullptr;
+                static long trace_launches = 0;
+                const size_t trace_n = (size_t)8 * FFT_WPB * 32 * 12;
+                if (!trace) {
+                    LR_HIP(hipMalloc(&trace, trace_n * 8));
+                    LR_HIP(hipMemcpyToSymbol(HIP_SYMBOL(lrhip_fft_trace), &trace, sizeof(trace)));
+                }
+                if (++trace_launches == 12) LR_HIP(hipMemsetAsync(trace, 0, trace_n * 8, ctx().stream));
+#endif
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FFT_WPB), lds_bytes, ctx().stream, h, x, tables, y, Mp, n, n_out, nblocks,
                                    1.0 / disc_gain, dp, ho, M, (long)part * FFT_PART, part > 0 ? 1 : 0, rounds, n_full, taper);
+#ifdef LRHIP_FFT_TRACE
+                if (trace_launches == 12) {
+                    // stamps: 0 loop top, 1 loads issued (the first dft16 waits for them), 2 stage 1 done, 3 E1 exchanged, 4 stage 2 + inner transpose done,
+                    // 5 stage 3 / H / inverse stage 3 + inner transpose done, 6 inverse stage 2 done, 7 E1 back, 8 inverse stage 1 done, 9 stores issued
+                    LR_HIP(hipStreamSynchronize(ctx().stream));
+                    std::vector<unsigned long long> tr(trace_n);
+                    LR_HIP(hipMemcpy(tr.data(), trace, trace_n * 8, hipMemcpyDeviceToHost));
+                    static const char *names[9] = {"issue", "load+st1", "E1", "st2+T", "st3 H st3 T", "ist2", "E1back", "ist1", "store"};
+                    double sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, blk = 0;
+                    int cnt = 0;
+                    for (int w = 0; w < 8 * FFT_WPB; w++)
+                        for (int t = 1; t < 30; t++) {
+                            const unsigned long long *s = &tr[((size_t)w * 32 + t) * 12], *nx = s + 12;
+                            if (!s[0] || !s[9] || !nx[0]) continue;
+                            for (int i = 0; i < 9; i++) sum[i] += (double)(s[i + 1] - s[i]);
+                            blk += (double)(nx[0] - s[0]);
+                            cnt++;
+                        }
+                    if (cnt) {
+                        fprintf(stderr, "fft trace (%d blocks):", cnt);
+                        for (int i = 0; i < 9; i++) fprintf(stderr, "  %s %.0f", names[i], sum[i] / cnt);
+                        fprintf(stderr, "  | block %.0f clocks\n", blk / cnt);
+                    }
+                }
+#endif
                 if (ho) hist_in_kernel = true;
                 return 0;
             };
