@@ -50,13 +50,16 @@ constexpr int F64_EX = (64 * F64_ROW + 1) / 2;                // per wave, in fl
 // LDS map (float2 units): [4 x transpose buffer | H 64x64 | C 16x64 = W_1024^(t c)]
 constexpr int F64_HSYM_ROW = 33;                              // symmetric H storage: [k1][l = 0..32]
 __host__ __device__ constexpr int f64_lds_h(int waves) { return waves * F64_EX; }
-__host__ __device__ constexpr int f64_lds_c(int waves) { return f64_lds_h(waves) + (waves <= 4 ? F4K_N : 64 * F64_HSYM_ROW); }
-__host__ __device__ constexpr int f64_lds_elems(int waves) { return f64_lds_c(waves) + 16 * 64; }
+__host__ __device__ constexpr int f64_lds_c(int waves, int np = 1) { return f64_lds_h(waves) + np * (waves <= 4 ? F4K_N : 64 * F64_HSYM_ROW); }
+__host__ __device__ constexpr int f64_lds_elems(int waves, int np = 1) { return f64_lds_c(waves, np) + 16 * 64; }
 // host table (float2 units): [C 16x64 | D 4x64 | H[r][l] = H(64 k1(r) + l) / 4096, r = 16 d + c <-> k1 = d + 4 c | Hsym[k1][l = 0..32] = H(64 k1 + l) / 4096]
 constexpr int F64_TAB_D = 16 * 64;
 constexpr int F64_TAB_H = F64_TAB_D + 4 * 64;
 constexpr int F64_TAB_HSYM = F64_TAB_H + F4K_N;
 constexpr int F64_TABLE_ELEMS = F64_TAB_HSYM + 64 * F64_HSYM_ROW;
+// round 5, two partitions (1 282 .. 4 097 taps at an overlap of 2 048: y_b = IFFT(X_b H_0 + X_(b-1) H_1)): the full H of partition 1 behind the table
+constexpr int F64_TAB_H1 = F64_TABLE_ELEMS;
+constexpr int F64_TABLE_ELEMS2 = F64_TAB_H1 + F4K_N;
 
 // cos / sin of 2 pi m / 64
 constexpr float F64_COS[64] = {
@@ -107,11 +110,16 @@ __host__ __device__ __forceinline__ void dft64(cf (&v)[64])
 // register 16 d + c of a dft64 spectrum holds index d + 4 c
 __host__ __device__ constexpr int f64_index(int r) { return (r >> 4) + 4 * (r & 15); }
 
-template <int V, int F64_WAVES>
+// NP = 2 (round 5): uniformly partitioned overlap-save with TWO partitions of 2 048 taps on the same engine - V = 2 048, hop 2 048, four waves per CU with both
+// partitions' H whole in LDS.  A wave walks a RUN of consecutive blocks and keeps the previous block's spectrum in 128 registers (the wave has 512); the
+// block in front of its run is transformed once to fill them (one forward transform in ~33 at 2^26 samples).  One launch, every sample read once (+ the
+// overlap through L2): 4 096 taps on 2^26 samples in one pass instead of two passes of the 1024-point partitioned kernel.
+template <int V, int F64_WAVES, int NP = 1>
 __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float2 *__restrict__ tables,
                                                            float *__restrict__ y, int M, long n, long n_out, long nblocks, float *__restrict__ hist_out, int xcd_map)
 {
     static_assert(V % 64 == 0 && V >= 64 && V < F4K_N, "the overlap is a whole number of 64-sample rows");
+    static_assert(NP == 1 || (NP == 2 && F64_WAVES == 4 && 2 * V == F4K_N), "two partitions: hop = overlap = 2 048, four waves, full H");
     constexpr int L = F4K_N - V;
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -121,12 +129,14 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
     cf *flc = reinterpret_cast<cf *>(fl);
     float *ex = reinterpret_cast<float *>(flc + wave * F64_EX);
     constexpr bool HSYM = F64_WAVES > 4;
-    constexpr int F64_LDS_H = f64_lds_h(F64_WAVES), F64_LDS_C = f64_lds_c(F64_WAVES);
+    constexpr int F64_LDS_H = f64_lds_h(F64_WAVES), F64_LDS_C = f64_lds_c(F64_WAVES, NP);
     const cf *Ct = flc + F64_LDS_C, *Hs = flc + F64_LDS_H;
     if (HSYM)
         for (int i = tid; i < 64 * F64_HSYM_ROW; i += 64 * F64_WAVES) fl[F64_LDS_H + i] = tables[F64_TAB_HSYM + i];
     else
         for (int i = tid; i < F4K_N; i += 64 * F64_WAVES) fl[F64_LDS_H + i] = tables[F64_TAB_H + i];
+    if (NP == 2)
+        for (int i = tid; i < F4K_N; i += 64 * F64_WAVES) fl[F64_LDS_H + F4K_N + i] = tables[F64_TAB_H1 + i];
     for (int i = tid; i < 16 * 64; i += 64 * F64_WAVES) fl[F64_LDS_C + i] = tables[i];
     // symmetric H: element index of H[k1][lane] = hs_a + k1 * hs_s, imaginary part times hs_sgn
     const int hs_a = lane <= 32 ? lane : 63 * F64_HSYM_ROW + (64 - lane), hs_s0 = lane <= 32 ? F64_HSYM_ROW : -F64_HSYM_ROW;
@@ -173,9 +183,15 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
             for (int i = 0; i < 64; i++) pre[i] = (src + 64 * i)[(unsigned)lane];
         }
     };
+    // two partitions: this wave's run of consecutive blocks [r0, r1), entered one block early (warm-up: forward transform only)
+    [[maybe_unused]] cf zp[NP == 2 ? 64 : 1];
+    const long nwaves = (long)gridDim.x * F64_WAVES, run = (nblocks + nwaves - 1) / nwaves;
+    const long r0 = ((long)blockIdx.x * F64_WAVES + wave) * run, r1 = r0 + run < nblocks ? r0 + run : nblocks;
+    if (NP == 2) { slot0 = r0 - 1; sstep = 1; send = r1; }
     for (long slot = slot0; slot < send; slot += sstep) {
-        const long fb = slot * F64_WAVES + wave;
+        const long fb = NP == 2 ? slot : slot * F64_WAVES + wave;
         if (fb >= nblocks) continue;                         // no workgroup barrier inside the loop: a wave may skip
+        [[maybe_unused]] const bool warm = NP == 2 && fb < r0;
         const long xlo = fb * L - V;
         cf v[64];
         if (have) {
@@ -216,8 +232,15 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
 #pragma unroll
         for (int t = 0; t < 64; t++) z[t].y = ex[lane * F64_ROW + t];
         F64_FENCE();
-        prefetch((slot + sstep) * F64_WAVES + wave);                  // v is dead until the inverse transpose
+        if (NP == 1) prefetch((slot + sstep) * F64_WAVES + wave);     // v is dead until the inverse transpose
         dft64<1>(z);
+        if constexpr (NP == 2) {
+            if (warm) {                                               // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 64; r++) zp[r] = z[r];
+                continue;
+            }
+        }
         // ---- x H (1 / N folded in): register r of lane l holds X[64 k1(r) + l]
         // (scheduling fences: without them the 64 H reads are hoisted above the transform to cover their latency - 128 more live registers at the point
         // where the wave already holds 128, and the allocator falls back to the accumulation registers and to scratch)
@@ -236,8 +259,21 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
                 for (int r = 0; r < LRHIP_F64_HGROUP; r++) h[r] = (Hs + (g + r) * 64)[(unsigned)lane];      // row pointer + the lane's index
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NP == 2) {
+                cf h1[LRHIP_F64_HGROUP];
 #pragma unroll
-            for (int r = 0; r < LRHIP_F64_HGROUP; r++) z[g + r] = cmul(z[g + r], h[r]);
+                for (int r = 0; r < LRHIP_F64_HGROUP; r++) h1[r] = (Hs + F4K_N + (g + r) * 64)[(unsigned)lane];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < LRHIP_F64_HGROUP; r++) {
+                    const cf xb = z[g + r];
+                    z[g + r] = cmul(xb, h[r]) + cmul(zp[g + r], h1[r]);
+                    zp[g + r] = xb;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < LRHIP_F64_HGROUP; r++) z[g + r] = cmul(z[g + r], h[r]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- inverse: IDFT over k1 -> t, transpose back, conjugate twiddle, IDFT over k2 -> i

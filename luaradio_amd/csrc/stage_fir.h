@@ -38,6 +38,7 @@ struct FirStage : lrhip_stage {
     DeviceBuf d_fft_tables;
     DeviceBuf d_fft4k_tables;             // 513 .. 1281 taps on a ComplexFloat32 stream: the 4096-point kernel (kernels_firfft4k.h)
     DeviceBuf d_fft64_tables;             // ... and its one-wave-per-block form (kernels_firfft64.h)
+    int fft64_np = 0;                     // round 5: 1 282 .. 2 049 taps (1) / 2 050 .. 4 097 taps (2 partitions) on that form at an overlap of 2 048
     int fft4k_V = 0, fft4k_blocks = 0;    // its overlap (768 / 1024 / 1280; 0 = not built)
     int fft_blocks_per_cu = 0;
     // decimating polyphase-FFT form (kernels_firdecfft.h): ComplexFloat32 stream, D >= 2, ceil(M / D) <= 32
@@ -430,6 +431,23 @@ struct FirStage : lrhip_stage {
         hist_in_kernel = true;
         return 0;
     }
+    // round 5: V = 2 048, one partition (eight waves on real taps, four on complex ones) or two (four waves, a run of consecutive blocks per wave)
+    template <int NP>
+    int launch_fft64_long(const float *x, long n, float *y, long n_out)
+    {
+        constexpr int VV = 2048, WAVES = 4;
+        constexpr long Lf = F4K_N - VV;
+        const size_t lds_bytes = (size_t)f64_lds_elems(WAVES, NP) * sizeof(float2);
+        auto kern = fir_fft64_kernel<VV, WAVES, NP>;
+        if (prepared_blocks(kern, lds_bytes, 64 * WAVES) < 0) return -1;
+        const long nblocks = (n_out + Lf - 1) / Lf, nslots = (nblocks + WAVES - 1) / WAVES;
+        const unsigned grid = (unsigned)(nslots < ctx().num_cus ? nslots : ctx().num_cus);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (const float2 *)d_fft64_tables.p, y, M, n,
+                           n_out, nblocks, M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : (float *)nullptr, 0);
+        LR_LAUNCH_CHECK();
+        hist_in_kernel = true;
+        return 0;
+    }
     template <int VV>
     int launch_fft64_v(const float *x, long n, float *y, long n_out)
     {
@@ -498,6 +516,19 @@ struct FirStage : lrhip_stage {
         // 1 281 taps - instead of one accumulating pass of the 1024-point kernel per 512 taps.  LRHIP_FFT_POLS=1 / 0 forces it on (also for 513 .. 1 281
         // taps on a ComplexFloat32 stream) / off (A/B)
         static const int pols_knob = getenv("LRHIP_FFT_POLS") ? atoi(getenv("LRHIP_FFT_POLS")) : -1;
+        // round 5: 1 282 .. 4 097 taps on a ComplexFloat32 stream as ONE launch of the 64 x 64 kernel at an overlap of 2 048 (two partitions above 2 049 taps) once
+        // a wave's run is long enough to pay for its warm-up block; LRHIP_F64_LONG=0 keeps the partitioned 1024-point kernel (A/B)
+        static const int long_knob = getenv("LRHIP_F64_LONG") ? atoi(getenv("LRHIP_F64_LONG")) : 1;
+        if (fft64_np && long_knob && pols_knob != 1 && !pre_disc && !post_disc && S == 2) {
+            const long nb = (n_out + 2047) / 2048;
+            // (size sweep 2^20 .. 2^26 samples, same box: faster than the partitioned kernel at every size - 4 096 taps 0.072 / 0.106 / 0.196 / 0.575 ms against
+            // 0.188 / 0.208 / 0.243 / 1.104 at 2^20 / 2^22 / 2^24 / 2^26, 2 048 taps 0.048 against 0.093 at 2^22 - so there is no lower bound; LRHIP_F64_LONG_MIN = blocks per CU)
+            static const long long_min = getenv("LRHIP_F64_LONG_MIN") ? atol(getenv("LRHIP_F64_LONG_MIN")) : 0;
+            if (nb >= long_min * ctx().num_cus) {
+                if (fft64_np == 1) return taps_complex ? launch_fft64<2048, 4>(x, n, y, n_out) : launch_fft64<2048, 8>(x, n, y, n_out);
+                return launch_fft64_long<2>(x, n, y, n_out);
+            }
+        }
         if (M > FFT_PART && !pre_disc && !post_disc && pols_knob != 0 && (pols_knob == 1 || !fft4k_V || no_4k))
             return S == 2 ? launch_pols<2>(x, n, y, n_out) : launch_pols<1>(x, n, y, n_out);
         // one wave per 4096-point block (fir_fft64_kernel, one 512- / 256-thread workgroup per CU) once the launch has at least eight blocks per CU; smaller
@@ -1310,6 +1341,46 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
             if (upload(q->d_fft64_tables, t6.data(), t6.size() * sizeof(float))) return nullptr;
             q->fft4k_V = (int)((ntaps - 1 + 255) / 256) * 256;
             if (q->fft4k_V < 768) q->fft4k_V = 768;
+        }
+        if (input_complex && ntaps > 1281 && ntaps <= 4097) {
+            // round 5: the 64 x 64 form at an overlap of 2 048 - one partition to 2 049 taps, two (taps [0, 2 048) and [2 048, ntaps)) above
+            const int np = ntaps <= 2049 ? 1 : 2;
+            std::vector<float> t6((size_t)F64_TABLE_ELEMS2 * 2, 0.f);
+            auto put6 = [&](size_t o, double a) { t6[2 * o] = (float)std::cos(a); t6[2 * o + 1] = (float)std::sin(a); };
+            for (int c = 0; c < 16; c++)
+                for (int t = 0; t < 64; t++) put6((size_t)c * 64 + t, -PI2 * (double)((c * t) % FFTN) / FFTN);
+            for (int d = 0; d < 4; d++)
+                for (int t = 0; t < 64; t++) put6((size_t)F64_TAB_D + d * 64 + t, -PI2 * (double)(t * d) / F4K_N);
+            std::vector<double> cs(F4K_N), sn(F4K_N), Hr(F4K_N), Hi(F4K_N);
+            for (int k = 0; k < F4K_N; k++) { cs[k] = std::cos(-PI2 * k / F4K_N); sn[k] = std::sin(-PI2 * k / F4K_N); }
+            for (int part = 0; part < np; part++) {
+                const unsigned m0 = np == 1 ? 0 : part * 2048u, m1 = np == 1 ? ntaps : (part == 0 ? 2048u : ntaps);
+                for (int k = 0; k < F4K_N; k++) {
+                    double sr = 0, si = 0;
+                    for (unsigned m = m0; m < m1; m++) {
+                        const int a = (int)(((long)k * (m - m0)) % F4K_N);
+                        const double hr = taps_complex ? taps[2 * m] : taps[m], hi = taps_complex ? taps[2 * m + 1] : 0.0;
+                        sr += hr * cs[a] - hi * sn[a];
+                        si += hr * sn[a] + hi * cs[a];
+                    }
+                    Hr[k] = sr / F4K_N;
+                    Hi[k] = si / F4K_N;
+                }
+                for (int r = 0; r < 64; r++)
+                    for (int l = 0; l < 64; l++) {
+                        const int k = 64 * f64_index(r) + l;
+                        const size_t o = (size_t)(part == 0 ? F64_TAB_H : F64_TAB_H1) + (size_t)r * 64 + l;
+                        t6[2 * o] = (float)Hr[k];
+                        t6[2 * o + 1] = (float)Hi[k];
+                        if (part == 0 && l <= 32) {
+                            const size_t os = (size_t)F64_TAB_HSYM + (size_t)f64_index(r) * F64_HSYM_ROW + l;
+                            t6[2 * os] = (float)Hr[k];
+                            t6[2 * os + 1] = (float)Hi[k];
+                        }
+                    }
+            }
+            if (upload(q->d_fft64_tables, t6.data(), t6.size() * sizeof(float))) return nullptr;
+            q->fft64_np = np;
         }
     }
     if (q->use_fft) {

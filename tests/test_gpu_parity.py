@@ -303,11 +303,14 @@ def test_partitioned_form_equals_the_4096_point_kernels_filter():
     assert G.max_abs_err(whole, O.FIR(taps, True, O.MODE_F64).process(x)) < 1e-6
 
 
-@pytest.mark.parametrize("ntaps,cplx_taps", [(600, False), (1000, False), (1276, False), (1276, True), (770, True)])
+@pytest.mark.parametrize("ntaps,cplx_taps", [(600, False), (1000, False), (1276, False), (1276, True), (770, True),
+                                             (1282, False), (2049, False), (2000, True), (2050, False), (3000, False), (4096, False), (4097, False), (4096, True)])
 def test_one_wave_per_4096_point_block_kernel_on_a_large_launch(ntaps, cplx_taps):
     """513 .. 1 281 taps on a ComplexFloat32 stream, launches of at least eight 4096-point blocks per CU: fir_fft64_kernel (kernels_firfft64.h, round 4) -
     4096 = 64 x 64 with both 64-point transforms in registers and one transpose per direction; eight waves per CU on the conjugate-symmetric H of real
-    taps, four on the full H of complex taps.  2^23 samples against the f64 oracle on slabs (first, two interior, last), then the same stream in ragged
+    taps, four on the full H of complex taps.  Round 5: 1 282 .. 2 049 taps at an overlap of 2 048 and 2 050 .. 4 097 taps as TWO partitions in one launch
+    (a wave walks a run of consecutive blocks with the previous block's spectrum in registers; the chunk cuts below land inside runs, and every chunk starts
+    with warm-up blocks that reach into the carried history).  2^23 samples against the f64 oracle on slabs (first, two interior, last), then the same stream in ragged
     chunks that straddle the small-launch kernel (workgroup per block) and this one."""
     rng = np.random.default_rng(900 + ntaps + cplx_taps)
     n = 1 << 23
