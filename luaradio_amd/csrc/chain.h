@@ -54,12 +54,23 @@ struct lrhip_chain {
 struct HostRanges {
     std::mutex m;
     std::vector<std::pair<const char *, size_t>> r;
+    std::vector<char *> dev;         // the device-side address of each range (hipHostGetDevicePointer; null: not mapped)
     long pid = 0;
+    // the device address of a host pointer inside a registered range, or null
+    void *device_ptr(const void *p, size_t bytes)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        if (pid != (long)getpid()) return nullptr;
+        const char *q = (const char *)p;
+        for (size_t i = 0; i < r.size(); i++)
+            if (q >= r[i].first && q + bytes <= r[i].first + r[i].second) return dev[i] ? dev[i] + (q - r[i].first) : nullptr;
+        return nullptr;
+    }
     bool has(const void *p, size_t bytes)
     {
         if (!bytes) return true;
         std::lock_guard<std::mutex> lk(m);
-        if (pid != (long)getpid()) { r.clear(); pid = (long)getpid(); }      // registrations do not survive fork()
+        if (pid != (long)getpid()) { r.clear(); dev.clear(); pid = (long)getpid(); }      // registrations do not survive fork()
         const char *q = (const char *)p;
         for (auto &e : r)
             if (q >= e.first && q + bytes <= e.first + e.second) return true;
@@ -111,7 +122,7 @@ static unsigned long host_piece_min()
 template <typename Runner>
 static long host_execute(PinnedBuf &h_in, PinnedBuf &h_out, DeviceBuf &d_in, DeviceBuf &d_out, int in_size, int out_size,
                          unsigned long max_out, const void *in_host, unsigned long n_in, void *out_host,
-                         unsigned long out_capacity, Runner run, unsigned long align = 1)
+                         unsigned long out_capacity, Runner run, unsigned long align = 1, bool direct_ok = false)
 {
     if (n_in && !in_host) return set_error("null input buffer");
     size_t in_bytes = (size_t)n_in * in_size;
@@ -119,6 +130,23 @@ static long host_execute(PinnedBuf &h_in, PinnedBuf &h_out, DeviceBuf &d_in, Dev
     if (max_out > out_capacity) return set_error("output capacity %lu < required %lu", out_capacity, max_out);
     if (max_out && !out_host) return set_error("null output buffer");
     const bool in_reg = host_ranges().has(in_host, in_bytes), out_reg = host_ranges().has(out_host, (size_t)cap * out_size);
+    // Round 5, DIRECT mode: both vectors registered and the stage / chain reads its input once and writes its output once (direct_io_ok) - the kernels load
+    // the caller's vector and store into the caller's vector across the link, no device staging buffers, no copy engines, no pieces: ONE launch and one
+    // synchronisation per call.  A stand-alone LowpassFilter cf32 -> cf32: 3.3 -> 4.4 GS/s at 2^20-sample vectors, 3.7 -> 5.5 at 2^22, 6.0 GS/s = 48 GB/s in
+    // each direction at 2^24 (the link's measured both-way rate, tools/mb_link.py); kernels that know of it run a short persistent grid so that reads and
+    // writes overlap (host_io_grid, common.h).  LRHIP_HOST_DIRECT=0 keeps the staged pipeline (A/B).
+    static const bool direct_env = !getenv("LRHIP_HOST_DIRECT") || atoi(getenv("LRHIP_HOST_DIRECT")) != 0;
+    if (direct_env && direct_ok && in_reg && out_reg && n_in) {
+        void *din = host_ranges().device_ptr(in_host, in_bytes), *dout = cap ? host_ranges().device_ptr(out_host, (size_t)cap * out_size) : (void *)nullptr;
+        if (din && (dout || !cap)) {
+            host_io_grid_ref() = 32;
+            const long n_out = run(din, n_in, dout, cap);
+            host_io_grid_ref() = 0;
+            if (n_out < 0) return n_out;
+            LR_HIP(hipStreamSynchronize(ctx().stream));
+            return n_out;
+        }
+    }
     if ((!in_reg && h_in.reserve(in_bytes ? in_bytes : 16)) || d_in.reserve(in_bytes ? in_bytes : 16)) return -1;
     if ((!out_reg && h_out.reserve((size_t)cap * out_size + 16)) || d_out.reserve((size_t)cap * out_size + 16 * (size_t)HOST_PIECES * out_size + 16)) return -1;
     static const bool no_pieces = getenv("LRHIP_HOST_NO_PIECES") != nullptr;      // A/B knob: one piece, as in round 3

@@ -17,6 +17,16 @@
 
 namespace lrhip {
 
+// Set by host_execute (chain.h) around a launch whose input / output pointers are the caller's registered HOST memory: kernels that know of it launch a short
+// persistent grid (0 = device memory, the normal grids).  LRHIP_HOST_IO_GRID overrides the workgroup count (A/B).
+inline int &host_io_grid_ref() { static thread_local int v = 0; return v; }
+inline int host_io_grid()
+{
+    static const int env = getenv("LRHIP_HOST_IO_GRID") ? atoi(getenv("LRHIP_HOST_IO_GRID")) : 0;
+    return env < 0 ? host_io_grid_ref() > 0 ? -env : 0 : env > 0 ? env : host_io_grid_ref();
+}
+
+
 // A 16-byte store that tells the caches the line will not be read again by this launch.  tools/mb_chunk.hip, 2^26 ComplexFloat32 samples: a 1 : 1 stream moves
 // 6.27 -> 6.44 TB/s with it, one read per two writes 5.95 -> 8.07, one per five 5.48 -> 6.88: the more of a kernel's traffic is output, the more it matters.
 #ifdef __HIPCC__

@@ -668,9 +668,11 @@ __global__ __launch_bounds__(256) void fir_decim_lds_kernel(const float *__restr
             } else {
                 const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const cf *>(x) + gb);
 #pragma unroll
+                // (round 5: no branch around a load - a lane past the end repeats the last word.  A conditional load is a basic block of its own and hipcc puts
+                // s_waitcnt vmcnt(0) in front of each: the prefetch went out one load at a time, kernels_firdecim.h)
                 for (int k = 0; k < KF; k++) {
                     const int f = tid + 256 * k;
-                    if (f < nf) rawp[(!ROT && S == 2 && !FMT) ? k : 0] = src[f];
+                    rawp[(!ROT && S == 2 && !FMT) ? k : 0] = src[f < nf ? f : nf - 1];
                 }
             }
         }

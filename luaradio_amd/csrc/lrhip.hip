@@ -497,7 +497,7 @@ long lrhip_stage_execute(lrhip_stage_t *q, const void *in_host, unsigned long n_
     if (!q) return set_error("null stage");
     return host_execute(q->h_in, q->h_out, q->d_in, q->d_out, q->in_size, q->out_size, q->max_output(n_in), in_host, n_in,
                         out_host, out_capacity,
-                        [&](const void *di, unsigned long n, void *dout, unsigned long cap) { return q->run(di, n, dout, cap); }, q->align());
+                        [&](const void *di, unsigned long n, void *dout, unsigned long cap) { return q->run(di, n, dout, cap); }, q->align(), q->direct_io_ok());
 }
 
 long lrhip_stage_execute2_device(lrhip_stage_t *q, const void *in1_dev, const void *in2_dev, unsigned long n_in, void *out_dev,
@@ -988,7 +988,7 @@ long lrhip_chain_execute(lrhip_chain_t *c, const void *in_host, unsigned long n_
     return host_execute(c->h_in, c->h_out, c->d_in, c->d_out, c->ops.front().stage->in_size, c->ops.back().stage->out_size,
                         lrhip_chain_max_output(c, n_in), in_host, n_in, out_host, out_capacity,
                         [&](const void *di, unsigned long n, void *dout, unsigned long cap) { return lrhip_chain_execute_device(c, di, n, dout, cap); },
-                        lrhip_chain_shard_align(c));
+                        lrhip_chain_shard_align(c), c->ops.front().stage->direct_io_ok() && c->ops.back().stage->direct_io_ok());
 }
 
 int lrhip_chain_last_launches(const lrhip_chain_t *c) { return c ? c->last_launches : set_error("null chain"); }
@@ -1048,7 +1048,9 @@ int lrhip_chain_set_ring(lrhip_chain_t *c, unsigned depth, unsigned long max_chu
     return 0;
 }
 
-long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_in)
+static long chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_in, bool allow_inplace);
+long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_in) { return chain_submit(c, in_host, n_in, true); }
+static long chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_in, bool allow_inplace)
 {
     if (!c) return set_error("null chain");
     if (c->ring.empty()) return set_error("chain has no ring: call lrhip_chain_set_ring first");
@@ -1059,18 +1061,27 @@ long lrhip_chain_submit(lrhip_chain_t *c, const void *in_host, unsigned long n_i
     if (n_in && !in_host) return set_error("null input buffer");
     int in_size = c->ops.front().stage->in_size, out_size = c->ops.back().stage->out_size;
     size_t bytes = (size_t)n_in * in_size;
+    const void *zin = nullptr;           // input read in place across the link
     // the slot was collected (ev_out waited) before it can be reused, so its buffers are free on host and device
     if (bytes) {
         // lrhip_chain_ring_input(): the caller filled the slot itself.  A vector inside a range registered with lrhip_host_register() is DMA'd from where it
         // lies (a recording mmap()ed and registered once: the page cache is the staging buffer); the caller keeps it valid until the batch is collected.
         const bool direct = in_host != sl.h_in.p && host_ranges().has(in_host, bytes);
         if (in_host != sl.h_in.p && !direct) host_copy(sl.h_in.p, in_host, bytes);
-        LR_HIP(hipMemcpyAsync(sl.d_in.p, direct ? in_host : sl.h_in.p, bytes, hipMemcpyHostToDevice, c->s_in));
+        // round 5: a chain whose first stage reads its input once takes the slot's pinned input (or the caller's registered vector) AS its input - the
+        // kernel loads the records across the link itself; no copy engine, no event hop in front of the launch.  Same box, u8 records -> receiver: pushes of
+        // 131 072 records 7.4 -> 9.2 GS/s, read(2) into the slot 9.6 -> 10.6; NOT for lrhip_chain_submit_fd, whose copy threads are the bound either way
+        // (15.2 -> 14.3 GS/s: the copy engine costs the GPU nothing while they read).  LRHIP_RING_DIRECT=0: always the copy (A/B)
+        static const bool ring_direct = !getenv("LRHIP_RING_DIRECT") || atoi(getenv("LRHIP_RING_DIRECT")) != 0;
+        if (ring_direct && allow_inplace && c->ops.front().stage->direct_io_ok()) zin = direct ? host_ranges().device_ptr(in_host, bytes) : sl.h_in.p;
+        if (!zin) LR_HIP(hipMemcpyAsync(sl.d_in.p, direct ? in_host : sl.h_in.p, bytes, hipMemcpyHostToDevice, c->s_in));
     }
-    LR_HIP(hipEventRecord(sl.ev_in, c->s_in));
-    LR_HIP(hipStreamWaitEvent(ctx().stream, sl.ev_in, 0));
+    if (!zin) {
+        LR_HIP(hipEventRecord(sl.ev_in, c->s_in));
+        LR_HIP(hipStreamWaitEvent(ctx().stream, sl.ev_in, 0));
+    }
     unsigned long cap = (unsigned long)(sl.d_out.cap / out_size);
-    long n_out = lrhip_chain_execute_device(c, sl.d_in.p, n_in, sl.d_out.p, cap);
+    long n_out = lrhip_chain_execute_device(c, zin ? zin : sl.d_in.p, n_in, sl.d_out.p, cap);
     if (n_out < 0) return n_out;
     LR_HIP(hipEventRecord(sl.ev_done, ctx().stream));
     LR_HIP(hipStreamWaitEvent(c->s_out, sl.ev_done, 0));
@@ -1102,7 +1113,7 @@ long lrhip_chain_submit_fd(lrhip_chain_t *c, int fd, unsigned long long offset, 
     lrhip_chain::Slot &sl = *c->ring[c->head];
     const int err = host_pread(sl.h_in.p, fd, (long long)offset, (size_t)n * in_size);
     if (err) return set_error("pread(%d): %s", fd, strerror(err));
-    const long rc = lrhip_chain_submit(c, sl.h_in.p, n);
+    const long rc = chain_submit(c, sl.h_in.p, n, false);
     return rc < 0 ? rc : (long)n;
 }
 
@@ -1332,7 +1343,7 @@ int lrhip_host_register(void *ptr, unsigned long bytes)
     HostRanges &h = host_ranges();
     {
         std::lock_guard<std::mutex> lk(h.m);
-        if (h.pid != (long)getpid()) { h.r.clear(); h.pid = (long)getpid(); }
+        if (h.pid != (long)getpid()) { h.r.clear(); h.dev.clear(); h.pid = (long)getpid(); }
         for (auto &e : h.r)
             if (e.first == (const char *)ptr) {
                 if (e.second == bytes) return 0;
@@ -1340,8 +1351,11 @@ int lrhip_host_register(void *ptr, unsigned long bytes)
             }
     }
     LR_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, ptr, 0) != hipSuccess) { (void)hipGetLastError(); d = nullptr; }      // not mapped: the staged path only
     std::lock_guard<std::mutex> lk(h.m);
     h.r.emplace_back((const char *)ptr, (size_t)bytes);
+    h.dev.push_back((char *)d);
     return 0;
 }
 int lrhip_host_unregister(void *ptr)
@@ -1354,6 +1368,7 @@ int lrhip_host_unregister(void *ptr)
         for (; it != h.r.end(); ++it)
             if (it->first == (const char *)ptr) break;
         if (it == h.r.end()) return set_error("host_unregister: %p is not registered", ptr);
+        if (h.dev.size() == h.r.size()) h.dev.erase(h.dev.begin() + (it - h.r.begin()));
         h.r.erase(it);
     }
     // nothing of this range may still be in flight: every host-pointer entry point has synchronised before it returned

@@ -30,6 +30,9 @@ struct lrhip_stage {
     // align(): partitions that start on a multiple of this many input samples of the stage see the same tile grid in its scan kernels as the
     // uninterrupted stream, which makes a recurrence's output bit-identical as well (1: the stage has no such grid)
     virtual unsigned long align() const { return 1; }
+    // round 5: the stage reads its input ONCE and writes its output once, so the host-pointer entry points may hand it the caller's registered host memory
+    // itself (kernels load and store across the link; host_execute's direct mode in chain.h) instead of staging through device buffers
+    virtual bool direct_io_ok() const { return false; }
     // input samples per output sample as a ratio (decimation num/den), for mapping memories back to the chain input
     virtual void rate(unsigned long *num, unsigned long *den) const { *num = 1; *den = 1; }
 };

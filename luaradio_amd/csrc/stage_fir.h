@@ -579,6 +579,9 @@ struct FirStage : lrhip_stage {
                 int rounds = rounds_env >= 0 ? rounds_env : 0;
                 if (want <= slots) rounds = 0;
                 unsigned grid = rounds > 0 ? (unsigned)((want + rounds - 1) / rounds) : (unsigned)(want < slots ? want : slots);
+                // input / output in HOST memory (host_execute's direct mode, chain.h): a short persistent grid, so that the reads of one block and the writes of
+                // another share the link instead of every wave loading, then every wave storing
+                if (host_io_grid() > 0 && rounds == 0 && grid > (unsigned)host_io_grid()) grid = (unsigned)host_io_grid();
                 // tapered tail of the one-shot order (kernels_firfft.h): the last three "waves" of workgroups own rounds/2, rounds/4, rounds/8 batches
                 // (measured equal on 2^28 samples, same box: 0.865-0.878 ms with, 0.860-0.867 without - the ~45 us fixed cost the size sweep shows is not
                 // the tail of long workgroups; opt-in, LRHIP_FFT_TAPER=1)
@@ -979,6 +982,18 @@ struct FirStage : lrhip_stage {
         if ((D == 1 && ksteps == 36) || (D == 5 && ksteps == 51)) return true;
         static const bool off = getenv("LRHIP_NO_DISC_EPI_OTHER_D") != nullptr;      // A/B knob: the round-4 behaviour
         return !off && rot && (D == 4 || D == 8 || D == 10) && ksteps == disc_ksteps(D);
+    }
+
+    // round 5 (host_execute's direct mode, the ring's in-place input): the forms that stage their input through LDS ONCE in one launch and never read
+    // their output back - overlap-save in one launch, the Toeplitz kernels, the LDS-staged decimators, the polyphase-FFT decimator.  Not the last-resort
+    // direct kernel (M global reads per output), the multi-launch partitioned filters (they accumulate into y), the opt-in window kernels
+    bool direct_io_ok() const override
+    {
+        if (pre_disc || fix_src) return false;
+        if (decfft) return true;
+        if (fft_arith) return M <= FFT_PART || (S == 2 && (fft4k_V || fft64_np));
+        if (win_real_ok() || win_cplx_ok() || short_real_ok()) return false;
+        return ksteps != 0 || (D > 1 && decim_lds_ok());
     }
 
     // filter n inputs (device), emit the retained outputs; advances history / index / count

@@ -19,6 +19,7 @@ struct RxStage : lrhip_stage {
     int last_form = 0;                    // diagnostics: 1 = single launch, 2 = two launches, 3 = single launch on u8 records (last run)
 
     const char *kind() const override { return "fm-receiver"; }
+    bool direct_io_ok() const override { return true; }      // both forms read the RF input once (round 5: host_execute's direct mode, the ring's in-place input)
     unsigned long max_output(unsigned long n) const override { return B->max_output(A->max_output(n)); }
     int reset() override { return (A->reset() || B->reset()) ? -1 : 0; }
     int seek(unsigned long long n0, unsigned long long *n0_out) override

@@ -375,6 +375,46 @@ def test_host_path_travels_in_pieces_and_takes_registered_vectors_without_a_copy
     assert L.lrhip_host_unregister(x.ctypes.data_as(C.c_void_p)) < 0                        # not registered any more
 
 
+def test_registered_vectors_are_read_and_written_in_place():
+    """Round 5, host_execute's direct mode (luaradio_amd/csrc/chain.h): with both vectors registered, a stage or chain whose first kernel reads its input once
+    and whose last kernel writes its output once is handed the caller's HOST memory itself - the overlap-save kernel then runs a short persistent grid.  Same
+    kernels on the same values: the bits of the device-resident run, for a filter at three sizes (one block, part of a grid, many rounds of the grid) and for
+    the single-launch receiver."""
+    import ctypes as C
+    import torch
+    L = _lib.load()
+    rng = np.random.default_rng(77)
+    n = (1 << 22) + 12345
+    x = _aligned(n, np.complex64)
+    x[:] = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+    y = _aligned(n, np.complex64)
+    audio = _aligned(n // 25 + 64, np.float32)
+    for v in (x, y, audio):
+        _lib.check(L.lrhip_host_register(v.ctypes.data_as(C.c_void_p), v.nbytes), "register")
+    try:
+        xd = torch.from_numpy(x.view(np.float32).copy()).cuda()
+        for m in (900, 200001, n):
+            blk = make(lr.LowpassFilterBlock, [128, 15e3], types.ComplexFloat32, FS)
+            got = L.lrhip_stage_execute(blk.stage_handle(), x.ctypes.data_as(C.c_void_p), m, y.ctypes.data_as(C.c_void_p), m)
+            assert got == m, _lib.last_error()
+            ref = make(lr.LowpassFilterBlock, [128, 15e3], types.ComplexFloat32, FS)
+            yd = torch.empty(2 * m, device="cuda")
+            assert ref.process_device(xd.data_ptr(), m, yd.data_ptr(), m) == m
+            torch.cuda.synchronize()
+            assert np.array_equal(y[:m].view(np.float32), yd.cpu().numpy()), m
+        rx = lr.Chain(receiver_blocks())
+        got = L.lrhip_chain_execute(rx._chain, x.ctypes.data_as(C.c_void_p), n, audio.ctypes.data_as(C.c_void_p), len(audio))
+        assert got == (n + 24) // 25, _lib.last_error()
+        want = lr.Chain(receiver_blocks())
+        ad = torch.empty(len(audio), device="cuda")
+        assert want.process_device(xd.data_ptr(), n, ad.data_ptr(), len(audio)) == got
+        torch.cuda.synchronize()
+        assert np.array_equal(audio[:got], ad.cpu().numpy()[:got])
+    finally:
+        for v in (x, y, audio):
+            assert L.lrhip_host_unregister(v.ctypes.data_as(C.c_void_p)) == 0
+
+
 def test_poll_due_stays_bounded_while_a_launched_batch_is_in_flight():
     """batch == chunk - push() launches the full batch, its non-waiting collect finds it unfinished, then the source stalls.  Nothing is
     accumulating, but the batch's output still has to reach the host: poll_due() keeps the wait for input bounded until the ring has drained, and poll()
