@@ -110,6 +110,18 @@ __host__ __device__ __forceinline__ void dft64(cf (&v)[64])
 // register 16 d + c of a dft64 spectrum holds index d + 4 c
 __host__ __device__ constexpr int f64_index(int r) { return (r >> 4) + 4 * (r & 15); }
 
+// tools/ab_fft64.hip builds this header with -DLRHIP_F64_TRACE: lane 0 of every wave of the first workgroups stamps the phases of its first blocks
+#ifdef LRHIP_F64_TRACE
+__device__ unsigned long long *lrhip_f64_trace;         // [block 8][wave 8][iteration 16][16]
+#define F64_STAMP(i)                                                                                                                                \
+    do {                                                                                                                                            \
+        if (lrhip_f64_trace && blockIdx.x < 8 && trace_it < 16 && (threadIdx.x & 63) == 0)                                                          \
+            lrhip_f64_trace[(((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + trace_it) * 16 + (i)] = clock64();                                  \
+    } while (0)
+#else
+#define F64_STAMP(i) do { } while (0)
+#endif
+
 // NP = 2 (round 5): uniformly partitioned overlap-save with TWO partitions of 2 048 taps on the same engine - V = 2 048, hop 2 048, four waves per CU with both
 // partitions' H whole in LDS.  A wave walks a RUN of consecutive blocks and keeps the previous block's spectrum in 128 registers (the wave has 512); the
 // block in front of its run is transformed once to fill them (one forward transform in ~33 at 2^26 samples).  One launch, every sample read once (+ the
@@ -188,9 +200,11 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
     const long nwaves = (long)gridDim.x * F64_WAVES, run = (nblocks + nwaves - 1) / nwaves;
     const long r0 = ((long)blockIdx.x * F64_WAVES + wave) * run, r1 = r0 + run < nblocks ? r0 + run : nblocks;
     if (NP == 2) { slot0 = r0 - 1; sstep = 1; send = r1; }
+    [[maybe_unused]] int trace_it = 0;
     for (long slot = slot0; slot < send; slot += sstep) {
         const long fb = NP == 2 ? slot : slot * F64_WAVES + wave;
         if (fb >= nblocks) continue;                         // no workgroup barrier inside the loop: a wave may skip
+        F64_STAMP(0);
         [[maybe_unused]] const bool warm = NP == 2 && fb < r0;
         const long xlo = fb * L - V;
         cf v[64];
@@ -217,9 +231,12 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
         // (F64_FENCE = scheduling fence between phases: left alone, the scheduler pulls the next phase's 64 loads up to cover their latency and the wave
         // holds 128 + 128 values at the seams; with two waves per SIMD the other wave covers the latency and the registers are worth more)
         F64_FENCE();
+        F64_STAMP(1);
         dft64<1>(v);
+        F64_STAMP(2);
         twiddle(v, std::false_type{});
         F64_FENCE();
+        F64_STAMP(3);
         cf z[64];
         // transpose: lane t writes row k2 of register 16 d + c (k2 = d + 4 c), lane k2 reads its row (t = 0..63); real parts, then imaginary parts
 #pragma unroll
@@ -232,8 +249,10 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
 #pragma unroll
         for (int t = 0; t < 64; t++) z[t].y = ex[lane * F64_ROW + t];
         F64_FENCE();
+        F64_STAMP(4);
         if (NP == 1) prefetch((slot + sstep) * F64_WAVES + wave);     // v is dead until the inverse transpose
         dft64<1>(z);
+        F64_STAMP(5);
         if constexpr (NP == 2) {
             if (warm) {                                               // wave-uniform
 #pragma unroll
@@ -276,9 +295,11 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        F64_STAMP(6);
         // ---- inverse: IDFT over k1 -> t, transpose back, conjugate twiddle, IDFT over k2 -> i
         dft64<-1>(z);
         F64_FENCE();
+        F64_STAMP(7);
 #pragma unroll
         for (int t = 0; t < 64; t++) ex[lane * F64_ROW + t] = z[t].x;
 #pragma unroll
@@ -289,8 +310,11 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
 #pragma unroll
         for (int r = 0; r < 64; r++) v[r].y = ex[f64_index(r) * F64_ROW + lane];
         F64_FENCE();
+        F64_STAMP(8);
         twiddle(v, std::true_type{});
+        F64_STAMP(9);
         dft64<-1>(v);
+        F64_STAMP(10);
         // ---- rows at or behind the overlap are this block's outputs
         const long ob = fb * L - V;
         cf *dst = reinterpret_cast<cf *>(y) + ob;
@@ -302,6 +326,10 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
             for (int i = V / 64; i < 64; i++)
                 if (ob + 64 * i + lane < n_out) __builtin_nontemporal_store(v[i], (dst + 64 * i) + (unsigned)lane);
         }
+        F64_STAMP(11);
+#ifdef LRHIP_F64_TRACE
+        trace_it++;
+#endif
     }
 }
 

@@ -96,8 +96,43 @@ int main(int argc, char **argv)
         else if (V == 1024) launch<1024>(hist, x, tables, y, ntaps, n, grid, xcd);
         else launch<1280>(hist, x, tables, y, ntaps, n, grid, xcd);
     };
+#ifdef LRHIP_F64_TRACE
+    unsigned long long *trace;
+    const size_t trace_n = (size_t)8 * 8 * 16 * 16;
+    CK(hipMalloc(&trace, trace_n * 8));
+    CK(hipMemset(trace, 0, trace_n * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(lrhip_f64_trace), &trace, sizeof(trace)));
+#endif
     go();
     CK(hipDeviceSynchronize());
+#ifdef LRHIP_F64_TRACE
+    {
+        for (int i = 0; i < 3; i++) go();
+        CK(hipMemset(trace, 0, trace_n * 8));
+        go();
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> tr(trace_n);
+        CK(hipMemcpy(tr.data(), trace, trace_n * 8, hipMemcpyDeviceToHost));
+        // stamps: 0 loop top, 1 window loaded (issued), 2 first dft64 done (waits for the loads), 3 big twiddle, 4 transpose (both planes), 5 second dft64, 6 x H, 7 idft64,
+        // 8 transpose back, 9 conjugate twiddle, 10 idft64, 11 stores issued
+        static const char *names[11] = {"load issue", "dft64 (+wait)", "twiddle", "transpose", "dft64", "x H", "idft64", "transpose back", "twiddle", "idft64", "store issue"};
+        double sum[11] = {0}, blk = 0;
+        int cnt = 0;
+        for (int w = 0; w < 64; w++)
+            for (int t = 1; t < 14; t++) {
+                const unsigned long long *s = &tr[((size_t)w * 16 + t) * 16], *nx = s + 16;
+                if (!s[0] || !s[11] || !nx[0]) continue;
+                for (int i = 0; i < 11; i++) sum[i] += (double)(s[i + 1] - s[i]);
+                blk += (double)(nx[0] - s[0]);
+                cnt++;
+            }
+        if (cnt) {
+            printf("f64 trace (%d blocks, %d waves per CU):", cnt, F64_WAVES);
+            for (int i = 0; i < 11; i++) printf("  %s %.0f", names[i], sum[i] / cnt);
+            printf("  | block %.0f clocks\n", blk / cnt);
+        }
+    }
+#endif
     std::vector<float> yh(xh.size());
     CK(hipMemcpy(yh.data(), y, yh.size() * 4, hipMemcpyDeviceToHost));
     // check: 4096 positions spread over the vector (and the first / last 700) against the direct form in double
