@@ -1,6 +1,7 @@
-// kernels_firdecim.h - round 5: second form of the LDS-staged decimating FIR (fir_decim_lds_kernel of kernels_fir.h stays for Float32 streams, ComplexFloat32
-// taps and decimations that are a multiple of four) for a ComplexFloat32 stream, real taps, decimation odd or 2 mod 4: TunerBlock(offset, bw, 50) of
-// radio/composites/tuner.lua:34-44 as rtlsdr_am_envelope.lua / rtlsdr_ssb.lua / rtlsdr_nbfm.lua use it, DecimatorBlock(25), ...
+// kernels_firdecim.h - round 5: second form of the LDS-staged decimating FIR (fir_decim_lds_kernel of kernels_fir.h stays for Float32 streams and ComplexFloat32
+// taps) for a ComplexFloat32 stream - or the raw records of an IQ file - and real taps: TunerBlock(offset, bw, 50) of radio/composites/tuner.lua:34-44 as
+// rtlsdr_am_envelope.lua / rtlsdr_ssb.lua / rtlsdr_nbfm.lua use it, TunerBlock(.., 80) of rtlsdr_pocsag.lua / rtlsdr_ax25.lua (a multiple of four: the
+// phase-array layout below), DecimatorBlock(25), ...
 //
 // Same result as the first form, bit for bit, wherever the taps of an output stay one chain (one fmaf chain per output in the reference's tap order; the
 // rotator's phasor is the library-wide P(n & ~7) W[n & 7] of kernels_elem.h).  What changed is where a tile's ~19 000 clocks went (clock64 stamps of lane 0
@@ -27,10 +28,10 @@
 namespace lrhip {
 
 constexpr int DECIM2_SPAN_MAX = 6128;                         // (span + 14) / 8 <= 768 blocks of eight = twelve 16-byte words per thread
-constexpr int DECIM2_PAD_SLOTS = 16;
+constexpr int DECIM2_PAD_SLOTS = 16;                          // slots in front of / behind the window that the whole-block staging may write
 #ifndef LRHIP_DECIM2_SPLIT
 #define LRHIP_DECIM2_SPLIT 1      /* rotator form, tiles of <= 128 outputs: 1 - the upper half-wave takes the second half of the taps; 0 - it idles as in the plain form */
-#endif                          // slots in front of / behind the window that the whole-block staging may write
+#endif
 
 // Decimations that are a multiple of four: a thread stride of D samples would put 4 .. 32 lanes of a half-wave on one bank pair, so the window is dealt out
 // over E = 4 / 8 / 16 phase arrays (sample p -> array p mod E, index p / E).  D is a multiple of E: a thread's tap r lies in array (a + r) mod E for EVERY
