@@ -70,16 +70,21 @@ __device__ __forceinline__ float quad_bcast(float v, int j)       // j: a consta
 template <bool ROT, int FMT = 0, bool PH = false>
 __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_rev,
                                                              float *__restrict__ y, int M, long n, long n_out, long first, long D, int OW, long ntiles,
-                                                             uint64_t rot_step_fx, uint64_t rot_count0, float *__restrict__ hist_out, int post_op, int rounds)
+                                                             uint64_t rot_step_fx, uint64_t rot_count0, float *__restrict__ hist_out, int post_op, int rounds,
+                                                             double inv_gain, const float2 *__restrict__ disc_prev_in, float2 *__restrict__ disc_prev_out)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *ldsT = lds;                                  // M reversed taps
     float *ldsX = lds + ((M + 3) & ~3);                 // staged samples as (re, im), slot = window position + a
+    // FrequencyDiscriminatorBlock behind the filter (frequencydiscriminator.lua:62-78) as an epilogue: OW counts the STORED outputs of a tile; lane 0 of every
+    // wave recomputes the output in front of its wave's first (the tile's first wave: in front of the tile), so no angle needs another wave's or another
+    // workgroup's output - one redundant output in 31 (63), no exchange, no third barrier.  The stream's first angle takes the carried output *disc_prev_in.
+    const int disc = disc_prev_out != nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (hist_out && blockIdx.x == 0)
         for (int i = tid; i < (M - 1) * 2; i += 256) hist_out[i] = stream_at_raw<FMT>(hist, x, n + i / 2, i % 2, M, n);
     for (int i = tid; i < M; i += 256) ldsT[i] = taps_rev[i];
-    const int span = (int)((OW - 1) * D) + M;
+    const int span = (int)((OW - 1 + disc) * D) + M;
     const int esh = PH ? decim2_esh(D) : 0, emask = (1 << esh) - 1, arr = PH ? decim2_arr(span, esh) : 0;
     auto slot_of = [&](int p) { return esh ? (p & emask) * arr + (p >> esh) : p; };
     // Rotator form: a thread takes the 16-byte words tid + 256 k of the window (lane-contiguous loads and LDS writes): always pair q = tid & 3 of an aligned
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__r
     auto prefetch = [&](long tt) {
         have = false;
         if (tt >= ntiles) return;
-        const long g0n = first + tt * OW * D - (M - 1);
+        const long g0n = first + (tt * OW - disc) * D - (M - 1);
         if constexpr (ROT) {
             const int an = (int)((rot_count0 + (uint64_t)g0n) & 7), nblkn = (span + an + 7) >> 3, nfn = 4 * nblkn;
             const long lo = g0n - an;                   // chunk index of slot 0
@@ -142,8 +147,9 @@ __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__r
     };
     // outputs of a tile over the threads: up to 128 -> 32 per wave in the lower half-wave (all four SIMDs filter), the upper half-wave idle (plain) or on the
     // second half of the taps of the same outputs (rotator form); more than 128 -> one per thread
-    const bool spread = OW <= 128;
-    const int oi = spread ? wave * 32 + (lane & 31) : tid;
+    const bool spread = OW <= (disc ? 124 : 128);
+    const int lane_l = spread ? (lane & 31) : lane, LWQ = (spread ? 32 : 64) - disc;      // output lanes of a wave; stored outputs per wave
+    const int oi = wave * LWQ + lane_l - disc;          // tile-local output (-1: the one in front of the tile)
     const int part = spread ? lane >> 5 : 0;
     const bool split = spread && ROT && LRHIP_DECIM2_SPLIT;
     const int Mh = split ? (((M >> 1) + 15) & ~15) : M;           // taps [0, Mh) in part 0, [Mh, M) in part 1
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__r
     for (long t = t_first; t < t_end; t += t_step) {
         DECIM_STAMP(0);
         const long k0 = t * OW;                         // first output of the tile
-        const long q0 = first + k0 * D;                 // stream position of window sample 0 (stream = [M-1 history | chunk])
+        const long q0 = first + (k0 - disc) * D;        // stream position of window sample 0 (stream = [M-1 history | chunk])
         const long g0 = q0 - (M - 1);                   // the same as an index into x (negative: history)
         const int a = ROT ? (int)((rot_count0 + (uint64_t)g0) & 7) : (int)(g0 & 1);
         if (have) {
@@ -247,10 +253,10 @@ __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__r
         prefetch(t + t_step < t_end ? t + t_step : ntiles);
         DECIM_STAMP(3);
         const long k = k0 + oi;
-        const bool active = oi < OW && k < n_out && t_lo < t_hi;
+        const bool active = oi < OW && k >= 0 && k < n_out && t_lo < t_hi;
         cf acc = cf{0.f, 0.f};
         if (active && (!PH || esh == 0)) {
-            const cf *xs = reinterpret_cast<const cf *>(ldsX) + oi * (int)D + a;
+            const cf *xs = reinterpret_cast<const cf *>(ldsX) + (oi + disc) * (int)D + a;
             int tt = t_lo;
             for (; tt + 16 <= t_hi; tt += 16) {
                 cf hp[8], xv[16];
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__r
         } else if (active) {
             // phase arrays: the same chain; tap r of every lane lies in array (a + r) mod E at the lane's base + (a + r) / E.  With r = tt + j, tt a multiple
             // of 16 and E | 16: array (a_lo + j) mod E, index (a_lo + j) / E + a / E + tt / E - the sixteen offsets eoff[j] are the same for every tile of the launch
-            const cf *xl = reinterpret_cast<const cf *>(ldsX) + oi * (int)(D >> esh) + (a >> esh);
+            const cf *xl = reinterpret_cast<const cf *>(ldsX) + (oi + disc) * (int)(D >> esh) + (a >> esh);
             int tt = t_lo;
             for (; tt + 16 <= t_hi; tt += 16) {
                 cf hp[8], xv[16];
@@ -305,7 +311,15 @@ __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__r
             acc.x += __shfl_xor(acc.x, 32);
             acc.y += __shfl_xor(acc.y, 32);
         }
-        if (oi < OW && k < n_out && part == 0) {
+        if (disc) {
+            // the output in front of this lane's: lane - 1 of the same wave (lane 0 of a wave holds only that predecessor)
+            float2 pv = make_float2(__shfl_up(acc.x, 1), __shfl_up(acc.y, 1));
+            if (k == 0) pv = *disc_prev_in;                                // the stream's first output: the carried one (zero at the very start)
+            if (oi >= 0 && oi < OW && k < n_out && part == 0 && lane_l >= 1) {
+                y[k] = discriminate(make_float2(acc.x, acc.y), pv, inv_gain);
+                if (k == n_out - 1) *disc_prev_out = make_float2(acc.x, acc.y);
+            }
+        } else if (oi < OW && k < n_out && part == 0) {
             const float re = acc.x, im = acc.y;
             // post_op = 1 + a complex -> real element-wise operation folded into the store (ComplexMagnitude behind the AM receiver's tuner ...): Float32 out
             if (post_op) y[k] = post_op == 1 + UN_CMAG ? unary_c2r<UN_CMAG>(re, im) : post_op == 1 + UN_CPHASE ? unary_c2r<UN_CPHASE>(re, im) : post_op == 1 + UN_CREAL ? re : im;

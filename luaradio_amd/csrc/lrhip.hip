@@ -857,7 +857,7 @@ lrhip_chain_t *lrhip_chain_create_ex(lrhip_stage_t **stages, unsigned nstages, u
     for (size_t k = 0; k + 1 < c->ops.size() && !no_fixup_fold; k++) {
         FirStage *prod = c->ops[k].owned ? dynamic_cast<FirStage *>(c->ops[k].stage) : nullptr;
         FirStage *cons = c->ops[k + 1].owned ? dynamic_cast<FirStage *>(c->ops[k + 1].stage) : nullptr;
-        if (prod && cons && prod->post_disc && !prod->decfft && !prod->win_cplx_ok() && cons->iir_fused && cons->win_pair_ok()) {
+        if (prod && cons && prod->post_disc && prod->ksteps != 0 && !prod->decfft && !prod->win_cplx_ok() && cons->iir_fused && cons->win_pair_ok()) {
             prod->defer_fixup = true;
             cons->fix_src = prod;
         }

@@ -665,10 +665,12 @@ struct FirStage : lrhip_stage {
         static const long span_env = getenv("LRHIP_DECIM_SPAN") ? atol(getenv("LRHIP_DECIM_SPAN")) : 0;
         const long span_cap = v2 ? DECIM2_SPAN_MAX : DECIM_SPAN_MAX;
         const long span_max = span_env >= 512 && span_env < span_cap && span_env >= M + 64 ? span_env : span_cap;
-        long ow = (span_max - M) / (long)D + 1;
-        int OW = (int)(ow > 256 ? 256 : ow < 1 ? 1 : ow);
+        const int dsc = post_disc ? 1 : 0;       // discriminator epilogue (second form only): OW counts the stored outputs, every tile computes one more in front
+        if (dsc && !v2) return set_error("internal: discriminator epilogue on the first LDS-staged decimator form");
+        long ow = (span_max - M) / (long)D + 1 - dsc;
+        int OW = (int)(ow > 256 - 4 * dsc ? 256 - 4 * dsc : ow < 1 ? 1 : ow);
         long ntiles = (n_out + OW - 1) / OW;
-        long span = (long)(OW - 1) * D + M;
+        long span = (long)(OW - 1 + dsc) * D + M;
         size_t lds_bytes = v2 ? ((size_t)((M + 3) & ~3) + (size_t)2 * decim2_slots((int)span, (long)D)) * sizeof(float)
                               : ((size_t)(((taps_complex ? 2 : 1) * M + 3) & ~3) + (size_t)S * (span + (span >> 5) + 2)) * sizeof(float);
         const float *h = (const float *)hist[cur].p + hist_pad;
@@ -684,16 +686,30 @@ struct FirStage : lrhip_stage {
             hist_in_kernel = ho != nullptr;
             return 0;
         };
+        auto go2 = [&](auto kern) -> int {
+            if ((decim_blocks_per_cu = prepared_blocks(kern, lds_bytes)) < 0) return -1;
+            long slots = (long)ctx().num_cus * decim_blocks_per_cu;
+            static const int rounds_env = getenv("LRHIP_DECIM_ROUNDS") ? atoi(getenv("LRHIP_DECIM_ROUNDS")) : 0;
+            const int rounds = ntiles > slots && rounds_env > 0 ? rounds_env : 0;
+            unsigned grid = rounds > 0 ? (unsigned)((ntiles + rounds - 1) / rounds) : (unsigned)(ntiles < slots ? ntiles : slots);
+            float2 *dp = (float2 *)disc_prev.p;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, (const float *)d_taps.p, y, M, n, n_out, (long)index, (long)D, OW,
+                               ntiles, rot ? rot_step : (uint64_t)0, rot ? count : (uint64_t)0, ho, post_unary, rounds, 1.0 / disc_gain,
+                               dsc ? (const float2 *)(dp + disc_cur) : (const float2 *)nullptr, dsc ? dp + (disc_cur ^ 1) : (float2 *)nullptr);
+            hist_in_kernel = ho != nullptr;
+            if (dsc) disc_cur ^= 1;
+            return 0;
+        };
         int rc;
         if (v2) {
             auto pick = [&](auto ph) -> int {
                 constexpr bool PH = decltype(ph)::value;
                 if (raw_now)
-                    return rot ? (in_fmt == RX_FMT_U8 ? go(fir_decim_lds2_kernel<true, RX_FMT_U8, PH>) : in_fmt == RX_FMT_S8 ? go(fir_decim_lds2_kernel<true, RX_FMT_S8, PH>)
-                                                                                                        : go(fir_decim_lds2_kernel<true, RX_FMT_S16LE, PH>))
-                               : (in_fmt == RX_FMT_U8 ? go(fir_decim_lds2_kernel<false, RX_FMT_U8, PH>) : in_fmt == RX_FMT_S8 ? go(fir_decim_lds2_kernel<false, RX_FMT_S8, PH>)
-                                                                                                         : go(fir_decim_lds2_kernel<false, RX_FMT_S16LE, PH>));
-                return rot ? go(fir_decim_lds2_kernel<true, RX_FMT_CF32, PH>) : go(fir_decim_lds2_kernel<false, RX_FMT_CF32, PH>);
+                    return rot ? (in_fmt == RX_FMT_U8 ? go2(fir_decim_lds2_kernel<true, RX_FMT_U8, PH>) : in_fmt == RX_FMT_S8 ? go2(fir_decim_lds2_kernel<true, RX_FMT_S8, PH>)
+                                                                                                        : go2(fir_decim_lds2_kernel<true, RX_FMT_S16LE, PH>))
+                               : (in_fmt == RX_FMT_U8 ? go2(fir_decim_lds2_kernel<false, RX_FMT_U8, PH>) : in_fmt == RX_FMT_S8 ? go2(fir_decim_lds2_kernel<false, RX_FMT_S8, PH>)
+                                                                                                         : go2(fir_decim_lds2_kernel<false, RX_FMT_S16LE, PH>));
+                return rot ? go2(fir_decim_lds2_kernel<true, RX_FMT_CF32, PH>) : go2(fir_decim_lds2_kernel<false, RX_FMT_CF32, PH>);
             };
             rc = decim2_esh((long)D) ? pick(std::true_type{}) : pick(std::false_type{});
         } else if (raw_now) {
@@ -980,6 +996,10 @@ struct FirStage : lrhip_stage {
         if (decfft || win_cplx_ok()) return true;
         if (!(S == 2 && !taps_complex && !fft_arith && !use_fft)) return false;
         if ((D == 1 && ksteps == 36) || (D == 5 && ksteps == 51)) return true;
+        // round 5: the second LDS-staged decimator form (kernels_firdecim.h) has the epilogue at every decimation it takes - Tuner(.., 50) / (.., 80) +
+        // FrequencyDiscriminator of rtlsdr_nbfm.lua, rtlsdr_pocsag.lua, rtlsdr_ax25.lua: one launch less, the ComplexFloat32 tuner output never reaches HBM
+        static const bool no_lds_disc = getenv("LRHIP_NO_DISC_EPI_LDS") != nullptr;      // A/B knob
+        if (!no_lds_disc && ksteps == 0 && D > 1 && decim_lds_ok() && decim_lds2_ok()) return true;
         static const bool off = getenv("LRHIP_NO_DISC_EPI_OTHER_D") != nullptr;      // A/B knob: the round-4 behaviour
         return !off && rot && (D == 4 || D == 8 || D == 10) && ksteps == disc_ksteps(D);
     }

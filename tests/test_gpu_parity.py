@@ -875,6 +875,41 @@ def test_lds_staged_decimator_second_form_many_tiles(decim, ntaps, rotate):
         assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("decim,ntaps", [(50, 128), (80, 128), (25, 128), (18, 64), (100, 200), (9, 33)])
+def test_lds_staged_decimator_discriminator_epilogue(decim, ntaps):
+    """Tuner(.., 50) -> FrequencyDiscriminator (rtlsdr_nbfm.lua:11-13; decimation 80: rtlsdr_pocsag.lua, rtlsdr_ax25.lua) as ONE launch of the second
+    LDS-staged decimator form: the angle is taken on the accumulators, lane 0 of every wave recomputing its wave's predecessor.  Same filter outputs, same
+    discriminate(): the bits of the Tuner block followed by the FrequencyDiscriminator block, under any chunking - cuts inside tiles, chunks of one
+    sample, chunks with no output at all - and the oracle's angles to the conditioning of a small product."""
+    rng = np.random.default_rng(300 + decim + ntaps)
+    rate = 1102500.0
+    n = 1_200_003
+    t = np.arange(n) / rate
+    x = (np.exp(2j * np.pi * (-100e3 * t + 2.5e3 / 400.0 * np.sin(2 * np.pi * 400.0 * t))) + 0.05 * rand_c(rng, n)).astype(np.complex64)
+    bw = rate / decim * 0.8
+    gain = 1.25
+
+    def fused():
+        # radio/composites/tuner.lua:34-44 flattened, as DeviceChainBlock.collapse() hands it over
+        return lr.Chain([make(lr.FrequencyTranslatorBlock, [-100e3], x, rate=rate), make(lr.LowpassFilterBlock, [ntaps, bw / 2], x, rate=rate),
+                         make(lr.DownsamplerBlock, [decim], x, rate=rate), make(lr.FrequencyDiscriminatorBlock, [gain], x, rate=rate / decim)])
+
+    tun = make(lr.TunerBlock, [-100e3, bw, decim, {"num_taps": ntaps}], x, rate=rate)
+    dsc = make(lr.FrequencyDiscriminatorBlock, [gain], x, rate=rate / decim)
+    o = tun.process(x)
+    want = dsc.process(o)
+    ch = fused()
+    whole = ch.process(x)
+    assert ch.last_launches == 1
+    assert len(whole) == len(want) == (n + decim - 1) // decim
+    assert np.array_equal(whole, want)
+    cuts = [1, 2, 3, decim - 1, decim, decim + 1, 5 * decim + 2, 300001, 300002, 300002 + decim // 2, 900007]
+    got = chunked(fused(), x, sorted(set(cuts)))
+    assert np.array_equal(got, want)
+    ora = O.Chain(O.tuner(-100e3, bw, decim, rate, num_taps=ntaps, mode=O.MODE_FMA, rot_mode=O.MODE_F64).stages + [O.FMDiscriminator(gain)]).process(x)
+    assert disc_err(got, ora, o, gain) < 2e-6
+
+
 @pytest.mark.parametrize("decim", [1, 5])
 def test_rotator_fir_fusion_odd_sample_offsets(decim):
     """the fused rotator stages aligned blocks of 8 samples; after an odd number of consumed samples the blocks no longer line

@@ -17,6 +17,7 @@ using namespace lrhip;
 #define CK(c) do { hipError_t e_ = (c); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #c, hipGetErrorString(e_)); exit(1); } } while (0)
 
 #ifdef AB_V2
+#define AB_EXTRA , 0.0, (const float2 *)nullptr, (float2 *)nullptr
 #include "kernels_firdecim.h"
 #ifdef AB_PH
 #define AB_KERNEL_ROT fir_decim_lds2_kernel<true, 0, true>
@@ -33,6 +34,9 @@ using namespace lrhip;
 #define AB_SPAN_MAX DECIM2_SPAN_MAX
 #else
 #define AB_SPAN_MAX DECIM_SPAN_MAX
+#endif
+#ifndef AB_EXTRA
+#define AB_EXTRA
 #endif
 #ifndef AB_KERNEL_ROT
 #define AB_KERNEL_ROT fir_decim_lds_kernel<2, true>
@@ -78,8 +82,8 @@ int main(int argc, char **argv)
     const long slots = (long)cus * per_cu;
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
     auto go = [&]() {
-        if (rot) hipLaunchKernelGGL(AB_KERNEL_ROT, dim3(grid), dim3(256), lds_bytes, 0, hist, x, dt, y, M, n, n_out, 0L, (long)D, OW, ntiles, rot_step, count0, ho, 0, 0);
-        else hipLaunchKernelGGL(AB_KERNEL_PLAIN, dim3(grid), dim3(256), lds_bytes, 0, hist, x, dt, y, M, n, n_out, 0L, (long)D, OW, ntiles, (uint64_t)0, (uint64_t)0, ho, 0, 0);
+        if (rot) hipLaunchKernelGGL(AB_KERNEL_ROT, dim3(grid), dim3(256), lds_bytes, 0, hist, x, dt, y, M, n, n_out, 0L, (long)D, OW, ntiles, rot_step, count0, ho, 0, 0 AB_EXTRA);
+        else hipLaunchKernelGGL(AB_KERNEL_PLAIN, dim3(grid), dim3(256), lds_bytes, 0, hist, x, dt, y, M, n, n_out, 0L, (long)D, OW, ntiles, (uint64_t)0, (uint64_t)0, ho, 0, 0 AB_EXTRA);
     };
 #ifdef LRHIP_DECIM_TRACE
     unsigned long long *trace;
