@@ -875,6 +875,44 @@ def test_lds_staged_decimator_second_form_many_tiles(decim, ntaps, rotate):
         assert np.array_equal(got, want)
 
 
+def test_lds_staged_decimator_second_form_random_shapes():
+    """forty random (decimation, taps, length, cuts) draws through the second LDS-staged decimator form: tap counts that are no multiple of 4 or 16 (the
+    tap split's halves, the tail loops), filters shorter than one group of sixteen, decimations of every residue modulo 16 (all four window layouts), streams
+    shorter than a tile, chunks that produce no output.  Plain: the direct form's bits.  With the rotator: the bits of another chunking, the oracle to 2e-6.
+    With the discriminator behind it: the bits of the unfused blocks."""
+    rng = np.random.default_rng(20250925)
+    rate = 1102500.0
+    toeplitz = {1, 2, 3, 4, 5, 6, 7, 8, 10}
+    for case in range(40):
+        decim = int(rng.choice([d for d in range(9, 131) if d not in toeplitz]))
+        ntaps = int(rng.choice([5, 13, 16, 17, 31, 33, 48, 63, 64, 65, 77, 100, 127, 128, 129, 160, 255, 300]))
+        n = int(rng.integers(1, 400000))
+        x = rand_c(rng, n)
+        ncuts = int(rng.integers(0, 6))
+        cuts = sorted(set(int(c) for c in rng.integers(1, max(2, n), ncuts))) if n > 1 else []
+        kind = case % 3
+        bw = rate / decim * 0.8
+        tag = (case, decim, ntaps, n, cuts, kind)
+        if kind == 0:
+            got = chunked(make(lr.DecimatorBlock, [decim, {"num_taps": ntaps}], x, rate=rate), x, cuts)
+            want = O.decimator(decim, rate, True, num_taps=ntaps, mode=O.MODE_FMA).process(x)
+            assert len(got) == len(want) and np.array_equal(got, want), tag
+        elif kind == 1:
+            whole = make(lr.TunerBlock, [-100e3, bw, decim, {"num_taps": ntaps}], x, rate=rate).process(x)
+            got = chunked(make(lr.TunerBlock, [-100e3, bw, decim, {"num_taps": ntaps}], x, rate=rate), x, cuts)
+            assert len(got) == len(whole) and np.array_equal(got, whole), tag
+            want = O.tuner(-100e3, bw, decim, rate, num_taps=ntaps, mode=O.MODE_FMA, rot_mode=O.MODE_F64).process(x)
+            assert len(got) == len(want) and (len(got) == 0 or G.max_abs_err(got, want) < 2e-6), tag
+        else:
+            def fused():
+                return lr.Chain([make(lr.FrequencyTranslatorBlock, [-100e3], x, rate=rate), make(lr.LowpassFilterBlock, [ntaps, bw / 2], x, rate=rate),
+                                 make(lr.DownsamplerBlock, [decim], x, rate=rate), make(lr.FrequencyDiscriminatorBlock, [1.25], x, rate=rate / decim)])
+            o = make(lr.TunerBlock, [-100e3, bw, decim, {"num_taps": ntaps}], x, rate=rate).process(x)
+            want = make(lr.FrequencyDiscriminatorBlock, [1.25], x, rate=rate / decim).process(o)
+            got = chunked(fused(), x, cuts)
+            assert len(got) == len(want) and np.array_equal(got, want), tag
+
+
 @pytest.mark.parametrize("decim,ntaps", [(50, 128), (80, 128), (25, 128), (18, 64), (100, 200), (9, 33)])
 def test_lds_staged_decimator_discriminator_epilogue(decim, ntaps):
     """Tuner(.., 50) -> FrequencyDiscriminator (rtlsdr_nbfm.lua:11-13; decimation 80: rtlsdr_pocsag.lua, rtlsdr_ax25.lua) as ONE launch of the second
