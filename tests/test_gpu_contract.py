@@ -406,6 +406,16 @@ def test_registered_vectors_are_read_and_written_in_place():
             assert ref.process_device(xd.data_ptr(), m, yd.data_ptr(), m) == m
             torch.cuda.synchronize()
             assert np.array_equal(y[:m].view(np.float32), yd.cpu().numpy()), m
+        # vectors that start inside the registered ranges, off the 16-byte grid (a pipe's read position, radio/core/pipe.lua:131-160)
+        for off_in, off_out, m in ((5, 3, 100001), (1, 0, 4097), (2, 7, 1)):
+            blk = make(lr.LowpassFilterBlock, [128, 15e3], types.ComplexFloat32, FS)
+            got = L.lrhip_stage_execute(blk.stage_handle(), C.c_void_p(x.ctypes.data + 8 * off_in), m, C.c_void_p(y.ctypes.data + 8 * off_out), m)
+            assert got == m, _lib.last_error()
+            ref = make(lr.LowpassFilterBlock, [128, 15e3], types.ComplexFloat32, FS)
+            yd = torch.empty(2 * m, device="cuda")
+            assert ref.process_device(xd.data_ptr() + 8 * off_in, m, yd.data_ptr(), m) == m
+            torch.cuda.synchronize()
+            assert np.array_equal(y[off_out:off_out + m].view(np.float32), yd.cpu().numpy()), (off_in, off_out, m)
         rx = lr.Chain(receiver_blocks())
         got = L.lrhip_chain_execute(rx._chain, x.ctypes.data_as(C.c_void_p), n, audio.ctypes.data_as(C.c_void_p), len(audio))
         assert got == (n + 24) // 25, _lib.last_error()
