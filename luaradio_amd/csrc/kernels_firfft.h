@@ -539,7 +539,7 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) {
             dft16<1>(v[b]);
-#if LRHIP_FFT_PREFETCH
+#if LRHIP_FFT_PREFETCH == 1
             if (S == 2 && b == 0) prefetch(fbase + FFT_NB * fstep);
 #endif
 #pragma unroll
@@ -631,6 +631,11 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             dft16<-1>(v[b]);
         }
         FFT_STAMP(8);
+#if LRHIP_FFT_PREFETCH == 2
+        // LATE prefetch (round 5, A/B): the next block's sixteen loads go out in front of this block's stores - the only point of the loop where nothing but
+        // the sixteen outputs is live, so the 32 registers cost no occupancy - and land while the stores are issued
+        if (S == 2) prefetch(fbase + FFT_NB * fstep < fend ? fbase + FFT_NB * fstep : nblocks);
+#endif
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++)
             if (live[b]) store_block(fbase + b * fstep, v[b]);
