@@ -27,12 +27,21 @@
 
 namespace lrhip {
 
-constexpr int CHAN_RT = 2;         // 16-frame row tiles per wave
+// Round 5: one row tile per wave and W slabs of 32 k values - 41 KB of data + 2 x 18.5 KB of W = 78 KB, TWO workgroups per CU (two waves per SIMD), where rounds
+// 1-4 ran two row tiles per wave and slabs of 64 (147 KB, one workgroup per CU).  Same box, alternating: 1.317 / 1.310 -> 1.272 / 1.272 ms (0.665 -> 0.687 of the
+// f32 matrix peak); LRHIP_CHAN_RT=2 LRHIP_CHAN_KSLAB=64 is the old shape.
+#ifndef LRHIP_CHAN_RT
+#define LRHIP_CHAN_RT 1
+#endif
+#ifndef LRHIP_CHAN_KSLAB
+#define LRHIP_CHAN_KSLAB 32
+#endif
+constexpr int CHAN_RT = LRHIP_CHAN_RT;         // 16-frame row tiles per wave
 constexpr int CHAN_MT = 64 * CHAN_RT;   // frames per workgroup
-constexpr int CHAN_KSLAB = 64;     // k values (floats of the window) per W slab (2 x 37 KB; with the 73 KB data tile: one workgroup per CU)
+constexpr int CHAN_KSLAB = LRHIP_CHAN_KSLAB;     // k values (floats of the window) per W slab
 
 template <int NCT>      // number of 16-column tiles: 2K = 16*NCT
-__global__ __launch_bounds__(256, 1) void channelizer_kernel(const float *__restrict__ hist, const float *__restrict__ x,
+__global__ __launch_bounds__(256, CHAN_RT == 1 ? 2 : 1) void channelizer_kernel(const float *__restrict__ hist, const float *__restrict__ x,
                                                              const float *__restrict__ W, float *__restrict__ y,
                                                              int M, long n, long nframes, long first)
 {
