@@ -358,7 +358,11 @@ void  lrhip_host_free(void *host_ptr);
  * read buffers likewise (platform.alloc, radio/core/pipe.lua:72-76).  A registered range is pinned where it lies (hipHostRegister); the synchronous
  * host-pointer entry points (lrhip_stage_execute, lrhip_chain_execute) then DMA from / to it directly instead of staging through the library's own pinned
  * buffers - whenever the WHOLE input (or output) vector of a call lies inside one registered range.  The owner unregisters before it frees or reallocates
- * (a Vector that grew: radio/core/vector.lua:108-136).  Registrations do not survive fork().  Unregistered vectors work as before. */
+ * (a Vector that grew: radio/core/vector.lua:108-136).  Registrations do not survive fork().  Unregistered vectors work as before.
+ * Round 5: with BOTH vectors of a call registered, a stage or chain whose first kernel reads its input once and whose last kernel writes its output once
+ * (the FIR forms, Tuner / Decimator, the FM receiver) is handed the host vectors themselves - its loads and stores cross the link, one launch per call, no
+ * staging on the device.  The values are those of the same call on device-resident vectors (an overlap-save filter sees the call as ONE chunk, where the
+ * staged path cuts calls of 2^20 samples and more into pieces that are chunks of their own: Float32 rounding apart, include the statement above). */
 int   lrhip_host_register(void *host_ptr, unsigned long bytes);
 int   lrhip_host_unregister(void *host_ptr);
 
