@@ -22,6 +22,13 @@
 -- the readers.  A join whose inputs momentarily differ in length (an overlap-save filter with the reference's block framing on one side) consumes the
 -- shorter count and keeps the excess of the longer input on the device for the next batch, like a pipe would.
 --
+-- Round 5: when EVERY graph input is a file source (IQFileSource / RealFileSource with the raw-record hooks of radio/blocks/sources/file_hip.lua) that only
+-- members of the subgraph read - tests/top_spec.lua is `IQFileSource x 2 -> ...` - the sources are absorbed like a DeviceChainBlock's: the block has no
+-- input port, reads batch_samples raw records per source and batch itself (fread() into pinned memory, no interpreter per sample, no socket), uploads the
+-- RECORDS (2 bytes per sample for 'u8' instead of 8) and converts them on the device (lrhip_format_convert_create) in front of the first members.  A source
+-- that comes up short keeps the others' surplus for the next batch; the first source at its end ends the block, as PipeMux:_read_multiple would.
+-- DeviceGraph.absorb_sources = false (or LUARADIO_HIP_NO_GRAPH_SOURCES=1) keeps the input ports.
+--
 -- Restrictions: exactly one output port leaves the subgraph (a block has ONE rate, radio/core/pipe.lua:36-38: Pipe:get_rate asks the owner of the output
 -- port); members have one or two inputs and one output.  Anything else keeps the chains and the stand-alone blocks it had.
 -- DeviceGraph.enabled = false (or LUARADIO_HIP_NO_GRAPH=1) switches the rewrite off.
@@ -35,7 +42,7 @@ local pipe = require('radio.core.pipe')
 local lrhip = require('radio.core.lrhip')
 local DeviceChainBlock = require('radio.composites.devicechain')
 
-local M = {enabled = not os.getenv("LUARADIO_HIP_NO_GRAPH")}
+local M = {enabled = not os.getenv("LUARADIO_HIP_NO_GRAPH"), absorb_sources = not os.getenv("LUARADIO_HIP_NO_GRAPH_SOURCES")}
 
 local DeviceGraphBlock = block.factory("DeviceGraphBlock")
 
@@ -43,13 +50,18 @@ DeviceGraphBlock.batch_samples = 1048576
 DeviceGraphBlock.device = nil
 
 -- members: the blocks in topological order.  wiring[b][j] = {input = i} (graph input i feeds input j of member b) or {member = a} (member a's output).
--- output_member: the member whose output port leaves the subgraph.
-function DeviceGraphBlock:instantiate(members, wiring, input_types, output_member)
+-- output_member: the member whose output port leaves the subgraph.  sources (optional): the file source behind every graph input - the block then has no
+-- input ports and reads the files itself.
+function DeviceGraphBlock:instantiate(members, wiring, input_types, output_member, sources)
     self.blocks = assert(members, "Missing argument #1 (members)")
     self.wiring = assert(wiring, "Missing argument #2 (wiring)")
     self.output_member = assert(output_member, "Missing argument #4 (output member)")
+    self.input_types = assert(input_types, "Missing argument #3 (input types)")
+    self.sources = sources
     local inputs = {}
-    for i, data_type in ipairs(input_types) do inputs[i] = block.Input("in" .. i, data_type) end
+    if not sources then
+        for i, data_type in ipairs(input_types) do inputs[i] = block.Input("in" .. i, data_type) end
+    end
     self:add_type_signature(inputs, {block.Output("out", output_member:get_output_type())})
 end
 
@@ -60,6 +72,12 @@ end
 function DeviceGraphBlock:initialize()
     self.out = self:get_output_type().vector()
     self.started = false
+    self.finished = false
+    -- the descriptors the absorbed sources opened stay open in this block's process (radio/core/composite.lua:594-611 closes everything that is not in
+    -- block.files or one of its pipes)
+    for _, src in ipairs(self.sources or {}) do
+        for file, _ in pairs(src.files or {}) do self.files[file] = true end
+    end
 end
 
 local function check(rc, what)
@@ -133,9 +151,17 @@ local function start(self)
     for _, step in ipairs(self.steps) do self.step_of[step.tail] = step end
     -- graph inputs: pinned staging for the batch, a device vector each
     self.input = {}
-    for i = 1, #self.inputs do
-        local size = ffi.sizeof(self:get_input_type(i))
-        self.input[i] = {size = size, staging = lrhip.check_object(lib.lrhip_host_alloc(self.batch * size), "lrhip_host_alloc"), dev = {}}
+    for i = 1, #self.input_types do
+        local size = ffi.sizeof(self.input_types[i])
+        if self.sources then
+            -- the source's records: pinned staging for a batch of them, their device copy, the conversion stage (format_utils.lua:82-97 on the device)
+            local src = self.sources[i]
+            local raw_size = src:raw_record_size()
+            self.input[i] = {size = size, raw_size = raw_size, have = 0, eof = false, dev = {}, raw_dev = {}, fmt = src:create_stage(),
+                             raw_staging = lrhip.check_object(lib.lrhip_host_alloc(self.batch * raw_size), "lrhip_host_alloc")}
+        else
+            self.input[i] = {size = size, staging = lrhip.check_object(lib.lrhip_host_alloc(self.batch * size), "lrhip_host_alloc"), dev = {}}
+        end
     end
     self.fill = 0
     self.out_size = ffi.sizeof(self:get_output_type())
@@ -191,7 +217,15 @@ local function run_batch(self)
     self.batch_count = n
     for _, inp in ipairs(self.input) do
         reserve(inp.dev, math.max(n, 1) * inp.size)
-        if n > 0 then check(lib.lrhip_memcpy_h2d(inp.dev.ptr, inp.staging, n * inp.size), "lrhip_memcpy_h2d") end
+        if n > 0 and inp.fmt then
+            reserve(inp.raw_dev, n * inp.raw_size)
+            check(lib.lrhip_memcpy_h2d(inp.raw_dev.ptr, inp.raw_staging, n * inp.raw_size), "lrhip_memcpy_h2d")
+            if tonumber(lib.lrhip_stage_execute_device(inp.fmt, inp.raw_dev.ptr, n, inp.dev.ptr, n)) ~= n then
+                error("DeviceGraphBlock (file records): " .. ffi.string(lib.lrhip_strerror()))
+            end
+        elseif n > 0 then
+            check(lib.lrhip_memcpy_h2d(inp.dev.ptr, inp.staging, n * inp.size), "lrhip_memcpy_h2d")
+        end
     end
     for _, step in ipairs(self.steps) do
         local got
@@ -224,9 +258,45 @@ local function run_batch(self)
     return self.out
 end
 
+-- A graph fed by its own file sources: one call = one batch.  Every source is asked for what its staging still lacks; the batch is the common count.  Returns
+-- the batch's output, an empty vector when nothing could run yet (a rewind: iqfile.lua:86-90 returns an empty vector from that call too), nil at the end
+local function process_sources(self)
+    if self.finished then return nil end
+    for i, src in ipairs(self.sources) do
+        local inp = self.input[i]
+        if not inp.eof and inp.have < self.batch then
+            local got = src:read_raw(ffi.cast("char *", inp.raw_staging) + inp.have * inp.raw_size, self.batch - inp.have)
+            if got == nil then inp.eof = true else inp.have = inp.have + got end
+        end
+    end
+    local n = self.batch
+    for _, inp in ipairs(self.input) do n = math.min(n, inp.have) end
+    if n == 0 then
+        for _, inp in ipairs(self.input) do
+            if inp.eof and inp.have == 0 then self.finished = true end
+        end
+        if self.finished then return nil end
+        return self.out:resize(0)
+    end
+    self.fill = n
+    local out = run_batch(self)
+    for _, inp in ipairs(self.input) do
+        local left = inp.have - n
+        if left > 0 then
+            -- (rare: the sources came up with different counts) the surplus moves to the front through a scratch copy - ffi.copy is memcpy
+            local scratch = ffi.new("char[?]", left * inp.raw_size)
+            ffi.copy(scratch, ffi.cast("char *", inp.raw_staging) + n * inp.raw_size, left * inp.raw_size)
+            ffi.copy(inp.raw_staging, scratch, left * inp.raw_size)
+        end
+        inp.have = left
+    end
+    return out
+end
+
 -- process(x1, ..., xk): the vectors of one read share their length
 function DeviceGraphBlock:process(...)
     if not self.started then start(self) end
+    if self.sources then return process_sources(self) end
     local vectors = {...}
     local n, done = vectors[1].length, 0
     local out = nil
@@ -252,7 +322,7 @@ end
 
 -- flush(): run what has been accumulated now (a live graph that wants its samples through; cleanup() at EOF) - returns the output vector
 function DeviceGraphBlock:flush()
-    if not self.started or self.fill == 0 then return self.out:resize(0) end
+    if not self.started or self.fill == 0 or self.sources then return self.out:resize(0) end
     return run_batch(self)
 end
 
@@ -265,8 +335,12 @@ function DeviceGraphBlock:cleanup()
     end
     local lib = lrhip.lib
     for _, inp in ipairs(self.input) do
-        lib.lrhip_host_free(inp.staging)
+        lib.lrhip_host_free(inp.staging or inp.raw_staging)
         if inp.dev.ptr ~= nil then lib.lrhip_free(inp.dev.ptr) end
+        if inp.raw_dev and inp.raw_dev.ptr ~= nil then lib.lrhip_free(inp.raw_dev.ptr) end
+    end
+    if self.sources then
+        for _, src in ipairs(self.sources) do src:cleanup() end          -- fclose(): the composite no longer runs them as blocks
     end
     for _, step in ipairs(self.steps) do
         if step.out.ptr ~= nil then lib.lrhip_free(step.out.ptr) end
@@ -390,8 +464,19 @@ function M.collapse(connections)
                         end
                     end
                 end
-                local graph = DeviceGraphBlock(order, wiring, input_types, out_port.owner)
-                graph:differentiate(input_types)
+                -- every graph input a file source with the raw-record hooks, read by members of this subgraph only: absorbed
+                local sources = M.absorb_sources and {} or nil
+                for i, output in ipairs(outside_ports) do
+                    if sources and not DeviceChainBlock.is_raw_source(output.owner) then sources = nil end
+                    if sources then
+                        for input, out in pairs(connections) do
+                            if out == output and not inside[input.owner] then sources = nil end
+                        end
+                    end
+                    if sources then sources[i] = output.owner end
+                end
+                local graph = DeviceGraphBlock(order, wiring, input_types, out_port.owner, sources)
+                graph:differentiate(sources and {} or input_types)
                 -- upstream: graph input i reads outside port i; the members' own entries leave the table
                 for _, b in ipairs(order) do
                     for j, inp in ipairs(b.inputs) do
@@ -401,11 +486,18 @@ function M.collapse(connections)
                             inp.pipe = pipe.Pipe(w.member.outputs[1], inp)         -- rate-only (radio/core/pipe.lua:36-38)
                         else
                             local i = w.input
-                            inp.pipe = {get_rate = function () return graph.inputs[i].pipe:get_rate() end}
+                            if sources then
+                                local src = sources[i]
+                                inp.pipe = {get_rate = function () return src:get_rate() end}
+                            else
+                                inp.pipe = {get_rate = function () return graph.inputs[i].pipe:get_rate() end}
+                            end
                         end
                     end
                 end
-                for i, output in ipairs(outside_ports) do result[graph.inputs[i]] = output end
+                if not sources then
+                    for i, output in ipairs(outside_ports) do result[graph.inputs[i]] = output end
+                end
                 -- downstream: whoever read the leaving port reads the graph
                 for input, output in pairs(connections) do
                     if output == out_port and not inside[input.owner] then result[input] = graph.outputs[1] end

@@ -250,6 +250,73 @@ def test_reference_top_level_graph_collapses_to_one_device_graph_block():
     assert [ml.index(d, "name") for d in lua_list(devs2)] == ["DeviceChainBlock"]
 
 
+TOP_SPEC_FROM_FILES = r'''
+local R = require('reference_standins')
+local types = require('radio.types')
+local path1, path2, lp_taps, dec_taps = ...
+local g = R.graph()
+local s1, s2 = R.IQFileSource(path1, 'u8', 1e6), R.IQFileSource(path2, 'u8', 1e6)
+local mc, lp, fd, dlp, dds = R.MultiplyConjugateBlock(), R.FIRFilterBlock(lp_taps), R.FrequencyDiscriminatorBlock(5.0), R.FIRFilterBlock(dec_taps), R.DownsamplerBlock(25)
+local sink = R.HostSink(types.Float32)
+s1:differentiate({}); s2:differentiate({})
+mc:differentiate({types.ComplexFloat32, types.ComplexFloat32})
+lp:differentiate({types.ComplexFloat32}); fd:differentiate({types.ComplexFloat32})
+dlp:differentiate({types.Float32}); dds:differentiate({types.Float32}); sink:differentiate({types.Float32})
+g.connect(s1, "out", mc, "in1")
+g.connect(s2, "out", mc, "in2")
+g.connect(mc, lp, fd, dlp, dds, sink)
+local connections, device_blocks = R.prepare(g.connections, {s1, s2, mc, lp, fd, dlp, dds, sink})
+return connections, device_blocks, s1, s2, sink
+'''
+
+
+def test_top_level_graph_reads_its_two_recordings_itself(tmp_path):
+    """tests/top_spec.lua as the reference writes it - IQFileSource x 2 -> MultiplyConjugate -> ... -> sink: both sources are read by members of the
+    subgraph only, so the DeviceGraphBlock absorbs them.  No input port, no socket in front of it: a batch of raw records per source and call (2 bytes per
+    sample), converted on the device; the shorter recording ends the block"""
+    n1, n2 = 3 * 4096 + 100, 3 * 4096 + 700
+    rng = np.random.default_rng(4)
+    p1, p2 = tmp_path / "a.u8", tmp_path / "b.u8"
+    p1.write_bytes(rng.integers(0, 256, 2 * n1, dtype=np.uint8).tobytes())
+    p2.write_bytes(rng.integers(0, 256, 2 * n2, dtype=np.uint8).tobytes())
+    I, proxy, ffi = interp()
+    conns, devs, s1, s2, sink = I.run(TOP_SPEC_FROM_FILES, "topf", [str(p1), str(p2), fvec(np.ones(16) / 16), fvec(np.ones(16) / 16)])
+    devs = lua_list(devs)
+    assert [ml.index(d, "name") for d in devs] == ["DeviceGraphBlock"]
+    g = devs[0]
+    assert ml.index(g, "inputs").length() == 0 and ml.index(g, "outputs").length() == 1 and ml.index(g, "blocks").length() == 5
+    assert len(conns.hash) == 1 and conns.get(ml.index(sink, "inputs").get(1)) is ml.index(g, "outputs").get(1)
+    assert ml.call(ml.index(g, "get_rate"), [g])[0] == 1e6 / 25
+    for s in (s1, s2):
+        assert ml.index(g, "files").get(ml.index(s, "file")) is True            # the recordings stay open in the graph's process after fork()
+    g.set("batch_samples", 4096.0)
+    process = ml.index(g, "process")
+    outs = []
+    while True:
+        r = ml.call(process, [g])
+        if not r or r[0] is None:
+            break
+        outs.append(r[0].length)
+    assert outs == [4096, 4096, 4096, 100]                          # the fake emits one sample per input sample; the shorter recording decides
+    reads = ffi.get("_state")["fread_sizes"]
+    assert all(r[0] == 2 for r in reads)                             # records of 2 bytes
+    t = proxy.trace
+    fmt = [a_ for n_, a_ in proxy.fake.calls if n_ == "lrhip_format_convert_create"]
+    assert fmt == [[b"u8", 1], [b"u8", 1]]
+    per_batch = [x for x in t if x in ("lrhip_memcpy_h2d", "lrhip_stage_execute_device", "lrhip_stage_execute2_device", "lrhip_chain_execute_device", "lrhip_memcpy_d2h")]
+    assert per_batch == ["lrhip_memcpy_h2d", "lrhip_stage_execute_device", "lrhip_memcpy_h2d", "lrhip_stage_execute_device", "lrhip_stage_execute2_device",
+                         "lrhip_chain_execute_device", "lrhip_memcpy_d2h"] * 4
+    up = [a_[2] for n_, a_ in proxy.fake.calls if n_ == "lrhip_memcpy_h2d"]
+    assert up[:2] == [8192, 8192] and up[-2:] == [200, 200]          # bytes uploaded per source and batch: 2 per sample
+    ml.call(ml.index(g, "cleanup"), [g])
+    assert ml.index(s1, "file").closed and ml.index(s2, "file").closed
+    # the knob keeps the sources as blocks and the graph's two input ports
+    I2, _, _ = interp(env={"LUARADIO_HIP_NO_GRAPH_SOURCES": "1"})
+    conns2, devs2, _, _, _ = I2.run(TOP_SPEC_FROM_FILES, "topf", [str(p1), str(p2), fvec(np.ones(16) / 16), fvec(np.ones(16) / 16)])
+    g2 = lua_list(devs2)[0]
+    assert ml.index(g2, "name") == "DeviceGraphBlock" and ml.index(g2, "inputs").length() == 2 and len(conns2.hash) == 3
+
+
 FANOUT_JOIN_GRAPH = r'''
 local R = require('reference_standins')
 local types = require('radio.types')
@@ -787,6 +854,52 @@ def test_gpu_lua_top_level_graph_equals_the_python_device_graph_bit_for_bit():
         assert len(got) == len(want) and G.max_abs_err(got, want) < 1e-6
         assert np.array_equal(got, py)
         assert "lrhip_stage_execute2" not in proxy.trace and proxy.trace.count("lrhip_stage_execute2_device") == len(cuts) + 1
+
+
+@pytest.mark.gpu
+def test_gpu_lua_top_level_graph_fed_by_its_own_recordings(tmp_path):
+    """the -m gpu twin of test_top_level_graph_reads_its_two_recordings_itself: two u8 recordings -> ONE DeviceGraphBlock without input ports; the bits of
+    luaradio_amd.DeviceGraph on the reference's conversion of the same records (iqfile.lua:99-113: (raw - 127.5) / 127.5 in double, stored as Float32),
+    batch by batch, the shorter recording deciding the length"""
+    lr, L = real_lib()
+    from luaradio_amd import types
+    rng = np.random.default_rng(41)
+    n1, n2, batch = 3 * 4096 + 100, 3 * 4096 + 700, 4096
+    raw1, raw2 = rng.integers(0, 256, 2 * n1, dtype=np.uint8), rng.integers(0, 256, 2 * n2, dtype=np.uint8)
+    p1, p2 = tmp_path / "a.u8", tmp_path / "b.u8"
+    p1.write_bytes(raw1.tobytes())
+    p2.write_bytes(raw2.tobytes())
+
+    def convert(raw):
+        return ((raw.astype(np.float64) - 127.5) / 127.5).astype(np.float32).view(np.complex64)
+
+    a, b = convert(raw1), convert(raw2)
+    lp_taps = lowpass_taps(16, 100e3, 1e6)
+    dec_taps = np.asarray(lr.filter_utils.firwin_lowpass(16, 1.0 / 25), np.float32)
+    g = lr.DeviceGraph()
+    i1, i2 = g.input("a", types.ComplexFloat32, 1e6), g.input("b", types.ComplexFloat32, 1e6)
+    mc = lr.MultiplyConjugateBlock()
+    g.connect(i1, "out", mc, "in1")
+    g.connect(i2, "out", mc, "in2")
+    g.connect(mc, lr.LowpassFilterBlock(16, 100e3), lr.FrequencyDiscriminatorBlock(5.0), lr.DecimatorBlock(25, {"num_taps": 16}))
+    g.initialize()
+    n = min(n1, n2)
+    want = np.concatenate([next(iter(g.process(a=a[p:min(p + batch, n)], b=b[p:min(p + batch, n)]).values())) for p in range(0, n, batch)])
+    I, proxy, _ = interp(real_lib=L)
+    conns, devs, s1, s2, sink = I.run(TOP_SPEC_FROM_FILES, "topf", [str(p1), str(p2), fvec(lp_taps), fvec(dec_taps)])
+    lg = lua_list(devs)[0]
+    assert ml.index(lg, "inputs").length() == 0
+    lg.set("batch_samples", float(batch))
+    parts = []
+    while True:
+        r = ml.call(ml.index(lg, "process"), [lg])
+        if not r or r[0] is None:
+            break
+        parts.append(r[0].array().copy())
+    ml.call(ml.index(lg, "cleanup"), [lg])
+    got = np.concatenate(parts)
+    assert len(got) == len(want) == (n + 24) // 25 and np.array_equal(got, want)
+    assert proxy.trace.count("lrhip_format_convert_create") == 2 and "lrhip_stage_execute2" not in proxy.trace
 
 
 @pytest.mark.gpu
