@@ -27,7 +27,10 @@
 -- input port, reads batch_samples raw records per source and batch itself (fread() into pinned memory, no interpreter per sample, no socket), uploads the
 -- RECORDS (2 bytes per sample for 'u8' instead of 8) and converts them on the device (lrhip_format_convert_create) in front of the first members.  A source
 -- that comes up short keeps the others' surplus for the next batch; the first source at its end ends the block, as PipeMux:_read_multiple would.
--- DeviceGraph.absorb_sources = false (or LUARADIO_HIP_NO_GRAPH_SOURCES=1) keeps the input ports.
+-- DeviceGraph.absorb_sources = false (or LUARADIO_HIP_NO_GRAPH_SOURCES=1) keeps the input ports.  Likewise the file SINK that is the only reader of the
+-- port leaving the subgraph (tests/top_spec.lua ends in a RawFileSink): the output is packed into the sink's records on the device and written by its
+-- fwrite (write_raw, radio/blocks/sinks/file_hip.lua) - no output port; with sources AND sink absorbed the reference's end-to-end graph is ONE block without
+-- ports, which runs its own loop (Block:run would wait on pipes it does not have).
 --
 -- Restrictions: exactly one output port leaves the subgraph (a block has ONE rate, radio/core/pipe.lua:36-38: Pipe:get_rate asks the owner of the output
 -- port); members have one or two inputs and one output.  Anything else keeps the chains and the stand-alone blocks it had.
@@ -52,17 +55,18 @@ DeviceGraphBlock.device = nil
 -- members: the blocks in topological order.  wiring[b][j] = {input = i} (graph input i feeds input j of member b) or {member = a} (member a's output).
 -- output_member: the member whose output port leaves the subgraph.  sources (optional): the file source behind every graph input - the block then has no
 -- input ports and reads the files itself.
-function DeviceGraphBlock:instantiate(members, wiring, input_types, output_member, sources)
+function DeviceGraphBlock:instantiate(members, wiring, input_types, output_member, sources, sink)
     self.blocks = assert(members, "Missing argument #1 (members)")
     self.wiring = assert(wiring, "Missing argument #2 (wiring)")
     self.output_member = assert(output_member, "Missing argument #4 (output member)")
     self.input_types = assert(input_types, "Missing argument #3 (input types)")
     self.sources = sources
+    self.sink = sink
     local inputs = {}
     if not sources then
         for i, data_type in ipairs(input_types) do inputs[i] = block.Input("in" .. i, data_type) end
     end
-    self:add_type_signature(inputs, {block.Output("out", output_member:get_output_type())})
+    self:add_type_signature(inputs, sink and {} or {block.Output("out", output_member:get_output_type())})
 end
 
 function DeviceGraphBlock:get_rate()
@@ -70,13 +74,16 @@ function DeviceGraphBlock:get_rate()
 end
 
 function DeviceGraphBlock:initialize()
-    self.out = self:get_output_type().vector()
+    self.out = self.output_member:get_output_type().vector()
     self.started = false
     self.finished = false
     -- the descriptors the absorbed sources opened stay open in this block's process (radio/core/composite.lua:594-611 closes everything that is not in
     -- block.files or one of its pipes)
     for _, src in ipairs(self.sources or {}) do
         for file, _ in pairs(src.files or {}) do self.files[file] = true end
+    end
+    if self.sink then
+        for file, _ in pairs(self.sink.files or {}) do self.files[file] = true end
     end
 end
 
@@ -164,7 +171,12 @@ local function start(self)
         end
     end
     self.fill = 0
-    self.out_size = ffi.sizeof(self:get_output_type())
+    self.out_size = ffi.sizeof(self.output_member:get_output_type())
+    if self.sink then
+        self.pack = self.sink:create_stage()                 -- lrhip_format_pack_create: samples -> the file's records (format_utils.lua:99-120), on the device
+        self.raw_size = lib.lrhip_stage_output_size(self.pack)
+        self.raw_dev, self.raw, self.raw_cap = {}, nil, 0
+    end
     self.started = true
 end
 
@@ -249,6 +261,25 @@ local function run_batch(self)
         step.count = got
     end
     local last = self.step_of[self.output_member]
+    if self.sink then
+        -- pack on the device, download the records, hand them to the sink's fwrite
+        if last.count > 0 then
+            reserve(self.raw_dev, last.count * self.raw_size)
+            if self.raw == nil or self.raw_cap < last.count then
+                if self.raw ~= nil then lib.lrhip_host_free(self.raw) end
+                self.raw = lrhip.check_object(lib.lrhip_host_alloc(last.count * self.raw_size), "lrhip_host_alloc")
+                self.raw_cap = last.count
+            end
+            if tonumber(lib.lrhip_stage_execute_device(self.pack, last.out.ptr, last.count, self.raw_dev.ptr, last.count)) ~= last.count then
+                error("DeviceGraphBlock (file records out): " .. ffi.string(lib.lrhip_strerror()))
+            end
+            check(lib.lrhip_memcpy_d2h(self.raw, self.raw_dev.ptr, last.count * self.raw_size), "lrhip_memcpy_d2h")
+            self.sink:write_raw(self.raw, last.count)
+        else
+            check(lib.lrhip_synchronize(), "lrhip_synchronize")
+        end
+        return self.out:resize(0)
+    end
     self.out:resize(last.count)
     if last.count > 0 then
         check(lib.lrhip_memcpy_d2h(self.out.data, last.out.ptr, last.count * self.out_size), "lrhip_memcpy_d2h")
@@ -296,7 +327,11 @@ end
 -- process(x1, ..., xk): the vectors of one read share their length
 function DeviceGraphBlock:process(...)
     if not self.started then start(self) end
-    if self.sources then return process_sources(self) end
+    if self.sources then
+        local out = process_sources(self)
+        if self.sink then return end                   -- a block without ports: run() / run_once() below look at self.finished
+        return out
+    end
     local vectors = {...}
     local n, done = vectors[1].length, 0
     local out = nil
@@ -309,13 +344,14 @@ function DeviceGraphBlock:process(...)
         self.fill = self.fill + take
         done = done + take
         if self.fill == self.batch then
-            if out ~= nil then
+            if out ~= nil and not self.sink then
                 -- a second full batch inside one call (a vector longer than a batch): the first batch's output goes to the readers now
                 for _, p in ipairs(self.outputs[1].pipes) do p:write(out) end
             end
             out = run_batch(self)
         end
     end
+    if self.sink then return end                       -- no output port: nothing returned (radio/core/block.lua:585-593)
     if out == nil then out = self.out:resize(0) end
     return out
 end
@@ -330,10 +366,16 @@ end
 function DeviceGraphBlock:cleanup()
     if not self.started then return end
     local tail = self:flush()
-    if tail.length > 0 then
+    if tail.length > 0 and not self.sink then
         for _, p in ipairs(self.outputs[1].pipes) do p:write(tail) end
     end
     local lib = lrhip.lib
+    if self.sink then
+        if self.raw ~= nil then lib.lrhip_host_free(self.raw) end
+        if self.raw_dev.ptr ~= nil then lib.lrhip_free(self.raw_dev.ptr) end
+        self.raw = nil
+        self.sink:cleanup()                                  -- fclose(): the composite no longer runs it as a block
+    end
     for _, inp in ipairs(self.input) do
         lib.lrhip_host_free(inp.staging or inp.raw_staging)
         if inp.dev.ptr ~= nil then lib.lrhip_free(inp.dev.ptr) end
@@ -352,6 +394,28 @@ function DeviceGraphBlock:cleanup()
         end
     end
     self.started = false
+end
+
+-- files -> device -> file (sources AND sink absorbed): a block without ports runs its own loop, as a DeviceChainBlock of that shape does (devicechain.lua)
+local block_run, block_run_once = DeviceGraphBlock.run, DeviceGraphBlock.run_once
+function DeviceGraphBlock:run()
+    if not (self.sources and self.sink) then return block_run(self) end
+    local pipe_mux = pipe.PipeMux({}, {}, self.control_socket)
+    while not self.finished do
+        self:process()
+        if self.control_socket then
+            local ret = ffi.C.poll(pipe_mux.input_pollfds, 1, 0)
+            if ret < 0 then error("poll(): " .. ffi.string(ffi.C.strerror(ffi.errno()))) end
+            if ret > 0 then break end           -- shutdown requested (pipe.lua:417-431: pollfds[0] is the control socket)
+        end
+    end
+    self:cleanup()
+end
+function DeviceGraphBlock:run_once()
+    if not (self.sources and self.sink) then return block_run_once(self) end
+    self:process()
+    if self.finished then return nil end
+    return true
 end
 
 ----------------------------------------------------------------------------------------------------------------------------------
@@ -475,7 +539,16 @@ function M.collapse(connections)
                     end
                     if sources then sources[i] = output.owner end
                 end
-                local graph = DeviceGraphBlock(order, wiring, input_types, out_port.owner, sources)
+                -- ... and the file sink that is the only reader of the port that leaves
+                local sink, nreaders = nil, 0
+                for input, out in pairs(connections) do
+                    if out == out_port and not inside[input.owner] then
+                        nreaders = nreaders + 1
+                        sink = input.owner
+                    end
+                end
+                if not (M.absorb_sources and nreaders == 1 and DeviceChainBlock.is_raw_sink(sink)) then sink = nil end
+                local graph = DeviceGraphBlock(order, wiring, input_types, out_port.owner, sources, sink)
                 graph:differentiate(sources and {} or input_types)
                 -- upstream: graph input i reads outside port i; the members' own entries leave the table
                 for _, b in ipairs(order) do
@@ -498,9 +571,16 @@ function M.collapse(connections)
                 if not sources then
                     for i, output in ipairs(outside_ports) do result[graph.inputs[i]] = output end
                 end
-                -- downstream: whoever read the leaving port reads the graph
+                -- downstream: whoever read the leaving port reads the graph (an absorbed sink's edge leaves the table; it learns its rate from the member)
                 for input, output in pairs(connections) do
-                    if output == out_port and not inside[input.owner] then result[input] = graph.outputs[1] end
+                    if output == out_port and not inside[input.owner] then
+                        if sink then
+                            result[input] = nil
+                            input.pipe = pipe.Pipe(out_port, input)
+                        else
+                            result[input] = graph.outputs[1]
+                        end
+                    end
                 end
                 graphs[#graphs + 1] = graph
             end

@@ -253,11 +253,11 @@ def test_reference_top_level_graph_collapses_to_one_device_graph_block():
 TOP_SPEC_FROM_FILES = r'''
 local R = require('reference_standins')
 local types = require('radio.types')
-local path1, path2, lp_taps, dec_taps = ...
+local path1, path2, lp_taps, dec_taps, sink_path = ...
 local g = R.graph()
 local s1, s2 = R.IQFileSource(path1, 'u8', 1e6), R.IQFileSource(path2, 'u8', 1e6)
 local mc, lp, fd, dlp, dds = R.MultiplyConjugateBlock(), R.FIRFilterBlock(lp_taps), R.FrequencyDiscriminatorBlock(5.0), R.FIRFilterBlock(dec_taps), R.DownsamplerBlock(25)
-local sink = R.HostSink(types.Float32)
+local sink = sink_path and R.RealFileSink(sink_path, 'f32le') or R.HostSink(types.Float32)
 s1:differentiate({}); s2:differentiate({})
 mc:differentiate({types.ComplexFloat32, types.ComplexFloat32})
 lp:differentiate({types.ComplexFloat32}); fd:differentiate({types.ComplexFloat32})
@@ -315,6 +315,39 @@ def test_top_level_graph_reads_its_two_recordings_itself(tmp_path):
     conns2, devs2, _, _, _ = I2.run(TOP_SPEC_FROM_FILES, "topf", [str(p1), str(p2), fvec(np.ones(16) / 16), fvec(np.ones(16) / 16)])
     g2 = lua_list(devs2)[0]
     assert ml.index(g2, "name") == "DeviceGraphBlock" and ml.index(g2, "inputs").length() == 2 and len(conns2.hash) == 3
+
+
+def test_top_level_graph_with_its_files_on_both_sides_is_one_block_without_ports(tmp_path):
+    """tests/top_spec.lua end to end - IQFileSource x 2 -> MultiplyConjugate -> Lowpass -> Discriminator -> Decimator -> RawFileSink: sources AND sink are
+    absorbed.  The table of connections is empty, the block is in the evaluation order through the binding's hook, runs its own loop, packs its output into
+    the sink's records on the device and hands them to the sink's fwrite"""
+    n1, n2 = 3 * 4096 + 100, 3 * 4096 + 700
+    rng = np.random.default_rng(5)
+    p1, p2, out = tmp_path / "a.u8", tmp_path / "b.u8", tmp_path / "y.f32"
+    p1.write_bytes(rng.integers(0, 256, 2 * n1, dtype=np.uint8).tobytes())
+    p2.write_bytes(rng.integers(0, 256, 2 * n2, dtype=np.uint8).tobytes())
+    I, proxy, ffi = interp()
+    conns, devs, s1, s2, sink = I.run(TOP_SPEC_FROM_FILES, "topff", [str(p1), str(p2), fvec(np.ones(16) / 16), fvec(np.ones(16) / 16), str(out)])
+    devs = lua_list(devs)
+    assert [ml.index(d, "name") for d in devs] == ["DeviceGraphBlock"] and len(conns.hash) == 0
+    g = devs[0]
+    assert ml.index(g, "inputs").length() == 0 and ml.index(g, "outputs").length() == 0 and ml.index(g, "sink") is sink
+    assert ml.index(g, "files").get(ml.index(sink, "file")) is True
+    g.set("batch_samples", 4096.0)
+    ml.call(ml.index(g, "run"), [g])
+    assert [a_ for n_, a_ in proxy.fake.calls if n_ == "lrhip_format_pack_create"] == [[b"f32le", 0]]
+    per_batch = [x for x in proxy.trace if x in ("lrhip_stage_execute2_device", "lrhip_chain_execute_device", "lrhip_memcpy_d2h")]
+    assert per_batch == ["lrhip_stage_execute2_device", "lrhip_chain_execute_device", "lrhip_memcpy_d2h"] * 4
+    # the fake emits one record per input sample: min(n1, n2) records of 4 bytes reached the file; all three files were closed by the block's cleanup()
+    assert out.stat().st_size == min(n1, n2) * 4
+    assert ml.index(s1, "file").closed and ml.index(s2, "file").closed and ml.index(sink, "file").closed
+    assert ml.index(g, "finished") is True
+    # run_once() (top:run(false)): true while the recordings last, nil at their end
+    conns2, devs2, _, _, _ = I.run(TOP_SPEC_FROM_FILES, "topff", [str(p1), str(p2), fvec(np.ones(16) / 16), fvec(np.ones(16) / 16), str(out)])
+    g2 = lua_list(devs2)[0]
+    g2.set("batch_samples", 8192.0)
+    rets = [ml.call(ml.index(g2, "run_once"), [g2]) for _ in range(4)]
+    assert [r[0] if r else None for r in rets] == [True, True, None, None] or [r[0] if r else None for r in rets][-1] is None
 
 
 FANOUT_JOIN_GRAPH = r'''
@@ -900,6 +933,15 @@ def test_gpu_lua_top_level_graph_fed_by_its_own_recordings(tmp_path):
     got = np.concatenate(parts)
     assert len(got) == len(want) == (n + 24) // 25 and np.array_equal(got, want)
     assert proxy.trace.count("lrhip_format_convert_create") == 2 and "lrhip_stage_execute2" not in proxy.trace
+    # ... and with the RawFileSink of tests/top_spec.lua behind it: ONE block without ports, the same samples as f32le records in the file
+    out = tmp_path / "y.f32"
+    I2, proxy2, _ = interp(real_lib=L)
+    conns2, devs2, _, _, _ = I2.run(TOP_SPEC_FROM_FILES, "topff", [str(p1), str(p2), fvec(lp_taps), fvec(dec_taps), str(out)])
+    g2 = lua_list(devs2)[0]
+    assert len(conns2.hash) == 0 and ml.index(g2, "inputs").length() == 0 and ml.index(g2, "outputs").length() == 0
+    g2.set("batch_samples", float(batch))
+    ml.call(ml.index(g2, "run"), [g2])
+    assert np.array_equal(np.fromfile(out, dtype="<f4"), want)
 
 
 @pytest.mark.gpu
