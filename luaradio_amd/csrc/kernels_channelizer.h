@@ -30,6 +30,9 @@ namespace lrhip {
 // Round 5: one row tile per wave and W slabs of 32 k values - 41 KB of data + 2 x 18.5 KB of W = 78 KB, TWO workgroups per CU (two waves per SIMD), where rounds
 // 1-4 ran two row tiles per wave and slabs of 64 (147 KB, one workgroup per CU).  Same box, alternating: 1.317 / 1.310 -> 1.272 / 1.272 ms (0.665 -> 0.687 of the
 // f32 matrix peak); LRHIP_CHAN_RT=2 LRHIP_CHAN_KSLAB=64 is the old shape.
+#ifndef LRHIP_CHAN_INTERLEAVE
+#define LRHIP_CHAN_INTERLEAVE 1      /* same box, three alternations: 1.239 / 1.251 / 1.244 -> 1.209 / 1.216 / 1.190 ms */
+#endif
 #ifndef LRHIP_CHAN_RT
 #define LRHIP_CHAN_RT 1
 #endif
@@ -140,6 +143,21 @@ __global__ __launch_bounds__(256, CHAN_RT == 1 ? 2 : 1) void channelizer_kernel(
         fetch(0, 0);
 #pragma unroll
         for (int st = 0; st < NST; st++) {
+#if LRHIP_CHAN_INTERLEAVE
+            // A/B (round 5): the next step's fragment reads issued BETWEEN this step's MFMAs (one DS read behind each) instead of in front of them
+            if (st + 1 < NST) fetch((st + 1) & 1, st + 1);
+#pragma unroll
+            for (int c = 0; c < NCT; c++)
+#pragma unroll
+                for (int r = 0; r < CHAN_RT; r++)
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st & 1][r], bv[st & 1][c], acc[r][c], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NCT * CHAN_RT; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one DS read
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#else
             if (st + 1 < NST) fetch((st + 1) & 1, st + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -148,6 +166,7 @@ __global__ __launch_bounds__(256, CHAN_RT == 1 ? 2 : 1) void channelizer_kernel(
                 for (int r = 0; r < CHAN_RT; r++)
                     acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st & 1][r], bv[st & 1][c], acc[r][c], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         if (more) {
             float *wdst = ldsW + ((s + 1) & 1) * (CHAN_KSLAB * WROW);
