@@ -30,6 +30,9 @@
 #ifndef LRHIP_F64_PREFETCH
 #define LRHIP_F64_PREFETCH 0      /* measured equal at one wave per SIMD (0.385 against 0.381 ms), impossible at two (128 more registers) */
 #endif
+#ifndef LRHIP_F64_CARRY
+#define LRHIP_F64_CARRY 1      /* two partitions: the half window two consecutive blocks share stays in registers (0: re-read through L2, A/B) */
+#endif
 #ifndef LRHIP_F64_HGROUP
 #define LRHIP_F64_HGROUP 16
 #endif
@@ -197,6 +200,8 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
     };
     // two partitions: this wave's run of consecutive blocks [r0, r1), entered one block early (warm-up: forward transform only)
     [[maybe_unused]] cf zp[NP == 2 ? 64 : 1];
+    [[maybe_unused]] cf keep[(NP == 2 && LRHIP_F64_CARRY) ? 32 : 1];
+    [[maybe_unused]] bool kept = false;
     const long nwaves = (long)gridDim.x * F64_WAVES, run = (nblocks + nwaves - 1) / nwaves;
     const long r0 = ((long)blockIdx.x * F64_WAVES + wave) * run, r1 = r0 + run < nblocks ? r0 + run : nblocks;
     if (NP == 2) { slot0 = r0 - 1; sstep = 1; send = r1; }
@@ -213,8 +218,22 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
             for (int i = 0; i < 64; i++) v[i] = pre[i];
         } else if (xlo >= 0 && xlo + F4K_N <= n) {
             const cf *src = reinterpret_cast<const cf *>(x) + xlo;
+            if constexpr (NP == 2 && LRHIP_F64_CARRY) {
+                // a run of consecutive blocks at a hop of half a window: the first half of this window IS the second half of the previous one - kept in
+                // 64 registers (the wave has 512), so every sample of the stream is loaded exactly once
+                if (kept) {
 #pragma unroll
-            for (int i = 0; i < 64; i++) v[i] = (src + 64 * i)[(unsigned)lane];
+                    for (int i = 0; i < 32; i++) v[i] = keep[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 32; i++) v[i] = (src + 64 * i)[(unsigned)lane];
+                }
+#pragma unroll
+                for (int i = 32; i < 64; i++) v[i] = (src + 64 * i)[(unsigned)lane];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 64; i++) v[i] = (src + 64 * i)[(unsigned)lane];
+            }
         } else {
             // edge blocks (the window reaches into the carried history or past the chunk): staged through the transpose buffer by a ROLLED loop, so that the
             // 64 x 2 guarded loads do not compete for registers with the main path
@@ -226,6 +245,11 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
             for (int i = 0; i < 64; i++) ex[i * 64 + lane] = stream_at<2>(hist, x, xlo + 64 * i + lane + (M - 1), 1, M, n);
 #pragma unroll
             for (int i = 0; i < 64; i++) v[i].y = ex[i * 64 + lane];
+        }
+        if constexpr (NP == 2 && LRHIP_F64_CARRY) {
+#pragma unroll
+            for (int i = 0; i < 32; i++) keep[i] = v[32 + i];
+            kept = true;
         }
         // ---- forward: DFT over i, twiddle, transpose, DFT over t
         // (F64_FENCE = scheduling fence between phases: left alone, the scheduler pulls the next phase's 64 loads up to cover their latency and the wave
