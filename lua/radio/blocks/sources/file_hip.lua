@@ -25,6 +25,10 @@ local ffi = require('ffi')
 
 local lrhip = require('radio.core.lrhip')
 
+ffi.cdef[[
+long ftell(FILE *stream);
+]]
+
 local M = {}
 
 local function patch_source(Source, complex_out)
@@ -67,20 +71,22 @@ local function patch_source(Source, complex_out)
     -- slot itself - positional reads on its copy threads, several times what one read(2) stream delivers - and submits the slot
     -- (lrhip_chain_submit_fd).  Returns the number of records submitted (0 right after a rewind), nil at the end of the file, false when the descriptor is
     -- not a regular file (a FIFO, a character device: DeviceChainBlock then uses read_raw() for the rest of the run).
-    -- The FILE *'s own position is not used: the offset starts where the stream stood when the chain took over.
+    -- The offset starts at the STREAM's position when the chain took over - ftell(), which counts what stdio has buffered, not the descriptor's lseek()
+    -- position (a source built on a caller's FILE * / fd that was read from before: the kernel offset is ahead of the stream by the unread part of the
+    -- buffer) - and a repeating source goes back to byte 0, as the reference's rewind() and read_raw() do (iqfile.lua:86-90).
     function Source:submit_raw(chain, max_records)
         if self.raw_fd == nil then
             self.raw_fd = ffi.C.fileno(self.file)
-            self.raw_offset = tonumber(ffi.C.lseek(self.raw_fd, 0, 1))          -- SEEK_CUR: 0 for a file opened by name, the caller's position for an fd
+            self.raw_offset = tonumber(ffi.C.ftell(self.file))
+            if self.raw_offset < 0 then self.raw_offset = tonumber(ffi.C.lseek(self.raw_fd, 0, 1)) end          -- SEEK_CUR
             if self.raw_offset < 0 then return false end
-            self.raw_start = self.raw_offset
         end
         local n = tonumber(lrhip.lib.lrhip_chain_submit_fd(chain, self.raw_fd, self.raw_offset, max_records))
         if n == -4 then return false end
         if n < 0 then error("lrhip_chain_submit_fd: " .. ffi.string(lrhip.lib.lrhip_strerror())) end
         if n == 0 then
             if not self.repeat_on_eof then return nil end
-            self.raw_offset = self.raw_start
+            self.raw_offset = 0
             return 0
         end
         self.raw_offset = self.raw_offset + n * self:raw_record_size()

@@ -107,6 +107,22 @@ function DeviceChainBlock:initialize()
     end
 end
 
+-- start_at() / seek() record what was asked; this applies it to self.chain and returns the sample the source has to deliver from
+local function position(self)
+    local lib = lrhip.lib
+    if self.pending_start ~= nil then
+        local seek_sample = ffi.new("unsigned long long[1]")
+        if lib.lrhip_chain_start_at(self.chain, self.pending_start, seek_sample) ~= 0 then
+            error("lrhip_chain_start_at: " .. ffi.string(lib.lrhip_strerror()))
+        end
+        return tonumber(seek_sample[0])
+    end
+    if lib.lrhip_chain_seek(self.chain, self.pending_seek) ~= 0 then
+        error("lrhip_chain_seek: " .. ffi.string(lib.lrhip_strerror()))
+    end
+    return self.pending_seek
+end
+
 local function create_chain(self)
     lrhip.ensure(self.device)       -- binds this process to its device BEFORE the members create their stages
     local lib = lrhip.lib
@@ -127,6 +143,8 @@ local function create_chain(self)
         error("lrhip_chain_set_latency: " .. ffi.string(lib.lrhip_strerror()))
     end
     if self.sink then self.raw_size = lib.lrhip_stage_output_size(self.sink:create_stage()) end
+    -- a position asked for before this process existed (start_at() / seek() in the flow graph's parent): applied to THIS process's chain
+    if self.pending_start ~= nil or self.pending_seek ~= nil then self.position_sample = position(self) end
 end
 
 -- Output of a call: `cap` samples of room, fill(ptr, cap) -> n.  Without a sink member the samples land in self.out (returned, as process() output);
@@ -335,35 +353,50 @@ end
 -- the single-process run emits for input sample first_sample.  Chains holding a stage with unbounded memory (AGC, ...) raise an
 -- error: they cannot be sharded.
 function DeviceChainBlock:start_at(first_sample)
-    if self.chain == nil then create_chain(self) end
-    local lib = lrhip.lib
-    local seek_sample = ffi.new("unsigned long long[1]")
-    if lib.lrhip_chain_start_at(self.chain, first_sample, seek_sample) ~= 0 then
-        error("lrhip_chain_start_at: " .. ffi.string(lib.lrhip_strerror()))
+    self.pending_start, self.pending_seek = first_sample, nil
+    if self.chain ~= nil then
+        self.position_sample = position(self)
+        return self.position_sample
     end
-    return tonumber(seek_sample[0])
+    return (lrhip.in_helper(function ()
+        create_chain(self)
+        return self.position_sample
+    end))
 end
 
 -- The partition helpers next to start_at(): how many input samples a partition replays in front of its first own sample (-1 with an error message for
 -- chains with unbounded memory), and the grid partition boundaries should lie on to reproduce the uninterrupted run's tiles (include/lrhip.h).
+--
+-- WHERE these run (ADVICE r05): a partitioned flow graph asks them in its PARENT, before top:run() forks the block processes - and a parent that has
+-- created device objects leaves its children a device they cannot use (lrhip.in_helper).  So while this block has no chain of its own yet the answer
+-- comes from a fork()ed helper process, the request (start_at / seek) is recorded in the object, and create_chain() applies it to the chain the block's
+-- own process builds on its first process().  Once the chain exists (the block's process, or top:run(false)) the calls go to it directly.
 function DeviceChainBlock:halo()
-    if self.chain == nil then create_chain(self) end
-    local h = tonumber(lrhip.lib.lrhip_chain_halo(self.chain))
-    if h < 0 then error("lrhip_chain_halo: " .. ffi.string(lrhip.lib.lrhip_strerror())) end
-    return h
+    local function ask()
+        local h = tonumber(lrhip.lib.lrhip_chain_halo(self.chain))
+        if h < 0 then error("lrhip_chain_halo: " .. ffi.string(lrhip.lib.lrhip_strerror())) end
+        return h
+    end
+    if self.chain ~= nil then return ask() end
+    return (lrhip.in_helper(function ()
+        create_chain(self)
+        return ask()
+    end))
 end
 
 function DeviceChainBlock:shard_align()
-    if self.chain == nil then create_chain(self) end
-    return tonumber(lrhip.lib.lrhip_chain_shard_align(self.chain))
+    if self.chain ~= nil then return tonumber(lrhip.lib.lrhip_chain_shard_align(self.chain)) end
+    return (lrhip.in_helper(function ()
+        create_chain(self)
+        return tonumber(lrhip.lib.lrhip_chain_shard_align(self.chain))
+    end))
 end
 
--- seek(n0): forget every carried sample, the next vector is sample n0 of the stream (no replay: the caller feeds the halo itself and drops its output)
+-- seek(n0): forget every carried sample, the next vector is sample n0 of the stream (no replay: the caller feeds the halo itself and drops its output).
+-- Before the block's process exists the position is only recorded (nothing to ask the device).
 function DeviceChainBlock:seek(n0)
-    if self.chain == nil then create_chain(self) end
-    if lrhip.lib.lrhip_chain_seek(self.chain, n0) ~= 0 then
-        error("lrhip_chain_seek: " .. ffi.string(lrhip.lib.lrhip_strerror()))
-    end
+    self.pending_start, self.pending_seek = nil, n0
+    if self.chain ~= nil then self.position_sample = position(self) end
 end
 
 -- reset(): back to the initial state (a flow graph run a second time in the same process, top:run(false) twice)

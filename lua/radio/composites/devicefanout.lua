@@ -65,6 +65,8 @@ local function sock_read(fd, buf, size)
     local p, got = ffi.cast("char *", buf), 0
     while got < size do
         local r = tonumber(ffi.C.read(fd, p + got, size - got))
+        -- ECONNRESET (104 on Linux): the peer went away with tokens of ours unread in its socket buffer - the same news as EOF, and the caller words it
+        if r < 0 and ffi.errno() == 104 then return false end
         if r < 0 then error("read(): " .. ffi.string(ffi.C.strerror(ffi.errno()))) end
         if r == 0 then return false end
         got = got + r

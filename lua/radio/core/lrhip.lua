@@ -174,6 +174,53 @@ function M.ensure(device)
 end
 
 ---
+-- Answer a question that needs device objects (a chain's halo, its partition grid, where a partition's source must start) from a process that must
+-- NOT touch the device: the flow graph's parent.  CompositeBlock forks one process per block after initialize() (radio/core/composite.lua:443 vs :569),
+-- and a child forked after its parent created a device context cannot use the device (the library refuses with a message: the HIP runtime's threads and
+-- queues exist only in the parent).  So the question is asked in a short-lived fork()ed helper: it binds to the device, builds the objects, writes up to
+-- three numbers to a pipe and _exit()s - no ffi.gc finalisers, no atexit handlers; the parent stays clean and the block processes forked later create
+-- their own objects as always.  A process that already owns a device context (top:run(false): every block in one process; or a block's own process) just
+-- calls fn().  fn returns up to three numbers; an error in the helper is re-raised here with its message.
+ffi.cdef[[
+int pipe(int pipefd[2]);
+void _exit(int status);
+]]
+function M.in_helper(fn)
+    if M.lib.lrhip_device() >= 0 then return fn() end
+    local fds = ffi.new("int[2]")
+    if ffi.C.pipe(fds) ~= 0 then error("pipe(): " .. ffi.string(ffi.C.strerror(ffi.errno()))) end
+    local pid = ffi.C.fork()
+    if pid < 0 then error("fork(): " .. ffi.string(ffi.C.strerror(ffi.errno()))) end
+    local head = ffi.new("double[4]")
+    if pid == 0 then
+        ffi.C.close(fds[0])
+        local ok, a, b, c = pcall(fn)
+        head[0] = ok and 1 or 0
+        if ok then head[1], head[2], head[3] = tonumber(a) or 0, tonumber(b) or 0, tonumber(c) or 0 end
+        ffi.C.write(fds[1], head, 32)
+        if not ok then
+            local msg = tostring(a)
+            ffi.C.write(fds[1], msg, #msg)
+        end
+        ffi.C._exit(ok and 0 or 1)
+    end
+    ffi.C.close(fds[1])
+    local buf, got = ffi.new("uint8_t[?]", 32 + 1024), 0
+    while got < 32 + 1024 do
+        local r = tonumber(ffi.C.read(fds[0], buf + got, 32 + 1024 - got))
+        if r <= 0 then break end
+        got = got + r
+    end
+    ffi.C.close(fds[0])
+    local status = ffi.new("int[1]")
+    ffi.C.waitpid(pid, status, 0)
+    if got < 32 then error("lrhip helper process ended without an answer") end
+    ffi.copy(head, buf, 32)
+    if head[0] ~= 1 then error(ffi.string(buf + 32, got - 32), 0) end
+    return head[1], head[2], head[3]
+end
+
+---
 -- Make `Block` a device block: `create(self)` returns a fresh lrhip_stage_t* built from the block's host-side
 -- parameters.  The stage is created lazily, in the process that runs the block (see ensure()), and exposed as
 -- Block:create_stage() - which is also what DeviceChainBlock collects to build one lrhip_chain_t for a run of blocks.

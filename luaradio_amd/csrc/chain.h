@@ -136,7 +136,11 @@ static long host_execute(PinnedBuf &h_in, PinnedBuf &h_out, DeviceBuf &d_in, Dev
     // each direction at 2^24 (the link's measured both-way rate, tools/mb_link.py); kernels that know of it run a short persistent grid so that reads and
     // writes overlap (host_io_grid, common.h).  LRHIP_HOST_DIRECT=0 keeps the staged pipeline (A/B).
     static const bool direct_env = !getenv("LRHIP_HOST_DIRECT") || atoi(getenv("LRHIP_HOST_DIRECT")) != 0;
-    if (direct_env && direct_ok && in_reg && out_reg && n_in) {
+    // (an in-place call - out_host == in_host or overlapping slices of one registered buffer - was safe on the staged path and stays on it: tiles of a
+    // persistent grid would store outputs over inputs other tiles have not loaded yet)
+    const char *ia = (const char *)in_host, *oa = (const char *)out_host;
+    const bool disjoint = !cap || ia + in_bytes <= oa || oa + (size_t)cap * out_size <= ia;
+    if (direct_env && direct_ok && in_reg && out_reg && n_in && disjoint) {
         void *din = host_ranges().device_ptr(in_host, in_bytes), *dout = cap ? host_ranges().device_ptr(out_host, (size_t)cap * out_size) : (void *)nullptr;
         if (din && (dout || !cap)) {
             host_io_grid_ref() = 32;
@@ -152,6 +156,7 @@ static long host_execute(PinnedBuf &h_in, PinnedBuf &h_out, DeviceBuf &d_in, Dev
     static const bool no_pieces = getenv("LRHIP_HOST_NO_PIECES") != nullptr;      // A/B knob: one piece, as in round 3
     unsigned long pieces = (no_pieces || n_in < 2 * host_piece_min()) ? 1 : n_in / host_piece_min();
     if (pieces > HOST_PIECES) pieces = HOST_PIECES;
+    if (!disjoint) pieces = 1;      // overlapping vectors: the whole input is on the device before the first output byte comes back
     // ONE set of copy streams and events per process (HostPipe): a second host thread - another stage or chain; ctypes and LuaJIT release their lock around the
     // call - must not record and wait on them while this call's pieces are in flight, or its kernels could run before their own H2D has landed.  The thread
     // that does not get the lock takes the single-piece path, which touches only its own object's buffers and the library stream.

@@ -11,7 +11,7 @@
 //                  stride of D complex samples is conflict-free for odd D and two-way for D = 2 mod 4), one v_pk_fma_f32 per tap on (re, im), and tiles of
 //                  <= 128 outputs spread over all four waves (32 outputs per wave).  With the rotator (whose output is compared with the oracle to a
 //                  tolerance anyway) the upper half-wave takes the second half of the taps of the same 32 outputs and the halves meet in one cross-half
-//                  add: 64 taps per lane (0.117 -> 0.106 ms);
+//                  add: 64 taps per lane (0.117 -> 0.106 ms) - not in an exact chain (`one_chain`), which keeps one chain per output and with it the bits;
 //   stage 6-8 000  a partial first / last block of eight sent ONE lane down the per-sample path and the whole wave with it, and a lane owned whole blocks
 //                  (64 bytes: every load instruction touched 64 half-lines, eight-way bank conflicts on the way into LDS without the padding).  Now the
 //                  window is staged from the aligned block below it to the one above (slot = window position + a: whole blocks only on interior tiles)
@@ -71,7 +71,8 @@ template <bool ROT, int FMT = 0, bool PH = false>
 __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float *__restrict__ taps_rev,
                                                              float *__restrict__ y, int M, long n, long n_out, long first, long D, int OW, long ntiles,
                                                              uint64_t rot_step_fx, uint64_t rot_count0, float *__restrict__ hist_out, int post_op, int rounds,
-                                                             double inv_gain, const float2 *__restrict__ disc_prev_in, float2 *__restrict__ disc_prev_out)
+                                                             double inv_gain, const float2 *__restrict__ disc_prev_in, float2 *__restrict__ disc_prev_out,
+                                                             int one_chain)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *ldsT = lds;                                  // M reversed taps
@@ -151,7 +152,9 @@ __global__ __launch_bounds__(256, 3) void fir_decim_lds2_kernel(const float *__r
     const int lane_l = spread ? (lane & 31) : lane, LWQ = (spread ? 32 : 64) - disc;      // output lanes of a wave; stored outputs per wave
     const int oi = wave * LWQ + lane_l - disc;          // tile-local output (-1: the one in front of the tile)
     const int part = spread ? lane >> 5 : 0;
-    const bool split = spread && ROT && LRHIP_DECIM2_SPLIT;
+    // one_chain (LRHIP_CHAIN_EXACT_ROTATOR / LRHIP_TUNER_EXACT: FirStage::rel_rot == false): every output stays ONE fmaf chain in the reference's tap order - the
+    // bits of FrequencyTranslatorBlock and the filter run one by one (include/lrhip.h, LRHIP_CHAIN_EXACT); the upper half-wave then idles as in the plain form
+    const bool split = spread && ROT && LRHIP_DECIM2_SPLIT && !one_chain;
     const int Mh = split ? (((M >> 1) + 15) & ~15) : M;           // taps [0, Mh) in part 0, [Mh, M) in part 1
     const int t_lo = part ? (Mh < M ? Mh : M) : 0, t_hi = part ? (split ? M : 0) : (Mh < M ? Mh : M);
     const long t_first = rounds > 0 ? (long)blockIdx.x * rounds : (long)blockIdx.x, t_step = rounds > 0 ? 1 : (long)gridDim.x;

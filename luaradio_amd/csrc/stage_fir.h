@@ -695,7 +695,8 @@ struct FirStage : lrhip_stage {
             float2 *dp = (float2 *)disc_prev.p;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, ctx().stream, h, x, (const float *)d_taps.p, y, M, n, n_out, (long)index, (long)D, OW,
                                ntiles, rot ? rot_step : (uint64_t)0, rot ? count : (uint64_t)0, ho, post_unary, rounds, 1.0 / disc_gain,
-                               dsc ? (const float2 *)(dp + disc_cur) : (const float2 *)nullptr, dsc ? dp + (disc_cur ^ 1) : (float2 *)nullptr);
+                               dsc ? (const float2 *)(dp + disc_cur) : (const float2 *)nullptr, dsc ? dp + (disc_cur ^ 1) : (float2 *)nullptr,
+                               rel_rot ? 0 : 1);      // an exact chain keeps one fmaf chain per output (no tap split over the half-waves)
             hist_in_kernel = ho != nullptr;
             if (dsc) disc_cur ^= 1;
             return 0;
@@ -1010,6 +1011,7 @@ struct FirStage : lrhip_stage {
     bool direct_io_ok() const override
     {
         if (pre_disc || fix_src) return false;
+        if (use_fft) return false;            // the reference's block-emission framing: run() copies x into `pending` / `work` first (a second pass, device-to-device)
         if (decfft) return true;
         if (fft_arith) return M <= FFT_PART || (S == 2 && (fft4k_V || fft64_np));
         if (win_real_ok() || win_cplx_ok() || short_real_ok()) return false;

@@ -8,7 +8,7 @@ the parent, then ONE fork() per block; the child closes EVERY descriptor that is
     parent: ctypes.CDLL(liblrhip.so)  - no HIP call - pipes / socket pairs created - fork() per block - close its copies - read results - waitpid
     child : close all other descriptors - lrhip_init (first device call of the process) - run - write the result to its pipe - _exit
 
-    fork_model.py <shape> <out.npz>      shape: stage | chain | fanout | init_then_fork
+    fork_model.py <shape> <out.npz>      shape: stage | chain | fanout | init_then_fork | lua_partition
 """
 import os
 import socket
@@ -144,6 +144,55 @@ def child_init_then_fork(wfd):
     send(wfd, ("%d|%d|%s" % (rc, count, msg)).encode())
 
 
+LUA_PARTITION = r"""
+local R = require('reference_standins')
+local types = require('radio.types')
+local taps = ...
+local g = R.graph()
+local src, t, f, d, k = R.HostSource(1102500), R.FrequencyTranslatorBlock(-250e3), R.FIRFilterBlock(taps), R.DownsamplerBlock(5), R.HostSink()
+src:differentiate({})
+for _, b in ipairs({t, f, d, k}) do b:differentiate({types.ComplexFloat32}) end
+g.connect(src, t, f, d, k)
+local connections, device_blocks = R.prepare(g.connections, {src, t, f, d, k})
+return device_blocks[1]
+"""
+PARTITION_FIRST = 300000
+
+
+def lua_partition_parent(L):
+    """the partition helpers of lua/radio/composites/devicechain.lua asked in the PARENT (the Lua glue itself, executed by tests/helpers/minilua.py
+    on the real library): each answer comes from a fork()ed helper process (lrhip.in_helper), the parent never owns a device, and the block process forked
+    afterwards builds its own chain armed with the recorded start_at()"""
+    import luaradio_amd as lr
+    from tests.helpers import lua_mocks as LM
+    from tests.helpers import minilua as ml
+    I, proxy, ffi = LM.make_interpreter(L)
+    I.globals.set("__copy_vector", lambda v: LM.Vector(v.data_type, 0, v.array().copy()))
+    taps = np.asarray(lr.filter_utils.firwin_lowpass(128, 50e3 / (FS / 2)), np.float32)
+    chain = I.run(LUA_PARTITION, "partition", [LM.Vector(LM.DataType("Float32", np.float32), 0, taps.copy())])[0]
+    halo = ml.call(ml.index(chain, "halo"), [chain])[0]
+    align = ml.call(ml.index(chain, "shard_align"), [chain])[0]
+    seek = ml.call(ml.index(chain, "start_at"), [chain, float(PARTITION_FIRST)])[0]
+    parent_device = L.lrhip_device()                # -1: three helpers have come and gone, this process still has no device context
+
+    def child(wfd):
+        x = stream()[int(seek):]
+        cf = LM.DataType("ComplexFloat32", np.complex64)
+        parts = []
+        for a in range(0, len(x), 8192):
+            y = ml.call(ml.index(chain, "process"), [chain, LM.Vector(cf, 0, x[a:a + 8192].copy())])[0]
+            parts.append(y.array().copy())
+        ml.call(ml.index(chain, "cleanup"), [chain])
+        pipes = ml.index(ml.index(chain, "outputs").get(1), "pipes")
+        written = ml.index(pipes.get(1), "written")
+        for i in range(1, written.length() + 1):
+            parts.append(written.get(i).array().copy())
+        send(wfd, np.concatenate(parts).tobytes())
+
+    results, codes = run_children([("block", child, ())])
+    return results, codes, np.array([halo, align, seek, parent_device], np.float64)
+
+
 def run_children(jobs, parent_closes=()):
     """jobs: [(name, function(wfd), descriptors the child keeps)]: one fork() per job, as CompositeBlock:start forks one process per block"""
     readers, pids = {}, {}
@@ -198,6 +247,11 @@ def main():
             r = results["branch%d" % k] or b""
             out["y%d" % k] = np.frombuffer(r, np.complex64) if not r.startswith(b"ERROR") else np.zeros(0, np.complex64)
         out["head"] = np.frombuffer(results["head"] or b"", np.int64) if results["head"] and not results["head"].startswith(b"ERROR") else np.zeros(0, np.int64)
+    elif shape == "lua_partition":
+        results, codes, answers = lua_partition_parent(L)
+        r = results["block"] or b""
+        out["y"] = np.frombuffer(r, np.complex64) if not r.startswith(b"ERROR") else np.zeros(0, np.complex64)
+        out["answers"] = answers
     elif shape == "init_then_fork":
         assert L.lrhip_init(0) == 0                 # the mistake: a device call in the parent
         results, codes = run_children([("child", child_init_then_fork, ())])

@@ -65,3 +65,18 @@ def test_a_child_forked_after_the_parent_touched_the_device_fails_with_a_message
     rc, count, msg = str(r["messages"][0]).split("|", 2)
     assert int(rc) != 0 and int(count) < 0
     assert "before fork()" in msg and "first process()" in msg
+
+
+def test_partition_helpers_in_the_parent_then_a_forked_block_process(tmp_path):
+    """DeviceChainBlock:halo() / shard_align() / start_at() are called in the flow graph's parent (a time-partitioned graph positions its source
+    there), top:run() forks the block processes afterwards.  The glue asks a fork()ed helper process, so the parent never owns a device and the block
+    process - forked later, building its own chain - starts where start_at() said: its output is the uninterrupted run's from that sample on"""
+    from oracle import oracle as O
+    from tests.helpers.fork_model import FS, PARTITION_FIRST, stream
+    r = run_shape("lua_partition", tmp_path)
+    assert list(r["codes"]) == [0], (r["codes"], r["messages"])
+    halo, align, seek, parent_device = [int(v) for v in r["answers"]]
+    assert parent_device == -1
+    assert halo >= 127 and align >= 1 and seek % align == 0 and seek <= PARTITION_FIRST - halo < seek + align + halo
+    want = O.tuner(-250e3, 100e3, 5, FS, mode=O.MODE_FMA, rot_mode=O.MODE_F64).process(stream())[PARTITION_FIRST // 5:]
+    assert len(r["y"]) == len(want) and float(np.max(np.abs(r["y"] - want))) < 2e-6

@@ -90,6 +90,49 @@ def test_exact_flag_gives_the_blocks_own_bits_for_any_chunking():
     assert fast.last_launches < exact.last_launches
 
 
+@pytest.mark.parametrize("decim,ntaps", [(50, 128), (25, 128), (80, 128), (50, 200)])
+@pytest.mark.parametrize("with_disc", [False, True])
+def test_exact_chain_on_the_lds_staged_decimator_shapes(decim, ntaps, with_disc):
+    """the second LDS-staged decimator form (kernels_firdecim.h) splits an output's taps over the two half-waves in its rotator form
+    (tiles of <= 128 outputs: decimation 50 / 25 / 80 with 128 taps) - one add joins two partial chains, which is not the bits of the blocks run
+    one by one.  An exact chain (include/lrhip.h: LRHIP_CHAIN_EXACT, 'bit for bit for direct-form filters') must keep one fmaf chain per output:
+    TunerBlock(.., decim) [+ FrequencyDiscriminatorBlock] of rtlsdr_nbfm.lua / rtlsdr_ax25.lua flattened, on ragged chunks."""
+    c = types.ComplexFloat32
+    x = fm_signal(300000, seed=11)
+    cuts = [3, 4099, 4100, 77777, 200001]
+
+    def blocks():
+        lp = lr.LowpassFilterBlock(ntaps, 10e3)
+        lp.use_fft = lr.block.fir_mode(False)                  # the direct form: the contract's 'bit for bit' case
+        lp.rate = FS
+        lp.differentiate([c])
+        lp.initialize()
+        bs = [make(lr.FrequencyTranslatorBlock, [-250e3], c, FS), lp, make(lr.DownsamplerBlock, [decim], c, FS)]
+        if with_disc:
+            bs.append(make(lr.FrequencyDiscriminatorBlock, [1.25], c, FS / decim))
+        return bs
+
+    ref = blocks()
+
+    def one_by_one(v):
+        for b in ref:
+            v = b.process(v)
+        return v
+
+    want = run_chunked(one_by_one, x, cuts)
+    exact = lr.Chain(blocks(), exact=True)
+    got = run_chunked(exact.process, x, cuts)
+    assert len(got) == len(want) == len(x) // decim
+    assert np.array_equal(got, want)
+    assert exact.last_launches < len(ref)                     # still fused: the flag changes the arithmetic's order, not the launch count
+    # the default contract on the same shape: same values to Float32 rounding of the filter outputs (the angles behind them are as well
+    # conditioned as the filtered signal is strong - not compared here)
+    if not with_disc:
+        fast = lr.Chain(blocks())
+        got2 = run_chunked(fast.process, x, cuts)
+        assert float(np.max(np.abs(got2.astype(np.complex128) - want))) < 2e-6
+
+
 def test_no_fusion_flag_and_unknown_bits():
     x = fm_signal(100000)
     blocks = receiver_blocks()
@@ -416,6 +459,41 @@ def test_registered_vectors_are_read_and_written_in_place():
             assert ref.process_device(xd.data_ptr() + 8 * off_in, m, yd.data_ptr(), m) == m
             torch.cuda.synchronize()
             assert np.array_equal(y[off_out:off_out + m].view(np.float32), yd.cpu().numpy()), (off_in, off_out, m)
+        # the reference's block-emission framing (use_fft = true, firfilter.lua:361-398) copies its input into a pending buffer first - it is not a
+        # read-once form and stays on the staged path; registered vectors give the values of the device-resident run all the same
+        def framed():
+            b = lr.LowpassFilterBlock(128, 15e3)
+            b.use_fft = lr.block.fir_mode(True)
+            b.rate = FS
+            b.differentiate([types.ComplexFloat32])
+            b.initialize()
+            return b
+        blk, ref, m = framed(), framed(), 300001
+        got = L.lrhip_stage_execute(blk.stage_handle(), x.ctypes.data_as(C.c_void_p), m, y.ctypes.data_as(C.c_void_p), m)
+        assert got > 0 and got <= m, _lib.last_error()
+        yd = torch.empty(2 * m, device="cuda")
+        assert ref.process_device(xd.data_ptr(), m, yd.data_ptr(), m) == got
+        torch.cuda.synchronize()
+        assert np.array_equal(y[:got].view(np.float32), yd.cpu().numpy()[:2 * got])
+        # an in-place call (output vector == input vector, or overlapping slices of one registered buffer) takes the staged path, where it is
+        # safe - in direct mode tiles of the persistent grid would store over samples other tiles have not loaded yet
+        for shift in (0, 100, -100):
+            m = 1 << 21
+            z = _aligned(m + 4096, np.complex64)
+            z[:] = x[:len(z)]
+            _lib.check(L.lrhip_host_register(z.ctypes.data_as(C.c_void_p), z.nbytes), "register")
+            try:
+                blk = make(lr.LowpassFilterBlock, [128, 15e3], types.ComplexFloat32, FS)
+                src, dst = 2048, 2048 + shift
+                got = L.lrhip_stage_execute(blk.stage_handle(), C.c_void_p(z.ctypes.data + 8 * src), m, C.c_void_p(z.ctypes.data + 8 * dst), m)
+                assert got == m, _lib.last_error()
+                ref = make(lr.LowpassFilterBlock, [128, 15e3], types.ComplexFloat32, FS)
+                yd = torch.empty(2 * m, device="cuda")
+                assert ref.process_device(xd.data_ptr() + 8 * src, m, yd.data_ptr(), m) == m
+                torch.cuda.synchronize()
+                assert np.array_equal(z[dst:dst + m].view(np.float32), yd.cpu().numpy()), shift
+            finally:
+                assert L.lrhip_host_unregister(z.ctypes.data_as(C.c_void_p)) == 0
         rx = lr.Chain(receiver_blocks())
         got = L.lrhip_chain_execute(rx._chain, x.ctypes.data_as(C.c_void_p), n, audio.ctypes.data_as(C.c_void_p), len(audio))
         assert got == (n + 24) // 25, _lib.last_error()

@@ -162,6 +162,30 @@ def test_iq_file_source_becomes_the_head_of_the_device_chain(tmp_path, fifo):
     assert proxy.trace[-2:] == ["lrhip_chain_destroy", "lrhip_stage_destroy"]
 
 
+def test_a_stream_that_was_read_from_before_starts_at_the_stream_position_and_repeats_from_byte_zero(tmp_path):
+    """submit_raw() bypasses the FILE *.  Its first offset must be the STREAM's position (ftell: what the caller consumed), not the
+    descriptor's (lseek: stdio has read a buffer ahead) - or records are skipped; and a repeating source goes back to byte 0, the reference's rewind()"""
+    n = 65536 + 1234
+    path = tmp_path / "x.u8"
+    path.write_bytes(wbfm_u8_capture(n))
+    I, proxy, ffi = interp()
+    b, a = deemphasis_taps(75e-6, 220500.0)
+    conns, devs, blocks = I.run(WBFM_FROM_FILE, "wbfm", [str(path), fvec(lowpass_taps(128, 100e3, 1102500.0)), fvec(lowpass_taps(128, 15e3, 220500.0)), fvec(b), fvec(a), None])
+    chain, src = lua_list(devs)[0], blocks.get(1)
+    fh = ml.index(src, "file").fh
+    assert len(fh.read(200)) == 200                                  # a header the caller parsed through the same FILE *: 100 records
+    assert fh.tell() == 200 and os.lseek(fh.fileno(), 0, os.SEEK_CUR) > 200         # stdio read a whole buffer
+    src.set("repeat_on_eof", True)
+    chain.set("batch_samples", 65536.0)
+    chain.set("source_batch_bytes", 0.0)
+    for _ in range(6):
+        ml.call(ml.index(chain, "process"), [chain])
+    fd_calls = [a_ for n_, a_ in proxy.fake.calls if n_ == "lrhip_chain_submit_fd"]
+    offs = [c_[2] for c_ in fd_calls]
+    assert offs[:3] == [200, 200 + 2 * 65536, 2 * n]                 # from the stream position; the third call finds the end of the file ...
+    assert offs[3:5] == [0, 2 * 65536]                               # ... and the repeat starts over at byte 0 (iqfile.lua:86-90: rewind())
+
+
 def test_file_to_file_chain_has_no_ports_and_runs_its_own_loop(tmp_path):
     """source AND sink absorbed: a block without ports (the hook of tools/apply_lua_binding.py adds it to the evaluation order).  run() must not sit in
     PipeMux:_read_control forever; the raw records of the chain's output go through the sink's fwrite"""
@@ -757,6 +781,44 @@ def test_synchronous_chain_and_stand_alone_blocks_pin_the_pipe_buffer():
     ml.call(ml.index(lone, "process"), [lone, cvec(np.zeros(100))])
     regs = [a for n, a in proxy.fake.calls if n == "lrhip_host_register"]
     assert len(regs) == 4 and regs[2] == [rbuf.ctypes.data + 4096, 4096]
+
+
+def test_partition_helpers_asked_in_the_parent_leave_it_without_a_device():
+    """start_at() / halo() / shard_align() / seek() are what a time-partitioned flow graph calls in its PARENT, before top:run() forks one process
+    per block (radio/core/composite.lua:569) - and the library refuses the device to a child forked after its parent initialised it.  While the block has no
+    chain of its own the answers come from a fork()ed helper process (lrhip.in_helper: a real fork() of this interpreter here), the request is recorded, and
+    the block's own process applies it to the chain it builds on its first process()"""
+    I, proxy, ffi = interp()
+    chain, _ = I.run(SYNC_CHAIN, "sync", [fvec(np.ones(16) / 16)])
+    assert ml.call(ml.index(chain, "halo"), [chain])[0] == 127
+    assert ml.call(ml.index(chain, "shard_align"), [chain])[0] == 1
+    assert ml.call(ml.index(chain, "start_at"), [chain, 1000000.0])[0] == 1000000 - 127           # the fake's answer, through the helper's pipe
+    pids = ffi.get("_state")["forked_pids"]
+    assert len(pids) == 3 and "forked_child" not in ffi.get("_state")
+    # the parent made no device call except the question "do I own a device" - no init, no stage, no chain
+    assert set(proxy.trace) == {"lrhip_version", "lrhip_device"} and proxy.fake.device == -1         # (lrhip_version: the module load, no device)
+    assert ml.index(chain, "chain") is None and ml.index(chain, "pending_start") == 1000000
+    # ... and "the block's own process" (here: the same interpreter, later) builds its chain and arms it with the recorded request
+    y = ml.call(ml.index(chain, "process"), [chain, cvec(np.zeros(5000))])[0]
+    t = proxy.trace
+    assert t.index("lrhip_init") < t.index("lrhip_chain_create_ex") < t.index("lrhip_chain_start_at") < t.index("lrhip_chain_push")
+    assert [a_[1] for n_, a_ in proxy.fake.calls if n_ == "lrhip_chain_start_at"] == [1000000]
+    # a process that owns a device (top:run(false), or the block's own) asks its chain directly: no further helper
+    assert ml.call(ml.index(chain, "start_at"), [chain, 2000000.0])[0] == 2000000 - 127 and len(pids) == 3
+    # seek() before the process exists: recorded only
+    I2, proxy2, ffi2 = interp()
+    chain2, _ = I2.run(SYNC_CHAIN, "sync", [fvec(np.ones(16) / 16)])
+    ml.call(ml.index(chain2, "seek"), [chain2, 4096.0])
+    assert proxy2.trace == ["lrhip_version"] and "forked_pids" not in ffi2.get("_state")
+    ml.call(ml.index(chain2, "process"), [chain2, cvec(np.zeros(100))])
+    assert [a_[1] for n_, a_ in proxy2.fake.calls if n_ == "lrhip_chain_seek"] == [4096]
+    # an error in the helper is the caller's error, with the library's message
+    I3, proxy3, _ = interp()
+    chain3, _ = I3.run(SYNC_CHAIN, "sync", [fvec(np.ones(16) / 16)])
+    real_call = proxy3.fake.call
+    proxy3.fake.call = lambda name, args: -1 if name == "lrhip_chain_halo" else real_call(name, args)
+    with pytest.raises(ml.LuaError, match="lrhip_chain_halo: fake error"):
+        ml.call(ml.index(chain3, "halo"), [chain3])
 
 
 # ====================================================================================================================== GPU: the same glue on the real library

@@ -17,7 +17,7 @@ using namespace lrhip;
 #define CK(c) do { hipError_t e_ = (c); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #c, hipGetErrorString(e_)); exit(1); } } while (0)
 
 #ifdef AB_V2
-#define AB_EXTRA , 0.0, (const float2 *)nullptr, (float2 *)nullptr
+#define AB_EXTRA , 0.0, (const float2 *)nullptr, (float2 *)nullptr, (getenv("AB_ONE_CHAIN") ? 1 : 0)
 #include "kernels_firdecim.h"
 #ifdef AB_PH
 #define AB_KERNEL_ROT fir_decim_lds2_kernel<true, 0, true>
