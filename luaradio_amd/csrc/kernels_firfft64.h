@@ -129,18 +129,25 @@ __device__ unsigned long long *lrhip_f64_trace;         // [block 8][wave 8][ite
 // partitions' H whole in LDS.  A wave walks a RUN of consecutive blocks and keeps the previous block's spectrum in 128 registers (the wave has 512); the
 // block in front of its run is transformed once to fill them (one forward transform in ~33 at 2^26 samples).  One launch, every sample read once (+ the
 // overlap through L2): 4 096 taps on 2^26 samples in one pass instead of two passes of the 1024-point partitioned kernel.
-template <int V, int F64_WAVES, int NP = 1>
+//
+// S = 1 (round 6): a Float32 stream with REAL taps - two stream blocks ride as the real and the imaginary plane of one transform (H of real taps is
+// conjugate-symmetric: the planes come back separately), as in fir_fft_kernel<1, .>.  NP = 1: planes = the adjacent stream blocks 2 f, 2 f + 1 and `nblocks`
+// counts TRANSFORMS.  NP = 2: a wave walks TWO runs of consecutive blocks at once, run A in the real plane and the run behind it in the imaginary plane, so the
+// delayed spectrum in its registers is the previous block's in BOTH planes (adjacent blocks in one transform would need the spectrum of a pair shifted by one
+// block); `nblocks` counts stream blocks.  Replaces the partitioned 1024-point kernel for 513 .. 4 097 real taps on Float32 streams (0.33 of the roof).
+template <int V, int F64_WAVES, int NP = 1, int S = 2>
 __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float2 *__restrict__ tables,
                                                            float *__restrict__ y, int M, long n, long n_out, long nblocks, float *__restrict__ hist_out, int xcd_map)
 {
     static_assert(V % 64 == 0 && V >= 64 && V < F4K_N, "the overlap is a whole number of 64-sample rows");
     static_assert(NP == 1 || (NP == 2 && F64_WAVES == 4 && 2 * V == F4K_N), "two partitions: hop = overlap = 2 048, four waves, full H");
+    static_assert(S == 2 || S == 1, "ComplexFloat32 or Float32 stream");
     constexpr int L = F4K_N - V;
     extern __shared__ __attribute__((aligned(16))) float2 fl[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (hist_out && blockIdx.x == 0)
-        for (int i = tid; i < (M - 1) * 2; i += 64 * F64_WAVES) hist_out[i] = stream_at<2>(hist, x, n + i / 2, i % 2, M, n);
+        for (int i = tid; i < (M - 1) * S; i += 64 * F64_WAVES) hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
     cf *flc = reinterpret_cast<cf *>(fl);
     float *ex = reinterpret_cast<float *>(flc + wave * F64_EX);
     constexpr bool HSYM = F64_WAVES > 4;
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
     bool have = false;
     auto prefetch = [&](long nb) {
         const long plo = nb * L - V;
-        have = LRHIP_F64_PREFETCH && nb < nblocks && plo >= 0 && plo + F4K_N <= n;
+        have = LRHIP_F64_PREFETCH && S == 2 && nb < nblocks && plo >= 0 && plo + F4K_N <= n;
         if (have) {
             const cf *src = reinterpret_cast<const cf *>(x) + plo;
 #pragma unroll
@@ -202,8 +209,9 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
     [[maybe_unused]] cf zp[NP == 2 ? 64 : 1];
     [[maybe_unused]] cf keep[(NP == 2 && LRHIP_F64_CARRY) ? 32 : 1];
     [[maybe_unused]] bool kept = false;
-    const long nwaves = (long)gridDim.x * F64_WAVES, run = (nblocks + nwaves - 1) / nwaves;
-    const long r0 = ((long)blockIdx.x * F64_WAVES + wave) * run, r1 = r0 + run < nblocks ? r0 + run : nblocks;
+    // (S = 1: a wave's run is 2 x `run` stream blocks - [r0, r0 + run) in the real plane, [r0 + run, r0 + 2 run) in the imaginary plane)
+    const long nwaves = (long)gridDim.x * F64_WAVES, run = (nblocks + nwaves * (3 - S) - 1) / (nwaves * (3 - S));
+    const long r0 = ((long)blockIdx.x * F64_WAVES + wave) * run * (3 - S), r1 = r0 + run < nblocks ? r0 + run : nblocks;
     if (NP == 2) { slot0 = r0 - 1; sstep = 1; send = r1; }
     [[maybe_unused]] int trace_it = 0;
     for (long slot = slot0; slot < send; slot += sstep) {
@@ -211,8 +219,42 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
         if (fb >= nblocks) continue;                         // no workgroup barrier inside the loop: a wave may skip
         F64_STAMP(0);
         [[maybe_unused]] const bool warm = NP == 2 && fb < r0;
-        const long xlo = fb * L - V;
+        // stream block(s) of this transform: S = 2 - block fb; S = 1 - blocks (2 fb, 2 fb + 1) or, two partitions, (fb, fb + run)
+        const long ba = (S == 1 && NP == 1) ? 2 * fb : fb;
+        [[maybe_unused]] const long bb = NP == 1 ? ba + 1 : ba + run;
+        const long xlo = ba * L - V;
+        [[maybe_unused]] const long xlob = bb * L - V;
         cf v[64];
+        if constexpr (S == 1) {
+            const long xhi = xlo > xlob ? xlo : xlob;
+            if (xlo >= 0 && xlob >= 0 && xhi + F4K_N <= n) {
+                const float *sa = x + xlo, *sb = x + xlob;
+                if constexpr (NP == 2 && LRHIP_F64_CARRY) {
+                    if (kept) {
+#pragma unroll
+                        for (int i = 0; i < 32; i++) v[i] = keep[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 32; i++) v[i] = cf{(sa + 64 * i)[(unsigned)lane], (sb + 64 * i)[(unsigned)lane]};
+                    }
+#pragma unroll
+                    for (int i = 32; i < 64; i++) v[i] = cf{(sa + 64 * i)[(unsigned)lane], (sb + 64 * i)[(unsigned)lane]};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 64; i++) v[i] = cf{(sa + 64 * i)[(unsigned)lane], (sb + 64 * i)[(unsigned)lane]};
+                }
+            } else {
+                // edge transforms (a window reaches into the carried history or past the chunk - the second plane of the last pair): rolled, through the buffer
+#pragma unroll 1
+                for (int i = 0; i < 64; i++) ex[i * 64 + lane] = stream_at<1>(hist, x, xlo + 64 * i + lane + (M - 1), 0, M, n);
+#pragma unroll
+                for (int i = 0; i < 64; i++) v[i].x = ex[i * 64 + lane];
+#pragma unroll 1
+                for (int i = 0; i < 64; i++) ex[i * 64 + lane] = stream_at<1>(hist, x, xlob + 64 * i + lane + (M - 1), 0, M, n);
+#pragma unroll
+                for (int i = 0; i < 64; i++) v[i].y = ex[i * 64 + lane];
+            }
+        } else
         if (have) {
 #pragma unroll
             for (int i = 0; i < 64; i++) v[i] = pre[i];
@@ -340,6 +382,29 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
         dft64<-1>(v);
         F64_STAMP(10);
         // ---- rows at or behind the overlap are this block's outputs
+        if constexpr (S == 1) {
+            const long oa = ba * L - V, ob1 = bb * L - V;
+            float *da = y + oa, *db = y + ob1;
+            const long ohi = oa > ob1 ? oa : ob1;
+            if (ohi + F4K_N <= n_out) {
+#pragma unroll
+                for (int i = V / 64; i < 64; i++) {
+                    __builtin_nontemporal_store(v[i].x, (da + 64 * i) + (unsigned)lane);
+                    __builtin_nontemporal_store(v[i].y, (db + 64 * i) + (unsigned)lane);
+                }
+            } else {
+#pragma unroll
+                for (int i = V / 64; i < 64; i++) {
+                    if (oa + 64 * i + lane < n_out) __builtin_nontemporal_store(v[i].x, (da + 64 * i) + (unsigned)lane);
+                    if (ob1 + 64 * i + lane < n_out) __builtin_nontemporal_store(v[i].y, (db + 64 * i) + (unsigned)lane);
+                }
+            }
+            F64_STAMP(11);
+#ifdef LRHIP_F64_TRACE
+            trace_it++;
+#endif
+            continue;
+        }
         const long ob = fb * L - V;
         cf *dst = reinterpret_cast<cf *>(y) + ob;
         if (ob + F4K_N <= n_out) {

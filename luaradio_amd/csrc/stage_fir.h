@@ -415,15 +415,16 @@ struct FirStage : lrhip_stage {
     }
     int fft4k_blocks2 = 0;
     // one WAVE per 4096-point block as 64 x 64 (kernels_firfft64.h): eight waves per CU with the conjugate-symmetric H of real taps, four with complex taps
-    template <int VV, int WAVES>
+    template <int VV, int WAVES, int SS = 2>
     int launch_fft64(const float *x, long n, float *y, long n_out)
     {
         constexpr long Lf = F4K_N - VV;
         const size_t lds_bytes = (size_t)f64_lds_elems(WAVES) * sizeof(float2);
-        auto kern = fir_fft64_kernel<VV, WAVES>;
+        auto kern = fir_fft64_kernel<VV, WAVES, 1, SS>;
         if (prepared_blocks(kern, lds_bytes, 64 * WAVES) < 0) return -1;
         static const int xcd_map = getenv("LRHIP_F4K_XCD_MAP") ? atoi(getenv("LRHIP_F4K_XCD_MAP")) : 1;
-        const long nblocks = (n_out + Lf - 1) / Lf, nslots = (nblocks + WAVES - 1) / WAVES;
+        // (Float32 stream: two stream blocks per transform - the kernel's block count is the number of transforms)
+        const long nblocks = ((n_out + Lf - 1) / Lf + (2 - SS)) / (3 - SS), nslots = (nblocks + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)(nslots < ctx().num_cus ? nslots : ctx().num_cus);      // 108 / 158 KB of LDS: one workgroup per CU
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (const float2 *)d_fft64_tables.p, y, M, n,
                            n_out, nblocks, M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : (float *)nullptr, xcd_map);
@@ -432,13 +433,13 @@ struct FirStage : lrhip_stage {
         return 0;
     }
     // round 5: V = 2 048, one partition (eight waves on real taps, four on complex ones) or two (four waves, a run of consecutive blocks per wave)
-    template <int NP>
+    template <int NP, int SS = 2>
     int launch_fft64_long(const float *x, long n, float *y, long n_out)
     {
         constexpr int VV = 2048, WAVES = 4;
         constexpr long Lf = F4K_N - VV;
         const size_t lds_bytes = (size_t)f64_lds_elems(WAVES, NP) * sizeof(float2);
-        auto kern = fir_fft64_kernel<VV, WAVES, NP>;
+        auto kern = fir_fft64_kernel<VV, WAVES, NP, SS>;
         if (prepared_blocks(kern, lds_bytes, 64 * WAVES) < 0) return -1;
         const long nblocks = (n_out + Lf - 1) / Lf, nslots = (nblocks + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)(nslots < ctx().num_cus ? nslots : ctx().num_cus);
@@ -451,6 +452,7 @@ struct FirStage : lrhip_stage {
     template <int VV>
     int launch_fft64_v(const float *x, long n, float *y, long n_out)
     {
+        if (S == 1) return launch_fft64<VV, 8, 1>(x, n, y, n_out);
         return taps_complex ? launch_fft64<VV, 4>(x, n, y, n_out) : launch_fft64<VV, 8>(x, n, y, n_out);
     }
     template <int VV>
@@ -519,23 +521,28 @@ struct FirStage : lrhip_stage {
         // round 5: 1 282 .. 4 097 taps on a ComplexFloat32 stream as ONE launch of the 64 x 64 kernel at an overlap of 2 048 (two partitions above 2 049 taps) once
         // a wave's run is long enough to pay for its warm-up block; LRHIP_F64_LONG=0 keeps the partitioned 1024-point kernel (A/B)
         static const int long_knob = getenv("LRHIP_F64_LONG") ? atoi(getenv("LRHIP_F64_LONG")) : 1;
-        if (fft64_np && long_knob && pols_knob != 1 && !pre_disc && !post_disc && S == 2) {
+        // round 6: Float32 streams (real taps) ride the same kernels, two stream blocks per transform: LRHIP_F64_F32=0 keeps the partitioned kernel for them (A/B)
+        static const int f32_knob = getenv("LRHIP_F64_F32") ? atoi(getenv("LRHIP_F64_F32")) : 1;
+        if (fft64_np && long_knob && pols_knob != 1 && !pre_disc && !post_disc && (S == 2 || f32_knob)) {
             const long nb = (n_out + 2047) / 2048;
             // (size sweep 2^20 .. 2^26 samples, same box: faster than the partitioned kernel at every size - 4 096 taps 0.072 / 0.106 / 0.196 / 0.575 ms against
             // 0.188 / 0.208 / 0.243 / 1.104 at 2^20 / 2^22 / 2^24 / 2^26, 2 048 taps 0.048 against 0.093 at 2^22 - so there is no lower bound; LRHIP_F64_LONG_MIN = blocks per CU)
             static const long long_min = getenv("LRHIP_F64_LONG_MIN") ? atol(getenv("LRHIP_F64_LONG_MIN")) : 0;
             if (nb >= long_min * ctx().num_cus) {
+                if (S == 1) return fft64_np == 1 ? launch_fft64<2048, 8, 1>(x, n, y, n_out) : launch_fft64_long<2, 1>(x, n, y, n_out);
                 if (fft64_np == 1) return taps_complex ? launch_fft64<2048, 4>(x, n, y, n_out) : launch_fft64<2048, 8>(x, n, y, n_out);
                 return launch_fft64_long<2>(x, n, y, n_out);
             }
         }
-        if (M > FFT_PART && !pre_disc && !post_disc && pols_knob != 0 && (pols_knob == 1 || !fft4k_V || no_4k))
-            return S == 2 ? launch_pols<2>(x, n, y, n_out) : launch_pols<1>(x, n, y, n_out);
         // one wave per 4096-point block (fir_fft64_kernel, one 512- / 256-thread workgroup per CU) once the launch has at least eight blocks per CU; smaller
         // launches keep the workgroup-per-block form, which spreads over more CUs.  LRHIP_F4K_WAVE=1 / 0 forces one or the other (A/B)
         static const int wave_knob = getenv("LRHIP_F4K_WAVE") ? atoi(getenv("LRHIP_F4K_WAVE")) : -1;
         const long nblocks4k = fft4k_V ? (n_out + (F4K_N - fft4k_V) - 1) / (F4K_N - fft4k_V) : 0;
-        const bool wave4k = wave_knob >= 0 ? wave_knob != 0 : nblocks4k >= 8L * ctx().num_cus;
+        const bool wave4k = wave_knob >= 0 ? wave_knob != 0 : nblocks4k >= 8L * (3 - S) * ctx().num_cus;
+        // (a Float32 stream has no workgroup-per-block kernel: its small launches stay partitioned)
+        const bool f32_part = S == 1 && (!f32_knob || !wave4k);
+        if (M > FFT_PART && !pre_disc && !post_disc && pols_knob != 0 && (pols_knob == 1 || !fft4k_V || no_4k || f32_part))
+            return S == 2 ? launch_pols<2>(x, n, y, n_out) : launch_pols<1>(x, n, y, n_out);
         if (fft4k_V && !no_4k && !pre_disc && !post_disc && wave4k) {
             switch (fft4k_V) {
                 case 768: return launch_fft64_v<768>(x, n, y, n_out);
@@ -1321,7 +1328,9 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
         }
         if (upload(q->d_fft_tables, tab.data(), tab.size() * sizeof(float))) return nullptr;
         q->fft_arith = true;
-        if (input_complex && (int)ntaps > FirStage::FFT_PART && ntaps <= 1281) {
+        // (round 6: Float32 streams with real taps take the 64 x 64 kernel too - two stream blocks per transform; the workgroup-per-block kernel of small
+        // launches stays ComplexFloat32-only, small Float32 launches keep the partitioned kernel)
+        if ((input_complex || !taps_complex) && (int)ntaps > FirStage::FFT_PART && ntaps <= 1281) {
             // tables of the 4096-point kernel (kernels_firfft4k.h): tw1 | tw2 | c[w][i] = W_64^(i w) | b[w][t] = W_4096^(t w) | H[w][16 x 64] of the bins w + 4 k'
             std::vector<float> t4((size_t)F4K_TABLE_ELEMS * 2);
             auto put = [&](size_t o, double a) { t4[2 * o] = (float)std::cos(a); t4[2 * o + 1] = (float)std::sin(a); };
@@ -1355,7 +1364,7 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
                             t4[2 * o] = (float)Hr[k];
                             t4[2 * o + 1] = (float)Hi[k];
                         }
-            if (upload(q->d_fft4k_tables, t4.data(), t4.size() * sizeof(float))) return nullptr;
+            if (input_complex && upload(q->d_fft4k_tables, t4.data(), t4.size() * sizeof(float))) return nullptr;
             // tables of the 64 x 64 form: C[c][t] = W_1024^(t c) | D[d][t] = W_4096^(t d) | H[r][l] = H(64 k1(r) + l) | Hsym[k1][l <= 32] = H(64 k1 + l)
             std::vector<float> t6((size_t)F64_TABLE_ELEMS * 2, 0.f);
             auto put6 = [&](size_t o, double a) { t6[2 * o] = (float)std::cos(a); t6[2 * o + 1] = (float)std::sin(a); };
@@ -1379,7 +1388,7 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
             q->fft4k_V = (int)((ntaps - 1 + 255) / 256) * 256;
             if (q->fft4k_V < 768) q->fft4k_V = 768;
         }
-        if (input_complex && ntaps > 1281 && ntaps <= 4097) {
+        if ((input_complex || !taps_complex) && ntaps > 1281 && ntaps <= 4097) {
             // round 5: the 64 x 64 form at an overlap of 2 048 - one partition to 2 049 taps, two (taps [0, 2 048) and [2 048, ntaps)) above
             const int np = ntaps <= 2049 ? 1 : 2;
             std::vector<float> t6((size_t)F64_TABLE_ELEMS2 * 2, 0.f);

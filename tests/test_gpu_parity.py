@@ -336,6 +336,43 @@ def test_one_wave_per_4096_point_block_kernel_on_a_large_launch(ntaps, cplx_taps
     assert G.max_abs_err(got, got2) < 1e-6
 
 
+@pytest.mark.parametrize("ntaps", [600, 1000, 1276, 1282, 2049, 2050, 3000, 4096, 4097])
+def test_one_wave_per_4096_point_block_kernel_on_a_float32_stream(ntaps):
+    """Round 6: the 64 x 64 kernel on a Float32 stream with real taps - two stream blocks ride as the real and the imaginary plane of one transform
+    (fir_fft64_kernel<.., S = 1>): adjacent blocks for one partition (513 .. 2 049 taps), two RUNS of consecutive blocks per wave for two partitions (2 050 ..
+    4 097 taps: the delayed spectrum in registers is then the previous block's in both planes).  2^23 samples against the f64 oracle on slabs - the start
+    (history, the first wave's warm-up block), run boundaries in the interior, an odd number of stream blocks at the end (the second plane of the last
+    transform lies past the chunk) - then the same stream in ragged chunks that straddle the small-launch (partitioned) kernel and this one."""
+    rng = np.random.default_rng(1900 + ntaps)
+    n = (1 << 23) + 4321
+    x = rand_r(rng, n)
+    taps = rand_r(rng, ntaps)
+    taps = (taps / np.sum(np.abs(taps))).astype(np.float32)
+    blk = make(lr.FIRFilterBlock, [taps, "fast"], x)
+    got = blk.process(x)
+    assert len(got) == n and got.dtype == np.float32
+
+    def slab_err(y, a, b):
+        lo = max(0, a - (ntaps - 1))
+        want = O.FIR(taps, False, O.MODE_F64).process(x[lo:b])[a - lo:]
+        return G.max_abs_err(y[a:b], want)
+
+    slabs = [(0, 9000), (2816 * 700 - 100, 2816 * 700 + 6000), (n // 4 - 3000, n // 4 + 6000), (n // 2 + 12345, n // 2 + 18345), (n - 9000, n)]
+    for a, b in slabs:
+        assert slab_err(got, a, b) < 1e-6, (a, b)
+    # every sample against a second block fed 2^20-sample chunks: up to 1 281 taps those take the partitioned 1024-point kernel (an independent
+    # arithmetic); above, the same kernel with other run boundaries and a history carry every chunk
+    small = make(lr.FIRFilterBlock, [taps, "fast"], x)
+    step = 1 << 20
+    ref = np.concatenate([small.process(x[a:a + step]) for a in range(0, n, step)])
+    assert G.max_abs_err(got, ref) < 1e-6
+    blk.reset()
+    got2 = chunked(blk, x, [1, 4097, 7000000, 7000001, 7500000])
+    for a, b in slabs:
+        assert slab_err(got2, a, b) < 1e-6, (a, b)
+    assert G.max_abs_err(got, got2) < 1e-6
+
+
 def test_fir_auto_mode_picks_the_faster_arithmetic():
     rng = np.random.default_rng(8)
     x = rand_c(rng, 30000)

@@ -81,6 +81,9 @@ def main():
     # round 4: the partitioned overlap-save kernel (kernels_firpols.h) - Float32 streams above 512 taps, anything above 1 281 taps
     run("FIRFilter 1276 real taps, f32, overlap-save (partitioned, one launch)", lambda: mk(lr.FIRFilterBlock, [taps1276, "fast"], False), False, 8, 250)
     taps4096 = np.resize(taps1276, 4096).astype(np.float32) / 4.0
+    run("FIRFilter 768 real taps, f32, overlap-save (64 x 64 kernel, two stream blocks per transform)", lambda: mk(lr.FIRFilterBlock, [taps1276[:768], "fast"], False), False, 8, 160)
+    run("FIRFilter 2048 real taps, f32, overlap-save (64 x 64 kernel at an overlap of 2 048)", lambda: mk(lr.FIRFilterBlock, [taps4096[:2048], "fast"], False), False, 8, 240)
+    run("FIRFilter 4096 real taps, f32, overlap-save (two partitions of the 64 x 64 kernel, ONE launch)", lambda: mk(lr.FIRFilterBlock, [taps4096, "fast"], False), False, 8, 420)
     run("FIRFilter 4096 real taps, cf32, overlap-save (two partitions of the 64 x 64 kernel, ONE launch)", lambda: mk(lr.FIRFilterBlock, [taps4096, "fast"], True), True, 16, 420)
     run("FIRFilter 2048 real taps, cf32, overlap-save (64 x 64 kernel at an overlap of 2 048)", lambda: mk(lr.FIRFilterBlock, [taps4096[:2048], "fast"], True), True, 16, 240)
     run("FIRFilter 8192 real taps, cf32, overlap-save (partitioned 1024-point kernel, four launches)", lambda: mk(lr.FIRFilterBlock, [np.resize(taps1276, 8192).astype(np.float32) / 8.0, "fast"], True), True, 16, 1300)
