@@ -62,7 +62,7 @@ constexpr int F64_TAB_HSYM = F64_TAB_H + F4K_N;
 constexpr int F64_TABLE_ELEMS = F64_TAB_HSYM + 64 * F64_HSYM_ROW;
 // round 5, two partitions (1 282 .. 4 097 taps at an overlap of 2 048: y_b = IFFT(X_b H_0 + X_(b-1) H_1)): the full H of partition 1 behind the table
 constexpr int F64_TAB_H1 = F64_TABLE_ELEMS;
-constexpr int F64_TABLE_ELEMS2 = F64_TAB_H1 + F4K_N;
+constexpr int F64_TABLE_ELEMS2 = F64_TAB_H1 + F4K_N;      // (round 6: 4 098 .. 8 193 taps = two such sets, partitions (0, 1) and (2, 3), one launch each)
 
 // cos / sin of 2 pi m / 64
 constexpr float F64_COS[64] = {
@@ -137,8 +137,11 @@ __device__ unsigned long long *lrhip_f64_trace;         // [block 8][wave 8][ite
 // block); `nblocks` counts stream blocks.  Replaces the partitioned 1024-point kernel for 513 .. 4 097 real taps on Float32 streams (0.33 of the roof).
 template <int V, int F64_WAVES, int NP = 1, int S = 2>
 __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float2 *__restrict__ tables,
-                                                           float *__restrict__ y, int M, long n, long n_out, long nblocks, float *__restrict__ hist_out, int xcd_map)
+                                                           float *__restrict__ y, int M, long n, long n_out, long nblocks, float *__restrict__ hist_out, int xcd_map,
+                                                           long delay, int accumulate)
 {
+    // delay / accumulate (round 6): 4 098 .. 8 193 taps as TWO launches of the two-partition form - the second applies partitions 2 and 3 to the stream delayed
+    // by 4 096 samples (M stays the whole filter's length: the carried history holds M - 1 samples) and adds to y, as fir_fft_kernel's partitions do
     static_assert(V % 64 == 0 && V >= 64 && V < F4K_N, "the overlap is a whole number of 64-sample rows");
     static_assert(NP == 1 || (NP == 2 && F64_WAVES == 4 && 2 * V == F4K_N), "two partitions: hop = overlap = 2 048, four waves, full H");
     static_assert(S == 2 || S == 1, "ComplexFloat32 or Float32 stream");
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
     cf pre[64];
     bool have = false;
     auto prefetch = [&](long nb) {
-        const long plo = nb * L - V;
+        const long plo = nb * L - V - delay;
         have = LRHIP_F64_PREFETCH && S == 2 && nb < nblocks && plo >= 0 && plo + F4K_N <= n;
         if (have) {
             const cf *src = reinterpret_cast<const cf *>(x) + plo;
@@ -222,8 +225,8 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
         // stream block(s) of this transform: S = 2 - block fb; S = 1 - blocks (2 fb, 2 fb + 1) or, two partitions, (fb, fb + run)
         const long ba = (S == 1 && NP == 1) ? 2 * fb : fb;
         [[maybe_unused]] const long bb = NP == 1 ? ba + 1 : ba + run;
-        const long xlo = ba * L - V;
-        [[maybe_unused]] const long xlob = bb * L - V;
+        const long xlo = ba * L - V - delay;
+        [[maybe_unused]] const long xlob = bb * L - V - delay;
         cf v[64];
         if constexpr (S == 1) {
             const long xhi = xlo > xlob ? xlo : xlob;
@@ -386,7 +389,29 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
             const long oa = ba * L - V, ob1 = bb * L - V;
             float *da = y + oa, *db = y + ob1;
             const long ohi = oa > ob1 ? oa : ob1;
-            if (ohi + F4K_N <= n_out) {
+            if (accumulate && V % 1024 == 0 && ohi + F4K_N <= n_out) {
+                // groups of eight rows per plane: sixteen loads in flight, then the adds and stores (a load-add-store per row would be a memory round trip per row)
+#pragma unroll
+                for (int g = V / 64; g + 8 <= 64; g += 8) {
+                    float ta[8], tc[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        ta[i] = (da + 64 * (g + i))[(unsigned)lane];
+                        tc[i] = (db + 64 * (g + i))[(unsigned)lane];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        (da + 64 * (g + i))[(unsigned)lane] = ta[i] + v[g + i].x;
+                        (db + 64 * (g + i))[(unsigned)lane] = tc[i] + v[g + i].y;
+                    }
+                }
+            } else if (accumulate) {
+#pragma unroll
+                for (int i = V / 64; i < 64; i++) {
+                    if (oa + 64 * i + lane < n_out) (da + 64 * i)[(unsigned)lane] += v[i].x;
+                    if (ob1 + 64 * i + lane < n_out) (db + 64 * i)[(unsigned)lane] += v[i].y;
+                }
+            } else if (ohi + F4K_N <= n_out) {
 #pragma unroll
                 for (int i = V / 64; i < 64; i++) {
                     __builtin_nontemporal_store(v[i].x, (da + 64 * i) + (unsigned)lane);
@@ -407,7 +432,20 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
         }
         const long ob = fb * L - V;
         cf *dst = reinterpret_cast<cf *>(y) + ob;
-        if (ob + F4K_N <= n_out) {
+        if (accumulate && V % 1024 == 0 && ob + F4K_N <= n_out) {
+#pragma unroll
+            for (int g = V / 64; g + 16 <= 64; g += 16) {
+                cf t[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) t[i] = (dst + 64 * (g + i))[(unsigned)lane];
+#pragma unroll
+                for (int i = 0; i < 16; i++) (dst + 64 * (g + i))[(unsigned)lane] = t[i] + v[g + i];
+            }
+        } else if (accumulate) {
+#pragma unroll
+            for (int i = V / 64; i < 64; i++)
+                if (ob + 64 * i + lane < n_out) (dst + 64 * i)[(unsigned)lane] += v[i];
+        } else if (ob + F4K_N <= n_out) {
 #pragma unroll
             for (int i = V / 64; i < 64; i++) __builtin_nontemporal_store(v[i], (dst + 64 * i) + (unsigned)lane);
         } else {

@@ -16,6 +16,7 @@ struct RotatorStage : lrhip_stage {
     double omega = 0;
     uint64_t step = 0, count = 0;
     const char *kind() const override { return "rotator"; }
+    bool direct_io_ok() const override { return true; }      // round 6: one read, one write per sample (host_execute's direct mode; measured: stage_elem3.h)
     int reset() override { count = 0; return 0; }
     int seek(unsigned long long n0, unsigned long long *n0_out) override { count = n0; *n0_out = n0; return 0; }      // phase = step * absolute index
     long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
@@ -39,6 +40,7 @@ struct RotatorStage : lrhip_stage {
 struct DownsamplerStage : lrhip_stage {
     unsigned long factor = 1, index = 0;
     const char *kind() const override { return "downsampler"; }
+    bool direct_io_ok() const override { return true; }
     int reset() override { index = 0; return 0; }
     int seek(unsigned long long n0, unsigned long long *n0_out) override
     {

@@ -9,6 +9,11 @@ struct UnaryStage : lrhip_stage {
     int op = 0;
     float cr = 0.f, ci = 0.f;
     const char *kind() const override { return "unary"; }
+    // round 6, host_execute's direct mode (registered vectors read and written across the link by the kernel itself): measured against the staged piece
+    // pipeline on one box (tools/ab_direct_elem.py, profiles/r06_ab_direct_elem.txt) it pays for the translator (+14 % at 2^20-sample vectors) and the
+    // stages that write less than they read (Downsampler +11 %, complex -> real +3-6 %); 1 : 1 kernels without arithmetic (MultiplyConstant, conjugate)
+    // are equal at 2^20 and 7 % SLOWER at 2^24 - they stay staged
+    bool direct_io_ok() const override { return out_size < in_size; }
     int reset() override { return 0; }
     long run(const void *in_dev, unsigned long n, void *out_dev, unsigned long cap) override
     {

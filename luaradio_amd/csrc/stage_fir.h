@@ -427,7 +427,7 @@ struct FirStage : lrhip_stage {
         const long nblocks = ((n_out + Lf - 1) / Lf + (2 - SS)) / (3 - SS), nslots = (nblocks + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)(nslots < ctx().num_cus ? nslots : ctx().num_cus);      // 108 / 158 KB of LDS: one workgroup per CU
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (const float2 *)d_fft64_tables.p, y, M, n,
-                           n_out, nblocks, M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : (float *)nullptr, xcd_map);
+                           n_out, nblocks, M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : (float *)nullptr, xcd_map, 0L, 0);
         LR_LAUNCH_CHECK();
         hist_in_kernel = true;
         return 0;
@@ -443,9 +443,14 @@ struct FirStage : lrhip_stage {
         if (prepared_blocks(kern, lds_bytes, 64 * WAVES) < 0) return -1;
         const long nblocks = (n_out + Lf - 1) / Lf, nslots = (nblocks + WAVES - 1) / WAVES;
         const unsigned grid = (unsigned)(nslots < ctx().num_cus ? nslots : ctx().num_cus);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x, (const float2 *)d_fft64_tables.p, y, M, n,
-                           n_out, nblocks, M > 1 ? (float *)hist[cur ^ 1].p + hist_pad : (float *)nullptr, 0);
-        LR_LAUNCH_CHECK();
+        // round 6: 4 098 .. 8 193 taps (fft64_np = 3, 4) = a second launch with partitions 2 and 3 on the stream delayed by 4 096 samples, adding to y
+        const int launches = NP == 2 && fft64_np > 2 ? 2 : 1;
+        for (int l = 0; l < launches; l++) {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds_bytes, ctx().stream, (const float *)hist[cur].p + hist_pad, x,
+                               (const float2 *)d_fft64_tables.p + (size_t)l * F64_TABLE_ELEMS2, y, M, n, n_out, nblocks,
+                               (M > 1 && l == 0) ? (float *)hist[cur ^ 1].p + hist_pad : (float *)nullptr, 0, (long)l * F4K_N, l);
+            LR_LAUNCH_CHECK();
+        }
         hist_in_kernel = true;
         return 0;
     }
@@ -529,7 +534,7 @@ struct FirStage : lrhip_stage {
             // 0.188 / 0.208 / 0.243 / 1.104 at 2^20 / 2^22 / 2^24 / 2^26, 2 048 taps 0.048 against 0.093 at 2^22 - so there is no lower bound; LRHIP_F64_LONG_MIN = blocks per CU)
             static const long long_min = getenv("LRHIP_F64_LONG_MIN") ? atol(getenv("LRHIP_F64_LONG_MIN")) : 0;
             if (nb >= long_min * ctx().num_cus) {
-                if (S == 1) return fft64_np == 1 ? launch_fft64<2048, 8, 1>(x, n, y, n_out) : launch_fft64_long<2, 1>(x, n, y, n_out);
+                if (S == 1) return fft64_np == 1 ? launch_fft64<2048, 8, 1>(x, n, y, n_out) : launch_fft64_long<2, 1>(x, n, y, n_out);      // (np = 2, 3, 4: two partitions per launch)
                 if (fft64_np == 1) return taps_complex ? launch_fft64<2048, 4>(x, n, y, n_out) : launch_fft64<2048, 8>(x, n, y, n_out);
                 return launch_fft64_long<2>(x, n, y, n_out);
             }
@@ -1388,19 +1393,26 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
             q->fft4k_V = (int)((ntaps - 1 + 255) / 256) * 256;
             if (q->fft4k_V < 768) q->fft4k_V = 768;
         }
-        if ((input_complex || !taps_complex) && ntaps > 1281 && ntaps <= 4097) {
-            // round 5: the 64 x 64 form at an overlap of 2 048 - one partition to 2 049 taps, two (taps [0, 2 048) and [2 048, ntaps)) above
-            const int np = ntaps <= 2049 ? 1 : 2;
-            std::vector<float> t6((size_t)F64_TABLE_ELEMS2 * 2, 0.f);
+        if ((input_complex || !taps_complex) && ntaps > 1281 && ntaps <= 8193) {
+            // round 5: the 64 x 64 form at an overlap of 2 048 - one partition to 2 049 taps, two (taps [0, 2 048) and [2 048, ntaps)) above;
+            // round 6: three / four partitions of 2 048 taps (the last up to 2 049) to 8 193 taps - a second table set for the second launch
+            const int np = (int)((ntaps + 2046) / 2048);                      // ceil((ntaps - 1) / 2 048): 1 to 2 049 taps, 2 to 4 097, 3 to 6 145, 4 to 8 193
+            const int nsets = np > 2 ? 2 : 1;
+            std::vector<float> t6((size_t)F64_TABLE_ELEMS2 * 2 * nsets, 0.f);
             auto put6 = [&](size_t o, double a) { t6[2 * o] = (float)std::cos(a); t6[2 * o + 1] = (float)std::sin(a); };
-            for (int c = 0; c < 16; c++)
-                for (int t = 0; t < 64; t++) put6((size_t)c * 64 + t, -PI2 * (double)((c * t) % FFTN) / FFTN);
-            for (int d = 0; d < 4; d++)
-                for (int t = 0; t < 64; t++) put6((size_t)F64_TAB_D + d * 64 + t, -PI2 * (double)(t * d) / F4K_N);
+            for (int set = 0; set < nsets; set++) {
+                const size_t so = (size_t)set * F64_TABLE_ELEMS2;
+                for (int c = 0; c < 16; c++)
+                    for (int t = 0; t < 64; t++) put6(so + (size_t)c * 64 + t, -PI2 * (double)((c * t) % FFTN) / FFTN);
+                for (int d = 0; d < 4; d++)
+                    for (int t = 0; t < 64; t++) put6(so + (size_t)F64_TAB_D + d * 64 + t, -PI2 * (double)(t * d) / F4K_N);
+            }
             std::vector<double> cs(F4K_N), sn(F4K_N), Hr(F4K_N), Hi(F4K_N);
             for (int k = 0; k < F4K_N; k++) { cs[k] = std::cos(-PI2 * k / F4K_N); sn[k] = std::sin(-PI2 * k / F4K_N); }
             for (int part = 0; part < np; part++) {
-                const unsigned m0 = np == 1 ? 0 : part * 2048u, m1 = np == 1 ? ntaps : (part == 0 ? 2048u : ntaps);
+                const unsigned m0 = np == 1 ? 0 : part * 2048u, m1 = np == 1 ? ntaps : (part + 1 < np ? (part + 1) * 2048u : ntaps);
+                const size_t so = (size_t)(part / 2) * F64_TABLE_ELEMS2;
+                const bool second = (part & 1) != 0;
                 for (int k = 0; k < F4K_N; k++) {
                     double sr = 0, si = 0;
                     for (unsigned m = m0; m < m1; m++) {
@@ -1415,7 +1427,7 @@ static FirStage *fir_build(const float *taps, unsigned ntaps, int taps_complex, 
                 for (int r = 0; r < 64; r++)
                     for (int l = 0; l < 64; l++) {
                         const int k = 64 * f64_index(r) + l;
-                        const size_t o = (size_t)(part == 0 ? F64_TAB_H : F64_TAB_H1) + (size_t)r * 64 + l;
+                        const size_t o = so + (size_t)(second ? F64_TAB_H1 : F64_TAB_H) + (size_t)r * 64 + l;
                         t6[2 * o] = (float)Hr[k];
                         t6[2 * o + 1] = (float)Hi[k];
                         if (part == 0 && l <= 32) {

@@ -507,6 +507,50 @@ def test_registered_vectors_are_read_and_written_in_place():
             assert L.lrhip_host_unregister(v.ctypes.data_as(C.c_void_p)) == 0
 
 
+def test_single_pass_element_wise_stages_take_registered_vectors_in_place():
+    """Round 6: single-pass stages join host_execute's direct mode where it was measured to pay (FrequencyTranslator, Downsampler, the complex -> real
+    unary blocks; MultiplyConstant, conjugate, Upsampler stay on the staged pipeline - tools/ab_direct_elem.py): with both vectors registered the kernel
+    loads and stores the caller's host memory across the link - no staging, no pieces.  Either way the same kernels run on the same values: the bits of
+    the device-resident run, also off the 16-byte grid (the one-sample kernels) and across calls (the rotator's phase, the downsampler's index carry on)."""
+    import torch
+    if os.environ.get("LRHIP_HOST_DIRECT") == "0":
+        pytest.skip("LRHIP_HOST_DIRECT=0 (A/B knob)")
+    L = _lib.load()
+    rng = np.random.default_rng(78)
+    n = (1 << 21) + 777
+    x = _aligned(n, np.complex64)
+    x[:] = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+    y = _aligned(3 * n + 64, np.complex64)
+    for v in (x, y):
+        _lib.check(L.lrhip_host_register(v.ctypes.data_as(C.c_void_p), v.nbytes), "register")
+    c = types.ComplexFloat32
+    try:
+        xd = torch.from_numpy(x.view(np.float32).copy()).cuda()
+        cases = [(lr.FrequencyTranslatorBlock, [-250e3]), (lr.DownsamplerBlock, [5]), (lr.MultiplyConstantBlock, [0.5]), (lr.ComplexMagnitudeBlock, []),
+                 (lr.ComplexConjugateBlock, []), (lr.UpsamplerBlock, [3])]
+        for cls, args in cases:
+            for off in (0, 3):
+                blk, ref = make(cls, args, c, FS), make(cls, args, c, FS)
+                q = blk.stage_handle()
+                osz = L.lrhip_stage_output_size(q)
+                done_out = 0
+                yd = torch.zeros(2 * (3 * n + 64), device="cuda")
+                for a, m in ((off, 100001), (off + 100001, 4097), (off + 104098, n - 104098 - 3)):
+                    cap = L.lrhip_stage_max_output(q, m)
+                    got = L.lrhip_stage_execute(q, C.c_void_p(x.ctypes.data + 8 * a), m, C.c_void_p(y.ctypes.data + osz * done_out), cap)
+                    assert got >= 0, _lib.last_error()
+                    want = ref.process_device(xd.data_ptr() + 8 * a, m, yd.data_ptr() + osz * done_out, cap)
+                    assert got == want, (cls.__name__, off, got, want)
+                    done_out += got
+                torch.cuda.synchronize()
+                host = y.view(np.uint8)[:osz * done_out]
+                dev = yd.cpu().numpy().view(np.uint8)[:osz * done_out]
+                assert np.array_equal(host, dev), (cls.__name__, off)
+    finally:
+        for v in (x, y):
+            assert L.lrhip_host_unregister(v.ctypes.data_as(C.c_void_p)) == 0
+
+
 def test_poll_due_stays_bounded_while_a_launched_batch_is_in_flight():
     """batch == chunk - push() launches the full batch, its non-waiting collect finds it unfinished, then the source stalls.  Nothing is
     accumulating, but the batch's output still has to reach the host: poll_due() keeps the wait for input bounded until the ring has drained, and poll()

@@ -304,13 +304,15 @@ def test_partitioned_form_equals_the_4096_point_kernels_filter():
 
 
 @pytest.mark.parametrize("ntaps,cplx_taps", [(600, False), (1000, False), (1276, False), (1276, True), (770, True),
-                                             (1282, False), (2049, False), (2000, True), (2050, False), (3000, False), (4096, False), (4097, False), (4096, True)])
+                                             (1282, False), (2049, False), (2000, True), (2050, False), (3000, False), (4096, False), (4097, False), (4096, True),
+                                             (4098, False), (6145, False), (6146, True), (8192, False)])
 def test_one_wave_per_4096_point_block_kernel_on_a_large_launch(ntaps, cplx_taps):
     """513 .. 1 281 taps on a ComplexFloat32 stream, launches of at least eight 4096-point blocks per CU: fir_fft64_kernel (kernels_firfft64.h, round 4) -
     4096 = 64 x 64 with both 64-point transforms in registers and one transpose per direction; eight waves per CU on the conjugate-symmetric H of real
     taps, four on the full H of complex taps.  Round 5: 1 282 .. 2 049 taps at an overlap of 2 048 and 2 050 .. 4 097 taps as TWO partitions in one launch
     (a wave walks a run of consecutive blocks with the previous block's spectrum in registers; the chunk cuts below land inside runs, and every chunk starts
-    with warm-up blocks that reach into the carried history).  2^23 samples against the f64 oracle on slabs (first, two interior, last), then the same stream in ragged
+    with warm-up blocks that reach into the carried history).  Round 6: 4 098 .. 8 192 taps as two such launches, the second on the stream delayed by 4 096
+    samples and adding to the first's output.  2^23 samples against the f64 oracle on slabs (first, two interior, last), then the same stream in ragged
     chunks that straddle the small-launch kernel (workgroup per block) and this one."""
     rng = np.random.default_rng(900 + ntaps + cplx_taps)
     n = 1 << 23
@@ -336,7 +338,7 @@ def test_one_wave_per_4096_point_block_kernel_on_a_large_launch(ntaps, cplx_taps
     assert G.max_abs_err(got, got2) < 1e-6
 
 
-@pytest.mark.parametrize("ntaps", [600, 1000, 1276, 1282, 2049, 2050, 3000, 4096, 4097])
+@pytest.mark.parametrize("ntaps", [600, 1000, 1276, 1282, 2049, 2050, 3000, 4096, 4097, 4098, 5000, 6146, 8192])
 def test_one_wave_per_4096_point_block_kernel_on_a_float32_stream(ntaps):
     """Round 6: the 64 x 64 kernel on a Float32 stream with real taps - two stream blocks ride as the real and the imaginary plane of one transform
     (fir_fft64_kernel<.., S = 1>): adjacent blocks for one partition (513 .. 2 049 taps), two RUNS of consecutive blocks per wave for two partitions (2 050 ..

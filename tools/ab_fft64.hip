@@ -60,7 +60,7 @@ static void launch(const float *hist, const float *x, const float2 *tables, floa
     static bool set = false;
     if (!set) { CK(hipFuncSetAttribute((const void *)fir_fft64_kernel<V, F64_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
     const long nblocks = (n + (F4K_N - V) - 1) / (F4K_N - V);
-    hipLaunchKernelGGL((fir_fft64_kernel<V, F64_WAVES>), dim3(grid), dim3(64 * F64_WAVES), lds, 0, hist, x, tables, y, M, n, n, nblocks, (float *)nullptr, xcd);
+    hipLaunchKernelGGL((fir_fft64_kernel<V, F64_WAVES>), dim3(grid), dim3(64 * F64_WAVES), lds, 0, hist, x, tables, y, M, n, n, nblocks, (float *)nullptr, xcd, 0L, 0);
 }
 
 int main(int argc, char **argv)
