@@ -78,16 +78,18 @@ def main():
                            lr.filter_utils.firwin_lowpass(256, 0.5)).astype(np.float32)
     run("FIRFilter 1276 real taps, cf32, overlap-save (4096-point blocks)", lambda: mk(lr.FIRFilterBlock, [taps1276, "fast"], True), True, 16, 180)
     run("FIRFilter 768 real taps, cf32, overlap-save (4096-point blocks)", lambda: mk(lr.FIRFilterBlock, [taps1276[:768], "fast"], True), True, 16, 160)
-    # round 4: the partitioned overlap-save kernel (kernels_firpols.h) - Float32 streams above 512 taps, anything above 1 281 taps
-    run("FIRFilter 1276 real taps, f32, overlap-save (partitioned, one launch)", lambda: mk(lr.FIRFilterBlock, [taps1276, "fast"], False), False, 8, 250)
+    # round 6: Float32 streams above 512 taps on the 64 x 64 kernel (round 4-5: the partitioned kernel of kernels_firpols.h, LRHIP_F64_F32=0)
+    run("FIRFilter 1276 real taps, f32, overlap-save (64 x 64 kernel, two stream blocks per transform)", lambda: mk(lr.FIRFilterBlock, [taps1276, "fast"], False), False, 8, 250)
     taps4096 = np.resize(taps1276, 4096).astype(np.float32) / 4.0
+    # (the 8 192-tap rows first: their two launches are the kernel of the 4 096-tap rows, whose dispatches must be the LAST ones of that kernel in the trace -
+    # profiles/summarize_rocpd.py --last 10)
+    run("FIRFilter 8192 real taps, cf32, overlap-save (four partitions of the 64 x 64 kernel, TWO launches)", lambda: mk(lr.FIRFilterBlock, [np.resize(taps1276, 8192).astype(np.float32) / 8.0, "fast"], True), True, 16, 1300)
+    run("FIRFilter 8192 real taps, f32, overlap-save (four partitions of the 64 x 64 kernel, TWO launches)", lambda: mk(lr.FIRFilterBlock, [np.resize(taps1276, 8192).astype(np.float32) / 8.0, "fast"], False), False, 8, 650)
     run("FIRFilter 768 real taps, f32, overlap-save (64 x 64 kernel, two stream blocks per transform)", lambda: mk(lr.FIRFilterBlock, [taps1276[:768], "fast"], False), False, 8, 160)
     run("FIRFilter 2048 real taps, f32, overlap-save (64 x 64 kernel at an overlap of 2 048)", lambda: mk(lr.FIRFilterBlock, [taps4096[:2048], "fast"], False), False, 8, 240)
     run("FIRFilter 4096 real taps, f32, overlap-save (two partitions of the 64 x 64 kernel, ONE launch)", lambda: mk(lr.FIRFilterBlock, [taps4096, "fast"], False), False, 8, 420)
-    run("FIRFilter 8192 real taps, f32, overlap-save (four partitions of the 64 x 64 kernel, TWO launches)", lambda: mk(lr.FIRFilterBlock, [np.resize(taps1276, 8192).astype(np.float32) / 8.0, "fast"], False), False, 8, 650)
     run("FIRFilter 4096 real taps, cf32, overlap-save (two partitions of the 64 x 64 kernel, ONE launch)", lambda: mk(lr.FIRFilterBlock, [taps4096, "fast"], True), True, 16, 420)
     run("FIRFilter 2048 real taps, cf32, overlap-save (64 x 64 kernel at an overlap of 2 048)", lambda: mk(lr.FIRFilterBlock, [taps4096[:2048], "fast"], True), True, 16, 240)
-    run("FIRFilter 8192 real taps, cf32, overlap-save (four partitions of the 64 x 64 kernel, TWO launches)", lambda: mk(lr.FIRFilterBlock, [np.resize(taps1276, 8192).astype(np.float32) / 8.0, "fast"], True), True, 16, 1300)
     run("FIRFilter 1276 complex taps, cf32, overlap-save (4096-point blocks, four waves per CU)",
         lambda: mk(lr.FIRFilterBlock, [np.asarray(taps1276, np.complex64) * (1 + 0.5j), "fast"], True), True, 16, 180)
     run("FIRFilter 16 real taps, cf32", lambda: mk(lr.FIRFilterBlock, [taps128[:16], False], True), True, 16, 64)

@@ -42,7 +42,7 @@ def find(rows, *subs):
 
 def main():
     prof, out = sys.argv[1], sys.argv[2]
-    tag = sys.argv[3] if len(sys.argv) > 3 else "r05"
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r06"
     bench = parse(prof + "/summary_kernel_trace.txt")
     blocks = parse(prof + "/summary_blocks_kernel_trace.txt")
     pmc = parse_pmc(prof + "/summary_pmc_blocks.txt")
@@ -87,13 +87,15 @@ def main():
         ("IQ records u8 -> cf32", blocks, ("format_convert_vec_kernel<unsigned char, unsigned char",), 10, n26, 0),
         ("IQ records s16le -> cf32", blocks, ("format_convert_vec_kernel<unsigned short, short",), 12, n26, 0),
         ("IQ records f32be -> cf32", blocks, ("format_convert_vec_kernel<unsigned int, float, true",), 16, n26, 0),
-        ("FIR 1276 real taps cf32, overlap-save, one 4096-point launch (a wave per block, 64 x 64)", blocks, ("fir_fft64_kernel<1280, 8, 1>",), 16, n26, 180),
-        ("FIR 768 real taps cf32, overlap-save, one 4096-point launch (a wave per block, 64 x 64)", blocks, ("fir_fft64_kernel<768, 8, 1>",), 16, n26, 160),
-        ("FIR 1276 complex taps cf32, overlap-save, 4096-point launch (a wave per block, four waves per CU, full H)", blocks, ("fir_fft64_kernel<1280, 4, 1>",), 16, n26, 180),
-        ("FIR 1276 real taps f32, overlap-save, partitioned (kernels_firpols.h, one launch)", blocks, ("fir_pols_kernel<1, 3>",), 8, n26, 250),
-        ("FIR 4096 real taps cf32, overlap-save: two partitions of the 64 x 64 kernel, ONE launch", blocks, ("fir_fft64_kernel<2048, 4, 2>",), 16, n26, 420),
-        ("FIR 2048 real taps cf32, overlap-save: 64 x 64 kernel at an overlap of 2 048", blocks, ("fir_fft64_kernel<2048, 8, 1>",), 16, n26, 240),
-        ("FIR 8192 real taps cf32, overlap-save, partitioned 1024-point kernel: one of FOUR launches of four partitions each", blocks, ("fir_pols_kernel<2, 4>",), 16, n26, 330),
+        ("FIR 1276 real taps cf32, overlap-save, one 4096-point launch (a wave per block, 64 x 64)", blocks, ("fir_fft64_kernel<1280, 8, 1, 2>",), 16, n26, 180),
+        ("FIR 768 real taps cf32, overlap-save, one 4096-point launch (a wave per block, 64 x 64)", blocks, ("fir_fft64_kernel<768, 8, 1, 2>",), 16, n26, 160),
+        ("FIR 1276 complex taps cf32, overlap-save, 4096-point launch (a wave per block, four waves per CU, full H)", blocks, ("fir_fft64_kernel<1280, 4, 1, 2>",), 16, n26, 180),
+        ("FIR 1276 real taps f32, overlap-save: 64 x 64 kernel, two stream blocks per transform (round 6; round 5: partitioned, 0.322)", blocks, ("fir_fft64_kernel<1280, 8, 1, 1>",), 8, n26, 250),
+        ("FIR 768 real taps f32, overlap-save: 64 x 64 kernel, two stream blocks per transform", blocks, ("fir_fft64_kernel<768, 8, 1, 1>",), 8, n26, 160),
+        ("FIR 2048 real taps f32, overlap-save: 64 x 64 kernel at an overlap of 2 048", blocks, ("fir_fft64_kernel<2048, 8, 1, 1>",), 8, n26, 240),
+        ("FIR 4096 real taps f32, overlap-save: two partitions of the 64 x 64 kernel, ONE launch", blocks, ("fir_fft64_kernel<2048, 4, 2, 1>",), 8, n26, 420),
+        ("FIR 4096 real taps cf32, overlap-save: two partitions of the 64 x 64 kernel, ONE launch", blocks, ("fir_fft64_kernel<2048, 4, 2, 2>",), 16, n26, 420),
+        ("FIR 2048 real taps cf32, overlap-save: 64 x 64 kernel at an overlap of 2 048", blocks, ("fir_fft64_kernel<2048, 8, 1, 2>",), 16, n26, 240),
         ("WBFM mono receiver from u8 IQ records, ONE launch (bench_blocks: noise input)", blocks, ("rx_fused_kernel<1>",), 2.16, n26, 167),
         ("Tuner from u8 IQ records (fan-out branch fed from a file), ONE launch", blocks, ("fir_mfma_persistent_kernel<2, 5, 2, true, 51, 0, false, 4, 1",), 3.6, n26, 108.4),
         ("Tuner(decimation 50) from u8 IQ records, ONE launch (AM / SSB / NBFM receivers fed from a file)", blocks, ("fir_decim_lds2_kernel<true, 1, false>",), 2.16, n26, 16.2),
