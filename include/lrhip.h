@@ -362,7 +362,10 @@ void  lrhip_host_free(void *host_ptr);
  * Round 5: with BOTH vectors of a call registered, a stage or chain whose first kernel reads its input once and whose last kernel writes its output once
  * (the FIR forms, Tuner / Decimator, the FM receiver) is handed the host vectors themselves - its loads and stores cross the link, one launch per call, no
  * staging on the device.  The values are those of the same call on device-resident vectors (an overlap-save filter sees the call as ONE chunk, where the
- * staged path cuts calls of 2^20 samples and more into pieces that are chunks of their own: Float32 rounding apart, include the statement above). */
+ * staged path cuts calls of 2^20 samples and more into pieces that are chunks of their own: Float32 rounding apart, include the statement above).
+ * Round 6: the same for FrequencyTranslator, Downsampler and the complex -> real element-wise blocks (where it measured faster than the staged pipeline);
+ * NOT for a filter created with the reference's block-emission framing (use_fft = 1: it copies its input first), and not when the input and output ranges
+ * of a call overlap (an in-place call is served by the staged path, as one piece: the whole input is on the device before the first output byte returns). */
 int   lrhip_host_register(void *host_ptr, unsigned long bytes);
 int   lrhip_host_unregister(void *host_ptr);
 

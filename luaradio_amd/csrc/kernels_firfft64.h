@@ -135,7 +135,9 @@ __device__ unsigned long long *lrhip_f64_trace;         // [block 8][wave 8][ite
 // counts TRANSFORMS.  NP = 2: a wave walks TWO runs of consecutive blocks at once, run A in the real plane and the run behind it in the imaginary plane, so the
 // delayed spectrum in its registers is the previous block's in BOTH planes (adjacent blocks in one transform would need the spectrum of a pair shifted by one
 // block); `nblocks` counts stream blocks.  Replaces the partitioned 1024-point kernel for 513 .. 4 097 real taps on Float32 streams (0.33 of the roof).
-template <int V, int F64_WAVES, int NP = 1, int S = 2>
+// HG (round 6, A/B only - measured 8-10 % slower, stage_fir.h): H read from the global table (32 KB, resident in L2) instead of the LDS - COMPLEX taps at eight waves
+// per CU: their H has no symmetry to halve it, and the full table next to eight transpose buffers does not fit the LDS (the shipped form: four waves per CU)
+template <int V, int F64_WAVES, int NP = 1, int S = 2, bool HG = false>
 __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const float *__restrict__ hist, const float *__restrict__ x, const float2 *__restrict__ tables,
                                                            float *__restrict__ y, int M, long n, long n_out, long nblocks, float *__restrict__ hist_out, int xcd_map,
                                                            long delay, int accumulate)
@@ -153,12 +155,13 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
         for (int i = tid; i < (M - 1) * S; i += 64 * F64_WAVES) hist_out[i] = stream_at<S>(hist, x, n + i / S, i % S, M, n);
     cf *flc = reinterpret_cast<cf *>(fl);
     float *ex = reinterpret_cast<float *>(flc + wave * F64_EX);
-    constexpr bool HSYM = F64_WAVES > 4;
+    constexpr bool HSYM = F64_WAVES > 4 && !HG;
+    static_assert(!HG || (NP == 1 && S == 2), "H from the global table: one partition, ComplexFloat32 stream");
     constexpr int F64_LDS_H = f64_lds_h(F64_WAVES), F64_LDS_C = f64_lds_c(F64_WAVES, NP);
     const cf *Ct = flc + F64_LDS_C, *Hs = flc + F64_LDS_H;
     if (HSYM)
         for (int i = tid; i < 64 * F64_HSYM_ROW; i += 64 * F64_WAVES) fl[F64_LDS_H + i] = tables[F64_TAB_HSYM + i];
-    else
+    else if (!HG)
         for (int i = tid; i < F4K_N; i += 64 * F64_WAVES) fl[F64_LDS_H + i] = tables[F64_TAB_H + i];
     if (NP == 2)
         for (int i = tid; i < F4K_N; i += 64 * F64_WAVES) fl[F64_LDS_H + F4K_N + i] = tables[F64_TAB_H1 + i];
@@ -342,6 +345,10 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
                                                             // of the block loop into 64 registers the wave does not have
 #pragma unroll
                 for (int r = 0; r < LRHIP_F64_HGROUP; r++) h[r] = Hs[hs_a + f64_index(g + r) * hs_s] * hs_sgn;
+            } else if constexpr (HG) {
+                const cf *Hg = reinterpret_cast<const cf *>(tables) + F64_TAB_H;
+#pragma unroll
+                for (int r = 0; r < LRHIP_F64_HGROUP; r++) h[r] = (Hg + (g + r) * 64)[(unsigned)lane];
             } else {
 #pragma unroll
                 for (int r = 0; r < LRHIP_F64_HGROUP; r++) h[r] = (Hs + (g + r) * 64)[(unsigned)lane];      // row pointer + the lane's index

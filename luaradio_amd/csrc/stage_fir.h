@@ -415,12 +415,12 @@ struct FirStage : lrhip_stage {
     }
     int fft4k_blocks2 = 0;
     // one WAVE per 4096-point block as 64 x 64 (kernels_firfft64.h): eight waves per CU with the conjugate-symmetric H of real taps, four with complex taps
-    template <int VV, int WAVES, int SS = 2>
+    template <int VV, int WAVES, int SS = 2, bool HG = false>
     int launch_fft64(const float *x, long n, float *y, long n_out)
     {
         constexpr long Lf = F4K_N - VV;
         const size_t lds_bytes = (size_t)f64_lds_elems(WAVES) * sizeof(float2);
-        auto kern = fir_fft64_kernel<VV, WAVES, 1, SS>;
+        auto kern = fir_fft64_kernel<VV, WAVES, 1, SS, HG>;
         if (prepared_blocks(kern, lds_bytes, 64 * WAVES) < 0) return -1;
         static const int xcd_map = getenv("LRHIP_F4K_XCD_MAP") ? atoi(getenv("LRHIP_F4K_XCD_MAP")) : 1;
         // (Float32 stream: two stream blocks per transform - the kernel's block count is the number of transforms)
@@ -458,7 +458,12 @@ struct FirStage : lrhip_stage {
     int launch_fft64_v(const float *x, long n, float *y, long n_out)
     {
         if (S == 1) return launch_fft64<VV, 8, 1>(x, n, y, n_out);
-        return taps_complex ? launch_fft64<VV, 4>(x, n, y, n_out) : launch_fft64<VV, 8>(x, n, y, n_out);
+        // round 6, measured and left OFF: complex taps at eight waves per CU with H read from the global table (LRHIP_F64_HG=1) are 8-10 % SLOWER than four waves
+        // with H in the LDS (1 276 taps, 2^26 samples, three alternations on one box: 0.447 / 0.444 / 0.437 against 0.404 / 0.406 / 0.405 ms, profiles/r06_ab_hg.txt) -
+        // 64 more global loads per block in a kernel whose block is already a third memory-instruction issue
+        static const int hg_knob = getenv("LRHIP_F64_HG") ? atoi(getenv("LRHIP_F64_HG")) : 0;
+        if (taps_complex) return hg_knob ? launch_fft64<VV, 8, 2, true>(x, n, y, n_out) : launch_fft64<VV, 4>(x, n, y, n_out);
+        return launch_fft64<VV, 8>(x, n, y, n_out);
     }
     template <int VV>
     int launch_fft4k(const float *x, long n, float *y, long n_out)
@@ -535,7 +540,7 @@ struct FirStage : lrhip_stage {
             static const long long_min = getenv("LRHIP_F64_LONG_MIN") ? atol(getenv("LRHIP_F64_LONG_MIN")) : 0;
             if (nb >= long_min * ctx().num_cus) {
                 if (S == 1) return fft64_np == 1 ? launch_fft64<2048, 8, 1>(x, n, y, n_out) : launch_fft64_long<2, 1>(x, n, y, n_out);      // (np = 2, 3, 4: two partitions per launch)
-                if (fft64_np == 1) return taps_complex ? launch_fft64<2048, 4>(x, n, y, n_out) : launch_fft64<2048, 8>(x, n, y, n_out);
+                if (fft64_np == 1) return launch_fft64_v<2048>(x, n, y, n_out);
                 return launch_fft64_long<2>(x, n, y, n_out);
             }
         }
