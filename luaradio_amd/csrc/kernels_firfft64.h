@@ -37,6 +37,15 @@
 #define LRHIP_F64_HGROUP 16
 #endif
 
+#ifndef LRHIP_F64_NOMEM
+#define LRHIP_F64_NOMEM 0      /* 1 (stand-alone driver only, wrong results): no global loads / stores in interior blocks - what the arithmetic alone costs */
+#endif
+#ifndef LRHIP_F64_STAGGER
+#define LRHIP_F64_STAGGER 0
+#endif
+#ifndef LRHIP_F64_NOARITH
+#define LRHIP_F64_NOARITH 0      /* 1 (stand-alone driver only, wrong results): no transform - what the block's access shape alone costs */
+#endif
 #ifndef LRHIP_F64_FENCES
 #define LRHIP_F64_FENCES 0
 #endif
@@ -170,6 +179,12 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
     const int hs_a = lane <= 32 ? lane : 63 * F64_HSYM_ROW + (64 - lane), hs_s0 = lane <= 32 ? F64_HSYM_ROW : -F64_HSYM_ROW;
     const cf hs_sgn = cf{1.f, lane <= 32 ? 1.f : -1.f};
     __syncthreads();
+    // LRHIP_F64_STAGGER (round 6): all waves of the launch start their first block at the same moment and then stay in step - everybody loads, everybody
+    // transforms, everybody stores - so that the memory system and the vector ALUs take TURNS instead of working at the same time (measured: the block's
+    // traffic alone takes 0.22 ms, its arithmetic ~0.13 ms, the kernel 0.345 ms = the SUM).  Wave w of a workgroup therefore starts w x STAGGER x 8 128 clocks late
+    // (a block is ~60 000 clocks at eight waves per CU): an eighth of the chip's waves in every phase of the block at any time.
+    if (LRHIP_F64_STAGGER > 0)
+        for (int i = 0; i < wave * LRHIP_F64_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
     const cf *tb = reinterpret_cast<const cf *>(tables);
     const cf D1 = tb[F64_TAB_D + 64 + lane], D2 = tb[F64_TAB_D + 128 + lane], D3 = tb[F64_TAB_D + 192 + lane];      // W_4096^(lane d)
 
@@ -278,6 +293,9 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
                 }
 #pragma unroll
                 for (int i = 32; i < 64; i++) v[i] = (src + 64 * i)[(unsigned)lane];
+            } else if constexpr (LRHIP_F64_NOMEM != 0) {
+#pragma unroll
+                for (int i = 0; i < 64; i++) v[i] = cf{(float)(lane + i) * 1e-3f, (float)(fb & 7)};      // (ablation: no loads)
             } else {
 #pragma unroll
                 for (int i = 0; i < 64; i++) v[i] = (src + 64 * i)[(unsigned)lane];
@@ -302,6 +320,7 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
         // ---- forward: DFT over i, twiddle, transpose, DFT over t
         // (F64_FENCE = scheduling fence between phases: left alone, the scheduler pulls the next phase's 64 loads up to cover their latency and the wave
         // holds 128 + 128 values at the seams; with two waves per SIMD the other wave covers the latency and the registers are worth more)
+        if constexpr (!LRHIP_F64_NOARITH) {              // (ablation build of tools/ab_fft64.hip: the block's loads and stores with nothing in between)
         F64_FENCE();
         F64_STAMP(1);
         dft64<1>(v);
@@ -390,6 +409,7 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
         twiddle(v, std::true_type{});
         F64_STAMP(9);
         dft64<-1>(v);
+        }
         F64_STAMP(10);
         // ---- rows at or behind the overlap are this block's outputs
         if constexpr (S == 1) {
@@ -452,6 +472,10 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
 #pragma unroll
             for (int i = V / 64; i < 64; i++)
                 if (ob + 64 * i + lane < n_out) (dst + 64 * i)[(unsigned)lane] += v[i];
+        } else if (LRHIP_F64_NOMEM != 0 && ob + F4K_N <= n_out) {
+#pragma unroll
+            for (int i = V / 64; i < 64; i++)
+                if (v[i].x == 12345.678f) __builtin_nontemporal_store(v[i], (dst + 64 * i) + (unsigned)lane);      // (ablation: no stores, the arithmetic stays alive)
         } else if (ob + F4K_N <= n_out) {
 #pragma unroll
             for (int i = V / 64; i < 64; i++) __builtin_nontemporal_store(v[i], (dst + 64 * i) + (unsigned)lane);
