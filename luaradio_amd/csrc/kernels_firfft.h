@@ -344,6 +344,22 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
         }
     };
     prefetch(ffirst);
+    // LRHIP_FFT_PREFETCH == 3 (round 6, A/B): the next block's sixteen loads go out FOUR AT A TIME between the phases of this block instead of as one burst - a
+    // burst of sixteen wave-wide loads stalls in issue against the memory system's back-pressure (31 % of a block's clocks in the phase trace) and the wave, in
+    // order, issues nothing else meanwhile.  Measured 1.8 % SLOWER than no prefetch (0.826 against 0.812 ms, three alternations, profiles/r06_ab_fft_prefetch3.txt)
+    [[maybe_unused]] const cf *pf_src = nullptr;
+    [[maybe_unused]] auto prefetch_begin = [&](long b) {
+        const long lo = b * L - V;
+        have = S == 2 && b < nblocks && lo >= 0 && lo + FFTN <= n;
+        pf_src = reinterpret_cast<const cf *>(x) + (have ? lo : 0);
+    };
+    [[maybe_unused]] auto prefetch_part = [&](int q) {
+        if (have) {
+#pragma unroll
+            for (int i = 4 * q; i < 4 * q + 4; i++) pre[i] = (pf_src + 64 * i)[(unsigned)lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
 #endif
     // NB blocks per iteration (LRHIP_FFT_NB): block b of an iteration is transform fbase + b * fstep
     auto load_block = [&](long fb, cf (&v)[16], [[maybe_unused]] int b) {
@@ -542,6 +558,9 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #if LRHIP_FFT_PREFETCH == 1
             if (S == 2 && b == 0) prefetch(fbase + FFT_NB * fstep);
 #endif
+#if LRHIP_FFT_PREFETCH == 3
+            if (S == 2 && b == 0) { prefetch_begin(fbase + FFT_NB * fstep < fend ? fbase + FFT_NB * fstep : nblocks); prefetch_part(0); }
+#endif
 #pragma unroll
             for (int k = 1; k < 16; k++) v[b][k] = cmul(v[b][k], FFT_TW1(k));
         }
@@ -555,6 +574,9 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             exchange(ex0 + b * FFT_EX_ELEMS, v[b], [&](int k) { return k * FFT_E1_ROW + lane; }, [&](int i) { return k1s * FFT_E1_ROW + 4 * i + sub; });
 #endif
         FFT_STAMP(3);
+#if LRHIP_FFT_PREFETCH == 3
+        if (S == 2) prefetch_part(1);
+#endif
         // ---- forward stage 2: radix-16 over t1, twiddle W_64^(t2*k2)
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) {
@@ -577,6 +599,9 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
                      [&](int r) { return k1s * FFT_E2_ROW + 17 * (r & 3) + (r & 12) + sub; });       // r = 4j + t2
 #endif
         FFT_STAMP(4);
+#if LRHIP_FFT_PREFETCH == 3
+        if (S == 2) prefetch_part(2);
+#endif
         // ---- forward stage 3: radix-4 over t2 -> k3; multiply by H; inverse stage 3: radix-4 over k3 -> t2
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) {
@@ -610,6 +635,9 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
                      [&](int k) { return k1s * FFT_E2_ROW + 17 * sub + k; });
 #endif
         FFT_STAMP(5);
+#if LRHIP_FFT_PREFETCH == 3
+        if (S == 2) prefetch_part(3);
+#endif
         // ---- inverse stage 2: radix-16 over k2 -> t1
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++) dft16<-1>(v[b]);
