@@ -544,12 +544,21 @@ struct FirStage : lrhip_stage {
                 return launch_fft64_long<2>(x, n, y, n_out);
             }
         }
-        // one wave per 4096-point block (fir_fft64_kernel, one 512- / 256-thread workgroup per CU) once the launch has at least eight blocks per CU; smaller
+        // one wave per 4096-point block (fir_fft64_kernel, one 512- / 256-thread workgroup per CU) once the launch has enough blocks per CU (below); smaller
         // launches keep the workgroup-per-block form, which spreads over more CUs.  LRHIP_F4K_WAVE=1 / 0 forces one or the other (A/B)
         static const int wave_knob = getenv("LRHIP_F4K_WAVE") ? atoi(getenv("LRHIP_F4K_WAVE")) : -1;
         const long nblocks4k = fft4k_V ? (n_out + (F4K_N - fft4k_V) - 1) / (F4K_N - fft4k_V) : 0;
-        const bool wave4k = wave_knob >= 0 ? wave_knob != 0 : nblocks4k >= 8L * (3 - S) * ctx().num_cus;
-        // (a Float32 stream has no workgroup-per-block kernel: its small launches stay partitioned)
+        // Float32 streams (round 6, size sweep 2^18 .. 2^26 on one box, profiles/r06_f32_long_filter_sizes.txt): the wave-per-block kernel beats the partitioned
+        // one at EVERY size (1 276 taps: 0.034-0.051 against 0.064-0.071 ms up to 2^23 samples - the partitioned kernel has a 40-65 us floor) except where the
+        // launch is a little more than one round of the chip's 8 x CUs waves and the filter short (768 taps at 2^24: 2 521 transforms = 1.23 rounds, 0.070 against
+        // 0.052 ms): only that window keeps the partitioned kernel
+        const long transforms = (nblocks4k + 1) / 2, one_round = 8L * ctx().num_cus;
+        const bool f32_window = fft4k_V == 768 && transforms > one_round && 20 * transforms <= 27 * one_round;
+        // ComplexFloat32 streams: the workgroup-per-block kernel up to 20 blocks per CU (real taps; 32 with complex taps, whose wave-per-block form runs four waves per
+        // CU) - re-measured in round 6 on the same sweep: at 2^23 samples (2 521-2 979 blocks, the old bound of 8 per CU already on the wave kernel) it is 15-40 %
+        // faster (1 276 taps 0.057 against 0.067 ms, 768 taps 0.048 / 0.068, complex taps 0.057 / 0.081), at 2^24 the two cross (0.108 / 0.097, 0.091 / 0.095, 0.108 / 0.119)
+        const bool wave4k = wave_knob >= 0 ? wave_knob != 0 : S == 1 ? !f32_window : nblocks4k >= (taps_complex ? 32L : 20L) * ctx().num_cus;
+        // (a Float32 stream has no workgroup-per-block kernel: where the wave-per-block kernel is not taken it stays partitioned)
         const bool f32_part = S == 1 && (!f32_knob || !wave4k);
         if (M > FFT_PART && !pre_disc && !post_disc && pols_knob != 0 && (pols_knob == 1 || !fft4k_V || no_4k || f32_part))
             return S == 2 ? launch_pols<2>(x, n, y, n_out) : launch_pols<1>(x, n, y, n_out);

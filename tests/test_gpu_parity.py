@@ -307,7 +307,7 @@ def test_partitioned_form_equals_the_4096_point_kernels_filter():
                                              (1282, False), (2049, False), (2000, True), (2050, False), (3000, False), (4096, False), (4097, False), (4096, True),
                                              (4098, False), (6145, False), (6146, True), (8192, False)])
 def test_one_wave_per_4096_point_block_kernel_on_a_large_launch(ntaps, cplx_taps):
-    """513 .. 1 281 taps on a ComplexFloat32 stream, launches of at least eight 4096-point blocks per CU: fir_fft64_kernel (kernels_firfft64.h, round 4) -
+    """513 .. 1 281 taps on a ComplexFloat32 stream, large launches (20 4096-point blocks per CU and more): fir_fft64_kernel (kernels_firfft64.h, round 4) -
     4096 = 64 x 64 with both 64-point transforms in registers and one transpose per direction; eight waves per CU on the conjugate-symmetric H of real
     taps, four on the full H of complex taps.  Round 5: 1 282 .. 2 049 taps at an overlap of 2 048 and 2 050 .. 4 097 taps as TWO partitions in one launch
     (a wave walks a run of consecutive blocks with the previous block's spectrum in registers; the chunk cuts below land inside runs, and every chunk starts
@@ -315,7 +315,8 @@ def test_one_wave_per_4096_point_block_kernel_on_a_large_launch(ntaps, cplx_taps
     samples and adding to the first's output.  2^23 samples against the f64 oracle on slabs (first, two interior, last), then the same stream in ragged
     chunks that straddle the small-launch kernel (workgroup per block) and this one."""
     rng = np.random.default_rng(900 + ntaps + cplx_taps)
-    n = 1 << 23
+    # (round 6: the wave-per-block kernel takes 513 .. 1 281 taps from 20 blocks per CU - 32 with complex taps - instead of 8: 2^25 samples are 10 000-12 000 blocks)
+    n = 1 << (25 if ntaps <= 1281 else 23)
     x = rand_c(rng, n)
     taps = rand_c(rng, ntaps) if cplx_taps else rand_r(rng, ntaps)
     taps = (taps / np.sum(np.abs(taps))).astype(taps.dtype)
@@ -332,7 +333,7 @@ def test_one_wave_per_4096_point_block_kernel_on_a_large_launch(ntaps, cplx_taps
     for a, b in slabs:
         assert slab_err(got, a, b) < 1e-6, (a, b)
     blk.reset()
-    got2 = chunked(blk, x, [1, 4097, 7000000, 7000001, 7500000])
+    got2 = chunked(blk, x, [1, 4097, 7000000, 7000001, 7500000])          # (the 7 M-sample chunk is a small launch: the workgroup-per-block kernel)
     for a, b in slabs:
         assert slab_err(got2, a, b) < 1e-6, (a, b)
     assert G.max_abs_err(got, got2) < 1e-6
@@ -362,8 +363,8 @@ def test_one_wave_per_4096_point_block_kernel_on_a_float32_stream(ntaps):
     slabs = [(0, 9000), (2816 * 700 - 100, 2816 * 700 + 6000), (n // 4 - 3000, n // 4 + 6000), (n // 2 + 12345, n // 2 + 18345), (n - 9000, n)]
     for a, b in slabs:
         assert slab_err(got, a, b) < 1e-6, (a, b)
-    # every sample against a second block fed 2^20-sample chunks: up to 1 281 taps those take the partitioned 1024-point kernel (an independent
-    # arithmetic); above, the same kernel with other run boundaries and a history carry every chunk
+    # every sample against a second block fed 2^20-sample chunks: the same kernel with other block / run boundaries and a history carry every chunk (the
+    # independent arithmetic is the f64 oracle on the slabs above, and LRHIP_F64_F32=0 - the partitioned kernel - passes the same tests)
     small = make(lr.FIRFilterBlock, [taps, "fast"], x)
     step = 1 << 20
     ref = np.concatenate([small.process(x[a:a + step]) for a in range(0, n, step)])
