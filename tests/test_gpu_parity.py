@@ -376,6 +376,42 @@ def test_one_wave_per_4096_point_block_kernel_on_a_float32_stream(ntaps):
     assert G.max_abs_err(got, got2) < 1e-6
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LRHIP_FUZZ_SEEDS", "10"))))          # (a one-off sweep of 120 draws in round 6 found nothing)
+def test_long_filters_random_shapes_against_the_f64_oracle(seed):
+    """Round 6: the long-filter paths now branch on stream type, tap count AND launch size (wave-per-block 64 x 64 kernel with one or two partitions in one or two
+    launches, Float32 planes, the workgroup-per-block kernel below 20 / 32 blocks per CU, the partitioned kernel in one Float32 window).  Seeded draws of
+    (stream type, taps 513 .. 8 192, length, ragged chunk cuts) - lengths that leave an odd number of stream blocks, a last transform whose second plane lies past the
+    chunk, chunks shorter than the filter, runs that start inside the carried history - each against the f64 oracle on slabs at the start, at every chunk seam and
+    at the end."""
+    rng = np.random.default_rng(4200 + seed)
+    cplx = bool(rng.integers(0, 2))
+    cplx_taps = cplx and bool(rng.integers(0, 4) == 0)
+    ntaps = int(rng.choice([int(rng.integers(513, 1282)), int(rng.integers(1282, 2050)), int(rng.integers(2050, 4098)), int(rng.integers(4098, 8193))]))
+    n = int(rng.integers(200000, 6000000)) if seed % 3 else int(rng.integers(3000, 40000))
+    x = rand_c(rng, n) if cplx else rand_r(rng, n)
+    taps = rand_c(rng, ntaps) if cplx_taps else rand_r(rng, ntaps)
+    taps = (taps / np.sum(np.abs(taps))).astype(taps.dtype)
+    ncuts = int(rng.integers(0, 4))
+    cuts = sorted(int(c) for c in rng.integers(1, n, ncuts))
+    blk = make(lr.FIRFilterBlock, [taps, "fast"], x)
+    got = chunked(blk, x, cuts)
+    assert len(got) == n
+
+    def slab_err(a, b):
+        a, b = max(a, 0), min(b, n)
+        lo = max(0, a - (ntaps - 1))
+        want = O.FIR(taps, cplx, O.MODE_F64).process(x[lo:b])[a - lo:]
+        return G.max_abs_err(got[a:b], want)
+
+    w = 1500
+    spots = [0, n - w, n // 2] + [c - w // 2 for c in cuts]
+    for a in spots:
+        assert slab_err(a, a + w) < 1e-6, (cplx, cplx_taps, ntaps, n, cuts, a)
+    # ... and the same stream in one call: overlap-save arithmetic, so to rounding, not to the bit
+    blk.reset()
+    assert G.max_abs_err(blk.process(x), got) < 1e-6, (cplx, cplx_taps, ntaps, n, cuts)
+
+
 def test_fir_auto_mode_picks_the_faster_arithmetic():
     rng = np.random.default_rng(8)
     x = rand_c(rng, 30000)
