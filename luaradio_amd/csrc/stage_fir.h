@@ -1039,7 +1039,7 @@ struct FirStage : lrhip_stage {
         if (pre_disc || fix_src) return false;
         if (use_fft) return false;            // the reference's block-emission framing: run() copies x into `pending` / `work` first (a second pass, device-to-device)
         if (decfft) return true;
-        if (fft_arith) return M <= FFT_PART || (S == 2 && (fft4k_V || fft64_np));
+        if (fft_arith) return M <= FFT_PART || (S == 2 && (fft4k_V || (fft64_np && fft64_np <= 2)));      // (4 098 taps and more: the second launch re-reads y)
         if (win_real_ok() || win_cplx_ok() || short_real_ok()) return false;
         return ksteps != 0 || (D > 1 && decim_lds_ok());
     }

@@ -475,6 +475,18 @@ def test_registered_vectors_are_read_and_written_in_place():
         assert ref.process_device(xd.data_ptr(), m, yd.data_ptr(), m) == got
         torch.cuda.synchronize()
         assert np.array_equal(y[:got].view(np.float32), yd.cpu().numpy()[:2 * got])
+        # round 6: 4 098 taps and more run as TWO launches, the second adding to y - not a write-once form: registered vectors take the staged path (one piece
+        # at this size: the same launches as the device-resident run, hence its bits)
+        rngt = np.random.default_rng(5)
+        long_taps = rngt.uniform(-1, 1, 5000).astype(np.float32)
+        long_taps /= np.sum(np.abs(long_taps))
+        blk, ref, m = make(lr.FIRFilterBlock, [long_taps, "fast"], types.ComplexFloat32, FS), make(lr.FIRFilterBlock, [long_taps, "fast"], types.ComplexFloat32, FS), 300001
+        got = L.lrhip_stage_execute(blk.stage_handle(), x.ctypes.data_as(C.c_void_p), m, y.ctypes.data_as(C.c_void_p), m)
+        assert got == m, _lib.last_error()
+        yd = torch.empty(2 * m, device="cuda")
+        assert ref.process_device(xd.data_ptr(), m, yd.data_ptr(), m) == m
+        torch.cuda.synchronize()
+        assert np.array_equal(y[:m].view(np.float32), yd.cpu().numpy())
         # an in-place call (output vector == input vector, or overlapping slices of one registered buffer) takes the staged path, where it is
         # safe - in direct mode tiles of the persistent grid would store over samples other tiles have not loaded yet
         for shift in (0, 100, -100):
