@@ -358,10 +358,13 @@ function DeviceChainBlock:start_at(first_sample)
         self.position_sample = position(self)
         return self.position_sample
     end
-    return (lrhip.in_helper(function ()
+    -- one helper process answers all three questions (a helper binds to the device and builds the chain: seconds, not microseconds)
+    local seek, h, a = lrhip.in_helper(function ()
         create_chain(self)
-        return self.position_sample
-    end))
+        return self.position_sample, tonumber(lrhip.lib.lrhip_chain_halo(self.chain)), tonumber(lrhip.lib.lrhip_chain_shard_align(self.chain))
+    end)
+    if self.chain == nil then self.partition_halo, self.partition_align = h, a end
+    return seek
 end
 
 -- The partition helpers next to start_at(): how many input samples a partition replays in front of its first own sample (-1 with an error message for
@@ -369,27 +372,44 @@ end
 --
 -- WHERE these run (ADVICE r05): a partitioned flow graph asks them in its PARENT, before top:run() forks the block processes - and a parent that has
 -- created device objects leaves its children a device they cannot use (lrhip.in_helper).  So while this block has no chain of its own yet the answer
--- comes from a fork()ed helper process, the request (start_at / seek) is recorded in the object, and create_chain() applies it to the chain the block's
--- own process builds on its first process().  Once the chain exists (the block's process, or top:run(false)) the calls go to it directly.
-function DeviceChainBlock:halo()
-    local function ask()
-        local h = tonumber(lrhip.lib.lrhip_chain_halo(self.chain))
-        if h < 0 then error("lrhip_chain_halo: " .. ffi.string(lrhip.lib.lrhip_strerror())) end
-        return h
+-- comes from a fork()ed helper process (ONE helper answers halo and alignment together, and start_at() brings both along; the answers are kept), the request
+-- (start_at / seek) is recorded in the object, and create_chain() applies it to the chain the block's own process builds on its first process().  Once the
+-- chain exists (the block's process, or top:run(false)) the calls go to it directly.
+local function partition_info(self)
+    if self.chain ~= nil then
+        return tonumber(lrhip.lib.lrhip_chain_halo(self.chain)), tonumber(lrhip.lib.lrhip_chain_shard_align(self.chain))
     end
-    if self.chain ~= nil then return ask() end
-    return (lrhip.in_helper(function ()
-        create_chain(self)
-        return ask()
-    end))
+    if self.partition_halo == nil then
+        local h, a = lrhip.in_helper(function ()
+            create_chain(self)
+            return tonumber(lrhip.lib.lrhip_chain_halo(self.chain)), tonumber(lrhip.lib.lrhip_chain_shard_align(self.chain))
+        end)
+        if self.chain ~= nil then return h, a end           -- (in_helper ran in this process: it owns a device, the chain exists now)
+        self.partition_halo, self.partition_align = h, a
+    end
+    return self.partition_halo, self.partition_align
+end
+
+function DeviceChainBlock:halo()
+    local h = partition_info(self)
+    if h < 0 then
+        -- chains with unbounded memory (AGC, FM modulator ...): the library's message - from this process's chain, or from one more helper that asks again
+        local function complain()
+            lrhip.lib.lrhip_chain_halo(self.chain)
+            error("lrhip_chain_halo: " .. ffi.string(lrhip.lib.lrhip_strerror()), 0)
+        end
+        if self.chain ~= nil then complain() end
+        lrhip.in_helper(function ()
+            create_chain(self)
+            complain()
+        end)
+    end
+    return h
 end
 
 function DeviceChainBlock:shard_align()
-    if self.chain ~= nil then return tonumber(lrhip.lib.lrhip_chain_shard_align(self.chain)) end
-    return (lrhip.in_helper(function ()
-        create_chain(self)
-        return tonumber(lrhip.lib.lrhip_chain_shard_align(self.chain))
-    end))
+    local _, a = partition_info(self)
+    return a
 end
 
 -- seek(n0): forget every carried sample, the next vector is sample n0 of the stream (no replay: the caller feeds the halo itself and drops its output).

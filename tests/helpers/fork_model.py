@@ -173,7 +173,7 @@ def lua_partition_parent(L):
     halo = ml.call(ml.index(chain, "halo"), [chain])[0]
     align = ml.call(ml.index(chain, "shard_align"), [chain])[0]
     seek = ml.call(ml.index(chain, "start_at"), [chain, float(PARTITION_FIRST)])[0]
-    parent_device = L.lrhip_device()                # -1: three helpers have come and gone, this process still has no device context
+    parent_device = L.lrhip_device()                # -1: the helpers have come and gone (one for halo + alignment, one for start_at), this process still has no device context
 
     def child(wfd):
         x = stream()[int(seek):]
