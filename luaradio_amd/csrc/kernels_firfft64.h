@@ -179,10 +179,9 @@ __global__ __launch_bounds__(64 * F64_WAVES, 1) void fir_fft64_kernel(const floa
     const int hs_a = lane <= 32 ? lane : 63 * F64_HSYM_ROW + (64 - lane), hs_s0 = lane <= 32 ? F64_HSYM_ROW : -F64_HSYM_ROW;
     const cf hs_sgn = cf{1.f, lane <= 32 ? 1.f : -1.f};
     __syncthreads();
-    // LRHIP_F64_STAGGER (round 6): all waves of the launch start their first block at the same moment and then stay in step - everybody loads, everybody
-    // transforms, everybody stores - so that the memory system and the vector ALUs take TURNS instead of working at the same time (measured: the block's
-    // traffic alone takes 0.22 ms, its arithmetic ~0.13 ms, the kernel 0.345 ms = the SUM).  Wave w of a workgroup therefore starts w x STAGGER x 8 128 clocks late
-    // (a block is ~60 000 clocks at eight waves per CU): an eighth of the chip's waves in every phase of the block at any time.
+    // LRHIP_F64_STAGGER (round 6, A/B of the stand-alone driver; 0 in the library): are the launch's waves in lock step - everybody loads, everybody transforms,
+    // everybody stores, so that the memory system and the vector ALUs take turns?  Wave w of a workgroup starts w x STAGGER x 8 128 clocks late (a block is ~60 000
+    // clocks at eight waves per CU).  Measured: NO effect at 1, slower at 2 and 4 (profiles/r06_fft64_ablation.txt) - the waves are out of phase by themselves.
     if (LRHIP_F64_STAGGER > 0)
         for (int i = 0; i < wave * LRHIP_F64_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
     const cf *tb = reinterpret_cast<const cf *>(tables);

@@ -569,7 +569,7 @@ struct FirStage : lrhip_stage {
                 default: return launch_fft64_v<1280>(x, n, y, n_out);
             }
         }
-        if (fft4k_V && !no_4k && !pre_disc && !post_disc) {
+        if (fft4k_V && !no_4k && !pre_disc && !post_disc && S == 2) {      // (ComplexFloat32 only; a Float32 stream that gets here - LRHIP_FFT_POLS=0 - takes the per-partition passes below)
             switch (fft4k_V) {
                 case 768: return launch_fft4k<768>(x, n, y, n_out);
                 case 1024: return launch_fft4k<1024>(x, n, y, n_out);
