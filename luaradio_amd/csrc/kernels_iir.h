@@ -264,8 +264,14 @@ __global__ __launch_bounds__(256) void iir_scan_kernel(const float *__restrict__
 // there with the true carried state instead.  One launch, (1 + warm/run) reads + 1 write of the stream, no inter-
 // workgroup dependency.  Same per-sample arithmetic as the three-pass form.
 // ------------------------------------------------------------------------------------------------------------
+// LRHIP_IIR_CF_WGS (round 6, A/B): resident workgroups per CU the ComplexFloat32 instantiations are compiled for (0 = no bound: 159 registers, three per CU).
+// Measured on one box, three alternations, 2^26 samples: 4 (128 registers, 72 bytes of scratch per lane) is SLOWER - 5 ff / 3 fb 0.230 -> 0.299 ms, biquad 0.220 ->
+// 0.273; 1 (no register pressure from the bound at all) is equal.  The ComplexFloat32 recurrence holds 16 complex samples per thread; it stays at three per CU.
+#ifndef LRHIP_IIR_CF_WGS
+#define LRHIP_IIR_CF_WGS 0
+#endif
 template <int S, int P, int NBT>
-__global__ __launch_bounds__(256) void iir_stream_kernel(const float *__restrict__ x, float *__restrict__ y, long n,
+__global__ __launch_bounds__(256, (S == 2 && LRHIP_IIR_CF_WGS > 0) ? LRHIP_IIR_CF_WGS : 1) void iir_stream_kernel(const float *__restrict__ x, float *__restrict__ y, long n,
                                                          const float *__restrict__ xhist, const float *__restrict__ state_in,
                                                          float *__restrict__ state_out, long dec, long dfirst, int run, int warm, int warm_chunks, IirCoeffs co,
                                                          float *__restrict__ xhist_out, const typename IirScanT<P>::T *__restrict__ tpow, int no_coal)
