@@ -376,7 +376,14 @@ def channelizer_report(lr, L, torch, dev, with_cpu):
     cap = ch.max_output(n)
     y = torch.empty(2 * cap + 64, dtype=torch.float32, device=dev)
     ch.process_device(x.data_ptr(), n, y.data_ptr(), cap)
-    steps = 5
+    # clock ramp, as for the headline (the legs in front of this one end with seconds of host-side verification: the first launches of an idle GPU run at
+    # reduced clocks - 1.30 ms here against a traced 1.21 ms for the same kernel in the profiles of rounds 5 and 6)
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.15:
+        for _ in range(4):
+            ch.process_device(x.data_ptr(), n, y.data_ptr(), cap)
+        torch.cuda.synchronize()
+    steps = 10
     tm = L.lrhip_timer_create()
     L.lrhip_timer_start(tm)
     for _ in range(steps):
