@@ -69,6 +69,10 @@
 // blocks per wave and iteration (round 3 A/B): 2 = two independent 1024-point pipelines interleaved stage by stage in one wave, each with its own
 // exchange buffer, so that the LDS exchanges and global loads of one block can overlap the butterflies of the other ("dependent phases" hypothesis); needs
 // LRHIP_FFT_WPB = 8 (one 512-thread workgroup = 8 waves per CU: 8 x 2 x 8.7 KB of exchange buffers + 17 KB of tables)
+#ifndef LRHIP_FFT_SETPRIO
+#define LRHIP_FFT_SETPRIO 0      /* A/B (round 6): 1..3 = s_setprio around a block's loads and around its stores (+4: the priority stays up from the stores through the next loads).
+                                    Measured EQUAL: 0.8495 / 0.8522 / 0.8528 ms (off) against 0.8514 / 0.8543 / 0.8498 (2) and 0.8463 / 0.8507 / 0.8483 (6), one box */
+#endif
 #ifndef LRHIP_FFT_NB
 #define LRHIP_FFT_NB 1
 #endif
@@ -544,7 +548,15 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
             if (live[b] && early && b == 0 && fbase == ffirst) {
 #pragma unroll
                 for (int i = 0; i < 16; i++) v[b][i] = v_first[i];
-            } else if (live[b]) load_block(fb, v[b], b);
+            } else if (live[b]) {
+#if LRHIP_FFT_SETPRIO
+                __builtin_amdgcn_s_setprio(LRHIP_FFT_SETPRIO & 3);        // (A/B, round 6) a wave in its memory phase issues ahead of the waves that are computing
+#endif
+                load_block(fb, v[b], b);
+#if LRHIP_FFT_SETPRIO
+                if (!(LRHIP_FFT_SETPRIO & 4)) __builtin_amdgcn_s_setprio(0);
+#endif
+            }
             else {
 #pragma unroll
                 for (int i = 0; i < 16; i++) v[b][i] = cf{0.f, 0.f};
@@ -666,7 +678,15 @@ __global__ __launch_bounds__(64 * FFT_WPB, FFT_WAVES_PER_SIMD) void fir_fft_kern
 #endif
 #pragma unroll
         for (int b = 0; b < FFT_NB; b++)
-            if (live[b]) store_block(fbase + b * fstep, v[b]);
+            if (live[b]) {
+#if LRHIP_FFT_SETPRIO
+                __builtin_amdgcn_s_setprio(LRHIP_FFT_SETPRIO & 3);
+#endif
+                store_block(fbase + b * fstep, v[b]);
+#if LRHIP_FFT_SETPRIO
+                if (!(LRHIP_FFT_SETPRIO & 4)) __builtin_amdgcn_s_setprio(0);
+#endif
+            }
         FFT_STAMP(9);
 #ifdef LRHIP_FFT_TRACE
         trace_it++;
