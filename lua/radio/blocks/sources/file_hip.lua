@@ -47,10 +47,35 @@ local function patch_source(Source, complex_out)
         return ffi.sizeof((complex_out == 1) and self.format.complex_ctype or self.format.real_ctype)
     end
 
+    -- A TIME PARTITION of the recording (INTEGRATION.md 3a, DeviceChainBlock:partition): deliver records [first, first + count) only (count nil: to the end
+    -- of the file).  Runs in the flow graph's parent, after initialize() has opened the file; the position travels with the FILE * into the chain's process.
+    function Source:set_raw_window(first, count)
+        if ffi.C.fseek(self.file, first * self:raw_record_size(), ffi.C.SEEK_SET) ~= 0 then
+            error("fseek(): " .. ffi.string(ffi.C.strerror(ffi.errno())))
+        end
+        self.raw_fd, self.raw_offset = nil, nil          -- submit_raw() takes its offset from the stream again
+        self.raw_left = count
+    end
+
+    -- the records a window still allows (max_records itself without one); nil = the window is used up: end of the partition
+    local function window(self, max_records)
+        if self.raw_left == nil then return max_records end
+        if self.raw_left <= 0 then return nil end
+        return math.min(max_records, self.raw_left)
+    end
+
     -- up to `max_records` raw records into `dst`; returns the number read (0 right after a rewind, as the reference returns an empty vector from
     -- that call, iqfile.lua:86-90), or nil at the end of the file
     function Source:read_raw(dst, max_records)
+        max_records = window(self, max_records)
+        if max_records == nil then return nil end
         local num_samples = tonumber(ffi.C.fread(dst, self:raw_record_size(), max_records, self.file))
+        if self.raw_left ~= nil then
+            self.raw_left = self.raw_left - num_samples
+            if num_samples < max_records then self.raw_left = 0 end           -- a window that reaches past the end of the file ends with the file (no repeat)
+            if num_samples == 0 then return nil end
+            return num_samples
+        end
         if num_samples < max_records then
             if num_samples == 0 and ffi.C.feof(self.file) ~= 0 then
                 if self.repeat_on_eof then
@@ -81,9 +106,17 @@ local function patch_source(Source, complex_out)
             if self.raw_offset < 0 then self.raw_offset = tonumber(ffi.C.lseek(self.raw_fd, 0, 1)) end          -- SEEK_CUR
             if self.raw_offset < 0 then return false end
         end
+        max_records = window(self, max_records)
+        if max_records == nil then return nil end
         local n = tonumber(lrhip.lib.lrhip_chain_submit_fd(chain, self.raw_fd, self.raw_offset, max_records))
         if n == -4 then return false end
         if n < 0 then error("lrhip_chain_submit_fd: " .. ffi.string(lrhip.lib.lrhip_strerror())) end
+        if self.raw_left ~= nil then
+            if n == 0 then self.raw_left = 0; return nil end                 -- (no repeat inside a window)
+            self.raw_left = self.raw_left - n
+            self.raw_offset = self.raw_offset + n * self:raw_record_size()
+            return n
+        end
         if n == 0 then
             if not self.repeat_on_eof then return nil end
             self.raw_offset = 0

@@ -69,6 +69,11 @@ DeviceChainBlock.device = nil
 -- Set on the class before top:run(), or per chain on the object collapse() returns.
 DeviceChainBlock.exact = false
 
+-- on_initialized(chain): called at the end of every chain's initialize() - in the flow graph's PARENT, after the members' own initialize() (files are open)
+-- and before fork().  The one place a script can reach the chains collapse() built before they run: it positions a time partition there
+-- (chain:partition(first, last), examples/iqfile_wbfm_partitions.lua), sets chain.exact / chain.device / chain.max_latency per chain, ...
+DeviceChainBlock.on_initialized = nil
+
 -- a file source / sink with the raw-record hooks of radio/blocks/sources/file_hip.lua / radio/blocks/sinks/file_hip.lua
 local function is_raw_source(b)
     return type(b.read_raw) == "function" and type(b.create_stage) == "function" and #b.inputs == 0 and #b.outputs == 1
@@ -105,6 +110,8 @@ function DeviceChainBlock:initialize()
     for _, b in ipairs(self.blocks) do
         for file, _ in pairs(b.files or {}) do self.files[file] = true end
     end
+    local hook = self.on_initialized
+    if hook then hook(self) end
 end
 
 -- start_at() / seek() record what was asked; this applies it to self.chain and returns the sample the source has to deliver from
@@ -410,6 +417,17 @@ end
 function DeviceChainBlock:shard_align()
     local _, a = partition_info(self)
     return a
+end
+
+-- partition(first_sample, end_sample): this chain - headed by a file source it has absorbed - processes samples [first_sample, end_sample) of the recording
+-- and emits exactly what the uninterrupted run emits for them: start_at() arms the chain and says where the replay has to begin, the source's window is set
+-- to [that sample, end_sample).  Boundaries on multiples of shard_align() (and of the chain's total decimation) reproduce the uninterrupted run bit for bit
+-- where the chain promises that (include/lrhip.h).  Call it from DeviceChainBlock.on_initialized.  Returns the sample the replay starts at.
+function DeviceChainBlock:partition(first_sample, end_sample)
+    assert(self.source and self.source.set_raw_window, "partition(): the chain has to be headed by a file source (IQFileSource / RealFileSource)")
+    local seek = self:start_at(first_sample)
+    self.source:set_raw_window(seek, end_sample and (end_sample - seek) or nil)
+    return seek
 end
 
 -- seek(n0): forget every carried sample, the next vector is sample n0 of the stream (no replay: the caller feeds the halo itself and drops its output).

@@ -604,7 +604,8 @@ def make_ffi(interp, lib_proxy, sockets=None):
 
     Cns.set("lseek", lambda fd, off, whence: float(os.lseek(int(fd), int(ml.tonum(off)), int(ml.tonum(whence)))))
     for name, f in (("fopen", c_fopen), ("fread", c_fread), ("fwrite", c_fwrite), ("feof", lambda f: 1.0 if f.eof else 0.0), ("ferror", lambda f: 0.0),
-                    ("rewind", c_rewind), ("fclose", c_fclose), ("fileno", lambda f: float(f.fh.fileno())), ("ftell", lambda f: float(f.fh.tell()))):
+                    ("rewind", c_rewind), ("fclose", c_fclose), ("fileno", lambda f: float(f.fh.fileno())), ("ftell", lambda f: float(f.fh.tell())),
+                    ("fseek", lambda f, off, whence: (f.fh.seek(int(ml.tonum(off)), int(ml.tonum(whence))), setattr(f, "eof", False), 0.0)[2])):
         Cns.set(name, f)
 
     for name, f in (("getpid", lambda: float(os.getpid())), ("socketpair", c_socketpair), ("read", c_read), ("write", c_write), ("close", c_close),
@@ -639,6 +640,8 @@ def make_ffi(interp, lib_proxy, sockets=None):
 
     for name, f in (("pipe", c_pipe), ("fork", c_fork), ("waitpid", c_waitpid), ("_exit", c__exit)):
         Cns.set(name, f)
+    for name, v in (("SEEK_SET", 0.0), ("SEEK_CUR", 1.0), ("SEEK_END", 2.0)):
+        Cns.set(name, v)
     Cns.set("AF_UNIX", 1.0)
     Cns.set("SOCK_STREAM", 1.0)
 

@@ -186,6 +186,66 @@ def test_a_stream_that_was_read_from_before_starts_at_the_stream_position_and_re
     assert offs[3:5] == [0, 2 * 65536]                               # ... and the repeat starts over at byte 0 (iqfile.lua:86-90: rewind())
 
 
+PARTITIONED = r"""
+local R = require('reference_standins')
+local types = require('radio.types')
+local DeviceChainBlock = require('radio.composites.devicechain')
+local path, rf_taps, af_taps, b_taps, a_taps, sink_path, first, last, direct = ...
+local g = R.graph()
+local src = R.IQFileSource(path, 'u8', 1102500)
+local use_fft = nil
+if direct then use_fft = false end          -- FIRFilterBlock(taps, false): the direct form, the bit-exact arithmetic (firfilter.lua:43-74)
+local blocks = {src, R.FrequencyTranslatorBlock(-250e3), R.FIRFilterBlock(rf_taps, use_fft), R.DownsamplerBlock(5), R.FrequencyDiscriminatorBlock(1.25),
+                R.FIRFilterBlock(af_taps, use_fft), R.IIRFilterBlock(b_taps, a_taps), R.DownsamplerBlock(5), R.RealFileSink(sink_path, 'f32le')}
+src:differentiate({})
+local t = types.ComplexFloat32
+for i = 2, #blocks do
+    blocks[i]:differentiate({t})
+    if i < #blocks then t = blocks[i]:get_output_type() end
+end
+g.connect(unpack(blocks))
+-- what examples/iqfile_wbfm_partitions.lua does: the hook runs in the parent, after the source has opened its file, before the chain's process exists
+local seen = {}
+DeviceChainBlock.on_initialized = function (chain)
+    seen.align = chain:shard_align()
+    seen.seek = chain:partition(first, last)
+end
+local connections, device_blocks = R.prepare(g.connections, blocks)
+DeviceChainBlock.on_initialized = nil
+return device_blocks[1], seen, src
+"""
+
+
+def test_a_time_partition_is_positioned_in_the_parent_and_runs_its_window_only(tmp_path):
+    """examples/iqfile_wbfm_partitions.lua on the recording fake: DeviceChainBlock.on_initialized fires at the end of the chain's initialize() (parent, file
+    open); chain:partition(first, last) asks the helper process where the replay starts, arms the chain (recorded, applied by the chain's own process) and
+    sets the absorbed source's window - the library then reads records [seek, last) of the file and nothing else"""
+    n = 400000
+    path, out = tmp_path / "x.u8", tmp_path / "audio.f32"
+    path.write_bytes(wbfm_u8_capture(n))
+    I, proxy, ffi = interp()
+    b, a = deemphasis_taps(75e-6, 220500.0)
+    first, last = 128000, 256000
+    chain, seen, src = I.run(PARTITIONED, "partitioned", [str(path), fvec(lowpass_taps(128, 100e3, 1102500.0)), fvec(lowpass_taps(128, 15e3, 220500.0)), fvec(b), fvec(a),
+                                                          str(out), float(first), float(last)])
+    assert seen.get("align") == 1 and seen.get("seek") == first - 127                       # the fake's answers, through two helper processes
+    assert len(ffi.get("_state")["forked_pids"]) == 2 and proxy.fake.device == -1           # the parent still owns no device
+    assert ml.index(src, "raw_left") == last - (first - 127) and ml.index(src, "file").fh.tell() == 2 * (first - 127)
+    chain.set("batch_samples", 65536.0)
+    chain.set("source_batch_bytes", 0.0)
+    ml.call(ml.index(chain, "run"), [chain])
+    fd_calls = [a_ for n_, a_ in proxy.fake.calls if n_ == "lrhip_chain_submit_fd"]
+    assert fd_calls[0][2] == 2 * (first - 127)                                              # byte offset of the first read: the replay start
+    # every record of the window and none behind it: full batches, then the rest, each read where the one before ended
+    window = last - (first - 127)
+    assert [c_[3] for c_ in fd_calls] == [65536] * (window // 65536) + [window % 65536]
+    assert [c_[2] for c_ in fd_calls] == [2 * (first - 127 + 65536 * k) for k in range(len(fd_calls))]
+    got = [n_ for n_ in proxy.trace if n_ in ("lrhip_chain_start_at", "lrhip_chain_submit_fd")]
+    assert got[0] == "lrhip_chain_start_at"                                                 # armed by the chain's own process before the first batch
+    assert ml.index(src, "raw_left") == 0
+    assert [a_[1] for n_, a_ in proxy.fake.calls if n_ == "lrhip_chain_start_at"] == [first]
+
+
 def test_file_to_file_chain_has_no_ports_and_runs_its_own_loop(tmp_path):
     """source AND sink absorbed: a block without ports (the hook of tools/apply_lua_binding.py adds it to the evaluation order).  run() must not sit in
     PipeMux:_read_control forever; the raw records of the chain's output go through the sink's fwrite"""
@@ -911,6 +971,43 @@ def test_gpu_lua_file_to_file_chain_writes_the_bytes_of_the_python_blocks(tmp_pa
     got = out.read_bytes()
     assert len(got) == len(want) == 4 * ((n + 3) // 4)
     assert got == want
+
+
+@pytest.mark.gpu
+def test_gpu_lua_time_partitions_of_a_recording_add_up_to_the_single_run(tmp_path):
+    """examples/iqfile_wbfm_partitions.lua on the real library: ONE u8 recording cut into three partitions on the chain's own grid (shard_align, asked through
+    the glue), each an IQFileSource -> receiver -> RealFileSink chain built from Lua and positioned by DeviceChainBlock.on_initialized / chain:partition(); the
+    three audio files laid end to end are the single run's audio - same sample counts, values to 1e-6 (single-launch receiver) / 1e-7 (exact chain of
+    direct-form filters)"""
+    lr, L = real_lib()
+    n = 3 * 128000 + 54321
+    path = tmp_path / "x.u8"
+    path.write_bytes(wbfm_u8_capture(n))
+    b, a = deemphasis_taps(75e-6, 220500.0)
+    taps = [fvec(lowpass_taps(128, 100e3, 1102500.0)), fvec(lowpass_taps(128, 15e3, 220500.0)), fvec(b), fvec(a)]
+
+    def run(first, last, out, exact):
+        I, proxy, ffi = interp(real_lib=L)
+        chain, seen, src = I.run(PARTITIONED, "partitioned", [str(path)] + taps + [str(out), float(first), float(last), True if exact else None])
+        if exact:
+            chain.set("exact", True)
+        chain.set("batch_samples", 65536.0)
+        chain.set("source_batch_bytes", 0.0)
+        ml.call(ml.index(chain, "run"), [chain])
+        return seen, np.fromfile(out, np.float32)
+
+    for exact in (False, True):
+        seen, whole = run(0, n, tmp_path / "whole.f32", exact)
+        align = int(seen.get("align"))
+        assert 128000 % align == 0 and len(whole) == (n + 24) // 25
+        cut1, cut2 = 128000, 256000
+        parts = [run(a0, b0, tmp_path / ("p%d.f32" % k), exact)[1] for k, (a0, b0) in enumerate(((0, cut1), (cut1, cut2), (cut2, n)))]
+        assert [len(p) for p in parts] == [cut1 // 25, (cut2 - cut1) // 25, len(whole) - cut2 // 25]
+        got = np.concatenate(parts)
+        # not to the bit from here: the chain runs batch by batch and a partition's batches start at its replay start, not at sample 0 - the de-emphasis recurrence
+        # (a scan that rounds with its tile grid, which starts with the batch) and the single-launch receiver's runs see other cuts than the single run's.
+        # Measured 7e-9 (exact chain) and 1e-7; tests/test_timeshard.py holds the bit-identical case (whole partitions per call, on the grid)
+        assert float(np.max(np.abs(got - whole))) < (1e-7 if exact else 1e-6)
 
 
 @pytest.mark.gpu
