@@ -7,6 +7,9 @@
 -- script adds is WHERE each chain starts and stops: DeviceChainBlock.on_initialized runs in the parent - after the sources have opened the file, before the block
 -- processes are forked - and calls chain:partition(first, last).  That asks a short-lived helper process for the chain's replay start (the parent itself never
 -- touches the device: its forked children could not use it then), positions the absorbed source and arms the chain; nothing is exchanged between the partitions.
+-- (LuaJIT is not in the build image: this file itself is not executed by the test suite; the same calls - hook, shard_align(), partition(), the source's record
+-- window, a chain that reads its window and nothing else, three partitions adding up to the single run on the GPU - are, from the script embedded in
+-- tests/test_lua_blocks.py: PARTITIONED.)
 local radio = require('radio')
 local DeviceChainBlock = require('radio.composites.devicechain')
 
