@@ -64,8 +64,10 @@ const char *lrhip_version(void);
  * use_fft: 0 = direct form (bit-identical to the fmaf chain in the reference's tap order);
  *          1 = overlap-save as the reference runs it (:320-398): only whole L = N-M+1 blocks are emitted,
  *              N = 2^floor(log2(8M)), the tail is retained; arithmetic by the fused FFT kernel for 32 <= M <= 8192;
- *          2 = overlap-save arithmetic (fused 1024-point FFT kernel, 32 <= M <= 8192, partitions of 512 taps) with
- *              sample-exact emission (every call returns one output per input, like the direct form) - the fast path;
+ *          2 = overlap-save arithmetic, 32 <= M <= 8192, with sample-exact emission (every call returns one output per input, like
+ *              the direct form) - the fast path: the fused 1024-point kernel to 512 taps, 4096-point blocks above (one per wave as
+ *              64 x 64 - real or complex taps on a ComplexFloat32 stream, real taps on a Float32 stream; two partitions per launch
+ *              above 2 049 taps, two launches above 4 097), <= 1e-6 of the exact result whichever kernel the launch size selects;
  *          3 = automatic: 2 when the filter qualifies and has at least 48 taps (where the FFT form is the faster one on
  *              MI355X), else 0.  Outside the stated tap range 1 and 2 keep their emission rule and use the direct arithmetic. */
 lrhip_stage_t *lrhip_fir_create(const float *taps, unsigned ntaps, int taps_complex, int input_complex,
